@@ -1,0 +1,387 @@
+"""CPU oracle for the PixelSSL sseg training hot path.
+
+TEST INFRASTRUCTURE ONLY -- this is the *checker*, never the product.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import it.  The product path (`pixelssl_amd`) never imports anything from
+`oracle/` and fails loudly when the HIP library is missing.
+
+What this is: a plain-PyTorch (CPU, fp32) functional restatement of the
+reference algorithm for the north-star path, written from the reference's
+behaviour (file:line cited per function; paths relative to /root/reference):
+a table of layers + stateless torch.nn.functional calls over a flat
+{name: tensor} dictionary that uses the reference's own state_dict key names, so
+a reference checkpoint loads into it unchanged.
+
+Pinning status: PINNED against the reference itself.  The reference ships no
+golden vectors or tests; `oracle/make_golden.py` imports the real
+reference from /root/reference (container only), runs its own classes
+(`DeepLabV2`, `CommonSSEGCriterion`, `SSLNULL._train`, `SSLMT._train`) on seeded
+inputs and (a) asserts this restatement reproduces them, (b) writes the small
+fixtures in `tests/golden/` that `tests/test_oracle_golden.py` re-checks on any
+box (the GPU box has no /root/reference).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5       # torch _BatchNorm default used by sync_batchnorm/batchnorm.py:32
+BN_MOMENTUM = 0.1   # same
+
+
+# -----------------------------------------------------------------------------
+# Architecture tables
+# -----------------------------------------------------------------------------
+
+def resnet101_os16_table():
+    """Layer table of the reference backbone.
+
+    Follows task/sseg/module/backbone/resnet.py:58-66 (os16: strides 1,2,2,1;
+    dilations 1,1,1,2), :87-100 (_make_layer), :102-119 (_make_MG_unit with
+    multi-grid 1,2,4) and :168-174 (ResNet101 = [3, 4, 23, 3]).
+
+    Returns a list of stages; each stage is a list of bottleneck dicts
+    {name, cin, planes, stride, dil, down}.
+    """
+    stages = []
+    cin = 64
+    plan = [("layer1", 64, 3, 1, [1, 1, 1]),
+            ("layer2", 128, 4, 2, [1, 1, 1, 1]),
+            ("layer3", 256, 23, 2, [1] * 23),
+            ("layer4", 512, 3, 1, [2, 4, 8])]   # dilation 2 x multi-grid (1,2,4)
+    for lname, planes, nblk, stride, dils in plan:
+        blocks = []
+        for b in range(nblk):
+            s = stride if b == 0 else 1
+            down = (b == 0) and (s != 1 or cin != planes * 4)
+            blocks.append(dict(name="%s.%d" % (lname, b), cin=cin, planes=planes,
+                               stride=s, dil=dils[b], down=down))
+            cin = planes * 4
+        stages.append(blocks)
+    return stages
+
+
+ASPP_RATES = (6, 12, 18, 24)   # task/sseg/module/deeplab_v2.py:23
+
+
+def deeplabv2_param_shapes(num_classes=21):
+    """OrderedDict name -> shape for every parameter and buffer, in the
+    reference's state_dict order and naming (prefix-free: 'backbone.conv1.weight')."""
+    sd = OrderedDict()
+
+    def bn(prefix, c):
+        sd[prefix + ".weight"] = (c,)
+        sd[prefix + ".bias"] = (c,)
+        sd[prefix + ".running_mean"] = (c,)
+        sd[prefix + ".running_var"] = (c,)
+        sd[prefix + ".num_batches_tracked"] = ()
+
+    sd["backbone.conv1.weight"] = (64, 3, 7, 7)
+    bn("backbone.bn1", 64)
+    for stage in resnet101_os16_table():
+        for blk in stage:
+            p = "backbone." + blk["name"]
+            pl = blk["planes"]
+            sd[p + ".conv1.weight"] = (pl, blk["cin"], 1, 1)
+            bn(p + ".bn1", pl)
+            sd[p + ".conv2.weight"] = (pl, pl, 3, 3)
+            bn(p + ".bn2", pl)
+            sd[p + ".conv3.weight"] = (pl * 4, pl, 1, 1)
+            bn(p + ".bn3", pl * 4)
+            if blk["down"]:
+                sd[p + ".downsample.0.weight"] = (pl * 4, blk["cin"], 1, 1)
+                bn(p + ".downsample.1", pl * 4)
+    for i in range(len(ASPP_RATES)):
+        sd["classifier.conv2d_list.%d.weight" % i] = (num_classes, 2048, 3, 3)
+        sd["classifier.conv2d_list.%d.bias" % i] = (num_classes,)
+    return sd
+
+
+def is_buffer(name):
+    return name.endswith("running_mean") or name.endswith("running_var") \
+        or name.endswith("num_batches_tracked")
+
+
+def init_deeplabv2_state(num_classes=21, seed=0):
+    """Random init with the reference's distributions (not its RNG stream):
+    conv ~ N(0, sqrt(2/(k*k*cout))) resnet.py:133-137; BN gamma=1 beta=0 :138-143;
+    ASPP weight ~ N(0, 0.01), bias = torch Conv2d default U(-1/sqrt(fan_in), ..)
+    deeplab_v2.py:76-79."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for name, shape in deeplabv2_param_shapes(num_classes).items():
+        if name.endswith("num_batches_tracked"):
+            sd[name] = torch.zeros((), dtype=torch.long)
+        elif name.endswith("running_mean"):
+            sd[name] = torch.zeros(shape)
+        elif name.endswith("running_var"):
+            sd[name] = torch.ones(shape)
+        elif name.startswith("classifier"):
+            if name.endswith("weight"):
+                sd[name] = torch.randn(shape, generator=g) * 0.01
+            else:
+                bound = 1.0 / math.sqrt(2048 * 9)
+                sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif len(shape) == 4:
+            n = shape[2] * shape[3] * shape[0]
+            sd[name] = torch.randn(shape, generator=g) * math.sqrt(2.0 / n)
+        elif name.endswith(".weight"):
+            sd[name] = torch.ones(shape)
+        else:
+            sd[name] = torch.zeros(shape)
+    return sd
+
+
+def clone_state(sd):
+    return OrderedDict((k, v.clone()) for k, v in sd.items())
+
+
+# -----------------------------------------------------------------------------
+# Forward pass (functional)
+# -----------------------------------------------------------------------------
+
+def _bn(sd, prefix, x, train):
+    """Single-device path of _SynchronizedBatchNorm.forward
+    (pixelssl/nn/module/third_party/sync_batchnorm/batchnorm.py:48-53):
+    F.batch_norm with momentum 0.1, eps 1e-5, (var+eps)^-1/2, running var unbiased.
+    Running buffers in `sd` are updated in place when train=True."""
+    if train and (prefix + ".num_batches_tracked") in sd:
+        sd[prefix + ".num_batches_tracked"] += 1
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+                        sd[prefix + ".weight"], sd[prefix + ".bias"],
+                        train, BN_MOMENTUM, BN_EPS)
+
+
+def resnet_forward(sd, x, train=True, prefix="backbone"):
+    """task/sseg/module/backbone/resnet.py:121-131 (+ Bottleneck.forward :30-50)."""
+    h = F.conv2d(x, sd[prefix + ".conv1.weight"], None, stride=2, padding=3)
+    h = F.relu(_bn(sd, prefix + ".bn1", h, train))
+    h = F.max_pool2d(h, kernel_size=3, stride=2, padding=1)
+    for stage in resnet101_os16_table():
+        for blk in stage:
+            p = prefix + "." + blk["name"]
+            o = F.conv2d(h, sd[p + ".conv1.weight"])
+            o = F.relu(_bn(sd, p + ".bn1", o, train))
+            o = F.conv2d(o, sd[p + ".conv2.weight"], None, stride=blk["stride"],
+                         padding=blk["dil"], dilation=blk["dil"])
+            o = F.relu(_bn(sd, p + ".bn2", o, train))
+            o = F.conv2d(o, sd[p + ".conv3.weight"])
+            o = _bn(sd, p + ".bn3", o, train)
+            if blk["down"]:
+                r = F.conv2d(h, sd[p + ".downsample.0.weight"], None, stride=blk["stride"])
+                r = _bn(sd, p + ".downsample.1", r, train)
+            else:
+                r = h
+            h = F.relu(o + r)
+    return h
+
+
+def aspp_forward(sd, feat, prefix="classifier"):
+    """Classifier_Module.forward: sum of 4 dilated 3x3 convs with bias
+    (task/sseg/module/deeplab_v2.py:81-85)."""
+    out = None
+    for i, r in enumerate(ASPP_RATES):
+        y = F.conv2d(feat, sd["%s.conv2d_list.%d.weight" % (prefix, i)],
+                     sd["%s.conv2d_list.%d.bias" % (prefix, i)], padding=r, dilation=r)
+        out = y if out is None else out + y
+    return out
+
+
+def deeplabv2_forward(sd, x, train=True):
+    """DeepLabV2.forward (task/sseg/module/deeplab_v2.py:29-33) followed by the
+    softmax of DeepLab.forward (task/sseg/model.py:59-65).
+
+    Returns (logits NCHW, softmax NCHW, latent NCHW, lowres_logits)."""
+    feat = resnet_forward(sd, x, train)
+    low = aspp_forward(sd, feat)
+    logits = F.interpolate(low, size=x.shape[2:], mode="bilinear", align_corners=True)
+    return logits, F.softmax(logits, dim=1), feat, low
+
+
+# -----------------------------------------------------------------------------
+# Losses and schedules
+# -----------------------------------------------------------------------------
+
+def sseg_criterion(logits, gt, ignore_index=255):
+    """CommonSSEGCriterion.forward (task/sseg/criterion.py:24-38): per-pixel CE
+    with ignore_index, then mean over ALL H*W pixels (ignored ones contribute 0
+    to the numerator but stay in the denominator) -> [N]."""
+    n, c, h, w = logits.shape
+    if gt.dim() == 4:
+        gt = gt.view(n, h, w)
+    loss = F.cross_entropy(logits, gt.long(), ignore_index=ignore_index, reduction="none")
+    return loss.mean(dim=(1, 2))
+
+
+def mse_loss(a, b):
+    """nn.MSELoss() default reduction='mean' (ssl_mt.py:115)."""
+    return F.mse_loss(a, b)
+
+
+def sigmoid_rampup(current, rampup_length):
+    """pixelssl/nn/func.py:12-20."""
+    if rampup_length == 0:
+        return 1.0
+    cur = min(max(float(current), 0.0), float(rampup_length))
+    phase = 1.0 - cur / rampup_length
+    return float(math.exp(-5.0 * phase * phase))
+
+
+def poly_lr(base_lr, cur_iter, max_iters, power=0.9):
+    """PolynomialLR.get_lr (pixelssl/nn/lrer.py:155-157)."""
+    return base_lr * ((1 - float(cur_iter) / max_iters) ** power)
+
+
+def lr_group_of(name):
+    """task/sseg/model.py:45-48: backbone params lr x1, classifier lr x10."""
+    return 0 if name.startswith("backbone") else 1
+
+
+def sgd_step(sd, grads, momentum_buf, lrs, momentum=0.9, weight_decay=5e-4):
+    """torch.optim.SGD semantics used by pixelssl/nn/optimizer.py:57-75
+    (dampening 0, no nesterov): d = g + wd*p ; buf = m*buf + d (buf = d on first
+    step) ; p -= lr*buf.   `lrs` = (lr_backbone, lr_head)."""
+    for name, g in grads.items():
+        p = sd[name]
+        d = g.add(p, alpha=weight_decay)
+        if name not in momentum_buf:
+            momentum_buf[name] = d.clone()
+        else:
+            momentum_buf[name].mul_(momentum).add_(d)
+        p.add_(momentum_buf[name], alpha=-lrs[lr_group_of(name)])
+
+
+def ema_update(t_sd, s_sd, ema_decay, cur_step):
+    """SSLMT._update_ema_variables (pixelssl/ssl_algorithm/ssl_mt.py:359-363):
+    alpha = min(1 - 1/(step+1), decay); parameters only, BN buffers untouched."""
+    alpha = min(1 - 1 / (cur_step + 1), ema_decay)
+    for name, tp in t_sd.items():
+        if is_buffer(name):
+            continue
+        tp.mul_(alpha).add_(s_sd[name], alpha=1 - alpha)
+    return alpha
+
+
+# -----------------------------------------------------------------------------
+# Training steps (the reference's _train bodies, one iteration each)
+# -----------------------------------------------------------------------------
+
+def _param_leaves(sd):
+    leaves = OrderedDict()
+    for k, v in sd.items():
+        if not is_buffer(k):
+            leaves[k] = v.detach().requires_grad_(True)
+    return leaves
+
+
+def _with_leaves(sd, leaves):
+    run = OrderedDict(sd)
+    run.update(leaves)
+    return run
+
+
+class OracleTrainer:
+    """One model + SGD + poly-LR, stepping like SSLNULL._train / SSLMT._train.
+
+    hp: dict(lr, momentum, weight_decay, power, max_iters, ignore_index,
+             cons_scale, cons_rampup_iters, cons_for_labeled, ema_decay)
+    """
+
+    def __init__(self, state, hp, teacher_state=None):
+        self.sd = state
+        self.t_sd = teacher_state
+        self.hp = dict(lr=2.5e-4, momentum=0.9, weight_decay=5e-4, power=0.9,
+                       max_iters=100, ignore_index=255, cons_scale=1.0,
+                       cons_rampup_iters=0, cons_for_labeled=False, ema_decay=0.99,
+                       lr_iter_offset=1)
+        self.hp.update(hp)
+        self.mom = {}
+        self.it = 0
+
+    def _lrs(self):
+        # Quirk pinned to the torch build of this image (2.10): _LRScheduler.__init__
+        # performs an initial step(), and PolynomialLR.step(epoch=None) increments
+        # cur_iter (pixelssl/nn/lrer.py:159-176) -> the first iteration already runs
+        # at cur_iter = 1.  (torch 1.0 called step(0), which left cur_iter at 0.)
+        lr = poly_lr(self.hp["lr"], self.it + self.hp["lr_iter_offset"],
+                     self.hp["max_iters"], self.hp["power"])
+        return (lr, lr * 10)
+
+    def suponly_step(self, x, gt):
+        """SSLNULL._train body (pixelssl/ssl_algorithm/ssl_null.py:97-143)."""
+        leaves = _param_leaves(self.sd)
+        run = _with_leaves(self.sd, leaves)
+        logits, prob, _, low = deeplabv2_forward(run, x, train=True)
+        for k in self.sd:                      # running stats were updated in `run`
+            if is_buffer(k):
+                self.sd[k] = run[k]
+        task_loss = sseg_criterion(logits, gt, self.hp["ignore_index"]).mean()
+        task_loss.backward()
+        grads = OrderedDict((k, v.grad) for k, v in leaves.items())
+        out = dict(task_loss=float(task_loss.detach()), logits=logits.detach(), low=low.detach(),
+                   grads=OrderedDict((k, g.clone()) for k, g in grads.items()))
+        with torch.no_grad():
+            sgd_step(self.sd, grads, self.mom, self._lrs(),
+                     self.hp["momentum"], self.hp["weight_decay"])
+        self.it += 1
+        return out
+
+    def mt_step(self, x, gt, lbs):
+        """SSLMT._train body (pixelssl/ssl_algorithm/ssl_mt.py:131-220).
+        x: [B,3,H,W] (labeled first), gt: [B,1,H,W]; teacher sees the same x
+        (gaussian noise disabled, ssl_mt.py:38)."""
+        hp = self.hp
+        ramp = sigmoid_rampup(self.it, hp["cons_rampup_iters"])
+        leaves = _param_leaves(self.sd)
+        run = _with_leaves(self.sd, leaves)
+        s_logits, _, _, s_low = deeplabv2_forward(run, x, train=True)
+        for k in self.sd:
+            if is_buffer(k):
+                self.sd[k] = run[k]
+        s_task = sseg_criterion(s_logits[:lbs], gt[:lbs], hp["ignore_index"]).mean()
+        with torch.no_grad():
+            t_logits, _, _, _ = deeplabv2_forward(self.t_sd, x, train=True)
+            t_task = sseg_criterion(t_logits[:lbs], gt[:lbs], hp["ignore_index"]).mean()
+        if hp["cons_for_labeled"]:
+            cons = mse_loss(s_logits, t_logits)
+        elif x.shape[0] > lbs:
+            cons = mse_loss(s_logits[lbs:], t_logits[lbs:])
+        else:
+            cons = torch.zeros(())
+        cons = ramp * hp["cons_scale"] * cons
+        loss = s_task + cons
+        loss.backward()
+        grads = OrderedDict((k, v.grad) for k, v in leaves.items())
+        out = dict(s_task_loss=float(s_task.detach()), t_task_loss=float(t_task),
+                   cons_loss=float(cons.detach()), s_logits=s_logits.detach(),
+                   t_logits=t_logits.detach(), s_low=s_low.detach(),
+                   grads=OrderedDict((k, g.clone()) for k, g in grads.items()))
+        with torch.no_grad():
+            sgd_step(self.sd, grads, self.mom, self._lrs(),
+                     hp["momentum"], hp["weight_decay"])
+            ema_update(self.t_sd, self.sd, hp["ema_decay"], self.it)
+        self.it += 1
+        return out
+
+
+# -----------------------------------------------------------------------------
+# Synthetic data
+# -----------------------------------------------------------------------------
+
+def synthetic_batch(batch, size, lbs, seed, num_classes=21, block=32):
+    """Images ~ N(0,1); labels: class ids per `block`x`block` cell with a 1-pixel
+    ring of 255 on cell edges; unlabeled samples get -1 everywhere
+    (task/sseg/data.py:104-105).  float32 labels [B,1,H,W] as the reference."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch, 3, size, size, generator=g)
+    cells = (size + block - 1) // block
+    ids = torch.randint(0, num_classes, (batch, 1, cells, cells), generator=g).float()
+    gt = F.interpolate(ids, scale_factor=block, mode="nearest")[:, :, :size, :size].contiguous()
+    yy = torch.arange(size)
+    edge = (yy % block == 0)
+    ring = edge[:, None] | edge[None, :]
+    gt[:, :, ring] = 255.0
+    if lbs < batch:
+        gt[lbs:] = -1.0
+    return x, gt
