@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Throughput of the hot path: one Mean-Teacher `sseg` training step (BASELINE.json configs[1]):
+DeepLab-v2 / ResNet-101, 8 x 513 x 513 synthetic crops per GPU (4 labeled + 4 unlabeled), 21
+classes, bf16 engine (fp32 accumulate, fp32 BN statistics, fp32 master weights / optimizer).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  A "step" is the full reference
+iteration (ssl_mt.py:131-220): student fwd + CE, teacher fwd (no-grad, train-mode BN), MSE
+consistency, backward, fused SGD step, EMA teacher update, poly-LR step; inputs are resident in HBM
+before the timed region.  `roofline` is measured live with HIP events bracketing every launch of
+the dominant contraction kernel on its launch stream; `cpu_baseline` times the CPU oracle
+(oracle/torch_oracle.py, a port pinned bit-exact to the reference) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}    # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--algo", default="mt", choices=["mt", "suponly"])
+    p.add_argument("--size", type=int, default=513)
+    p.add_argument("--lbs", type=int, default=4, help="labeled samples per GPU")
+    p.add_argument("--ubs", type=int, default=4, help="unlabeled samples per GPU")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-kernel-events", action="store_true")
+    p.add_argument("--cpu-sample-steps", type=int, default=2)
+    return p.parse_args()
+
+
+def make_args(a, world):
+    ns = argparse.Namespace(
+        backbone="resnet101", output_stride=16, num_classes=21, freeze_bn=False, engine_dtype=a.dtype,
+        # proxy.py:258-261: lr and batch sizes are multiplied by #GPUs; per rank we keep the per-GPU batch
+        lr=2.5e-4 * world, momentum=0.9, weight_decay=5e-4, dampening=-1, nesterov=False, power=-1,
+        last_epoch=-1, epochs=20, iters_per_epoch=1000, ignore_index=255, labeled_batch_size=a.lbs,
+        unlabeled_batch_size=a.ubs if a.algo == "mt" else 0, ignore_unlabeled=a.algo != "mt",
+        is_epoch_lrer=False, log_freq=10 ** 9, task="sseg", cons_for_labeled=False, cons_scale=1.0,
+        cons_rampup_epochs=3, ema_decay=0.99, gaussian_noise_std=None)
+    return ns
+
+
+def cpu_baseline(a):
+    """Reference CPU path (port): the oracle's MT step at the same image size on a bounded batch."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_oracle as TO
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    lbs, ubs = (2, 2) if a.algo == "mt" else (2, 0)
+    tr = TO.OracleTrainer(TO.init_deeplabv2_state(seed=0), dict(max_iters=20000, cons_rampup_iters=3000),
+                          teacher_state=TO.init_deeplabv2_state(seed=1) if a.algo == "mt" else None)
+    x, gt = TO.synthetic_batch(lbs + ubs, a.size, lbs, seed=5)
+    step = (lambda: tr.mt_step(x, gt, lbs)) if a.algo == "mt" else (lambda: tr.suponly_step(x, gt))
+    step()                                    # warm-up (allocator, oneDNN primitives)
+    t0 = time.time()
+    for _ in range(a.cpu_sample_steps):
+        step()
+    dt = time.time() - t0
+    return {"value": round((lbs + ubs) * a.cpu_sample_steps / dt, 4), "unit": "img/s", "cores": threads,
+            "kind": "port",
+            "sample": "%d timed %s steps (after 1 warm-up) of the CPU oracle at %dx%d, batch %d+%d, fp32, "
+                      "torch %s, %d threads" % (a.cpu_sample_steps, a.algo.upper(), a.size, a.size, lbs, ubs,
+                                                torch.__version__, threads)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import pixelssl_amd as P
+    from pixelssl_amd import dist as pdist
+    from pixelssl_amd.nn import optimizer as popt, lrer as plr
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != a.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(pdist.local_device())
+    pdist.init_from_env("nccl")
+    dev = pdist.local_device()
+
+    args = make_args(a, world)
+    factories = ({"model": P.sseg.model.deeplabv2()}, {"model": popt.sgd(args)}, {"model": plr.polynomiallr(args)},
+                 {"model": P.sseg.criterion.sseg_criterion()})
+    if a.algo == "mt":
+        algo = P.ssl_algorithm.ssl_mt.ssl_mt(args, *factories, None)
+        cores = [algo.s_model.module.model, algo.t_model.module.model]
+        algo.s_model.train()
+        algo.t_model.train()
+    else:
+        algo = P.ssl_algorithm.ssl_null.ssl_null(args, *factories, None)
+        cores = [algo.model.module.model]
+        algo.model.train()
+
+    # synthetic data, resident in HBM before timing; 4 distinct batches cycled
+    import torch_oracle as TO
+    per_gpu = a.lbs + (a.ubs if a.algo == "mt" else 0)
+    batches = []
+    for i in range(4):
+        x, gt = TO.synthetic_batch(per_gpu, a.size, a.lbs, seed=1234 + rank * 1000 + i)
+        batches.append(((x.to(dev),), (gt.to(dev),)))
+
+    def one_step(it):
+        inp, gt = batches[it % len(batches)]
+        if a.algo == "mt":
+            return algo.train_step(inp, gt, it, 3 * args.iters_per_epoch)[0]
+        return algo.train_step(inp, gt)[0]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(a.warmup):
+        one_step(it)
+    fence()
+    if not a.no_kernel_events:
+        for c in cores:
+            c.profile(True)
+    t0 = time.perf_counter()
+    last = None
+    for it in range(a.warmup, a.warmup + a.steps):
+        last = one_step(it)
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+
+    kern = {}
+    if not a.no_kernel_events:
+        for kind, name in ((0, "conv_igemm(fwd+dgrad)"), (1, "conv_wgrad")):
+            ms = n = fl = 0.0
+            for c in cores:
+                m_, n_, f_ = c.profile_read(kind)
+                ms, n, fl = ms + m_, n + n_, fl + f_
+            if n:
+                kern[name] = {"launches": int(n), "avg_us": round(1e3 * ms / n, 3), "total_ms": round(ms, 3),
+                              "algorithmic_gflop_per_launch": round(fl / n / 1e9, 4),
+                              "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
+        for c in cores:
+            c.profile(False)
+
+    if rank == 0:
+        loss_vals = {k: float(v) for k, v in last.items()} if isinstance(last, dict) else {"task_loss": float(last)}
+        gb = per_gpu * world
+        out = {"metric": "training images/sec (513x513, 21-cls)", "value": round(gb * a.steps / elapsed, 3),
+               "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": "%s sseg, DeepLab-v2/ResNet-101, %dx%dx%d (%d labeled + %d unlabeled) per GPU, "
+                                      "21 classes" % ("MT (mean-teacher)" if a.algo == "mt" else "SupOnly", per_gpu,
+                                                      a.size, a.size, a.lbs, per_gpu - a.lbs),
+                          "algorithm": "ssl_" + ("mt" if a.algo == "mt" else "null"), "global_batch": gb,
+                          "im_size": a.size, "parallelism": "dp%d" % world, "sync_bn": world > 1},
+               "final_losses": loss_vals}
+        if kern:
+            dom = max(kern, key=lambda k: kern[k]["total_ms"])
+            peak = MFMA_PEAK_TFLOPS[a.dtype]
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["achieved_tflops"],
+                               "peak": peak, "unit": "TFLOP/s", "frac": round(kern[dom]["achieved_tflops"] / peak, 4),
+                               "traffic": None, "avg_launch_us": kern[dom]["avg_us"],
+                               "algorithmic_gflop_per_launch": kern[dom]["algorithmic_gflop_per_launch"]}
+            out["kernels"] = kern
+            # whole-step view: algorithmic conv FLOPs per image over wall time
+            flop_img = 449.9e9 if a.algo == "mt" else 337.1e9
+            out["step_mfma_frac"] = round(out["value"] * flop_img / world / (peak * 1e12), 4) if a.size == 513 else None
+        if world == 1 and not a.no_cpu_baseline:
+            del algo
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

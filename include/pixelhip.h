@@ -1,0 +1,253 @@
+/*
+ * libpixelhip -- C-ABI of the MI355X (gfx950) kernels behind the PixelSSL `sseg` training step.
+ *
+ * This header is the drop-in boundary: plain pointers and sizes, no torch
+ * types.  The reference (ZHKKKe/PixelSSL) has no native component, so there is no existing FFI
+ * to replace; each entry point below names the torch operator call site(s) of the reference it
+ * stands in for (file:line relative to the reference root), and INTEGRATION.md shows the ctypes
+ * stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - return 0 (PXL_OK) on success, a negative PXL_ERR_* otherwise; pxl_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - every data pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator in
+ *     the shipped host code); the library never allocates or frees device memory.  Scratch space
+ *     is passed in explicitly and sized by the matching *_workspace / *_bytes query.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All work is enqueued
+ *     asynchronously on it; no entry point synchronises the device or the stream.
+ *   - activations are NHWC ("channels last") with an explicit channel pitch that is a multiple of
+ *     16 bytes; dtype selects fp32 (exact-parity mode, v_mfma_f32_32x32x2_f32) or bf16 with fp32
+ *     accumulation (throughput mode, v_mfma_f32_32x32x16_bf16).  Parameters and their gradients
+ *     are fp32 in [K][taps][C] order == the memory order of a channels_last OIHW torch tensor.
+ *   - re-entrant per (device, stream); one host thread per rank in the shipped design.
+ */
+#ifndef PIXELHIP_H
+#define PIXELHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PXL_VERSION 100
+
+#define PXL_F32 0
+#define PXL_BF16 1
+
+#define PXL_OK 0
+#define PXL_ERR_ARG (-1)
+#define PXL_ERR_HIP (-2)
+#define PXL_ERR_UNSUPPORTED (-3)
+#define PXL_ERR_WORKSPACE (-4)
+
+const char* pxl_last_error(void);
+int pxl_version(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Convolution as implicit GEMM                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Geometry of one gather-GEMM.  Input coordinate of output pixel (oy,ox) under tap t:
+ *     ny = oy*out_stride + dy[t],  iy = ny / div   (tap contributes iff ny % div == 0, 0 <= iy < Hi)
+ * forward conv (k, stride s, dilation d, pad p): out_stride = s, div = 1, dy = r*d - p
+ * data gradient of the same conv:                out_stride = 1, div = s, dy = p - r*d, transposed weights
+ * ASPP (sum of 4 dilated 3x3): 36 taps in one launch. */
+typedef struct pxl_conv_desc {
+  int32_t dtype;        /* PXL_F32 | PXL_BF16 */
+  int32_t B, Hi, Wi;    /* input tensor */
+  int32_t Cin;          /* input channel pitch (multiple of 16 B) == K extent per tap */
+  int32_t Ho, Wo;       /* output tensor */
+  int32_t Cout;         /* output channel pitch */
+  int32_t Kreal;        /* rows of the weight matrix (real output channels, <= Cout) */
+  int32_t ntaps;        /* 1..64 */
+  int32_t out_stride;
+  int32_t div;          /* 1 or 2 */
+  int32_t relu_in;      /* prologue: relu after the input affine */
+  int32_t tile_cfg;     /* -1 = heuristic; otherwise forces a tile configuration (tests/tuning) */
+  int16_t dy[64];
+  int16_t dx[64];
+} pxl_conv_desc;
+
+/* out[m][n] = sum_{t,c} act(in)[m,t,c] * w[n][t][c]  (+ bias[n]) (+ addend[m][n]);
+ * act(x) = relu?(x*in_scale[c] + in_shift[c]) applied to in-bounds taps only (zero padding stays 0);
+ * stats (optional, [2*Kreal] fp32, caller-zeroed): per-channel sum and sum of squares of `out`
+ * taken from the fp32 accumulators.
+ * Replaces: nn.Conv2d forward/backward-data at task/sseg/module/backbone/resnet.py:18-23,69,89,106,
+ * module/deeplab_v2.py:76,81-85; the fused prologue/epilogue replaces SynchronizedBatchNorm2d +
+ * nn.ReLU at resnet.py:33-41 (sync_batchnorm/batchnorm.py:48-78). */
+int pxl_conv_igemm(const pxl_conv_desc* desc, const void* in, const void* w, void* out,
+                   const float* in_scale, const float* in_shift, const float* bias,
+                   const void* addend, float* stats, void* stream);
+
+/* dw[k][t][c] += sum_m dy[m][k] * act(in)[m,t,c]   (fp32, atomically accumulated: zero dw first
+ * unless accumulating).  `desc` describes the FORWARD conv (in = its input, Ho/Wo/Cout = dy).
+ * creal = real input channels (<= Cin pitch), dw_cpitch = channel pitch of dw.
+ * Replaces: the weight-gradient half of autograd for the same nn.Conv2d call sites. */
+int pxl_conv_wgrad(const pxl_conv_desc* desc, const void* in, const float* in_scale,
+                   const float* in_shift, const void* dy, float* dw, int creal, int dw_cpitch,
+                   void* stream);
+
+/* master fp32 w[K][T][C] -> wf[K][T_total][Cp] (forward operand, taps placed at t_off) and, if wt != NULL,
+ * wt[C][T_total][Kp] (data-gradient operand), both in `dtype`, zero padded. */
+int pxl_pack_weights(int dtype, const float* w, int K, int T, int C, void* wf, int Cp, int T_total,
+                     int t_off, void* wt, int Kp, void* stream);
+
+/* layout conversion at the API edge: NCHW fp32 <-> NHWC engine dtype (channel pitch Cp >= C) */
+int pxl_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W, int Cp, void* stream);
+int pxl_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H, int W, int Cp, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* BatchNorm (training-mode, cross-device statistics)                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* stats [2C] (sum, sumsq over `count` elements per channel; all-reduced by the caller for SyncBN)
+ * -> coef [4C] = mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; updates running stats
+ * (momentum, unbiased variance).  training=0: coef from the running statistics.
+ * clamp_var=1 selects the reference's multi-device formula clamp(var,eps)^-1/2
+ * (sync_batchnorm/batchnorm.py:125) instead of (var+eps)^-1/2 (F.batch_norm, :50-53). */
+int pxl_bn_finalize(int C, const float* stats, float count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, int training,
+                    int clamp_var, float* coef, void* stream);
+/* sums [2C] (caller-zeroed) += sum dz', sum dz'*xhat with dz' = dz * (relu ? bn(y) > 0 : 1) */
+int pxl_bn_bwd_reduce(int dtype, int M, int C, const void* dz, const void* y, const float* coef, int relu,
+                      float* sums, void* stream);
+/* bcoef [2C] = sums / count ; dgamma += sum dz'*xhat ; dbeta += sum dz' */
+int pxl_bn_bwd_finalize(int C, const float* sums, float count, float* dgamma, float* dbeta, float* bcoef,
+                        void* stream);
+/* dy = scale * (dz' - bcoef0 - xhat*bcoef1)  -- gradient w.r.t. the raw conv output (in place allowed) */
+int pxl_bn_bwd_apply(int dtype, int M, int C, const void* dz, const void* y, const float* coef,
+                     const float* bcoef, int relu, void* dy, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* ResNet trunk element-wise / pooling                                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* out = relu( y*ycoef.scale+ycoef.shift + (rcoef ? res*rcoef.scale+rcoef.shift : res) )  resnet.py:44-48 */
+int pxl_residual_fwd(int dtype, long M, int C, const void* y, const float* ycoef, const void* res,
+                     const float* rcoef, void* out, void* stream);
+/* g = dout * (out > 0), optionally duplicated into g2 (the residual branch's gradient) */
+int pxl_relu_mask(int dtype, long n, const void* dout, const void* out, void* g, void* g2, void* stream);
+/* out[c] += sum_m x[m][c] for c < Creal (bias gradient; x NHWC with channel pitch Cp <= 256) */
+int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream);
+/* out = a + b + c + d (NULL operands are skipped): summed ASPP bias */
+int pxl_vec_sum4(int n, float* out, const float* a, const float* b, const float* c, const float* d, void* stream);
+int pxl_add_inplace(int dtype, long n, void* a, const void* b, void* stream);
+/* MaxPool2d(3,2,1) of relu(bn(y)) (coef may be NULL = raw input); idx = argmax code 0..8.  resnet.py:71-73 */
+int pxl_maxpool3x3s2_fwd(int dtype, int B, int Hi, int Wi, int C, const void* y, const float* coef, void* out,
+                         uint8_t* idx, void* stream);
+int pxl_maxpool3x3s2_bwd(int dtype, int B, int Hi, int Wi, int C, const void* dp, const uint8_t* idx, void* dz,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Head tail + losses                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* F.interpolate(bilinear, align_corners=True) + F.softmax(dim=1): low NHWC [B][h][w][Cp] ->
+ * logits / prob NCHW fp32 [B][C][H][W] (prob may be NULL).  deeplab_v2.py:32, task/sseg/model.py:62 */
+int pxl_upsample_softmax_fwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W, const void* low,
+                             float* logits, float* prob, void* stream);
+size_t pxl_upsample_bwd_workspace(int B, int w, int C, int H);
+/* adjoint: dlow = U^T (dlogits + softmax_bwd(dprob, prob)); dlogits or dprob may be NULL */
+int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W, const float* dlogits,
+                             const float* dprob, const float* prob, void* dlow, void* workspace,
+                             size_t ws_bytes, void* stream);
+
+/* CommonSSEGCriterion (task/sseg/criterion.py:24-38): loss[n] = mean over ALL HW pixels of CE with
+ * ignore_index (ignored pixels add 0); gt holds class ids as float32. */
+int pxl_ce_fwd(int N, int C, int HW, const float* logits, const float* gt, int ignore_index, float* loss,
+               void* stream);
+int pxl_ce_bwd(int N, int C, int HW, const float* logits, const float* gt, int ignore_index, const float* gout,
+               float* dlogits, void* stream);
+/* nn.MSELoss() (ssl_mt.py:115,182-184): out[0] = mean((a-b)^2); da = 2(a-b)/n * gout[0] */
+int pxl_mse_fwd(long n, const float* a, const float* b, float* out, void* stream);
+int pxl_mse_bwd(long n, const float* a, const float* b, const float* gout, float* da, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Optimizer / EMA over flat fp32 buffers                                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* torch.optim.SGD(momentum, weight_decay) semantics, pixelssl/nn/optimizer.py:57-75 */
+int pxl_sgd_step(long n, float* p, const float* g, float* buf, float lr, float momentum, float weight_decay,
+                 int first_step, void* stream);
+/* SSLMT._update_ema_variables, pixelssl/ssl_algorithm/ssl_mt.py:359-363 */
+int pxl_ema_update(long n, float* teacher, const float* student, float alpha, void* stream);
+int pxl_scale_inplace(long n, float* x, float a, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Network executor (see net.h section below)                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Layer program of one segmentation network (DeepLab-v2 trunk+head today).  The host describes the
+ * network once; forward/backward then run the whole launch sequence from C++ with no per-layer
+ * host round trip.  Offsets index the caller's flat fp32 parameter / gradient / running-stat
+ * buffers (in floats). */
+#define PXL_OP_INPUT 0      /* NCHW fp32 image -> NHWC tensor                        */
+#define PXL_OP_CONV 1       /* conv (+ optional BN statistics of the output)         */
+#define PXL_OP_MAXPOOL 2    /* 3x3/s2/p1 max-pool of relu(bn(in))                    */
+#define PXL_OP_RESIDUAL 3   /* out = relu(bn(in0) + (bn(in1) | in1))                 */
+#define PXL_OP_HEAD 4       /* upsample + softmax of the low-res logits -> outputs   */
+
+typedef struct pxl_op {
+  int32_t kind;
+  int32_t in0, in1, out;       /* tensor ids (-1 = none); HEAD: in0 = low-res logits, in1 = latent   */
+  int32_t bn_in0, bn_in1;      /* BN ids applied to in0/in1 on load (conv/maxpool add the ReLU)      */
+  int32_t bn_out;              /* BN id whose statistics this conv produces (-1 = none)              */
+  int32_t ngroups;             /* tap groups: 1 for plain convs, 4 for the ASPP sum                  */
+  int32_t w_off[4];            /* weight offset (floats) of each tap group in the parameter buffer   */
+  int32_t b_off[4];            /* bias offset of each tap group (-1 = no bias)                       */
+  int32_t dil[4];              /* dilation of each tap group                                         */
+  int32_t pads[4];             /* zero padding of each tap group                                     */
+  int32_t cin, cout;           /* real channels                                                      */
+  int32_t kh, kw, stride;
+  int32_t need_dgrad;          /* 0 for the stem (the image needs no gradient)                       */
+} pxl_op;
+
+typedef struct pxl_bn_desc {
+  int32_t C;
+  int32_t gamma_off, beta_off;      /* in the parameter buffer  */
+  int32_t rmean_off, rvar_off;      /* in the running-stat buffer */
+  float eps, momentum;
+} pxl_bn_desc;
+
+typedef struct pxl_net pxl_net;
+
+/* cross-device statistics hook (SyncBN): called between a conv's statistics epilogue and the
+ * matching finalize, must all-reduce(sum) `n` floats at `buf` on `stream`.  NULL = single device. */
+typedef int (*pxl_allreduce_fn)(void* user, float* buf, int n, void* stream);
+
+int pxl_net_create(int dtype, int num_classes, const pxl_op* ops, int nops, const pxl_bn_desc* bns, int nbns,
+                   int ntensors, pxl_net** out);
+void pxl_net_destroy(pxl_net* net);
+/* plan buffers for a batch of B images of H x W; must be called before the *_bytes queries */
+int pxl_net_plan(pxl_net* net, int B, int H, int W);
+size_t pxl_net_packed_bytes(const pxl_net* net);     /* persistent packed-weight buffer            */
+size_t pxl_net_arena_bytes(const pxl_net* net);      /* activations saved between fwd and bwd      */
+size_t pxl_net_scratch_bytes(const pxl_net* net);    /* backward gradient buffers                  */
+int pxl_net_set_sync(pxl_net* net, pxl_allreduce_fn fn, void* user, int world_size);
+/* repack params -> packed (call after every parameter update) */
+int pxl_net_pack(pxl_net* net, const float* params, void* packed, void* stream);
+/* x NCHW fp32 [B,3,H,W] -> logits/prob NCHW fp32 [B,classes,H,W]; training selects batch statistics
+ * (+ running-stat update) vs running statistics; the arena keeps what backward needs. */
+int pxl_net_forward(pxl_net* net, const float* params, const void* packed, float* running, const float* x,
+                    float* logits, float* prob, void* arena, size_t arena_bytes, int training, void* stream);
+/* latent (backbone feature, NCHW fp32 [B,2048,h,w]) of the last forward held in `arena` */
+int pxl_net_latent(pxl_net* net, const void* arena, float* latent, void* stream);
+int pxl_net_latent_shape(const pxl_net* net, int* C, int* h, int* w);
+/* accumulates parameter gradients into `grads` (same layout as params; caller zeroes when needed) */
+int pxl_net_backward(pxl_net* net, const float* params, const void* packed, const float* dlogits,
+                     const float* dprob, const float* prob, float* grads, void* arena, size_t arena_bytes,
+                     void* scratch, size_t scratch_bytes, void* stream);
+
+/* Measurement aid (bench.py roofline leg): bracket every contraction launch of this net with HIP
+ * events on the launch stream.  kind 0 = implicit-GEMM conv (forward + data gradient), 1 = weight
+ * gradient.  read() synchronises on the recorded events, returns the summed kernel time, the number
+ * of launches and their ALGORITHMIC flops (2*MAC of the real, unpadded problem), and resets. */
+int pxl_net_profile(pxl_net* net, int enable);
+int pxl_net_profile_read(pxl_net* net, int kind, double* ms, long* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIXELHIP_H */

@@ -1,0 +1,142 @@
+"""ctypes binding of libpixelhip.so (the C-ABI declared in include/pixelhip.h).
+
+The product path has NO fallback: if the HIP library is missing this module raises at import of
+the first symbol, and every op raises `PixelHipError` on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpixelhip.so")
+
+PXL_F32, PXL_BF16 = 0, 1
+OP_INPUT, OP_CONV, OP_MAXPOOL, OP_RESIDUAL, OP_HEAD = 0, 1, 2, 3, 4
+
+
+class PixelHipError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("B", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32),
+                ("Cin", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
+                ("Kreal", C.c_int32), ("ntaps", C.c_int32), ("out_stride", C.c_int32),
+                ("div", C.c_int32), ("relu_in", C.c_int32), ("tile_cfg", C.c_int32),
+                ("dy", C.c_int16 * 64), ("dx", C.c_int16 * 64)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("in0", C.c_int32), ("in1", C.c_int32), ("out", C.c_int32),
+                ("bn_in0", C.c_int32), ("bn_in1", C.c_int32), ("bn_out", C.c_int32),
+                ("ngroups", C.c_int32), ("w_off", C.c_int32 * 4), ("b_off", C.c_int32 * 4),
+                ("dil", C.c_int32 * 4), ("pads", C.c_int32 * 4), ("cin", C.c_int32),
+                ("cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
+                ("need_dgrad", C.c_int32)]
+
+
+class BnDesc(C.Structure):
+    _fields_ = [("C", C.c_int32), ("gamma_off", C.c_int32), ("beta_off", C.c_int32),
+                ("rmean_off", C.c_int32), ("rvar_off", C.c_int32), ("eps", C.c_float),
+                ("momentum", C.c_float)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_long
+_F = C.c_float
+_Z = C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/pixelhip.h declares
+SIGNATURES = {
+    "pxl_last_error": (C.c_char_p, []),
+    "pxl_version": (_I, []),
+    "pxl_conv_igemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pxl_conv_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _I, _P]),
+    "pxl_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P]),
+    "pxl_nchw_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "pxl_nhwc_to_nchw": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "pxl_bn_finalize": (_I, [_I, _P, _F, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P]),
+    "pxl_bn_bwd_reduce": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _P]),
+    "pxl_bn_bwd_finalize": (_I, [_I, _P, _F, _P, _P, _P, _P]),
+    "pxl_bn_bwd_apply": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "pxl_residual_fwd": (_I, [_I, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "pxl_relu_mask": (_I, [_I, _L, _P, _P, _P, _P, _P]),
+    "pxl_colsum": (_I, [_I, _I, _I, _I, _P, _P, _P]),
+    "pxl_vec_sum4": (_I, [_I, _P, _P, _P, _P, _P, _P]),
+    "pxl_add_inplace": (_I, [_I, _L, _P, _P, _P]),
+    "pxl_maxpool3x3s2_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "pxl_maxpool3x3s2_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "pxl_upsample_softmax_fwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "pxl_upsample_bwd_workspace": (_Z, [_I, _I, _I, _I]),
+    "pxl_upsample_softmax_bwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "pxl_ce_fwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P]),
+    "pxl_ce_bwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "pxl_mse_fwd": (_I, [_L, _P, _P, _P, _P]),
+    "pxl_mse_bwd": (_I, [_L, _P, _P, _P, _P, _P]),
+    "pxl_sgd_step": (_I, [_L, _P, _P, _P, _F, _F, _F, _I, _P]),
+    "pxl_ema_update": (_I, [_L, _P, _P, _F, _P]),
+    "pxl_scale_inplace": (_I, [_L, _P, _F, _P]),
+    "pxl_net_create": (_I, [_I, _I, C.POINTER(Op), _I, C.POINTER(BnDesc), _I, _I, C.POINTER(_P)]),
+    "pxl_net_destroy": (None, [_P]),
+    "pxl_net_plan": (_I, [_P, _I, _I, _I]),
+    "pxl_net_packed_bytes": (_Z, [_P]),
+    "pxl_net_arena_bytes": (_Z, [_P]),
+    "pxl_net_scratch_bytes": (_Z, [_P]),
+    "pxl_net_set_sync": (_I, [_P, ALLREDUCE_FN, _P, _I]),
+    "pxl_net_pack": (_I, [_P, _P, _P, _P]),
+    "pxl_net_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
+    "pxl_net_latent": (_I, [_P, _P, _P, _P]),
+    "pxl_net_latent_shape": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "pxl_net_profile": (_I, [_P, _I]),
+    "pxl_net_profile_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
+    "pxl_net_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PixelHipError(
+                "libpixelhip.so is missing (%s). Build it with `python -m pixelssl_amd.build`; "
+                "there is no CPU/PyTorch fallback for the accelerated path." % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise PixelHipError("libpixelhip error %d: %s" % (rc, lib().pxl_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dtype):
+    if dtype in (torch.float32, "fp32", "f32", PXL_F32):
+        return PXL_F32
+    if dtype in (torch.bfloat16, "bf16", PXL_BF16):
+        return PXL_BF16
+    raise ValueError("unsupported engine dtype %r" % (dtype,))
+
+
+def torch_dtype(code):
+    return torch.float32 if code == PXL_F32 else torch.bfloat16

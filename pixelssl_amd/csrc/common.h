@@ -1,0 +1,109 @@
+// Shared device/host helpers for libpixelhip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/pixelhip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+typedef uint16_t bf16_t;   // storage type of bf16 activations / packed weights
+
+// ----------------------------------------------------------------------------
+// error plumbing (thread-local last error, negative return codes)
+// ----------------------------------------------------------------------------
+int pxl_set_error(int code, const char* fmt, ...);
+#define PXL_CHECK_HIP(expr)                                                        \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess)                                                          \
+      return pxl_set_error(PXL_ERR_HIP, "%s failed: %s (%s:%d)", #expr,            \
+                           hipGetErrorString(_e), __FILE__, __LINE__);             \
+  } while (0)
+#define PXL_LAUNCH_CHECK() PXL_CHECK_HIP(hipGetLastError())
+#define PXL_REQUIRE(cond, ...)                                                     \
+  do {                                                                             \
+    if (!(cond)) return pxl_set_error(PXL_ERR_ARG, __VA_ARGS__);                   \
+  } while (0)
+
+// ----------------------------------------------------------------------------
+// element traits: T = float (parity mode) or bf16_t (throughput mode)
+// ----------------------------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int EPC = 4;          // elements per 16-byte chunk
+  static constexpr int DTYPE = PXL_F32;
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int EPC = 8;
+  static constexpr int DTYPE = PXL_BF16;
+};
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;   // RNE, lowers to v_cvt_pk_bf16_f32 on gfx950
+  return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  bf16x2 h = __builtin_convertvector(v, bf16x2);
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+// unpack one 16-byte chunk into EPC floats and back
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  static __device__ __forceinline__ void unpack(const uint4& c, float* f) {
+    f[0] = __uint_as_float(c.x); f[1] = __uint_as_float(c.y);
+    f[2] = __uint_as_float(c.z); f[3] = __uint_as_float(c.w);
+  }
+  static __device__ __forceinline__ uint4 pack(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]),
+                      __float_as_uint(f[2]), __float_as_uint(f[3]));
+  }
+};
+template <> struct Chunk<bf16_t> {
+  static __device__ __forceinline__ void unpack(const uint4& c, float* f) {
+    f[0] = bf_lo(c.x); f[1] = bf_hi(c.x); f[2] = bf_lo(c.y); f[3] = bf_hi(c.y);
+    f[4] = bf_lo(c.z); f[5] = bf_hi(c.z); f[6] = bf_lo(c.w); f[7] = bf_hi(c.w);
+  }
+  static __device__ __forceinline__ uint4 pack(const float* f) {
+    return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]),
+                      pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// XCD-aware bijective remap of a linear block id (guide T1): consecutive logical
+// tiles land on the same XCD (= same L2).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

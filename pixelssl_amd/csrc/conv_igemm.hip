@@ -1,0 +1,338 @@
+// Implicit-GEMM convolution for gfx950 (MI355X), NHWC activations, [K][taps][C] weights.
+//
+//   out[m][n] = sum_{t,c} A(m,t,c) * W[n][t][c]      m = (b,oy,ox), n = out channel
+//   A(m,t,c)  = act(in[b][iy][ix][c])                iy = (oy*so + dy[t]) / div  (if divisible & in range)
+//
+// One kernel covers every dense contraction of the hot path (SURVEY.md 8a'):
+//   * forward 1x1 / 3x3 (dilated, strided) / 7x7 stem / 4x4 / multi-rate ASPP (36 taps),
+//   * data-gradient (so=1, negated taps, div=stride, transposed weights),
+// with the producer's BatchNorm-apply(+ReLU) fused into the A-tile load (prologue) and
+// bias / residual-addend / per-channel sum & sum-of-squares (BN statistics) fused into
+// the epilogue.
+//
+// Mapping to CDNA4: 256 threads = 4 waves (2x2 or 4x1), each wave owns 32x32 MFMA tiles
+// (v_mfma_f32_32x32x16_bf16 for bf16, v_mfma_f32_32x32x2_f32 for the exact-fp32 parity
+// mode).  K is walked in 64-byte slices per row (32 bf16 / 16 fp32); global loads are
+// 16 B per lane along the channel axis (NHWC => coalesced), register-staged so that
+// the prologue can run, written to a double-buffered, XOR-swizzled LDS image
+// ([rows][4 x 16 B], chunk ^= (row>>2)&3 -> conflict-free ds_read_b128 for the 32-row
+// fragment pattern), one barrier per K step.  blockIdx is remapped so that tiles sharing
+// an A row-panel run on the same XCD (shared L2).
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+  const void* in;
+  const void* w;
+  void* out;
+  const float* in_scale;
+  const float* in_shift;
+  const float* bias;
+  const void* addend;
+  float* stats;
+  int B, Hi, Wi, Cin;
+  int Ho, Wo, Cout, Kreal;
+  int ntaps, so, div_shift, div_mask, relu_in;
+  int M;           // B*Ho*Wo
+  int Ktot;        // ntaps*Cin
+  int nk;          // K steps
+  int tiles_m, tiles_n;
+  int taps[64];    // (dy << 16) | (dx & 0xffff)
+};
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                  __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mfma<float> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BK = 4 * EPC;                // elements per 64-byte row slice
+  constexpr int RA = (BM + 63) / 64;         // A rows per thread
+  constexpr int RB = (BN + 63) / 64;         // B rows per thread
+  constexpr int TM = BM / (32 * WM);         // 32x32 tiles per wave along M
+  constexpr int TN = BN / (32 * WN);
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(TM >= 1 && TN >= 1, "tile");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // layout: [2][BM][64B] A | [2][BN][64B] B | taps[64] int | affine [2*Cin] float
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 2 * BM * 64;
+  int* sTaps = reinterpret_cast<int*>(smem + 2 * (BM + BN) * 64);
+  float* sAff = reinterpret_cast<float*>(smem + 2 * (BM + BN) * 64 + 256);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const bool has_aff = p.in_scale != nullptr;
+  if (tid < 64) sTaps[tid] = p.taps[tid];
+  if (has_aff) {
+    for (int i = tid; i < p.Cin; i += 256) {
+      sAff[i] = p.in_scale[i];
+      sAff[p.Cin + i] = p.in_shift[i];
+    }
+  }
+
+  // ---- per-thread load coordinates
+  const int chunk = tid & 3;
+  const int lrow = tid >> 2;                 // 0..63
+  int a_iy0[RA], a_ix0[RA], a_base[RA];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    const int row = lrow + 64 * i;
+    const int m = m0 + row;
+    if (row < BM && m < p.M) {
+      const int b = m / HoWo;
+      const int r = m - b * HoWo;
+      const int oy = r / p.Wo;
+      const int ox = r - oy * p.Wo;
+      a_iy0[i] = oy * p.so;
+      a_ix0[i] = ox * p.so;
+      a_base[i] = b * p.Hi * p.Wi;
+    } else {
+      a_iy0[i] = -(1 << 28);
+      a_ix0[i] = 0;
+      a_base[i] = 0;
+    }
+  }
+  // k cursor of this thread's chunk column: (tap, channel)
+  int kt = 0, kc = chunk * EPC;
+  while (kc >= p.Cin) { kc -= p.Cin; ++kt; }
+
+  const T* __restrict__ gin = reinterpret_cast<const T*>(p.in);
+  const T* __restrict__ gw = reinterpret_cast<const T*>(p.w);
+
+  uint4 ra[RA], rb[RB];
+
+  auto load_tiles = [&](int kstep) {
+    const bool kvalid = kt < p.ntaps;
+    int dy = 0, dx = 0;
+    if (kvalid) {
+      const int tp = sTaps[kt];
+      dy = tp >> 16;
+      dx = (int)(short)(tp & 0xffff);
+    }
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int ny = a_iy0[i] + dy, nx = a_ix0[i] + dx;
+      const int iy = ny >> p.div_shift, ix = nx >> p.div_shift;
+      const bool ok = kvalid && ((ny & p.div_mask) == 0) && ((nx & p.div_mask) == 0) &&
+                      ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi) &&
+                      (ny >= 0) && (nx >= 0);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) {
+        const size_t off = ((size_t)(a_base[i] + iy * p.Wi + ix)) * p.Cin + kc;
+        v = *reinterpret_cast<const uint4*>(gin + off);
+        if (has_aff) {
+          float f[EPC];
+          Chunk<T>::unpack(v, f);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            float z = f[e] * sAff[kc + e] + sAff[p.Cin + kc + e];
+            f[e] = p.relu_in ? fmaxf(z, 0.f) : z;
+          }
+          v = Chunk<T>::pack(f);
+        }
+      }
+      ra[i] = v;
+    }
+    const int kidx = kstep * BK + chunk * EPC;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int row = lrow + 64 * i;
+      const int n = n0 + row;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < BN && n < p.Kreal && kvalid)
+        v = *reinterpret_cast<const uint4*>(gw + (size_t)n * p.Ktot + kidx);
+      rb[i] = v;
+    }
+    // advance the k cursor by one K step
+    kc += BK;
+    while (kc >= p.Cin) { kc -= p.Cin; ++kt; }
+  };
+
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int row = lrow + 64 * i;
+      if (row < BM)
+        *reinterpret_cast<uint4*>(sA + (buf * BM + row) * 64 + swz(row, chunk) * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int row = lrow + 64 * i;
+      if (row < BN)
+        *reinterpret_cast<uint4*>(sB + (buf * BN + row) * 64 + swz(row, chunk) * 16) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  __syncthreads();   // taps / affine visible
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+  for (int ks = 0; ks < p.nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < p.nk) load_tiles(ks + 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = fhalf + 2 * kk;
+      uint4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + frow;
+        fa[i] = *reinterpret_cast<const uint4*>(sA + (buf * BM + row) * 64 + swz(row, ch) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 32 + frow;
+        fb[j] = *reinterpret_cast<const uint4*>(sB + (buf * BN + row) * 64 + swz(row, ch) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+    if (ks + 1 < p.nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+  T* __restrict__ gout = reinterpret_cast<T*>(p.out);
+  const T* __restrict__ gadd = reinterpret_cast<const T*>(p.addend);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + frow;
+    const bool ncol = n < p.Cout;
+    const float bv = (p.bias != nullptr && n < p.Kreal) ? p.bias[n] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        if (m < p.M && ncol) {
+          float v = acc[i][j][r] + bv;
+          const size_t o = (size_t)m * p.Cout + n;
+          if (gadd != nullptr) v += to_f(gadd[o]);
+          s1 += v;
+          s2 += v * v;
+          gout[o] = from_f<T>(v);
+        }
+      }
+    }
+    if (p.stats != nullptr) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (fhalf == 0 && n < p.Kreal) {
+        atomicAdd(p.stats + n, s1);
+        atomicAdd(p.stats + p.Kreal + n, s2);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_cfg(const ConvArgs& a, hipStream_t stream) {
+  ConvArgs p = a;
+  p.tiles_m = cdiv(p.M, BM);
+  p.tiles_n = cdiv(p.Cout, BN);
+  constexpr int BK = 4 * Elem<T>::EPC;
+  p.nk = cdiv(p.Ktot, BK);
+  const size_t smem = 2 * (BM + BN) * 64 + 256 + (p.in_scale ? 2 * (size_t)p.Cin * 4 : 0);
+  const int grid = p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN>), dim3(grid), dim3(256), smem, stream, p);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+template <typename T>
+int launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
+  const int M = a.M, N = a.Cout;
+  int cfg = force_cfg;
+  if (cfg < 0) {
+    if (N <= 32) cfg = 3;
+    else if (N <= 64) cfg = (cdiv(M, 128) >= 512) ? 1 : 2;
+    else {
+      const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
+      const long t12864 = (long)cdiv(M, 128) * cdiv(N, 64);
+      if (t128 >= 512) cfg = 0;
+      else if (t12864 >= 512) cfg = 1;
+      else cfg = 2;
+    }
+  }
+  switch (cfg) {
+    case 0: return launch_cfg<T, 128, 128, 2, 2>(a, stream);
+    case 1: return launch_cfg<T, 128, 64, 2, 2>(a, stream);
+    case 2: return launch_cfg<T, 64, 64, 2, 2>(a, stream);
+    case 3: return launch_cfg<T, 128, 32, 4, 1>(a, stream);
+    default: return pxl_set_error(PXL_ERR_ARG, "conv_igemm: unknown tile config %d", cfg);
+  }
+}
+
+}  // namespace
+
+extern "C" int pxl_conv_igemm(const pxl_conv_desc* d, const void* in, const void* w, void* out,
+                              const float* in_scale, const float* in_shift, const float* bias,
+                              const void* addend, float* stats, void* stream) {
+  PXL_REQUIRE(d && in && w && out, "conv_igemm: null argument");
+  PXL_REQUIRE(d->dtype == PXL_F32 || d->dtype == PXL_BF16, "conv_igemm: bad dtype %d", d->dtype);
+  const int epc = d->dtype == PXL_F32 ? 4 : 8;
+  PXL_REQUIRE(d->Cin > 0 && d->Cin % epc == 0, "conv_igemm: Cin pitch %d must be a multiple of %d", d->Cin, epc);
+  PXL_REQUIRE(d->ntaps >= 1 && d->ntaps <= 64, "conv_igemm: ntaps %d out of range", d->ntaps);
+  PXL_REQUIRE(d->div == 1 || d->div == 2, "conv_igemm: div must be 1 or 2 (got %d)", d->div);
+  PXL_REQUIRE(d->Kreal >= 1 && d->Kreal <= d->Cout, "conv_igemm: Kreal %d vs Cout pitch %d", d->Kreal, d->Cout);
+  PXL_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv_igemm: scale/shift must come together");
+  PXL_REQUIRE((long)d->B * d->Hi * d->Wi * d->Cin < (1L << 31) && (long)d->B * d->Ho * d->Wo * d->Cout < (1L << 31),
+              "conv_igemm: tensor too large for 32-bit indexing");
+  ConvArgs a;
+  a.in = in; a.w = w; a.out = out;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.addend = addend; a.stats = stats;
+  a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.Kreal = d->Kreal;
+  a.ntaps = d->ntaps; a.so = d->out_stride;
+  a.div_shift = d->div == 2 ? 1 : 0; a.div_mask = d->div - 1;
+  a.relu_in = d->relu_in;
+  a.M = d->B * d->Ho * d->Wo;
+  a.Ktot = d->ntaps * d->Cin;
+  for (int t = 0; t < 64; ++t)
+    a.taps[t] = t < d->ntaps ? (((int)d->dy[t]) << 16) | (((int)d->dx[t]) & 0xffff) : 0;
+  a.nk = 0; a.tiles_m = a.tiles_n = 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == PXL_F32) return launch_conv<float>(a, d->tile_cfg, s);
+  return launch_conv<bf16_t>(a, d->tile_cfg, s);
+}

@@ -1,0 +1,301 @@
+// HBM-bound element-wise / pooling kernels of the ResNet trunk (NHWC, 16 B per lane).
+//   * residual join:   out = relu( bn3(y3) + (bnd(yd) | identity) )      resnet.py:44-48
+//   * its backward mask: g = dout * (out > 0)
+//   * stem max-pool 3x3/s2/p1 with the stem BN+ReLU fused into the load   resnet.py:71-73
+#include "common.h"
+
+namespace {
+
+inline int grid_for(long n, int block = 256) {
+  long g = (n + block - 1) / block;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void residual_fwd_kernel(long nchunks, int C, const T* __restrict__ y,
+                                                           const float* __restrict__ ycoef,
+                                                           const T* __restrict__ res,
+                                                           const float* __restrict__ rcoef,
+                                                           T* __restrict__ out) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = C / EPC;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cpr) * EPC;
+    float fy[EPC], fr[EPC], o[EPC];
+    Chunk<T>::unpack(reinterpret_cast<const uint4*>(y)[i], fy);
+    Chunk<T>::unpack(reinterpret_cast<const uint4*>(res)[i], fr);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int c = c0 + e;
+      float v = fy[e] * ycoef[2 * C + c] + ycoef[3 * C + c];
+      float r = fr[e];
+      if (rcoef != nullptr) r = r * rcoef[2 * C + c] + rcoef[3 * C + c];
+      o[e] = fmaxf(v + r, 0.f);
+    }
+    reinterpret_cast<uint4*>(out)[i] = Chunk<T>::pack(o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relu_mask_kernel(long nchunks, const T* __restrict__ dout,
+                                                        const T* __restrict__ out, T* __restrict__ g,
+                                                        T* __restrict__ g2) {
+  constexpr int EPC = Elem<T>::EPC;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    float fd[EPC], fo[EPC];
+    Chunk<T>::unpack(reinterpret_cast<const uint4*>(dout)[i], fd);
+    Chunk<T>::unpack(reinterpret_cast<const uint4*>(out)[i], fo);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) fd[e] = fo[e] > 0.f ? fd[e] : 0.f;
+    const uint4 v = Chunk<T>::pack(fd);
+    reinterpret_cast<uint4*>(g)[i] = v;
+    if (g2 != nullptr) reinterpret_cast<uint4*>(g2)[i] = v;
+  }
+}
+
+// out[c] += sum_m x[m][c]  for c < Creal (bias gradient of the ASPP head)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int Cp, int Creal, const T* __restrict__ x,
+                                                     float* __restrict__ out, int rows_per_block) {
+  const int c = threadIdx.x % Cp;
+  const int rr = threadIdx.x / Cp;
+  const int rstep = 256 / Cp;
+  const int m_end = min(M, (int)(blockIdx.x + 1) * rows_per_block);
+  float acc = 0.f;
+  if (rr < rstep && c < Creal)
+    for (int m = blockIdx.x * rows_per_block + rr; m < m_end; m += rstep) acc += to_f(x[(size_t)m * Cp + c]);
+  if (rr < rstep && c < Creal) atomicAdd(out + c, acc);
+}
+
+__global__ void vec_sum4_kernel(int n, float* __restrict__ out, const float* a, const float* b, const float* c,
+                                const float* d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (a ? a[i] : 0.f) + (b ? b[i] : 0.f) + (c ? c[i] : 0.f) + (d ? d[i] : 0.f);
+}
+
+// a += b (gradient accumulation for multi-consumer tensors)
+template <typename T>
+__global__ __launch_bounds__(256) void add_inplace_kernel(long nchunks, T* __restrict__ a, const T* __restrict__ b) {
+  constexpr int EPC = Elem<T>::EPC;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    float fa[EPC], fb[EPC];
+    Chunk<T>::unpack(reinterpret_cast<const uint4*>(a)[i], fa);
+    Chunk<T>::unpack(reinterpret_cast<const uint4*>(b)[i], fb);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) fa[e] += fb[e];
+    reinterpret_cast<uint4*>(a)[i] = Chunk<T>::pack(fa);
+  }
+}
+
+// out[b][py][px][c] = max over 3x3 window (stride 2, pad 1) of relu(y*scale+shift); idx = first argmax
+// in row-major window order (PyTorch's tie rule: strict '>' keeps the first maximum).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(int B, int Hi, int Wi, int C, int Ho, int Wo,
+                                                          const T* __restrict__ y,
+                                                          const float* __restrict__ coef,
+                                                          T* __restrict__ out, uint8_t* __restrict__ idx) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = C / EPC;
+  const long total = (long)B * Ho * Wo * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpr);
+    long r = i / cpr;
+    const int px = (int)(r % Wo); r /= Wo;
+    const int py = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    float sc[EPC], sh[EPC], best[EPC];
+    int bi[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      sc[e] = coef ? coef[2 * C + cc * EPC + e] : 1.f;
+      sh[e] = coef ? coef[3 * C + cc * EPC + e] : 0.f;
+      best[e] = -INFINITY;
+      bi[e] = 0;
+    }
+#pragma unroll
+    for (int wy = 0; wy < 3; ++wy) {
+#pragma unroll
+      for (int wx = 0; wx < 3; ++wx) {
+        const int iy = py * 2 - 1 + wy, ix = px * 2 - 1 + wx;
+        if ((unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) {
+          float f[EPC];
+          Chunk<T>::unpack(*reinterpret_cast<const uint4*>(y + ((size_t)(b * Hi + iy) * Wi + ix) * C + cc * EPC), f);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            float z = f[e] * sc[e] + sh[e];
+            if (coef) z = fmaxf(z, 0.f);
+            if (z > best[e]) { best[e] = z; bi[e] = wy * 3 + wx; }
+          }
+        }
+      }
+    }
+    *reinterpret_cast<uint4*>(out + ((size_t)(b * Ho + py) * Wo + px) * C + cc * EPC) = Chunk<T>::pack(best);
+    uint8_t* ip = idx + ((size_t)(b * Ho + py) * Wo + px) * C + cc * EPC;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) ip[e] = (uint8_t)bi[e];
+  }
+}
+
+// dz[b][iy][ix][c] = sum over the (<=2x2) windows containing (iy,ix) whose argmax is (iy,ix) of dp
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(int B, int Hi, int Wi, int C, int Ho, int Wo,
+                                                          const T* __restrict__ dp,
+                                                          const uint8_t* __restrict__ idx, T* __restrict__ dz) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = C / EPC;
+  const long total = (long)B * Hi * Wi * cpr;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpr);
+    long r = i / cpr;
+    const int ix = (int)(r % Wi); r /= Wi;
+    const int iy = (int)(r % Hi);
+    const int b = (int)(r / Hi);
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    // windows containing iy: py*2-1 <= iy <= py*2+1  ->  py in [iy/2, (iy+1)/2]
+    for (int py = iy >> 1; py <= ((iy + 1) >> 1); ++py) {
+      if (py < 0 || py >= Ho) continue;
+      const int wy = iy - (py * 2 - 1);
+      if (wy < 0 || wy > 2) continue;
+      for (int px = ix >> 1; px <= ((ix + 1) >> 1); ++px) {
+        if (px < 0 || px >= Wo) continue;
+        const int wx = ix - (px * 2 - 1);
+        if (wx < 0 || wx > 2) continue;
+        const int code = wy * 3 + wx;
+        const size_t o = ((size_t)(b * Ho + py) * Wo + px) * C + cc * EPC;
+        float f[EPC];
+        Chunk<T>::unpack(*reinterpret_cast<const uint4*>(dp + o), f);
+        const uint8_t* ip = idx + o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+          if (ip[e] == code) acc[e] += f[e];
+      }
+    }
+    *reinterpret_cast<uint4*>(dz + ((size_t)(b * Hi + iy) * Wi + ix) * C + cc * EPC) = Chunk<T>::pack(acc);
+  }
+}
+
+}  // namespace
+
+template <typename T> static const T* cp(const void* p) { return reinterpret_cast<const T*>(p); }
+template <typename T> static T* mp(void* p) { return reinterpret_cast<T*>(p); }
+
+extern "C" int pxl_residual_fwd(int dtype, long M, int C, const void* y, const float* ycoef, const void* res,
+                                const float* rcoef, void* out, void* stream) {
+  PXL_REQUIRE(y && ycoef && res && out, "residual_fwd: null argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "residual_fwd: bad dtype");
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  PXL_REQUIRE(C % epc == 0, "residual_fwd: C=%d must be a multiple of %d", C, epc);
+  const long nchunks = M * (C / epc);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(residual_fwd_kernel<float>, dim3(grid_for(nchunks)), dim3(256), 0, s, nchunks, C,
+                       cp<float>(y), ycoef, cp<float>(res), rcoef, mp<float>(out));
+  else
+    hipLaunchKernelGGL(residual_fwd_kernel<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, s, nchunks, C,
+                       cp<bf16_t>(y), ycoef, cp<bf16_t>(res), rcoef, mp<bf16_t>(out));
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_relu_mask(int dtype, long n, const void* dout, const void* out, void* g, void* g2,
+                             void* stream) {
+  PXL_REQUIRE(dout && out && g, "relu_mask: null argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "relu_mask: bad dtype");
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  PXL_REQUIRE(n % epc == 0, "relu_mask: n must be a multiple of %d", epc);
+  const long nchunks = n / epc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(relu_mask_kernel<float>, dim3(grid_for(nchunks)), dim3(256), 0, s, nchunks,
+                       cp<float>(dout), cp<float>(out), mp<float>(g), mp<float>(g2));
+  else
+    hipLaunchKernelGGL(relu_mask_kernel<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, s, nchunks,
+                       cp<bf16_t>(dout), cp<bf16_t>(out), mp<bf16_t>(g), mp<bf16_t>(g2));
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream) {
+  PXL_REQUIRE(x && out && M > 0, "colsum: bad argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "colsum: bad dtype");
+  PXL_REQUIRE(Cp >= 1 && Cp <= 256 && Creal <= Cp, "colsum: channel pitch %d unsupported (max 256)", Cp);
+  int blocks = cdiv(M, 256);
+  if (blocks > 512) blocks = 512;
+  const int rpb = cdiv(M, blocks);
+  blocks = cdiv(M, rpb);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(256), 0, s, M, Cp, Creal, cp<float>(x), out, rpb);
+  else
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, M, Cp, Creal, cp<bf16_t>(x), out, rpb);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_vec_sum4(int n, float* out, const float* a, const float* b, const float* c, const float* d,
+                            void* stream) {
+  PXL_REQUIRE(out && n > 0, "vec_sum4: bad argument");
+  hipLaunchKernelGGL(vec_sum4_kernel, dim3(cdiv(n, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n,
+                     out, a, b, c, d);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_add_inplace(int dtype, long n, void* a, const void* b, void* stream) {
+  PXL_REQUIRE(a && b, "add_inplace: null argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "add_inplace: bad dtype");
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  PXL_REQUIRE(n % epc == 0, "add_inplace: n must be a multiple of %d", epc);
+  const long nchunks = n / epc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(grid_for(nchunks)), dim3(256), 0, s, nchunks,
+                       mp<float>(a), cp<float>(b));
+  else
+    hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, s, nchunks,
+                       mp<bf16_t>(a), cp<bf16_t>(b));
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_maxpool3x3s2_fwd(int dtype, int B, int Hi, int Wi, int C, const void* y, const float* coef,
+                                    void* out, uint8_t* idx, void* stream) {
+  PXL_REQUIRE(y && out && idx, "maxpool_fwd: null argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "maxpool_fwd: bad dtype");
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  PXL_REQUIRE(C % epc == 0, "maxpool_fwd: C=%d must be a multiple of %d", C, epc);
+  const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+  const long total = (long)B * Ho * Wo * (C / epc);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, B, Hi, Wi, C, Ho, Wo,
+                       cp<float>(y), coef, mp<float>(out), idx);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, B, Hi, Wi, C, Ho, Wo,
+                       cp<bf16_t>(y), coef, mp<bf16_t>(out), idx);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_maxpool3x3s2_bwd(int dtype, int B, int Hi, int Wi, int C, const void* dp, const uint8_t* idx,
+                                    void* dz, void* stream) {
+  PXL_REQUIRE(dp && idx && dz, "maxpool_bwd: null argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "maxpool_bwd: bad dtype");
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  PXL_REQUIRE(C % epc == 0, "maxpool_bwd: C=%d must be a multiple of %d", C, epc);
+  const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+  const long total = (long)B * Hi * Wi * (C / epc);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, B, Hi, Wi, C, Ho, Wo,
+                       cp<float>(dp), idx, mp<float>(dz));
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, B, Hi, Wi, C, Ho, Wo,
+                       cp<bf16_t>(dp), idx, mp<bf16_t>(dz));
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}

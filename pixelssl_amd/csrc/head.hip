@@ -1,0 +1,205 @@
+// Segmentation head tail: bilinear up-sampling (align_corners=True) of the low-resolution logits
+// to the input size, fused with the channel soft-max (deeplab_v2.py:32, task/sseg/model.py:62),
+// and its backward (adjoint of the interpolation, with the soft-max Jacobian folded in).
+//
+// Layouts: low-res logits NHWC [B][h][w][Cp] (Cp = padded channel pitch, real C <= 32) in the
+// engine dtype; full-res outputs NCHW fp32 [B][C][H][W] (what the plugin API hands to the SSL
+// algorithms).  HBM-bound: the forward writes 2*C*H*W floats per image; consecutive lanes walk x
+// so every channel-plane store is a coalesced 256-byte line.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 32;
+
+__device__ __forceinline__ void src_coord(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
+  // PyTorch area_pixel_compute_source_index(align_corners=True): src = scale * dst
+  const float src = scale * (float)o;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_softmax_fwd_kernel(int B, int h, int w, int Cp, int C, int H,
+                                                                   int W, float sy, float sx,
+                                                                   const T* __restrict__ low,
+                                                                   float* __restrict__ logits,
+                                                                   float* __restrict__ prob) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int b = blockIdx.z;
+  if (x >= W) return;
+  int y0, y1, x0, x1;
+  float ly, lx;
+  src_coord(y, sy, h, y0, y1, ly);
+  src_coord(x, sx, w, x0, x1, lx);
+  const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+  const T* p00 = low + ((size_t)(b * h + y0) * w + x0) * Cp;
+  const T* p01 = low + ((size_t)(b * h + y0) * w + x1) * Cp;
+  const T* p10 = low + ((size_t)(b * h + y1) * w + x0) * Cp;
+  const T* p11 = low + ((size_t)(b * h + y1) * w + x1) * Cp;
+  float v[MAXC];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    if (c < C) {
+      v[c] = w00 * to_f(p00[c]) + w01 * to_f(p01[c]) + w10 * to_f(p10[c]) + w11 * to_f(p11[c]);
+      mx = fmaxf(mx, v[c]);
+    }
+  }
+  const size_t plane = (size_t)H * W;
+  const size_t o = (size_t)b * C * plane + (size_t)y * W + x;
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    if (c < C) {
+      logits[o + c * plane] = v[c];
+      v[c] = __expf(v[c] - mx);
+      sum += v[c];
+    }
+  }
+  if (prob != nullptr) {
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) prob[o + c * plane] = v[c] * inv;
+  }
+}
+
+// pass 1 (one block per full-res row): G = dlogits + softmax_bwd(dprob, prob) ; reduce along x onto
+// the w low-res columns:  tmp[b][y][x0][c] = sum_x wx(x,x0) * G[b][c][y][x]
+__global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(int C, int H, int W, int w, float sx,
+                                                                const float* __restrict__ dlogits,
+                                                                const float* __restrict__ dprob,
+                                                                const float* __restrict__ prob,
+                                                                float* __restrict__ tmp) {
+  extern __shared__ float g[];   // [C][W+1]
+  const int y = blockIdx.x, b = blockIdx.y;
+  const size_t plane = (size_t)H * W;
+  const size_t base = (size_t)b * C * plane + (size_t)y * W;
+  const int ld = W + 1;
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    float dot = 0.f;
+    if (dprob != nullptr) {
+      for (int c = 0; c < C; ++c) dot += dprob[base + c * plane + x] * prob[base + c * plane + x];
+    }
+    for (int c = 0; c < C; ++c) {
+      float v = dlogits != nullptr ? dlogits[base + c * plane + x] : 0.f;
+      if (dprob != nullptr) v += prob[base + c * plane + x] * (dprob[base + c * plane + x] - dot);
+      g[c * ld + x] = v;
+    }
+  }
+  __syncthreads();
+  // each output (x0, c): full-res x with floor(sx*x) == x0 contribute (1-l), with floor == x0-1 contribute l
+  for (int o = threadIdx.x; o < w * C; o += blockDim.x) {
+    const int c = o % C, x0 = o / C;
+    // candidate range: x in ((x0-1)/sx, (x0+1)/sx)
+    int xlo = (int)floorf((float)(x0 - 1) / sx) - 1;
+    int xhi = (int)ceilf((float)(x0 + 1) / sx) + 1;
+    if (xlo < 0) xlo = 0;
+    if (xhi > W - 1) xhi = W - 1;
+    float acc = 0.f;
+    for (int x = xlo; x <= xhi; ++x) {
+      int i0, i1;
+      float l1;
+      src_coord(x, sx, w, i0, i1, l1);
+      float wgt = 0.f;
+      if (i0 == x0) wgt += 1.f - l1;
+      if (i1 == x0) wgt += l1;
+      acc += wgt * g[c * ld + x];
+    }
+    tmp[(((size_t)b * H + y) * w + x0) * C + c] = acc;
+  }
+}
+
+// pass 2: dlow[b][y0][x0][c] = sum_y wy(y,y0) * tmp[b][y][x0][c]   (written in the engine dtype, padded
+// channels zeroed)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(int B, int h, int w, int Cp, int C, int H,
+                                                                float sy, const float* __restrict__ tmp,
+                                                                T* __restrict__ dlow) {
+  const long total = (long)B * h * w * Cp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cp);
+    long r = i / Cp;
+    const int x0 = (int)(r % w); r /= w;
+    const int y0 = (int)(r % h);
+    const int b = (int)(r / h);
+    float acc = 0.f;
+    if (c < C) {
+      int ylo = (int)floorf((float)(y0 - 1) / sy) - 1;
+      int yhi = (int)ceilf((float)(y0 + 1) / sy) + 1;
+      if (ylo < 0) ylo = 0;
+      if (yhi > H - 1) yhi = H - 1;
+      for (int y = ylo; y <= yhi; ++y) {
+        int i0, i1;
+        float l1;
+        src_coord(y, sy, h, i0, i1, l1);
+        float wgt = 0.f;
+        if (i0 == y0) wgt += 1.f - l1;
+        if (i1 == y0) wgt += l1;
+        if (wgt != 0.f) acc += wgt * tmp[(((size_t)b * H + y) * w + x0) * C + c];
+      }
+    }
+    dlow[i] = from_f<T>(acc);
+  }
+}
+
+}  // namespace
+
+extern "C" int pxl_upsample_softmax_fwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W,
+                                        const void* low, float* logits, float* prob, void* stream) {
+  PXL_REQUIRE(low && logits, "upsample_softmax_fwd: null argument");
+  PXL_REQUIRE(C >= 1 && C <= MAXC && C <= Cp, "upsample_softmax_fwd: C=%d unsupported (max %d)", C, MAXC);
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "upsample_softmax_fwd: bad dtype");
+  const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+  const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  dim3 grid(cdiv(W, 256), H, B);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(upsample_softmax_fwd_kernel<float>, grid, dim3(256), 0, s, B, h, w, Cp, C, H, W, sy, sx,
+                       (const float*)low, logits, prob);
+  else
+    hipLaunchKernelGGL(upsample_softmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, B, h, w, Cp, C, H, W, sy, sx,
+                       (const bf16_t*)low, logits, prob);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" size_t pxl_upsample_bwd_workspace(int B, int w, int C, int H) {
+  return (size_t)B * H * w * C * sizeof(float);
+}
+
+extern "C" int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W,
+                                        const float* dlogits, const float* dprob, const float* prob,
+                                        void* dlow, void* workspace, size_t ws_bytes, void* stream) {
+  PXL_REQUIRE(dlow && workspace, "upsample_softmax_bwd: null argument");
+  PXL_REQUIRE(dlogits || dprob, "upsample_softmax_bwd: no incoming gradient");
+  PXL_REQUIRE(dprob == nullptr || prob != nullptr, "upsample_softmax_bwd: dprob needs prob");
+  PXL_REQUIRE(C >= 1 && C <= MAXC && C <= Cp, "upsample_softmax_bwd: C=%d unsupported", C);
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "upsample_softmax_bwd: bad dtype");
+  if (ws_bytes < pxl_upsample_bwd_workspace(B, w, C, H))
+    return pxl_set_error(PXL_ERR_WORKSPACE, "upsample_softmax_bwd: workspace too small");
+  PXL_REQUIRE(H > 1 && W > 1 && h > 1 && w > 1, "upsample_softmax_bwd: degenerate sizes");
+  const float sy = (float)(h - 1) / (float)(H - 1);
+  const float sx = (float)(w - 1) / (float)(W - 1);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t smem = (size_t)C * (W + 1) * sizeof(float);
+  PXL_REQUIRE(smem <= 64 * 1024, "upsample_softmax_bwd: row too wide for LDS staging (W=%d)", W);
+  hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(H, B), dim3(256), smem, s, C, H, W, w, sx, dlogits, dprob,
+                     prob, (float*)workspace);
+  PXL_LAUNCH_CHECK();
+  const long total = (long)B * h * w * Cp;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<float>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy,
+                       (const float*)workspace, (float*)dlow);
+  else
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy,
+                       (const float*)workspace, (bf16_t*)dlow);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}

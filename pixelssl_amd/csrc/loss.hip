@@ -1,0 +1,167 @@
+// Per-pixel losses of the SSL algorithms on full-resolution NCHW fp32 predictions (HBM-bound;
+// consecutive lanes walk the pixel axis so each channel plane is read in coalesced lines, the
+// per-sample / global reductions use wave shuffles + one atomic per block).
+//   * cross-entropy with ignore_index, mean over ALL H*W pixels per sample (task/sseg/criterion.py:24-38)
+//   * mean-squared error (nn.MSELoss(), ssl_mt.py:115,182-184)
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 32;
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return r;   // valid on thread 0
+}
+
+__global__ __launch_bounds__(256) void ce_fwd_kernel(int C, int HW, const float* __restrict__ logits,
+                                                     const float* __restrict__ gt, int ignore_index,
+                                                     float* __restrict__ loss) {
+  __shared__ float red[4];
+  const int n = blockIdx.y;
+  const float* lg = logits + (size_t)n * C * HW;
+  float acc = 0.f;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const int label = (int)gt[(size_t)n * HW + p];
+    if (label == ignore_index || label < 0 || label >= C) continue;
+    float v[MAXC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) { v[c] = lg[(size_t)c * HW + p]; mx = fmaxf(mx, v[c]); }
+    float sum = 0.f, pick = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) { sum += expf(v[c] - mx); if (c == label) pick = v[c]; }
+    acc += (mx + logf(sum)) - pick;
+  }
+  const float tot = block_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(loss + n, tot / (float)HW);
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(int C, int HW, const float* __restrict__ logits,
+                                                     const float* __restrict__ gt, int ignore_index,
+                                                     const float* __restrict__ gout, float* __restrict__ dlogits) {
+  const int n = blockIdx.y;
+  const float* lg = logits + (size_t)n * C * HW;
+  float* dl = dlogits + (size_t)n * C * HW;
+  const float gs = gout[n] / (float)HW;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const int label = (int)gt[(size_t)n * HW + p];
+    const bool valid = !(label == ignore_index || label < 0 || label >= C);
+    float v[MAXC];
+    float mx = -INFINITY;
+    if (valid) {
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) { v[c] = lg[(size_t)c * HW + p]; mx = fmaxf(mx, v[c]); }
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) { v[c] = expf(v[c] - mx); sum += v[c]; }
+      const float inv = gs / sum;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) dl[(size_t)c * HW + p] = v[c] * inv - (c == label ? gs : 0.f);
+    } else {
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) dl[(size_t)c * HW + p] = 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mse_fwd_kernel(long n4, long n, const float* __restrict__ a,
+                                                      const float* __restrict__ b, float inv_n,
+                                                      float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i];
+    const float4 y = reinterpret_cast<const float4*>(b)[i];
+    const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+    acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+  }
+  for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float d = a[i] - b[i];
+    acc += d * d;
+  }
+  const float tot = block_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(out, tot * inv_n);
+}
+
+__global__ __launch_bounds__(256) void mse_bwd_kernel(long n4, long n, const float* __restrict__ a,
+                                                      const float* __restrict__ b,
+                                                      const float* __restrict__ gout, float two_inv_n,
+                                                      float* __restrict__ da) {
+  const float s = gout[0] * two_inv_n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i];
+    const float4 y = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(da)[i] = make_float4(s * (x.x - y.x), s * (x.y - y.y), s * (x.z - y.z), s * (x.w - y.w));
+  }
+  for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    da[i] = s * (a[i] - b[i]);
+}
+
+}  // namespace
+
+extern "C" int pxl_ce_fwd(int N, int C, int HW, const float* logits, const float* gt, int ignore_index,
+                          float* loss, void* stream) {
+  PXL_REQUIRE(logits && gt && loss && N > 0, "ce_fwd: bad argument");
+  PXL_REQUIRE(C >= 1 && C <= MAXC, "ce_fwd: C=%d unsupported (max %d)", C, MAXC);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PXL_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float) * N, s));
+  int gx = cdiv(HW, 256);
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(gx, N), dim3(256), 0, s, C, HW, logits, gt, ignore_index, loss);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_ce_bwd(int N, int C, int HW, const float* logits, const float* gt, int ignore_index,
+                          const float* gout, float* dlogits, void* stream) {
+  PXL_REQUIRE(logits && gt && gout && dlogits && N > 0, "ce_bwd: bad argument");
+  PXL_REQUIRE(C >= 1 && C <= MAXC, "ce_bwd: C=%d unsupported (max %d)", C, MAXC);
+  int gx = cdiv(HW, 256);
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(gx, N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), C, HW,
+                     logits, gt, ignore_index, gout, dlogits);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_mse_fwd(long n, const float* a, const float* b, float* out, void* stream) {
+  PXL_REQUIRE(a && b && out && n > 0, "mse_fwd: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PXL_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), s));
+  // float4 path needs 16-byte aligned operands (a batch slice of an odd-sized plane is not); the
+  // scalar tail loop of the kernel covers everything when n4 == 0
+  const bool vec = ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0);
+  const long n4 = vec ? n / 4 : 0;
+  long g = ((vec ? n4 : n) + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(mse_fwd_kernel, dim3((int)g), dim3(256), 0, s, n4, n, a, b, 1.0f / (float)n, out);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_mse_bwd(long n, const float* a, const float* b, const float* gout, float* da, void* stream) {
+  PXL_REQUIRE(a && b && gout && da && n > 0, "mse_bwd: bad argument");
+  const bool vec = ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && ((uintptr_t)da % 16 == 0);
+  const long n4 = vec ? n / 4 : 0;
+  long g = ((vec ? n4 : n) + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n4, n,
+                     a, b, gout, 2.0f / (float)n, da);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}

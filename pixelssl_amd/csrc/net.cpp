@@ -1,0 +1,562 @@
+// Network executor: runs the whole forward / backward launch sequence of one segmentation network
+// (DeepLab-v2: ResNet-101 trunk + ASPP head + upsample/softmax) from C++, so the Python host makes
+// one call per network pass instead of ~1000 per-layer calls.
+//
+// Fusion plan (what the layer program expresses):
+//   conv  --epilogue-->  raw output y + per-channel [sum, sumsq]          (HBM: y written once)
+//   [SyncBN hook: all-reduce of the 2C statistics]
+//   bn_finalize        -> (scale, shift) of that BN, running-stat update
+//   the CONSUMER (next conv / max-pool / residual join) applies relu(y*scale+shift) while loading,
+//   so normalised activations are never materialised except the block outputs (consumed twice).
+// Backward mirrors it: relu-mask / BN reduce / BN apply produce the gradient of each raw conv
+// output in place, then wgrad (prologue = the same fused activation of the conv's input) and
+// dgrad (implicit GEMM with transposed weights, accumulate via the epilogue addend).
+//
+// Memory: the caller owns everything.  `arena` holds all forward tensors + BN statistics of one
+// forward pass (kept until its backward); `scratch` holds gradient buffers; `packed` the weights
+// in kernel layout (fwd + transposed).  288 GB of HBM3E means no recomputation and no buffer
+// aliasing games: every tensor gets its own slot.
+#include <vector>
+#include <cstring>
+#include <new>
+
+#include "common.h"
+
+extern "C" {
+int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream);
+}
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
+inline int pitch_of(int c) { return c <= 8 ? 8 : (c + 31) / 32 * 32; }
+
+struct TensorInfo {
+  int H = 0, W = 0, C = 0, Cp = 0;
+  size_t off = 0;        // arena offset (bytes)
+  size_t goff = 0;       // scratch offset of the gradient buffer
+  size_t bytes = 0;
+  bool planned = false;
+  bool needs_grad = false;
+};
+
+struct BnInfo {
+  pxl_bn_desc d;
+  int relu = 0;            // consumer applies ReLU right after this BN
+  int M = 0;               // elements per channel on this device
+  size_t stats_off = 0;    // arena: [2C] sums
+  size_t coef_off = 0;     // arena: [4C]
+  size_t bsum_off = 0;     // scratch: [2C]
+  size_t bcoef_off = 0;    // scratch: [2C]
+  int y_tensor = -1;
+};
+
+struct OpInfo {
+  pxl_op d;
+  int ntaps = 0;
+  pxl_conv_desc fwd;       // forward geometry (all groups)
+  pxl_conv_desc bwd;       // data-gradient geometry
+  pxl_conv_desc grp[4];    // per-group forward geometry (wgrad)
+  size_t wf_off = 0, wt_off = 0, bias_off = 0;   // packed buffer offsets
+  size_t idx_off = 0;      // arena: maxpool argmax
+};
+
+}  // namespace
+
+struct pxl_net {
+  int dtype = PXL_F32;
+  int esize = 4;
+  int classes = 21;
+  std::vector<OpInfo> ops;
+  std::vector<BnInfo> bns;
+  std::vector<TensorInfo> tensors;
+  int B = 0, H = 0, W = 0;
+  bool planned = false;
+  size_t packed_bytes = 0, arena_bytes = 0, scratch_bytes = 0;
+  size_t stats_region_off = 0, stats_region_bytes = 0;      // arena: all BN forward sums
+  size_t bsum_region_off = 0, bsum_region_bytes = 0;        // scratch: all BN backward sums
+  size_t up_ws_off = 0, up_ws_bytes = 0;                    // scratch: upsample backward workspace
+  pxl_allreduce_fn sync = nullptr;
+  void* sync_user = nullptr;
+  int world = 1;
+  int head_op = -1;
+  // optional per-launch timing of the contraction kernels (bench.py roofline leg)
+  bool profile = false;
+  struct Stamp { hipEvent_t a, b; int kind; double flops; };
+  std::vector<Stamp> stamps;
+  std::vector<hipEvent_t> pool;
+};
+
+namespace {
+
+int build_conv_descs(pxl_net* n, OpInfo& op, const TensorInfo& tin, const TensorInfo& tout) {
+  const pxl_op& d = op.d;
+  const int tpg = d.kh * d.kw;
+  op.ntaps = tpg * d.ngroups;
+  if (op.ntaps > 64) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net: conv with %d taps (max 64)", op.ntaps);
+  pxl_conv_desc f;
+  std::memset(&f, 0, sizeof(f));
+  f.dtype = n->dtype;
+  f.B = n->B; f.Hi = tin.H; f.Wi = tin.W; f.Cin = tin.Cp;
+  f.Ho = tout.H; f.Wo = tout.W; f.Cout = tout.Cp; f.Kreal = d.cout;
+  f.ntaps = op.ntaps; f.out_stride = d.stride; f.div = 1;
+  f.relu_in = d.bn_in0 >= 0 ? 1 : 0;
+  f.tile_cfg = -1;
+  for (int g = 0; g < d.ngroups; ++g)
+    for (int r = 0; r < d.kh; ++r)
+      for (int s = 0; s < d.kw; ++s) {
+        const int t = g * tpg + r * d.kw + s;
+        f.dy[t] = (int16_t)(r * d.dil[g] - d.pads[g]);
+        f.dx[t] = (int16_t)(s * d.dil[g] - d.pads[g]);
+      }
+  op.fwd = f;
+  // data gradient: roles of in/out swapped, negated taps, gather-with-divisor for strided convs
+  pxl_conv_desc b = f;
+  b.Hi = tout.H; b.Wi = tout.W; b.Cin = tout.Cp;
+  b.Ho = tin.H; b.Wo = tin.W; b.Cout = tin.Cp; b.Kreal = d.cin;
+  b.out_stride = 1; b.div = d.stride; b.relu_in = 0;
+  for (int t = 0; t < op.ntaps; ++t) { b.dy[t] = (int16_t)(-f.dy[t]); b.dx[t] = (int16_t)(-f.dx[t]); }
+  op.bwd = b;
+  for (int g = 0; g < d.ngroups; ++g) {
+    pxl_conv_desc q = f;
+    q.ntaps = tpg;
+    for (int t = 0; t < tpg; ++t) { q.dy[t] = f.dy[g * tpg + t]; q.dx[t] = f.dx[g * tpg + t]; }
+    op.grp[g] = q;
+  }
+  if (d.stride != 1 && d.stride != 2) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net: stride %d", d.stride);
+  return PXL_OK;
+}
+
+struct Timed {
+  // records an event pair around one launch when profiling is on
+  pxl_net* n; hipStream_t s; int kind; double flops; hipEvent_t a = nullptr, b = nullptr;
+  Timed(pxl_net* n_, hipStream_t s_, int kind_, double flops_) : n(n_), s(s_), kind(kind_), flops(flops_) {
+    if (!n->profile) return;
+    auto get = [&]() { hipEvent_t e = nullptr; if (!n->pool.empty()) { e = n->pool.back(); n->pool.pop_back(); } else if (hipEventCreate(&e) != hipSuccess) e = nullptr; return e; };
+    a = get(); b = get();
+    if (a) (void)hipEventRecord(a, s);
+  }
+  ~Timed() {
+    if (!n->profile || !a || !b) return;
+    (void)hipEventRecord(b, s);
+    n->stamps.push_back({a, b, kind, flops});
+  }
+};
+
+inline double conv_flops(const pxl_net* n, const pxl_op& d, const TensorInfo& tout) {
+  return 2.0 * n->B * tout.H * tout.W * (double)d.cout * d.kh * d.kw * d.ngroups * d.cin;
+}
+
+inline unsigned char* at(void* base, size_t off) { return reinterpret_cast<unsigned char*>(base) + off; }
+inline const unsigned char* at(const void* base, size_t off) { return reinterpret_cast<const unsigned char*>(base) + off; }
+inline float* fat(void* base, size_t off) { return reinterpret_cast<float*>(at(base, off)); }
+inline const float* fat(const void* base, size_t off) { return reinterpret_cast<const float*>(at(base, off)); }
+
+}  // namespace
+
+extern "C" int pxl_net_create(int dtype, int num_classes, const pxl_op* ops, int nops, const pxl_bn_desc* bns,
+                              int nbns, int ntensors, pxl_net** out) {
+  PXL_REQUIRE(ops && out && nops > 0 && ntensors > 0, "net_create: bad argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "net_create: bad dtype %d", dtype);
+  pxl_net* n = new (std::nothrow) pxl_net();
+  PXL_REQUIRE(n != nullptr, "net_create: out of host memory");
+  n->dtype = dtype;
+  n->esize = dtype == PXL_F32 ? 4 : 2;
+  n->classes = num_classes;
+  n->ops.resize(nops);
+  n->bns.resize(nbns);
+  n->tensors.resize(ntensors);
+  for (int i = 0; i < nbns; ++i) n->bns[i].d = bns[i];
+  for (int i = 0; i < nops; ++i) {
+    n->ops[i].d = ops[i];
+    const pxl_op& d = ops[i];
+    auto bad_t = [&](int t) { return t < -1 || t >= ntensors; };
+    auto bad_b = [&](int b) { return b < -1 || b >= nbns; };
+    if (bad_t(d.in0) || bad_t(d.in1) || bad_t(d.out) || bad_b(d.bn_in0) || bad_b(d.bn_in1) || bad_b(d.bn_out)) {
+      delete n;
+      return pxl_set_error(PXL_ERR_ARG, "net_create: op %d references an unknown tensor/BN", i);
+    }
+    if (d.kind == PXL_OP_CONV && (d.ngroups < 1 || d.ngroups > 4)) {
+      delete n;
+      return pxl_set_error(PXL_ERR_ARG, "net_create: op %d has %d tap groups", i, d.ngroups);
+    }
+    // the ReLU after a BN is decided by its consumer kind
+    if ((d.kind == PXL_OP_CONV || d.kind == PXL_OP_MAXPOOL) && d.bn_in0 >= 0) n->bns[d.bn_in0].relu = 1;
+    if (d.kind == PXL_OP_CONV && d.bn_out >= 0) n->bns[d.bn_out].y_tensor = d.out;
+    if (d.kind == PXL_OP_HEAD) n->head_op = i;
+  }
+  if (n->head_op < 0) {
+    delete n;
+    return pxl_set_error(PXL_ERR_ARG, "net_create: program has no HEAD op");
+  }
+  *out = n;
+  return PXL_OK;
+}
+
+extern "C" void pxl_net_destroy(pxl_net* net) {
+  if (!net) return;
+  for (auto& st : net->stamps) { (void)hipEventDestroy(st.a); (void)hipEventDestroy(st.b); }
+  for (auto e : net->pool) (void)hipEventDestroy(e);
+  delete net;
+}
+
+extern "C" int pxl_net_set_sync(pxl_net* net, pxl_allreduce_fn fn, void* user, int world_size) {
+  PXL_REQUIRE(net && world_size >= 1, "net_set_sync: bad argument");
+  net->sync = fn;
+  net->sync_user = user;
+  net->world = world_size;
+  return PXL_OK;
+}
+
+extern "C" int pxl_net_profile(pxl_net* net, int enable) {
+  PXL_REQUIRE(net, "net_profile: null net");
+  net->profile = enable != 0;
+  return PXL_OK;
+}
+
+extern "C" int pxl_net_profile_read(pxl_net* net, int kind, double* ms, long* launches, double* flops) {
+  PXL_REQUIRE(net && ms && launches && flops, "net_profile_read: null argument");
+  double t = 0.0, f = 0.0;
+  long c = 0;
+  std::vector<pxl_net::Stamp> keep;
+  for (auto& st : net->stamps) {
+    if (st.kind != kind) { keep.push_back(st); continue; }
+    PXL_CHECK_HIP(hipEventSynchronize(st.b));
+    float e = 0.f;
+    PXL_CHECK_HIP(hipEventElapsedTime(&e, st.a, st.b));
+    t += e; f += st.flops; ++c;
+    net->pool.push_back(st.a);
+    net->pool.push_back(st.b);
+  }
+  net->stamps.swap(keep);
+  *ms = t; *launches = c; *flops = f;
+  return PXL_OK;
+}
+
+extern "C" int pxl_net_plan(pxl_net* n, int B, int H, int W) {
+  PXL_REQUIRE(n && B > 0 && H > 0 && W > 0, "net_plan: bad argument");
+  n->B = B; n->H = H; n->W = W;
+  n->planned = false;
+  for (auto& t : n->tensors) t = TensorInfo();
+  size_t arena = 0, scratch = 0, packed = 0;
+  // BN statistics first (contiguous -> one memset per pass)
+  n->stats_region_off = arena;
+  for (auto& b : n->bns) { b.stats_off = arena; arena += align_up(2 * (size_t)b.d.C * 4); }
+  n->stats_region_bytes = arena - n->stats_region_off;
+  for (auto& b : n->bns) { b.coef_off = arena; arena += align_up(4 * (size_t)b.d.C * 4); }
+  n->bsum_region_off = scratch;
+  for (auto& b : n->bns) { b.bsum_off = scratch; scratch += align_up(2 * (size_t)b.d.C * 4); }
+  n->bsum_region_bytes = scratch - n->bsum_region_off;
+  for (auto& b : n->bns) { b.bcoef_off = scratch; scratch += align_up(2 * (size_t)b.d.C * 4); }
+
+  auto plan_tensor = [&](int id, int h, int w, int c) {
+    TensorInfo& t = n->tensors[id];
+    t.H = h; t.W = w; t.C = c; t.Cp = pitch_of(c);
+    t.bytes = align_up((size_t)B * h * w * t.Cp * n->esize);
+    t.off = arena; arena += t.bytes;
+    t.goff = scratch; scratch += t.bytes;
+    t.planned = true;
+  };
+
+  for (size_t i = 0; i < n->ops.size(); ++i) {
+    OpInfo& op = n->ops[i];
+    const pxl_op& d = op.d;
+    switch (d.kind) {
+      case PXL_OP_INPUT:
+        plan_tensor(d.out, H, W, d.cout);
+        break;
+      case PXL_OP_CONV: {
+        PXL_REQUIRE(d.in0 >= 0 && n->tensors[d.in0].planned, "net_plan: op %zu consumes an unplanned tensor", i);
+        const TensorInfo& tin = n->tensors[d.in0];
+        PXL_REQUIRE(tin.C == d.cin, "net_plan: op %zu expects %d input channels, tensor has %d", i, d.cin, tin.C);
+        const int eff_h = d.dil[0] * (d.kh - 1) + 1, eff_w = d.dil[0] * (d.kw - 1) + 1;
+        const int ho = (tin.H + 2 * d.pads[0] - eff_h) / d.stride + 1;
+        const int wo = (tin.W + 2 * d.pads[0] - eff_w) / d.stride + 1;
+        for (int g = 1; g < d.ngroups; ++g) {
+          const int eh = d.dil[g] * (d.kh - 1) + 1;
+          PXL_REQUIRE((tin.H + 2 * d.pads[g] - eh) / d.stride + 1 == ho, "net_plan: op %zu tap groups disagree on output size", i);
+        }
+        plan_tensor(d.out, ho, wo, d.cout);
+        int rc = build_conv_descs(n, op, n->tensors[d.in0], n->tensors[d.out]);
+        if (rc != PXL_OK) return rc;
+        const TensorInfo& tout = n->tensors[d.out];
+        op.wf_off = packed; packed += align_up((size_t)d.cout * op.ntaps * tin.Cp * n->esize);
+        if (d.need_dgrad) { op.wt_off = packed; packed += align_up((size_t)tin.Cp * op.ntaps * tout.Cp * n->esize); }
+        if (d.b_off[0] >= 0) { op.bias_off = packed; packed += align_up((size_t)d.cout * 4); }
+        if (d.bn_out >= 0) {
+          PXL_REQUIRE(n->bns[d.bn_out].d.C == d.cout, "net_plan: BN %d has %d channels, conv %zu has %d", d.bn_out,
+                      n->bns[d.bn_out].d.C, i, d.cout);
+          n->bns[d.bn_out].M = B * ho * wo;
+        }
+        break;
+      }
+      case PXL_OP_MAXPOOL: {
+        PXL_REQUIRE(d.in0 >= 0 && n->tensors[d.in0].planned, "net_plan: op %zu consumes an unplanned tensor", i);
+        const TensorInfo& tin = n->tensors[d.in0];
+        plan_tensor(d.out, (tin.H + 2 - 3) / 2 + 1, (tin.W + 2 - 3) / 2 + 1, tin.C);
+        op.idx_off = arena;
+        arena += align_up((size_t)B * n->tensors[d.out].H * n->tensors[d.out].W * n->tensors[d.out].Cp);
+        break;
+      }
+      case PXL_OP_RESIDUAL: {
+        PXL_REQUIRE(d.in0 >= 0 && d.in1 >= 0 && n->tensors[d.in0].planned && n->tensors[d.in1].planned,
+                    "net_plan: op %zu consumes an unplanned tensor", i);
+        const TensorInfo& a = n->tensors[d.in0];
+        const TensorInfo& r = n->tensors[d.in1];
+        PXL_REQUIRE(a.H == r.H && a.W == r.W && a.C == r.C, "net_plan: residual op %zu shape mismatch", i);
+        PXL_REQUIRE(d.bn_in0 >= 0, "net_plan: residual op %zu needs a BN on its main branch", i);
+        plan_tensor(d.out, a.H, a.W, a.C);
+        break;
+      }
+      case PXL_OP_HEAD: {
+        PXL_REQUIRE(d.in0 >= 0 && n->tensors[d.in0].planned, "net_plan: head consumes an unplanned tensor");
+        PXL_REQUIRE(n->tensors[d.in0].C == n->classes, "net_plan: head input has %d channels, expected %d",
+                    n->tensors[d.in0].C, n->classes);
+        n->up_ws_off = scratch;
+        n->up_ws_bytes = align_up((size_t)B * H * n->tensors[d.in0].W * n->classes * 4);
+        scratch += n->up_ws_bytes;
+        break;
+      }
+      default:
+        return pxl_set_error(PXL_ERR_ARG, "net_plan: unknown op kind %d", d.kind);
+    }
+  }
+  n->arena_bytes = arena;
+  n->scratch_bytes = scratch;
+  n->packed_bytes = packed;
+  n->planned = true;
+  return PXL_OK;
+}
+
+extern "C" size_t pxl_net_packed_bytes(const pxl_net* n) { return n && n->planned ? n->packed_bytes : 0; }
+extern "C" size_t pxl_net_arena_bytes(const pxl_net* n) { return n && n->planned ? n->arena_bytes : 0; }
+extern "C" size_t pxl_net_scratch_bytes(const pxl_net* n) { return n && n->planned ? n->scratch_bytes : 0; }
+
+extern "C" int pxl_net_pack(pxl_net* n, const float* params, void* packed, void* stream) {
+  PXL_REQUIRE(n && n->planned && params && packed, "net_pack: bad argument (plan first)");
+  for (auto& op : n->ops) {
+    const pxl_op& d = op.d;
+    if (d.kind != PXL_OP_CONV) continue;
+    const TensorInfo& tin = n->tensors[d.in0];
+    const TensorInfo& tout = n->tensors[d.out];
+    const int tpg = d.kh * d.kw;
+    for (int g = 0; g < d.ngroups; ++g) {
+      int rc = pxl_pack_weights(n->dtype, params + d.w_off[g], d.cout, tpg, d.cin, at(packed, op.wf_off), tin.Cp,
+                                op.ntaps, g * tpg, d.need_dgrad ? at(packed, op.wt_off) : nullptr, tout.Cp, stream);
+      if (rc != PXL_OK) return rc;
+    }
+    if (d.b_off[0] >= 0) {
+      const float* b[4] = {nullptr, nullptr, nullptr, nullptr};
+      for (int g = 0; g < d.ngroups; ++g) b[g] = d.b_off[g] >= 0 ? params + d.b_off[g] : nullptr;
+      int rc = pxl_vec_sum4(d.cout, fat(packed, op.bias_off), b[0], b[1], b[2], b[3], stream);
+      if (rc != PXL_OK) return rc;
+    }
+  }
+  return PXL_OK;
+}
+
+extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* packed, float* running,
+                               const float* x, float* logits, float* prob, void* arena, size_t arena_bytes,
+                               int training, void* stream) {
+  PXL_REQUIRE(n && n->planned && params && packed && x && logits && arena, "net_forward: bad argument (plan first)");
+  if (arena_bytes < n->arena_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_forward: arena too small (%zu < %zu)", arena_bytes, n->arena_bytes);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (training && n->stats_region_bytes)
+    PXL_CHECK_HIP(hipMemsetAsync(at(arena, n->stats_region_off), 0, n->stats_region_bytes, s));
+  const int dt = n->dtype;
+  for (size_t i = 0; i < n->ops.size(); ++i) {
+    OpInfo& op = n->ops[i];
+    const pxl_op& d = op.d;
+    int rc = PXL_OK;
+    switch (d.kind) {
+      case PXL_OP_INPUT: {
+        const TensorInfo& t = n->tensors[d.out];
+        rc = pxl_nchw_to_nhwc(dt, x, at(arena, t.off), n->B, t.C, t.H, t.W, t.Cp, stream);
+        break;
+      }
+      case PXL_OP_CONV: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        const float* sc = nullptr; const float* sh = nullptr;
+        if (d.bn_in0 >= 0) {
+          const BnInfo& b = n->bns[d.bn_in0];
+          sc = fat(arena, b.coef_off) + 2 * b.d.C;
+          sh = fat(arena, b.coef_off) + 3 * b.d.C;
+        }
+        float* stats = (d.bn_out >= 0 && training) ? fat(arena, n->bns[d.bn_out].stats_off) : nullptr;
+        const float* bias = d.b_off[0] >= 0 ? fat(packed, op.bias_off) : nullptr;
+        {
+          Timed t(n, s, 0, conv_flops(n, d, tout));
+          rc = pxl_conv_igemm(&op.fwd, at(arena, tin.off), at(packed, op.wf_off), at(arena, tout.off), sc, sh, bias,
+                              nullptr, stats, stream);
+        }
+        if (rc != PXL_OK) return rc;
+        if (d.bn_out >= 0) {
+          BnInfo& b = n->bns[d.bn_out];
+          if (training && n->sync && n->world > 1) {
+            rc = n->sync(n->sync_user, fat(arena, b.stats_off), 2 * b.d.C, stream);
+            if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_forward: SyncBN all-reduce hook failed (%d)", rc);
+          }
+          rc = pxl_bn_finalize(b.d.C, fat(arena, b.stats_off), (float)b.M * n->world, params + b.d.gamma_off,
+                               params + b.d.beta_off, running ? running + b.d.rmean_off : nullptr,
+                               running ? running + b.d.rvar_off : nullptr, b.d.momentum, b.d.eps, training,
+                               n->world > 1 ? 1 : 0, fat(arena, b.coef_off), stream);
+        }
+        break;
+      }
+      case PXL_OP_MAXPOOL: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        const float* coef = d.bn_in0 >= 0 ? fat(arena, n->bns[d.bn_in0].coef_off) : nullptr;
+        rc = pxl_maxpool3x3s2_fwd(dt, n->B, tin.H, tin.W, tin.Cp, at(arena, tin.off), coef, at(arena, tout.off),
+                                  at(arena, op.idx_off), stream);
+        break;
+      }
+      case PXL_OP_RESIDUAL: {
+        const TensorInfo& a = n->tensors[d.in0];
+        const TensorInfo& r = n->tensors[d.in1];
+        const TensorInfo& o = n->tensors[d.out];
+        const float* ac = fat(arena, n->bns[d.bn_in0].coef_off);
+        const float* rcoef = d.bn_in1 >= 0 ? fat(arena, n->bns[d.bn_in1].coef_off) : nullptr;
+        rc = pxl_residual_fwd(dt, (long)n->B * a.H * a.W, a.Cp, at(arena, a.off), ac, at(arena, r.off), rcoef,
+                              at(arena, o.off), stream);
+        break;
+      }
+      case PXL_OP_HEAD: {
+        const TensorInfo& low = n->tensors[d.in0];
+        rc = pxl_upsample_softmax_fwd(dt, n->B, low.H, low.W, low.Cp, n->classes, n->H, n->W, at(arena, low.off),
+                                      logits, prob, stream);
+        break;
+      }
+    }
+    if (rc != PXL_OK) return rc;
+  }
+  return PXL_OK;
+}
+
+extern "C" int pxl_net_latent_shape(const pxl_net* n, int* C, int* h, int* w) {
+  PXL_REQUIRE(n && n->planned && n->head_op >= 0, "net_latent_shape: plan first");
+  const int t = n->ops[n->head_op].d.in1;
+  PXL_REQUIRE(t >= 0, "net_latent_shape: program names no latent tensor");
+  if (C) *C = n->tensors[t].C;
+  if (h) *h = n->tensors[t].H;
+  if (w) *w = n->tensors[t].W;
+  return PXL_OK;
+}
+
+extern "C" int pxl_net_latent(pxl_net* n, const void* arena, float* latent, void* stream) {
+  PXL_REQUIRE(n && n->planned && arena && latent && n->head_op >= 0, "net_latent: bad argument");
+  const int t = n->ops[n->head_op].d.in1;
+  PXL_REQUIRE(t >= 0, "net_latent: program names no latent tensor");
+  const TensorInfo& ti = n->tensors[t];
+  return pxl_nhwc_to_nchw(n->dtype, at(arena, ti.off), latent, n->B, ti.C, ti.H, ti.W, ti.Cp, stream);
+}
+
+extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* packed, const float* dlogits,
+                                const float* dprob, const float* prob, float* grads, void* arena,
+                                size_t arena_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+  PXL_REQUIRE(n && n->planned && params && packed && grads && arena && scratch, "net_backward: bad argument");
+  PXL_REQUIRE(dlogits || dprob, "net_backward: no incoming gradient");
+  if (arena_bytes < n->arena_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_backward: arena too small");
+  if (scratch_bytes < n->scratch_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_backward: scratch too small (%zu < %zu)", scratch_bytes, n->scratch_bytes);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int dt = n->dtype;
+  if (n->bsum_region_bytes)
+    PXL_CHECK_HIP(hipMemsetAsync(at(scratch, n->bsum_region_off), 0, n->bsum_region_bytes, s));
+  std::vector<char> written(n->tensors.size(), 0);
+
+  for (int i = (int)n->ops.size() - 1; i >= 0; --i) {
+    OpInfo& op = n->ops[i];
+    const pxl_op& d = op.d;
+    int rc = PXL_OK;
+    switch (d.kind) {
+      case PXL_OP_HEAD: {
+        const TensorInfo& low = n->tensors[d.in0];
+        rc = pxl_upsample_softmax_bwd(dt, n->B, low.H, low.W, low.Cp, n->classes, n->H, n->W, dlogits, dprob, prob,
+                                      at(scratch, low.goff), at(scratch, n->up_ws_off), n->up_ws_bytes, stream);
+        written[d.in0] = 1;
+        break;
+      }
+      case PXL_OP_RESIDUAL: {
+        const TensorInfo& o = n->tensors[d.out];
+        if (!written[d.out]) return pxl_set_error(PXL_ERR_ARG, "net_backward: residual op %d output has no gradient", i);
+        const TensorInfo& a = n->tensors[d.in0];
+        const TensorInfo& r = n->tensors[d.in1];
+        const long nelem = (long)n->B * o.H * o.W * o.Cp;
+        if (written[d.in0]) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net_backward: residual main branch consumed twice");
+        if (!written[d.in1]) {
+          rc = pxl_relu_mask(dt, nelem, at(scratch, o.goff), at(arena, o.off), at(scratch, a.goff), at(scratch, r.goff), stream);
+          written[d.in1] = 1;
+        } else {
+          rc = pxl_relu_mask(dt, nelem, at(scratch, o.goff), at(arena, o.off), at(scratch, a.goff), nullptr, stream);
+          if (rc != PXL_OK) return rc;
+          rc = pxl_add_inplace(dt, nelem, at(scratch, r.goff), at(scratch, a.goff), stream);
+        }
+        written[d.in0] = 1;
+        break;
+      }
+      case PXL_OP_MAXPOOL: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        if (!written[d.out]) return pxl_set_error(PXL_ERR_ARG, "net_backward: maxpool op %d output has no gradient", i);
+        if (written[d.in0]) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net_backward: maxpool input consumed twice");
+        rc = pxl_maxpool3x3s2_bwd(dt, n->B, tin.H, tin.W, tin.Cp, at(scratch, tout.goff), at(arena, op.idx_off),
+                                  at(scratch, tin.goff), stream);
+        written[d.in0] = 1;
+        break;
+      }
+      case PXL_OP_CONV: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        if (!written[d.out]) return pxl_set_error(PXL_ERR_ARG, "net_backward: conv op %d output has no gradient", i);
+        const int M = n->B * tout.H * tout.W;
+        void* dy = at(scratch, tout.goff);
+        if (d.bn_out >= 0) {
+          BnInfo& b = n->bns[d.bn_out];
+          const float* coef = fat(arena, b.coef_off);
+          rc = pxl_bn_bwd_reduce(dt, M, tout.Cp, dy, at(arena, tout.off), coef, b.relu, fat(scratch, b.bsum_off), stream);
+          if (rc != PXL_OK) return rc;
+          if (n->sync && n->world > 1) {
+            rc = n->sync(n->sync_user, fat(scratch, b.bsum_off), 2 * b.d.C, stream);
+            if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_backward: SyncBN all-reduce hook failed (%d)", rc);
+          }
+          rc = pxl_bn_bwd_finalize(b.d.C, fat(scratch, b.bsum_off), (float)b.M * n->world, grads + b.d.gamma_off,
+                                   grads + b.d.beta_off, fat(scratch, b.bcoef_off), stream);
+          if (rc != PXL_OK) return rc;
+          rc = pxl_bn_bwd_apply(dt, M, tout.Cp, dy, at(arena, tout.off), coef, fat(scratch, b.bcoef_off), b.relu, dy, stream);
+          if (rc != PXL_OK) return rc;
+        }
+        const float* sc = nullptr; const float* sh = nullptr;
+        if (d.bn_in0 >= 0) {
+          const BnInfo& bi = n->bns[d.bn_in0];
+          sc = fat(arena, bi.coef_off) + 2 * bi.d.C;
+          sh = fat(arena, bi.coef_off) + 3 * bi.d.C;
+        }
+        for (int g = 0; g < d.ngroups; ++g) {
+          {
+            Timed t(n, s, 1, conv_flops(n, d, tout) / d.ngroups);
+            rc = pxl_conv_wgrad(&op.grp[g], at(arena, tin.off), sc, sh, dy, grads + d.w_off[g], d.cin, d.cin, stream);
+          }
+          if (rc != PXL_OK) return rc;
+          if (d.b_off[g] >= 0) {
+            rc = pxl_colsum(dt, M, tout.Cp, d.cout, dy, grads + d.b_off[g], stream);
+            if (rc != PXL_OK) return rc;
+          }
+        }
+        if (d.need_dgrad) {
+          void* din = at(scratch, tin.goff);
+          Timed t(n, s, 0, conv_flops(n, d, tout));
+          rc = pxl_conv_igemm(&op.bwd, dy, at(packed, op.wt_off), din, nullptr, nullptr, nullptr,
+                              written[d.in0] ? din : nullptr, nullptr, stream);
+          written[d.in0] = 1;
+        }
+        break;
+      }
+      case PXL_OP_INPUT:
+        break;
+    }
+    if (rc != PXL_OK) return rc;
+  }
+  return PXL_OK;
+}

@@ -1,0 +1,143 @@
+// Weight packing and layout conversion kernels (HBM-bound, 16 B/lane where the layout allows).
+#include "common.h"
+
+namespace {
+
+// master fp32 [K][T][C]  ->  fwd  [K][T_total][Cp]  (taps placed at t_off, channels zero-padded)
+template <typename T>
+__global__ void pack_fwd_kernel(const float* __restrict__ w, int K, int Tn, int C,
+                                T* __restrict__ wf, int Cp, int T_total, int t_off) {
+  const long total = (long)K * Tn * Cp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cp);
+    const long kt = i / Cp;
+    const int t = (int)(kt % Tn);
+    const int k = (int)(kt / Tn);
+    const float v = c < C ? w[((long)k * Tn + t) * C + c] : 0.f;
+    wf[((long)k * T_total + t_off + t) * Cp + c] = from_f<T>(v);
+  }
+}
+
+// master fp32 [K][T][C]  ->  dgrad [C][T_total][Kp] (transposed per tap through a 32x32 LDS tile,
+// out channels zero-padded).  grid = (ceil(C/32), ceil(Kp/32), T)
+template <typename T>
+__global__ void pack_t_kernel(const float* __restrict__ w, int K, int Tn, int C,
+                              T* __restrict__ wt, int Kp, int T_total, int t_off) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int c0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, c = c0 + tx;
+    tile[r][tx] = (k < K && c < C) ? w[((long)k * Tn + t) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, k = k0 + tx;
+    if (c < C && k < Kp) wt[((long)c * T_total + t_off + t) * Kp + k] = from_f<T>(tile[tx][r]);
+  }
+}
+
+// x NCHW fp32 [B][C][H][W] -> NHWC [B][H][W][Cp] (zero padded channels)
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C,
+                                    int H, int W, int Cp) {
+  const long total = (long)B * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long hw = i % ((long)H * W);
+    const long b = i / ((long)H * W);
+    for (int c = 0; c < Cp; ++c) {
+      const float v = c < C ? x[(b * C + c) * (long)H * W + hw] : 0.f;
+      y[i * Cp + c] = from_f<T>(v);
+    }
+  }
+}
+
+// NHWC [B][H][W][Cp] (first C channels) -> NCHW fp32, tiled through LDS (32 pixels x 32 channels)
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int C, int HW, int Cp) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    tile[r][tx] = (p < HW && c < C) ? to_f(x[((long)b * HW + p) * Cp + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    if (c < C && p < HW) y[((long)b * C + c) * HW + p] = tile[tx][r];
+  }
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = f2bf(x[i]);
+}
+
+inline int grid_for(long n, int block = 256) {
+  long g = (n + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+template <typename T>
+static int pack_weights_impl(const float* w, int K, int Tn, int C, T* wf, int Cp, int T_total, int t_off,
+                             T* wt, int Kp, hipStream_t s) {
+  hipLaunchKernelGGL(pack_fwd_kernel<T>, dim3(grid_for((long)K * Tn * Cp)), dim3(256), 0, s, w, K, Tn, C,
+                     wf, Cp, T_total, t_off);
+  PXL_LAUNCH_CHECK();
+  if (wt != nullptr) {
+    hipLaunchKernelGGL(pack_t_kernel<T>, dim3(cdiv(C, 32), cdiv(Kp, 32), Tn), dim3(256), 0, s, w, K, Tn, C,
+                       wt, Kp, T_total, t_off);
+    PXL_LAUNCH_CHECK();
+  }
+  return PXL_OK;
+}
+
+extern "C" int pxl_pack_weights(int dtype, const float* w, int K, int T, int C, void* wf, int Cp,
+                                int T_total, int t_off, void* wt, int Kp, void* stream) {
+  PXL_REQUIRE(w && wf, "pack_weights: null argument");
+  PXL_REQUIRE(Cp >= C && (wt == nullptr || Kp >= K) && t_off + T <= T_total, "pack_weights: bad padding");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PXL_F32)
+    return pack_weights_impl<float>(w, K, T, C, (float*)wf, Cp, T_total, t_off, (float*)wt, Kp, s);
+  if (dtype == PXL_BF16)
+    return pack_weights_impl<bf16_t>(w, K, T, C, (bf16_t*)wf, Cp, T_total, t_off, (bf16_t*)wt, Kp, s);
+  return pxl_set_error(PXL_ERR_ARG, "pack_weights: bad dtype %d", dtype);
+}
+
+extern "C" int pxl_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W, int Cp,
+                                void* stream) {
+  PXL_REQUIRE(x && y && Cp >= C, "nchw_to_nhwc: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)B * H * W;
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)y, B, C, H, W, Cp);
+  else if (dtype == PXL_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16_t*)y, B, C, H, W, Cp);
+  else
+    return pxl_set_error(PXL_ERR_ARG, "nchw_to_nhwc: bad dtype %d", dtype);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H, int W, int Cp,
+                                void* stream) {
+  PXL_REQUIRE(x && y && Cp >= C, "nhwc_to_nchw: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int HW = H * W;
+  dim3 grid(cdiv(HW, 32), cdiv(C, 32), B);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, (const float*)x, y, C, HW, Cp);
+  else if (dtype == PXL_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, y, C, HW, Cp);
+  else
+    return pxl_set_error(PXL_ERR_ARG, "nhwc_to_nchw: bad dtype %d", dtype);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}

@@ -1,0 +1,100 @@
+"""One process per GPU: the replacement of the reference's single-process nn.DataParallel
+(pixelssl/nn/func.py:54-62) and thread-based Sync-BN (sync_batchnorm/comm.py).
+
+Three exchanges, all through torch.distributed ("nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU
+tests):
+  * gradients: ONE all-reduce (sum, then 1/world) of the model's flat fp32 gradient buffer after each
+    backward -- equal per-rank batches make the mean of rank means the global mean;
+  * Sync-BN statistics: all-reduce(sum) of the [sum, sumsq] (forward) / [sum dz, sum dz*xhat]
+    (backward) vectors the executor hands to the hook between a conv and its BN finalize;
+  * scalars for logging.
+No parameter broadcast per forward, no scatter/gather of activations (C1-C3 are gone).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def local_device():
+    return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment (no-op for WORLD_SIZE=1)."""
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    if ws <= 1 or (dist.is_available() and dist.is_initialized()):
+        return
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local_device())
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group(backend=backend)
+
+
+def allreduce_mean_(flat):
+    """In-place average of a flat tensor over all ranks (gradient exchange)."""
+    if not is_distributed():
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.mul_(1.0 / world_size())
+    return flat
+
+
+def allreduce_sum_(t):
+    if is_distributed():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def shard_batch_sizes(labeled_batch_size, unlabeled_batch_size, n_ranks):
+    """Per-rank (labeled, unlabeled) counts: the reference scales the script's per-GPU sizes by #GPUs
+    (task_template/proxy.py:258-261); per rank we keep the per-GPU sizes, labeled first."""
+    if labeled_batch_size % n_ranks or unlabeled_batch_size % n_ranks:
+        raise ValueError('global batch (%d+%d) is not divisible by %d ranks'
+                         % (labeled_batch_size, unlabeled_batch_size, n_ranks))
+    return labeled_batch_size // n_ranks, unlabeled_batch_size // n_ranks
+
+
+class _DevView:
+    """Wrap a raw device pointer as a tensor via __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, p, n):
+        self.__cuda_array_interface__ = {'data': (int(p), False), 'shape': (int(n),), 'typestr': '<f4',
+                                         'version': 2, 'strides': None}
+
+
+def _sync_stats_callback(buf_ptr, n, stream):
+    t = torch.as_tensor(_DevView(buf_ptr, n), device=torch.device('cuda', torch.cuda.current_device()))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return 0
+
+
+def _post_backward(core):
+    allreduce_mean_(core.flat.grads)
+
+
+def attach(model):
+    """Wire every engine network inside `model` for multi-rank training (no-op on one rank)."""
+    if not is_distributed():
+        return model
+    from .engine import SegNetCore
+    ws = world_size()
+    for m in model.modules():
+        if isinstance(m, SegNetCore):
+            m.set_sync(_sync_stats_callback, ws)
+            m._post_backward_hook = _post_backward
+    return model

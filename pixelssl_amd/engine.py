@@ -1,0 +1,483 @@
+"""Host side of the network executor: flat parameter storage, the DeepLab-v2 layer program, and the
+autograd bridge that makes one C call per network pass.
+
+Design (MI355X-first):
+  * all parameters of a model live in ONE fp32 buffer (conv weights stored [K][kh][kw][C], i.e. the
+    memory order of a channels_last OIHW tensor, which is exactly what the kernels consume), all
+    gradients in a second one, BN running statistics in a third.  `nn.Parameter`s are strided views,
+    so state_dict / checkpoints keep the reference's names and OIHW shapes while the optimizer, the
+    EMA teacher update and the gradient all-reduce are single launches over contiguous memory.
+  * the network itself is a layer program interpreted by libpixelhip (csrc/net.cpp).
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import Op, BnDesc, check, lib, ptr, stream_ptr
+
+ASPP_RATES = (6, 12, 18, 24)          # task/sseg/module/deeplab_v2.py:23
+RESNET_LAYERS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet101-coco": (3, 4, 23, 3)}
+
+
+class FlatStore:
+    """Three flat fp32 device buffers (params / grads / running stats) + named strided views."""
+
+    def __init__(self, device):
+        self.device = device
+        self._p_entries = []     # (name, shape_oihw_or_1d, numel, offset)
+        self._r_entries = []
+        self.np = 0
+        self.nr = 0
+        self.params = None
+        self.grads = None
+        self.running = None
+        self.user_version = 0
+
+    def add_param(self, name, shape):
+        n = 1
+        for s in shape:
+            n *= s
+        off = self.np
+        self._p_entries.append((name, tuple(shape), n, off))
+        self.np += (n + 3) // 4 * 4        # keep every tensor 16-byte aligned
+        return off
+
+    def add_running(self, name, shape):
+        n = 1
+        for s in shape:
+            n *= s
+        off = self.nr
+        self._r_entries.append((name, tuple(shape), n, off))
+        self.nr += (n + 3) // 4 * 4
+        return off
+
+    def allocate(self):
+        self.params = torch.zeros(self.np, device=self.device, dtype=torch.float32)
+        self.grads = torch.zeros(self.np, device=self.device, dtype=torch.float32)
+        self.running = torch.zeros(max(self.nr, 4), device=self.device, dtype=torch.float32)
+
+    @staticmethod
+    def _view(flat, shape, n, off):
+        v = flat[off:off + n]
+        if len(shape) == 4:            # stored [O][kh][kw][I], exposed as OIHW
+            o, i, kh, kw = shape
+            return v.view(o, kh, kw, i).permute(0, 3, 1, 2)
+        return v.view(shape)
+
+    def param_views(self):
+        return OrderedDict((name, (self._view(self.params, shape, n, off), self._view(self.grads, shape, n, off),
+                                   off, n))
+                           for name, shape, n, off in self._p_entries)
+
+    def running_views(self):
+        return OrderedDict((name, self._view(self.running, shape, n, off)) for name, shape, n, off in self._r_entries)
+
+    def version(self):
+        return (self.params._version, self.user_version)
+
+    def touch(self):
+        """Call after a raw-pointer kernel modified `params` (bumps the repack trigger)."""
+        self.user_version += 1
+
+
+class _Leaf(nn.Module):
+    """Parameter holder with the reference's attribute names (weight / bias / running_*)."""
+
+
+class SynchronizedBatchNorm2d(_Leaf):
+    """Name-compatible stand-in of pixelssl.SynchronizedBatchNorm2d: it only *holds* gamma/beta and the
+    running statistics (views into the flat buffers); the normalisation itself is fused into the
+    producing / consuming convolution kernels, and the cross-device statistics exchange is one RCCL
+    all-reduce of [sum, sumsq] per layer (sync_batchnorm/batchnorm.py:48-78,113-125)."""
+    eps = 1e-5
+    momentum = 0.1
+
+
+class ProgramBuilder:
+    """Builds the op / BN tables for libpixelhip and the matching module tree."""
+
+    def __init__(self, store):
+        self.store = store
+        self.ops = []
+        self.bns = []
+        self.ntensors = 0
+        self.modules = OrderedDict()      # dotted name -> (_Leaf, kind)
+
+    def tensor(self):
+        self.ntensors += 1
+        return self.ntensors - 1
+
+    def _op(self, kind, **kw):
+        op = Op()
+        op.kind = kind
+        op.in0 = op.in1 = op.out = op.bn_in0 = op.bn_in1 = op.bn_out = -1
+        for g in range(4):
+            op.w_off[g] = -1
+            op.b_off[g] = -1
+            op.dil[g] = 1
+            op.pads[g] = 0
+        op.ngroups = 1
+        op.kh = op.kw = op.stride = 1
+        op.need_dgrad = 1
+        for k, v in kw.items():
+            setattr(op, k, v)
+        self.ops.append(op)
+        return op
+
+    def input(self, channels):
+        t = self.tensor()
+        self._op(_lib.OP_INPUT, out=t, cout=channels)
+        return t
+
+    def bn(self, name, C):
+        s = self.store
+        g = s.add_param(name + ".weight", (C,))
+        b = s.add_param(name + ".bias", (C,))
+        rm = s.add_running(name + ".running_mean", (C,))
+        rv = s.add_running(name + ".running_var", (C,))
+        d = BnDesc()
+        d.C, d.gamma_off, d.beta_off, d.rmean_off, d.rvar_off = C, g, b, rm, rv
+        d.eps, d.momentum = SynchronizedBatchNorm2d.eps, SynchronizedBatchNorm2d.momentum
+        self.bns.append(d)
+        self.modules[name] = "bn"
+        return len(self.bns) - 1
+
+    def conv(self, names, t_in, bn_in, cin, cout, k, stride, dils, pads, bias=False, bn_out=-1, need_dgrad=True):
+        if isinstance(names, str):
+            names, dils, pads = [names], [dils], [pads]
+        t = self.tensor()
+        op = self._op(_lib.OP_CONV, in0=t_in, out=t, bn_in0=bn_in, bn_out=bn_out, ngroups=len(names), cin=cin,
+                      cout=cout, kh=k, kw=k, stride=stride, need_dgrad=int(need_dgrad))
+        for g, nm in enumerate(names):
+            op.w_off[g] = self.store.add_param(nm + ".weight", (cout, cin, k, k))
+            op.b_off[g] = self.store.add_param(nm + ".bias", (cout,)) if bias else -1
+            op.dil[g] = dils[g]
+            op.pads[g] = pads[g]
+            self.modules[nm] = "conv_bias" if bias else "conv"
+        return t
+
+    def maxpool(self, t_in, bn_in):
+        t = self.tensor()
+        self._op(_lib.OP_MAXPOOL, in0=t_in, out=t, bn_in0=bn_in)
+        return t
+
+    def residual(self, t_main, bn_main, t_res, bn_res):
+        t = self.tensor()
+        self._op(_lib.OP_RESIDUAL, in0=t_main, in1=t_res, out=t, bn_in0=bn_main, bn_in1=bn_res)
+        return t
+
+    def head(self, t_low, t_latent):
+        self._op(_lib.OP_HEAD, in0=t_low, in1=t_latent)
+
+
+def build_resnet_trunk(pb, prefix, layers, output_stride=16):
+    """ResNet bottleneck trunk with atrous layer4 / multi-grid (1,2,4), as
+    task/sseg/module/backbone/resnet.py:58-119.  Returns (tensor id of the feature map, channels)."""
+    if output_stride == 16:
+        strides, dilations = (1, 2, 2, 1), (1, 1, 1, 2)
+    elif output_stride == 8:
+        strides, dilations = (1, 2, 1, 1), (1, 1, 2, 4)
+    else:
+        raise NotImplementedError("output_stride %r" % output_stride)
+    x = pb.input(3)
+    bn1 = pb.bn(prefix + ".bn1", 64)       # declared after conv1 in the state_dict; names are what matter
+    y = pb.conv(prefix + ".conv1", x, -1, 3, 64, 7, 2, 1, 3, bn_out=bn1, need_dgrad=False)
+    h = pb.maxpool(y, bn1)
+    cin = 64
+    for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), layers)):
+        for b in range(nblk if li < 3 else 3):
+            p = "%s.layer%d.%d" % (prefix, li + 1, b)
+            stride = strides[li] if b == 0 else 1
+            dil = dilations[li] * ((1, 2, 4)[b] if li == 3 else 1)
+            b1 = pb.bn(p + ".bn1", planes)
+            y1 = pb.conv(p + ".conv1", h, -1, cin, planes, 1, 1, 1, 0, bn_out=b1)
+            b2 = pb.bn(p + ".bn2", planes)
+            y2 = pb.conv(p + ".conv2", y1, b1, planes, planes, 3, stride, dil, dil, bn_out=b2)
+            b3 = pb.bn(p + ".bn3", planes * 4)
+            y3 = pb.conv(p + ".conv3", y2, b2, planes, planes * 4, 1, 1, 1, 0, bn_out=b3)
+            if b == 0 and (stride != 1 or cin != planes * 4):
+                bd = pb.bn(p + ".downsample.1", planes * 4)
+                yd = pb.conv(p + ".downsample.0", h, -1, cin, planes * 4, 1, stride, 1, 0, bn_out=bd)
+                h = pb.residual(y3, b3, yd, bd)
+            else:
+                h = pb.residual(y3, b3, h, -1)
+            cin = planes * 4
+    return h, cin
+
+
+class SegNetCore(nn.Module):
+    """A segmentation network executed by libpixelhip.  Holds the flat parameter store, exposes
+    reference-named parameters/buffers, and runs forward/backward as single C calls."""
+
+    def __init__(self, device, engine_dtype, num_classes):
+        super().__init__()
+        self._device = torch.device(device)
+        self._code = _lib.dtype_code(engine_dtype)
+        self.num_classes = num_classes
+        self._store = FlatStore(self._device)
+        self._pb = ProgramBuilder(self._store)
+        self._net = ctypes.c_void_p()
+        self._shape = None
+        self._packed = None
+        self._packed_version = None
+        self._scratch = None
+        self._eval_arena = None
+        self._sync_cb = None
+        self._anchor = None
+        self.freeze_bn = False
+
+    # -- construction -----------------------------------------------------------------------
+    def _finalize(self):
+        s, pb = self._store, self._pb
+        s.allocate()
+        pviews, rviews = s.param_views(), s.running_views()
+        self._param_list = []
+        for dotted, kind in pb.modules.items():
+            leaf = SynchronizedBatchNorm2d() if kind == "bn" else _Leaf()
+            for attr in ("weight", "bias"):
+                key = dotted + "." + attr
+                if key in pviews:
+                    pv, gv, off, n = pviews[key]
+                    prm = nn.Parameter(pv)
+                    prm.grad = gv
+                    prm._pxl_grad_view = gv
+                    prm._pxl_flat = (s, off, n)
+                    leaf.register_parameter(attr, prm)
+                    self._param_list.append(prm)
+            if kind == "bn":
+                leaf.register_buffer("running_mean", rviews[dotted + ".running_mean"])
+                leaf.register_buffer("running_var", rviews[dotted + ".running_var"])
+                leaf.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long, device=self._device))
+            self._attach(dotted, leaf)
+        ops = (Op * len(pb.ops))(*pb.ops)
+        bns = (BnDesc * len(pb.bns))(*pb.bns)
+        check(lib().pxl_net_create(self._code, self.num_classes, ops, len(pb.ops), bns, len(pb.bns), pb.ntensors,
+                                   ctypes.byref(self._net)))
+        self._anchor = torch.zeros((), device=self._device, requires_grad=True)
+
+    def _attach(self, dotted, leaf):
+        parts = dotted.split(".")
+        mod = self
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, nn.Module())
+            mod = getattr(mod, p)
+        mod.add_module(parts[-1], leaf)
+
+    def __del__(self):
+        try:
+            if self._net:
+                lib().pxl_net_destroy(self._net)
+        except Exception:
+            pass
+
+    # -- parameter plumbing -----------------------------------------------------------------
+    @property
+    def flat(self):
+        return self._store
+
+    def reset_parameters(self, generator=None):
+        raise NotImplementedError
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+
+    def mark_params_changed(self):
+        self._store.touch()
+
+    def ensure_grad_views(self):
+        """Re-attach .grad views (a foreign optimizer may have set them to None); returns True when
+        the flat gradient buffer had to be treated as fresh (and was zeroed)."""
+        fresh = False
+        for prm in self._param_list:
+            if prm.grad is None:
+                fresh = True
+                break
+        if fresh:
+            self._store.grads.zero_()
+            for prm in self._param_list:
+                prm.grad = prm._pxl_grad_view
+        return fresh
+
+    # -- planning ---------------------------------------------------------------------------
+    def _plan(self, B, H, W):
+        if self._shape == (B, H, W):
+            return
+        check(lib().pxl_net_plan(self._net, B, H, W))
+        self._shape = (B, H, W)
+        dev = self._device
+        self._packed = torch.empty(lib().pxl_net_packed_bytes(self._net), device=dev, dtype=torch.uint8)
+        self._packed_version = None
+        self._scratch = torch.empty(lib().pxl_net_scratch_bytes(self._net), device=dev, dtype=torch.uint8)
+        self._arena_bytes = lib().pxl_net_arena_bytes(self._net)
+        self._eval_arena = None
+
+    def _ensure_packed(self):
+        v = self._store.version()
+        if self._packed_version != v:
+            check(lib().pxl_net_pack(self._net, ptr(self._store.params), ptr(self._packed), stream_ptr()))
+            self._packed_version = v
+
+    def set_sync(self, callback, world_size):
+        """callback(buf_ptr:int, n:int, stream:int) -> int ; installs the SyncBN statistics hook."""
+        def _cb(user, buf, n, stream):
+            try:
+                return int(callback(buf, n, stream) or 0)
+            except Exception:       # never unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._sync_cb = _lib.ALLREDUCE_FN(_cb)
+        check(lib().pxl_net_set_sync(self._net, self._sync_cb, None, world_size))
+
+    # -- execution --------------------------------------------------------------------------
+    def _forward_raw(self, x, arena, want_prob=True):
+        B, _, H, W = x.shape
+        logits = torch.empty(B, self.num_classes, H, W, device=x.device, dtype=torch.float32)
+        prob = torch.empty_like(logits) if want_prob else None
+        training = self.training and not self.freeze_bn
+        check(lib().pxl_net_forward(self._net, ptr(self._store.params), ptr(self._packed), ptr(self._store.running),
+                                    ptr(x), ptr(logits), ptr(prob), ptr(arena), arena.numel(), int(training),
+                                    stream_ptr()))
+        if training:
+            for m in self._bn_leaves():
+                m.num_batches_tracked += 1
+        return logits, prob
+
+    def _bn_leaves(self):
+        if not hasattr(self, "_bn_cache"):
+            self._bn_cache = [m for m in self.modules() if isinstance(m, SynchronizedBatchNorm2d)]
+        return self._bn_cache
+
+    def forward(self, x):
+        """x: NCHW fp32 on the GPU -> (logits, softmax, latent_fn) with autograd attached."""
+        if not x.is_cuda:
+            raise _lib.PixelHipError("SegNetCore runs on the GPU only (input is on %s); there is no CPU path" % x.device)
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        self._plan(B, H, W)
+        self._ensure_packed()
+        need_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list[:1])
+        if need_graph:
+            arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
+            logits, prob = _SegNetFn.apply(x, self._anchor, self, arena)
+        else:
+            if self._eval_arena is None:
+                self._eval_arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
+            arena = self._eval_arena
+            logits, prob = self._forward_raw(x, arena)
+        return logits, prob, _LatentHandle(self, arena)
+
+    def profile(self, enable=True):
+        """Bracket every contraction launch with HIP events (bench.py roofline leg)."""
+        check(lib().pxl_net_profile(self._net, int(enable)))
+
+    def profile_read(self, kind):
+        """-> (kernel ms, launches, algorithmic flops) of kind 0 = conv igemm (fwd+dgrad), 1 = wgrad."""
+        ms, n, fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+        check(lib().pxl_net_profile_read(self._net, kind, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
+        return ms.value, n.value, fl.value
+
+    def latent_from(self, arena):
+        c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib().pxl_net_latent_shape(self._net, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)))
+        out = torch.empty(self._shape[0], c.value, h.value, w.value, device=self._device, dtype=torch.float32)
+        check(lib().pxl_net_latent(self._net, ptr(arena), ptr(out), stream_ptr()))
+        return out
+
+
+class _LatentHandle:
+    def __init__(self, core, arena):
+        self.core, self.arena = core, arena
+
+    def __call__(self):
+        return self.core.latent_from(self.arena)
+
+
+class _SegNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, core, arena):
+        logits, prob = core._forward_raw(x, arena)
+        ctx.core, ctx.arena = core, arena
+        ctx.save_for_backward(prob)
+        ctx.set_materialize_grads(False)
+        return logits, prob
+
+    @staticmethod
+    def backward(ctx, dlogits, dprob):
+        core = ctx.core
+        (prob,) = ctx.saved_tensors
+        if dlogits is None and dprob is None:
+            return None, None, None, None
+        if dlogits is not None:
+            dlogits = dlogits.contiguous()
+        if dprob is not None:
+            dprob = dprob.contiguous()
+        core.ensure_grad_views()
+        s = core._store
+        check(lib().pxl_net_backward(core._net, ptr(s.params), ptr(core._packed), ptr(dlogits), ptr(dprob), ptr(prob),
+                                     ptr(s.grads), ptr(ctx.arena), ctx.arena.numel(), ptr(core._scratch),
+                                     core._scratch.numel(), stream_ptr()))
+        hook = getattr(core, "_post_backward_hook", None)
+        if hook is not None:
+            hook(core)
+        ctx.arena = None
+        return None, None, None, None
+
+
+class DeepLabV2Core(SegNetCore):
+    """DeepLab-v2 = ResNet trunk + ASPP (sum of 4 dilated 3x3 convs with bias) + bilinear up-sampling to
+    the input size (task/sseg/module/deeplab_v2.py:13-33,71-85).  Parameter names follow the reference
+    module tree: backbone.*, classifier.conv2d_list.{0..3}."""
+
+    def __init__(self, backbone="resnet101", output_stride=16, num_classes=21, device="cuda",
+                 engine_dtype=torch.float32, freeze_bn=False):
+        super().__init__(device, engine_dtype, num_classes)
+        if backbone not in RESNET_LAYERS:
+            raise NotImplementedError("backbone %r" % backbone)
+        pb = self._pb
+        feat, c = build_resnet_trunk(pb, "backbone", RESNET_LAYERS[backbone], output_stride)
+        names = ["classifier.conv2d_list.%d" % i for i in range(len(ASPP_RATES))]
+        low = pb.conv(names, feat, -1, c, num_classes, 3, 1, list(ASPP_RATES), list(ASPP_RATES), bias=True)
+        pb.head(low, feat)
+        self._finalize()
+        self.freeze_bn = freeze_bn
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self, generator=None):
+        """Reference initialisers: conv ~ N(0, sqrt(2/(k*k*cout))), BN gamma=1/beta=0 (resnet.py:133-143);
+        ASPP weights ~ N(0, 0.01) and torch's default Conv2d bias init (deeplab_v2.py:76-79)."""
+        import math
+        for name, prm in self.named_parameters():
+            if name.startswith("classifier"):
+                if name.endswith("weight"):
+                    prm.copy_(torch.randn(prm.shape, generator=generator) * 0.01)
+                else:
+                    bound = 1.0 / math.sqrt(2048 * 9)
+                    prm.copy_((torch.rand(prm.shape, generator=generator) * 2 - 1) * bound)
+            elif prm.dim() == 4:
+                n = prm.shape[2] * prm.shape[3] * prm.shape[0]
+                prm.copy_(torch.randn(prm.shape, generator=generator) * math.sqrt(2.0 / n))
+            elif name.endswith("weight"):
+                prm.fill_(1.0)
+            else:
+                prm.zero_()
+        for name, buf in self.named_buffers():
+            if name.endswith("running_var"):
+                buf.fill_(1.0)
+            elif name.endswith("running_mean") or name.endswith("num_batches_tracked"):
+                buf.zero_()
+
+    def get_1x_lr_params(self):
+        for name, prm in self.named_parameters():
+            if name.startswith("backbone") and prm.requires_grad:
+                yield prm
+
+    def get_10x_lr_params(self):
+        for name, prm in self.named_parameters():
+            if name.startswith("classifier") and prm.requires_grad:
+                yield prm

@@ -1,0 +1,78 @@
+"""Fused per-pixel losses (autograd Functions over libpixelhip kernels, NCHW fp32 tensors)."""
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+
+def _gpu(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise _lib.PixelHipError("fused losses run on the GPU only (got %s); there is no CPU path" % t.device)
+
+
+class _CrossEntropyPerSample(torch.autograd.Function):
+    """CommonSSEGCriterion arithmetic (task/sseg/criterion.py:24-38): CE with ignore_index summed over a
+    sample and divided by ALL H*W pixels."""
+
+    @staticmethod
+    def forward(ctx, logits, gt, ignore_index):
+        _gpu(logits, gt)
+        logits = logits.contiguous()
+        gt = gt.contiguous().float()
+        N, C, H, W = logits.shape
+        loss = torch.empty(N, device=logits.device, dtype=torch.float32)
+        check(lib().pxl_ce_fwd(N, C, H * W, ptr(logits), ptr(gt), int(ignore_index), ptr(loss), stream_ptr()))
+        ctx.save_for_backward(logits, gt)
+        ctx.ignore_index = int(ignore_index)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, gt = ctx.saved_tensors
+        N, C, H, W = logits.shape
+        gout = gout.contiguous().float()
+        dlogits = torch.empty_like(logits)
+        check(lib().pxl_ce_bwd(N, C, H * W, ptr(logits), ptr(gt), ctx.ignore_index, ptr(gout), ptr(dlogits), stream_ptr()))
+        return dlogits, None, None
+
+
+def cross_entropy_per_sample(logits, gt, ignore_index=255):
+    """logits [N,C,H,W] fp32, gt [N,1,H,W] or [N,H,W] float class ids -> loss [N]."""
+    return _CrossEntropyPerSample.apply(logits, gt, ignore_index)
+
+
+class _MSE(torch.autograd.Function):
+    """nn.MSELoss() (mean reduction); the gradient flows to the first operand only (the second is the
+    detached teacher / pseudo-label, ssl_mt.py:179-184)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _gpu(a, b)
+        a = a.contiguous()
+        b = b.contiguous()
+        out = torch.empty(1, device=a.device, dtype=torch.float32)
+        check(lib().pxl_mse_fwd(a.numel(), ptr(a), ptr(b), ptr(out), stream_ptr()))
+        ctx.save_for_backward(a, b)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        gout = gout.contiguous().float().view(1)
+        da = torch.empty_like(a)
+        check(lib().pxl_mse_bwd(a.numel(), ptr(a), ptr(b), ptr(gout), ptr(da), stream_ptr()))
+        return da, None
+
+
+def mse_loss(a, b):
+    if a.shape != b.shape:
+        raise ValueError("mse_loss: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    return _MSE.apply(a, b.detach())
+
+
+class MSELoss(torch.nn.Module):
+    """Drop-in for the `nn.MSELoss()` the SSL algorithms instantiate."""
+
+    def forward(self, a, b):
+        return mse_loss(a, b)

@@ -1,0 +1,96 @@
+"""Optimizer factories with the reference's calling convention (pixelssl/nn/optimizer.py:57-75):
+`sgd(args)` returns `wrapper(param_groups) -> Optimizer`.  The optimizer is a single fused HIP launch per
+learning-rate group over the model's flat parameter buffer instead of 320 per-tensor updates."""
+import torch
+from torch.optim.optimizer import Optimizer
+
+from ..utils import cmd
+from .. import _lib
+from .. import ops
+
+VALID_OPTIMIZER = ['sgd']
+
+
+def add_parser_arguments(parser):
+    """Same flag names / '-1 = use the optimizer default' convention as the reference parser."""
+    parser.add_argument('--lr', type=float, default=-1, metavar='', help='optimizer - learning rate')
+    parser.add_argument('--dampening', type=float, default=-1, metavar='', help='optimizer - dampening (sgd)')
+    parser.add_argument('--nesterov', type=cmd.str2bool, default=False, metavar='', help='optimizer - nesterov (sgd)')
+    parser.add_argument('--weight-decay', type=float, default=-1, metavar='', help='optimizer - weight decay')
+    parser.add_argument('--momentum', type=float, default=-1, metavar='', help='optimizer - momentum (sgd)')
+    parser.add_argument('--alpha', type=float, default=-1, metavar='', help='optimizer - (rmsprop)')
+    parser.add_argument('--centered', type=cmd.str2bool, default=False, metavar='', help='optimizer - (rmsprop)')
+    parser.add_argument('--eps', type=float, default=-1, metavar='', help='optimizer - eps (adam family)')
+    parser.add_argument('--beta1', type=float, default=-1, metavar='', help='optimizer - beta1 (adam family)')
+    parser.add_argument('--beta2', type=float, default=-1, metavar='', help='optimizer - beta2 (adam family)')
+    parser.add_argument('--amsgrad', type=cmd.str2bool, default=False, metavar='', help='optimizer - (wdadam)')
+
+
+def _segments(params):
+    """Group pixelhip-managed parameters into maximal contiguous (store, offset, length) runs."""
+    runs = []
+    items = []
+    for p in params:
+        ref = getattr(p, '_pxl_flat', None)
+        if ref is None:
+            raise _lib.PixelHipError('FusedSGD only updates parameters owned by a pixelssl_amd engine model '
+                                     '(got a foreign tensor of shape %s)' % (tuple(p.shape),))
+        items.append(ref)
+    items.sort(key=lambda r: (id(r[0]), r[1]))
+    for store, off, n in items:
+        padded = (n + 3) // 4 * 4
+        if runs and runs[-1][0] is store and runs[-1][1] + runs[-1][2] == off:
+            runs[-1][2] += padded
+        else:
+            runs.append([store, off, padded])
+    return runs
+
+
+class FusedSGD(Optimizer):
+    """torch.optim.SGD semantics (momentum, weight decay, no dampening/nesterov):
+    d = g + wd*p ; buf = m*buf + d ; p -= lr*buf   (buf starts at 0, identical to torch's first step)."""
+
+    def __init__(self, params, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
+        if dampening not in (0, 0.0) or nesterov:
+            raise NotImplementedError('FusedSGD implements dampening=0, nesterov=False (what every shipped script uses)')
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self._runs = []
+        for group in self.param_groups:
+            group['params'] = list(group['params'])
+            self._runs.append(_segments(group['params']))
+        self._stores = {}
+        for runs in self._runs:
+            for store, _, _ in runs:
+                self._stores[id(store)] = store
+        for store in self._stores.values():
+            if not hasattr(store, 'momentum'):
+                store.momentum = torch.zeros_like(store.params)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group, runs in zip(self.param_groups, self._runs):
+            for store, off, n in runs:
+                ops.sgd_step(store.params[off:off + n], store.grads[off:off + n], store.momentum[off:off + n],
+                             float(group['lr']), float(group['momentum']), float(group['weight_decay']))
+        for store in self._stores.values():
+            store.touch()
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        # gradients are views of one flat buffer: one memset, views stay attached
+        for store in self._stores.values():
+            store.grads.zero_()
+
+
+def sgd(args):
+    args.lr = 0.01 if args.lr == -1 else args.lr
+    args.weight_decay = 0 if args.weight_decay == -1 else args.weight_decay
+    args.momentum = 0 if args.momentum == -1 else args.momentum
+    args.dampening = 0 if args.dampening == -1 else args.dampening
+
+    def sgd_wrapper(param_groups):
+        return FusedSGD(param_groups, lr=args.lr, momentum=args.momentum, dampening=args.dampening,
+                        weight_decay=args.weight_decay, nesterov=args.nesterov)
+
+    return sgd_wrapper

@@ -1,0 +1,150 @@
+"""Tensor-level wrappers over the C-ABI (device pointers + current HIP stream).
+
+Used by the fused-loss autograd functions, the optimizer/EMA, and the per-kernel parity tests.
+Activations here are NHWC tensors [B,H,W,Cp] in the engine dtype (fp32 or bf16).
+"""
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, lib, ptr, stream_ptr, dtype_code
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.PixelHipError("libpixelhip operands must live on the GPU (got a %s tensor)" % t.device)
+
+
+def conv_desc(dtype, B, Hi, Wi, Cin_p, Ho, Wo, Cout_p, Kreal, taps, out_stride=1, div=1, relu_in=False,
+              tile_cfg=-1):
+    d = ConvDesc()
+    d.dtype = dtype_code(dtype)
+    d.B, d.Hi, d.Wi, d.Cin = B, Hi, Wi, Cin_p
+    d.Ho, d.Wo, d.Cout, d.Kreal = Ho, Wo, Cout_p, Kreal
+    d.ntaps = len(taps)
+    d.out_stride, d.div, d.relu_in, d.tile_cfg = out_stride, div, int(relu_in), tile_cfg
+    for i, (dy, dx) in enumerate(taps):
+        d.dy[i], d.dx[i] = dy, dx
+    return d
+
+
+def fwd_taps(kh, kw, dil, pad):
+    return [(r * dil - pad, s * dil - pad) for r in range(kh) for s in range(kw)]
+
+
+def conv_igemm(desc, x, w, out, in_scale=None, in_shift=None, bias=None, addend=None, stats=None):
+    _require_cuda(x, w, out)
+    check(lib().pxl_conv_igemm(desc, ptr(x), ptr(w), ptr(out), ptr(in_scale), ptr(in_shift), ptr(bias),
+                               ptr(addend), ptr(stats), stream_ptr()))
+    return out
+
+
+def conv_wgrad(desc, x, dy, dw, creal, dw_cpitch, in_scale=None, in_shift=None):
+    _require_cuda(x, dy, dw)
+    check(lib().pxl_conv_wgrad(desc, ptr(x), ptr(in_scale), ptr(in_shift), ptr(dy), ptr(dw), creal, dw_cpitch,
+                               stream_ptr()))
+    return dw
+
+
+def pack_weights(dtype, w, K, T, C, wf, Cp, T_total=None, t_off=0, wt=None, Kp=0):
+    _require_cuda(w, wf)
+    check(lib().pxl_pack_weights(dtype_code(dtype), ptr(w), K, T, C, ptr(wf), Cp, T_total or T, t_off, ptr(wt), Kp,
+                                 stream_ptr()))
+
+
+def nchw_to_nhwc(dtype, x, Cp):
+    _require_cuda(x)
+    B, Cc, H, W = x.shape
+    y = torch.empty(B, H, W, Cp, device=x.device, dtype=_lib.torch_dtype(dtype_code(dtype)))
+    check(lib().pxl_nchw_to_nhwc(dtype_code(dtype), ptr(x), ptr(y), B, Cc, H, W, Cp, stream_ptr()))
+    return y
+
+
+def nhwc_to_nchw(x, C):
+    _require_cuda(x)
+    B, H, W, Cp = x.shape
+    y = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+    check(lib().pxl_nhwc_to_nchw(dtype_code(x.dtype), ptr(x), ptr(y), B, C, H, W, Cp, stream_ptr()))
+    return y
+
+
+def bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5, training=True, clamp_var=False):
+    Cc = gamma.numel()
+    coef = torch.empty(4 * Cc, device=gamma.device, dtype=torch.float32)
+    check(lib().pxl_bn_finalize(Cc, ptr(stats), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+                                momentum, eps, int(training), int(clamp_var), ptr(coef), stream_ptr()))
+    return coef
+
+
+def bn_backward(dz, y, coef, count, relu, dgamma, dbeta):
+    """dz,y: [M,C] engine dtype.  Returns dy (new tensor); accumulates dgamma/dbeta."""
+    M, Cc = dz.shape[0], dz.shape[1]
+    code = dtype_code(dz.dtype)
+    sums = torch.zeros(2 * Cc, device=dz.device, dtype=torch.float32)
+    bcoef = torch.empty(2 * Cc, device=dz.device, dtype=torch.float32)
+    dy = torch.empty_like(dz)
+    check(lib().pxl_bn_bwd_reduce(code, M, Cc, ptr(dz), ptr(y), ptr(coef), int(relu), ptr(sums), stream_ptr()))
+    check(lib().pxl_bn_bwd_finalize(Cc, ptr(sums), float(count), ptr(dgamma), ptr(dbeta), ptr(bcoef), stream_ptr()))
+    check(lib().pxl_bn_bwd_apply(code, M, Cc, ptr(dz), ptr(y), ptr(coef), ptr(bcoef), int(relu), ptr(dy),
+                                 stream_ptr()))
+    return dy
+
+
+def residual_fwd(y, ycoef, res, rcoef=None):
+    out = torch.empty_like(y)
+    M = y.numel() // y.shape[-1]
+    check(lib().pxl_residual_fwd(dtype_code(y.dtype), M, y.shape[-1], ptr(y), ptr(ycoef), ptr(res), ptr(rcoef),
+                                 ptr(out), stream_ptr()))
+    return out
+
+
+def relu_mask(dout, out, second=False):
+    g = torch.empty_like(dout)
+    g2 = torch.empty_like(dout) if second else None
+    check(lib().pxl_relu_mask(dtype_code(dout.dtype), dout.numel(), ptr(dout), ptr(out), ptr(g), ptr(g2), stream_ptr()))
+    return (g, g2) if second else g
+
+
+def maxpool_fwd(y, coef=None):
+    B, Hi, Wi, Cc = y.shape
+    Ho, Wo = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
+    out = torch.empty(B, Ho, Wo, Cc, device=y.device, dtype=y.dtype)
+    idx = torch.empty(B, Ho, Wo, Cc, device=y.device, dtype=torch.uint8)
+    check(lib().pxl_maxpool3x3s2_fwd(dtype_code(y.dtype), B, Hi, Wi, Cc, ptr(y), ptr(coef), ptr(out), ptr(idx),
+                                     stream_ptr()))
+    return out, idx
+
+
+def maxpool_bwd(dp, idx, Hi, Wi):
+    B, _, _, Cc = dp.shape
+    dz = torch.empty(B, Hi, Wi, Cc, device=dp.device, dtype=dp.dtype)
+    check(lib().pxl_maxpool3x3s2_bwd(dtype_code(dp.dtype), B, Hi, Wi, Cc, ptr(dp), ptr(idx), ptr(dz), stream_ptr()))
+    return dz
+
+
+def upsample_softmax_fwd(low, C, H, W, want_prob=True):
+    B, h, w, Cp = low.shape
+    logits = torch.empty(B, C, H, W, device=low.device, dtype=torch.float32)
+    prob = torch.empty_like(logits) if want_prob else None
+    check(lib().pxl_upsample_softmax_fwd(dtype_code(low.dtype), B, h, w, Cp, C, H, W, ptr(low), ptr(logits),
+                                         ptr(prob), stream_ptr()))
+    return logits, prob
+
+
+def upsample_softmax_bwd(dtype, dlogits, dprob, prob, h, w, Cp):
+    ref = dlogits if dlogits is not None else dprob
+    B, Cc, H, W = ref.shape
+    dlow = torch.empty(B, h, w, Cp, device=ref.device, dtype=_lib.torch_dtype(dtype_code(dtype)))
+    nbytes = lib().pxl_upsample_bwd_workspace(B, w, Cc, H)
+    ws = torch.empty(nbytes, device=ref.device, dtype=torch.uint8)
+    check(lib().pxl_upsample_softmax_bwd(dtype_code(dtype), B, h, w, Cp, Cc, H, W, ptr(dlogits), ptr(dprob), ptr(prob),
+                                         ptr(dlow), ptr(ws), nbytes, stream_ptr()))
+    return dlow
+
+
+def sgd_step(p, g, buf, lr, momentum, weight_decay):
+    check(lib().pxl_sgd_step(p.numel(), ptr(p), ptr(g), ptr(buf), lr, momentum, weight_decay, 0, stream_ptr()))
+
+
+def ema_update(teacher, student, alpha):
+    check(lib().pxl_ema_update(teacher.numel(), ptr(teacher), ptr(student), alpha, stream_ptr()))

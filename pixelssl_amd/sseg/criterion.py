@@ -1,0 +1,23 @@
+"""task/sseg/criterion.py on the fused HIP cross-entropy kernel."""
+from ..task_template import criterion as criterion_template
+from ..utils import logger
+from .. import functional as PF
+
+
+def add_parser_arguments(parser):
+    criterion_template.add_parser_arguments(parser)
+
+
+def sseg_criterion():
+    return CommonSSEGCriterion
+
+
+class CommonSSEGCriterion(criterion_template.TaskCriterion):
+    """Per-sample CE with ignore_index; mean over ALL H*W pixels (task/sseg/criterion.py:24-38).
+    NOTE: `pred` is not activated (logits)."""
+
+    def forward(self, pred, gt, inp):
+        if len(pred) != 1 or len(gt) != 1 or len(inp) != 1:
+            logger.log_err('DeepLab criterion for semantic segmentation requires\t=>\t'
+                           'len(pred) == 1 \t len(gt) == 1 \t len(inp) == 1\n')
+        return PF.cross_entropy_per_sample(pred[0], gt[0], self.args.ignore_index)

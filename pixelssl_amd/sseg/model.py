@@ -1,0 +1,67 @@
+"""task/sseg/model.py on the MI355X engine: `DeepLabV2(args)` is a TaskModel whose `.model` is the
+libpixelhip-executed network with the reference's parameter names (checkpoint compatible)."""
+import torch
+
+from ..task_template import model as model_template
+from ..utils import logger, cmd
+from ..engine import DeepLabV2Core
+from .. import dist as pdist
+
+
+def add_parser_arguments(parser):
+    model_template.add_parser_arguments(parser)
+    parser.add_argument('--output-stride', type=int, default=16, help='sseg - output stride of the ResNet backbone')
+    parser.add_argument('--backbone', type=str, default='resnet101', help='sseg - architecture of the backbone network')
+    parser.add_argument('--freeze-bn', type=cmd.str2bool, default=False,
+                        help='sseg - if true, the statistics in BatchNorm will not be updated')
+    parser.add_argument('--engine-dtype', type=str, default='bf16',
+                        help='sseg/amd - arithmetic of the HIP engine: bf16 (throughput) or fp32 (exact parity)')
+
+
+def deeplabv2():
+    return DeepLabV2
+
+
+class _Resulter(dict):
+    """resulter dict whose backbone latent ('sslcct_ad_inp') is converted NHWC->NCHW only when read."""
+
+    def __init__(self, latent_fn):
+        super().__init__()
+        self._latent_fn = latent_fn
+
+    def __missing__(self, key):
+        if key == 'sslcct_ad_inp':
+            self[key] = self._latent_fn()
+            return self[key]
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key == 'sslcct_ad_inp' or dict.__contains__(self, key)
+
+    def keys(self):
+        return list(dict.keys(self)) + ([] if dict.__contains__(self, 'sslcct_ad_inp') else ['sslcct_ad_inp'])
+
+
+class DeepLabV2(model_template.TaskModel):
+    def __init__(self, args):
+        super().__init__(args)
+        if args.backbone not in ('resnet50', 'resnet101', 'resnet101-coco'):
+            logger.log_err('DeepLabV2 does not support the backbone: {0}\n'.format(args.backbone))
+        dtype = getattr(args, 'engine_dtype', 'bf16')
+        self.model = DeepLabV2Core(backbone=args.backbone, output_stride=args.output_stride,
+                                   num_classes=args.num_classes, device=pdist.local_device(),
+                                   engine_dtype=torch.float32 if dtype in ('fp32', 'f32') else torch.bfloat16,
+                                   freeze_bn=args.freeze_bn)
+        self.param_groups = [{'params': self.model.get_1x_lr_params(), 'lr': self.args.lr},
+                             {'params': self.model.get_10x_lr_params(), 'lr': self.args.lr * 10}]
+
+    def forward(self, inp):
+        if not len(inp) == 1:
+            logger.log_err('Semantic segmentation model DeepLab requires only one input\n'
+                           'However, {0} inputs are given\n'.format(len(inp)))
+        pred, prob, latent_fn = self.model(inp[0])
+        resulter = _Resulter(latent_fn)
+        resulter['pred'] = (pred,)
+        resulter['activated_pred'] = (prob,)
+        resulter['ssls4l_rc_inp'] = pred
+        return resulter, {}

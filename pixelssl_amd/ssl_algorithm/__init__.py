@@ -1,0 +1,8 @@
+"""Registry of the SSL algorithms (pixelssl/ssl_algorithm/__init__.py:10-27): module name == NAME ==
+export-function name; looked up as `ssl_algorithm.__dict__[name].__dict__[name]`."""
+from . import ssl_base, ssl_null, ssl_mt
+
+SSL_NULL = ssl_null.SSLNULL.NAME
+SSL_MT = ssl_mt.SSLMT.NAME
+
+SSL_ALGORITHMS = [SSL_NULL, SSL_MT]

@@ -1,0 +1,80 @@
+"""Plugin ABI of the SSL algorithms, kept as in pixelssl/ssl_algorithm/ssl_base.py:19-159:
+an export function named like the module, and a class with NAME / SUPPORTED_TASK_TYPES,
+build / train / validate / save_checkpoint / load_checkpoint and the public dicts
+models / optimizers / lrers / criterions / meters."""
+from ..utils import logger
+
+
+def add_parser_arguments(parser):
+    pass
+
+
+def ssl_base(args, model_dict, optimizer_dict, lrer_dict, criterion_dict, task_func):
+    raise NotImplementedError
+
+
+class _SSLBase:
+    NAME = 'ssl_base'
+    SUPPORTED_TASK_TYPES = []
+
+    def __init__(self, args):
+        self.args = args
+        self.task_func = None
+        self.meters = logger.AvgMeterSet()
+        self.models, self.optimizers, self.lrers, self.criterions = {}, {}, {}, {}
+
+    # interface used by the task proxy
+    def build(self, model_funcs, optimizer_funcs, lrer_funcs, criterion_funcs, task_func):
+        self._build(model_funcs, optimizer_funcs, lrer_funcs, criterion_funcs, task_func)
+
+    def train(self, data_loader, epoch):
+        self._train(data_loader, epoch)
+
+    def validate(self, data_loader, epoch):
+        self._validate(data_loader, epoch)
+
+    def save_checkpoint(self, epoch):
+        self._save_checkpoint(epoch)
+
+    def load_checkpoint(self):
+        return self._load_checkpoint()
+
+    # to be provided by each algorithm
+    def _build(self, model_funcs, optimizer_funcs, lrer_funcs, criterion_funcs, task_func):
+        raise NotImplementedError
+
+    def _train(self, data_loader, epoch):
+        raise NotImplementedError
+
+    def _validate(self, data_loader, epoch):
+        raise NotImplementedError
+
+    def _save_checkpoint(self, epoch):
+        raise NotImplementedError
+
+    def _load_checkpoint(self):
+        raise NotImplementedError
+
+    # shared helpers -------------------------------------------------------------------------
+    @staticmethod
+    def _single_component(name, *dicts):
+        if not all(len(d) == 1 for d in dicts):
+            logger.log_err('The len(element_dict) of {0} should be 1\n'.format(name.upper()))
+        if list(dicts[0].keys())[0] != 'model':
+            logger.log_err("In {0}, the key of element_dict should be 'model',\nbut '{1}' is given\n"
+                           .format(name.upper(), list(dicts[0].keys())))
+        return [d['model'] for d in dicts]
+
+    @staticmethod
+    def _to_device(tensors):
+        """`Variable(i).cuda()` of every _batch_prehandle: non-blocking H2D onto this rank's GPU."""
+        import torch
+        dev = torch.device('cuda', torch.cuda.current_device())
+        return tuple(t.to(dev, non_blocking=True) for t in tensors)
+
+    @staticmethod
+    def _need_pred(resulter, name):
+        if 'pred' not in resulter.keys() or 'activated_pred' not in resulter.keys():
+            logger.log_err("In {0}, the 'resulter' dict returned by the task model should contain:\n"
+                           "   (1) 'pred'\t=>\tunactivated task predictions\n"
+                           "   (2) 'activated_pred'\t=>\tactivated task predictions\n".format(name))

@@ -1,0 +1,165 @@
+"""Pixel-wise Mean Teacher (pixelssl/ssl_algorithm/ssl_mt.py): student + EMA teacher of the same task
+model; CE on the labeled slice, MSE consistency between student and (detached) teacher LOGITS,
+scaled by cons_scale * sigmoid ramp-up; teacher runs under no_grad with train-mode BN."""
+import os
+import time
+
+import torch
+
+from ..utils import REGRESSION, CLASSIFICATION, logger, cmd, tool
+from ..nn import func
+from ..nn.module import patch_replication_callback, GaussianNoiseLayer
+from ..functional import MSELoss
+from .. import ops
+from . import ssl_base
+
+
+def add_parser_arguments(parser):
+    ssl_base.add_parser_arguments(parser)
+    parser.add_argument('--cons-for-labeled', type=cmd.str2bool, default=True,
+                        help='sslmt - consistency constraint on the labeled data too if True')
+    parser.add_argument('--cons-scale', type=float, default=-1, help='sslmt - consistency constraint coefficient')
+    parser.add_argument('--cons-rampup-epochs', type=int, default=-1, help='sslmt - ramp-up epochs of the constraint')
+    parser.add_argument('--ema-decay', type=float, default=0.999, help='sslmt - EMA coefficient of the teacher')
+    parser.add_argument('--gaussian-noise-std', type=float, default=None, help='sslmt - std of the input noise')
+
+
+def ssl_mt(args, model_dict, optimizer_dict, lrer_dict, criterion_dict, task_func):
+    mf, of, lf, cf = ssl_base._SSLBase._single_component('ssl_mt', model_dict, optimizer_dict, lrer_dict,
+                                                         criterion_dict)
+    algorithm = SSLMT(args)
+    algorithm.build([mf], [of], [lf], [cf], task_func)
+    return algorithm
+
+
+class SSLMT(ssl_base._SSLBase):
+    NAME = 'ssl_mt'
+    SUPPORTED_TASK_TYPES = [REGRESSION, CLASSIFICATION]
+
+    def __init__(self, args):
+        super().__init__(args)
+        self.s_model = self.t_model = None
+        self.s_optimizer = self.s_lrer = self.s_criterion = self.cons_criterion = None
+        self.gaussian_noiser = None
+        if self.args.cons_for_labeled or self.args.unlabeled_batch_size > 0:
+            if self.args.cons_scale < 0:
+                logger.log_err('The argument - cons_scale - is not set (or invalid)\n'
+                               'Please set - cons_scale >= 0 - for training\n')
+            if self.args.cons_rampup_epochs < 0:
+                logger.log_err('The argument - cons_rampup_epochs - is not set (or invalid)\n'
+                               'Please set - cons_rampup_epochs >= 0 - for training\n')
+
+    def _build(self, model_funcs, optimizer_funcs, lrer_funcs, criterion_funcs, task_func):
+        self.task_func = task_func
+        self.s_model = patch_replication_callback(func.create_model(model_funcs[0], 's_model', args=self.args))
+        self.t_model = patch_replication_callback(func.create_model(model_funcs[0], 't_model', args=self.args))
+        for param in self.t_model.parameters():      # the teacher is never trained by back-propagation
+            param.detach_()
+        self.models = {'s_model': self.s_model, 't_model': self.t_model}
+        self.s_optimizer = optimizer_funcs[0](self.s_model.module.param_groups)
+        self.optimizers = {'s_optimizer': self.s_optimizer}
+        self.s_lrer = lrer_funcs[0](self.s_optimizer)
+        self.lrers = {'s_lrer': self.s_lrer}
+        self.cons_criterion = MSELoss()
+        self.s_criterion = criterion_funcs[0](self.args)
+        self.criterions = {'s_criterion': self.s_criterion, 'cons_criterion': self.cons_criterion}
+        self.gaussian_noiser = GaussianNoiseLayer(self.args.gaussian_noise_std)
+
+    def train_step(self, inp, gt, cur_step, total_rampup_steps):
+        """One iteration of ssl_mt.py:131-220 on device-resident tuples.
+        Returns dict(s_task_loss, t_task_loss, cons_loss) of detached device scalars."""
+        lbs = self.args.labeled_batch_size
+        s_inp = tuple(self.gaussian_noiser(i) if k == 0 else i for k, i in enumerate(inp))
+        t_inp = s_inp      # noise disabled => same tensor; the reference uploads the batch twice (ssl_mt.py:344-348)
+        ramp = func.sigmoid_rampup(cur_step, total_rampup_steps)
+
+        self.s_optimizer.zero_grad()
+        s_resulter, _ = self.s_model.forward(s_inp)
+        self._need_pred(s_resulter, 'SSL_MT')
+        s_pred = tool.dict_value(s_resulter, 'pred')
+        l_gt = func.split_tensor_tuple(gt, 0, lbs)
+        s_task_loss = torch.mean(self.s_criterion.forward(func.split_tensor_tuple(s_pred, 0, lbs), l_gt,
+                                                          func.split_tensor_tuple(s_inp, 0, lbs)))
+        with torch.no_grad():
+            t_resulter, _ = self.t_model.forward(t_inp)
+            if 'pred' not in t_resulter.keys():
+                self._need_pred(t_resulter, 'SSL_MT')
+            t_pred = tool.dict_value(t_resulter, 'pred')
+            t_task_loss = torch.mean(self.s_criterion.forward(func.split_tensor_tuple(t_pred, 0, lbs), l_gt,
+                                                              func.split_tensor_tuple(t_inp, 0, lbs)))
+        t_pseudo_gt = t_pred[0].detach()
+        if self.args.cons_for_labeled:
+            cons_loss = self.cons_criterion(s_pred[0], t_pseudo_gt)
+        elif self.args.unlabeled_batch_size > 0:
+            cons_loss = self.cons_criterion(s_pred[0][lbs:, ...], t_pseudo_gt[lbs:, ...])
+        else:
+            cons_loss = torch.zeros((), device=s_pred[0].device)
+        cons_loss = ramp * self.args.cons_scale * torch.mean(cons_loss)
+
+        loss = s_task_loss + cons_loss
+        loss.backward()
+        self.s_optimizer.step()
+        self._update_ema_variables(self.s_model, self.t_model, self.args.ema_decay, cur_step)
+        if not self.args.is_epoch_lrer:
+            self.s_lrer.step()
+        return dict(s_task_loss=s_task_loss.detach(), t_task_loss=t_task_loss.detach(),
+                    cons_loss=cons_loss.detach()), s_resulter, t_resulter
+
+    def _train(self, data_loader, epoch):
+        self.meters.reset()
+        self.s_model.train()
+        self.t_model.train()
+        for idx, (inp, gt) in enumerate(data_loader):
+            timer = time.time()
+            inp, gt = self._to_device(inp), self._to_device(gt)
+            cur_step = len(data_loader) * epoch + idx
+            losses, _, _ = self.train_step(inp, gt, cur_step, len(data_loader) * self.args.cons_rampup_epochs)
+            for k, v in losses.items():
+                self.meters.update(k, v)
+            self.meters.update('batch_time', time.time() - timer)
+            if idx % self.args.log_freq == 0:
+                logger.log_info('step: [{0}][{1}/{2}]\tbatch-time: {3:.3f}\n'
+                                '  student-{4}\t=>\ts-task-loss: {5:.6f}\ts-cons-loss: {6:.6f}\n'
+                                '  teacher-{4}\t=>\tt-task-loss: {7:.6f}\n'
+                                .format(epoch + 1, idx, len(data_loader), self.meters['batch_time'].avg, self.args.task,
+                                        float(self.meters['s_task_loss'].avg), float(self.meters['cons_loss'].avg),
+                                        float(self.meters['t_task_loss'].avg)))
+        if self.args.is_epoch_lrer:
+            self.s_lrer.step()
+
+    def _validate(self, data_loader, epoch):
+        self.meters.reset()
+        self.s_model.eval()
+        self.t_model.eval()
+        for idx, (inp, gt) in enumerate(data_loader):
+            inp, gt = self._to_device(inp), self._to_device(gt)
+            for tag, model in (('student', self.s_model), ('teacher', self.t_model)):
+                resulter, _ = model.forward(inp)
+                self._need_pred(resulter, 'SSL_MT')
+                pred = tool.dict_value(resulter, 'pred')
+                self.meters.update(tag[0] + '_task_loss', torch.mean(self.s_criterion.forward(pred, gt, inp)).detach())
+                self.task_func.metrics(tool.dict_value(resulter, 'activated_pred'), gt, inp, self.meters, id_str=tag)
+
+    def _save_checkpoint(self, epoch):
+        state = {'algorithm': self.NAME, 'epoch': epoch, 's_model': self.s_model.state_dict(),
+                 't_model': self.t_model.state_dict(), 's_optimizer': self.s_optimizer.state_dict(),
+                 's_lrer': self.s_lrer.state_dict()}
+        torch.save(state, os.path.join(self.args.checkpoint_path, 'checkpoint_{0}.ckpt'.format(epoch)))
+
+    def _load_checkpoint(self):
+        checkpoint = torch.load(self.args.resume, map_location='cpu')
+        found = tool.dict_value(checkpoint, 'algorithm', default='unknown')
+        if found != self.NAME:
+            logger.log_err('Unmatched SSL algorithm format in checkpoint => required: {0} - given: {1}\n'
+                           .format(self.NAME, found))
+        self.s_model.load_state_dict(checkpoint['s_model'])
+        self.t_model.load_state_dict(checkpoint['t_model'])
+        return checkpoint['epoch']
+
+    def _update_ema_variables(self, s_model, t_model, ema_decay, cur_step):
+        """alpha = min(1 - 1/(step+1), decay); parameters only, BN buffers evolve by the teacher's own
+        forward (ssl_mt.py:359-363).  One fused launch over the flat parameter buffers."""
+        alpha = min(1 - 1 / (cur_step + 1), ema_decay)
+        s_core, t_core = s_model.module.model, t_model.module.model
+        ops.ema_update(t_core.flat.params, s_core.flat.params, alpha)
+        t_core.mark_params_changed()

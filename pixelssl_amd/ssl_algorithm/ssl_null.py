@@ -1,0 +1,103 @@
+"""SupOnly baseline (pixelssl/ssl_algorithm/ssl_null.py): zero_grad -> forward -> per-sample CE on the
+labeled slice -> backward -> SGD step -> per-iteration LR step."""
+import os
+import time
+
+import torch
+
+from ..utils import REGRESSION, CLASSIFICATION, logger, tool
+from ..nn import func
+from ..nn.module import patch_replication_callback
+from . import ssl_base
+
+
+def add_parser_arguments(parser):
+    ssl_base.add_parser_arguments(parser)
+
+
+def ssl_null(args, model_dict, optimizer_dict, lrer_dict, criterion_dict, task_func):
+    mf, of, lf, cf = ssl_base._SSLBase._single_component('ssl_null', model_dict, optimizer_dict, lrer_dict,
+                                                         criterion_dict)
+    algorithm = SSLNULL(args)
+    algorithm.build([mf], [of], [lf], [cf], task_func)
+    return algorithm
+
+
+class SSLNULL(ssl_base._SSLBase):
+    NAME = 'ssl_null'
+    SUPPORTED_TASK_TYPES = [REGRESSION, CLASSIFICATION]
+
+    def __init__(self, args):
+        super().__init__(args)
+        self.model = self.optimizer = self.lrer = self.criterion = None
+
+    def _build(self, model_funcs, optimizer_funcs, lrer_funcs, criterion_funcs, task_func):
+        self.task_func = task_func
+        self.model = patch_replication_callback(func.create_model(model_funcs[0], 'model', args=self.args))
+        self.models = {'model': self.model}
+        self.optimizer = optimizer_funcs[0](self.model.module.param_groups)
+        self.optimizers = {'optimizer': self.optimizer}
+        self.lrer = lrer_funcs[0](self.optimizer)
+        self.lrers = {'lrer': self.lrer}
+        self.criterion = criterion_funcs[0](self.args)
+        self.criterions = {'criterion': self.criterion}
+
+    def train_step(self, inp, gt):
+        """One iteration of ssl_null.py:97-136 on already-device-resident tuples; returns the loss tensor."""
+        lbs = self.args.labeled_batch_size
+        self.optimizer.zero_grad()
+        resulter, _ = self.model.forward(inp)
+        self._need_pred(resulter, 'SSL_NULL')
+        pred = tool.dict_value(resulter, 'pred')
+        task_loss = torch.mean(self.criterion.forward(func.split_tensor_tuple(pred, 0, lbs),
+                                                      func.split_tensor_tuple(gt, 0, lbs),
+                                                      func.split_tensor_tuple(inp, 0, lbs)))
+        task_loss.backward()
+        self.optimizer.step()
+        if not self.args.is_epoch_lrer:
+            self.lrer.step()
+        return task_loss.detach(), resulter
+
+    def _train(self, data_loader, epoch):
+        if not (self.args.ignore_unlabeled and self.args.unlabeled_batch_size == 0):
+            logger.log_err('SSL_NULL is a supervised-only algorithm\n'
+                           'Please set ignore_unlabeled = True and unlabeled_batch_size = 0\n')
+        self.meters.reset()
+        self.model.train()
+        for idx, (inp, gt) in enumerate(data_loader):
+            timer = time.time()
+            inp, gt = self._to_device(inp), self._to_device(gt)
+            task_loss, _ = self.train_step(inp, gt)
+            self.meters.update('task_loss', task_loss)
+            self.meters.update('batch_time', time.time() - timer)
+            if idx % self.args.log_freq == 0:
+                logger.log_info('step: [{0}][{1}/{2}]\tbatch-time: {3:.3f}\n  task-{4}\t=>\ttask-loss: {5:.6f}\t'
+                                .format(epoch + 1, idx, len(data_loader), self.meters['batch_time'].avg,
+                                        self.args.task, float(self.meters['task_loss'].avg)))
+        if self.args.is_epoch_lrer:
+            self.lrer.step()
+
+    def _validate(self, data_loader, epoch):
+        self.meters.reset()
+        self.model.eval()
+        for idx, (inp, gt) in enumerate(data_loader):
+            inp, gt = self._to_device(inp), self._to_device(gt)
+            resulter, _ = self.model.forward(inp)
+            self._need_pred(resulter, 'SSL_NULL')
+            pred = tool.dict_value(resulter, 'pred')
+            self.meters.update('task_loss', torch.mean(self.criterion.forward(pred, gt, inp)).detach())
+            self.task_func.metrics(tool.dict_value(resulter, 'activated_pred'), gt, inp, self.meters, id_str='task')
+
+    def _save_checkpoint(self, epoch):
+        state = {'algorithm': self.NAME, 'epoch': epoch, 'model': self.model.state_dict(),
+                 'optimizer': self.optimizer.state_dict(), 'lrer': self.lrer.state_dict()}
+        torch.save(state, os.path.join(self.args.checkpoint_path, 'checkpoint_{0}.ckpt'.format(epoch)))
+
+    def _load_checkpoint(self):
+        checkpoint = torch.load(self.args.resume, map_location='cpu')
+        found = tool.dict_value(checkpoint, 'algorithm', default='unknown')
+        if found != self.NAME:
+            logger.log_err('Unmatched SSL algorithm format in checkpoint => required: {0} - given: {1}\n'
+                           .format(self.NAME, found))
+        self.model.load_state_dict(checkpoint['model'])
+        return checkpoint['epoch']

@@ -1,0 +1,361 @@
+"""GPU parity of every libpixelhip kernel (called through the C-ABI via ctypes) against plain fp32
+PyTorch on the CPU (the same operator the reference uses at each call site).  Seeded inputs, odd
+sizes (513-style 16k+1 extents scaled down), ragged tiles, every tile configuration."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from pixelssl_amd import ops
+    return ops
+
+
+def to_nhwc(x, cp, dtype):
+    """NCHW cpu fp32 -> NHWC device tensor with channel pitch cp."""
+    b, c, h, w = x.shape
+    y = torch.zeros(b, h, w, cp)
+    y[..., :c] = x.permute(0, 2, 3, 1)
+    return y.to(DEV).to(dtype).contiguous()
+
+
+def from_nhwc(y, c):
+    return y[..., :c].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def pack_w(w, dtype, cp, kp=None):
+    """OIHW cpu -> fwd [K][T][Cp] and dgrad [C][T][Kp] device tensors via pxl_pack_weights."""
+    ops = _ops()
+    k, c, kh, kw = w.shape
+    master = w.permute(0, 2, 3, 1).contiguous().to(DEV)           # [K][kh][kw][C]
+    wf = torch.empty(k, kh * kw, cp, device=DEV, dtype=dtype)
+    wt = torch.empty(c, kh * kw, kp, device=DEV, dtype=dtype) if kp else None
+    ops.pack_weights(dtype, master, k, kh * kw, c, wf, cp, wt=wt, Kp=kp or 0)
+    return wf, wt
+
+
+def rel_err(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def qround(x, dtype):
+    return x.to(dtype).float() if dtype == torch.bfloat16 else x
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 6e-3}
+
+CONV_CASES = [
+    # name, B, Cin, Cout, H, W, k, stride, dil, pad
+    ("1x1", 2, 64, 256, 17, 17, 1, 1, 1, 0),
+    ("1x1_ragged", 3, 96, 72, 9, 13, 1, 1, 1, 0),
+    ("1x1_s2", 2, 64, 128, 17, 17, 1, 2, 1, 0),
+    ("3x3", 2, 64, 64, 17, 17, 3, 1, 1, 1),
+    ("3x3_s2", 2, 32, 64, 17, 17, 3, 2, 1, 1),
+    ("3x3_d2", 2, 32, 32, 9, 9, 3, 1, 2, 2),
+    ("3x3_d4", 1, 64, 160, 9, 9, 3, 1, 4, 4),
+    ("7x7_stem", 2, 3, 64, 33, 33, 7, 2, 1, 3),
+    ("4x4_s2", 2, 24, 64, 33, 33, 4, 2, 1, 1),
+    ("cout21", 2, 128, 21, 9, 9, 3, 1, 1, 1),
+]
+
+
+def _seed(name):
+    return sum(ord(ch) for ch in name)
+
+
+def _pitch(c):
+    return 8 if c <= 8 else (c + 31) // 32 * 32
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
+def test_conv_forward(dtype, case, cfg):
+    ops = _ops()
+    name, B, Cin, Cout, H, W, k, s, d, p = case
+    g = torch.Generator().manual_seed(_seed(name))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    ref = F.conv2d(qround(x, dtype), qround(w, dtype), None, s, p, d)
+    Ho, Wo = ref.shape[2:]
+    cip, cop = _pitch(Cin), _pitch(Cout)
+    xd = to_nhwc(x, cip, dtype)
+    wf, _ = pack_w(w, dtype, cip)
+    out = torch.full((B, Ho, Wo, cop), 7.0, device=DEV, dtype=dtype)
+    desc = ops.conv_desc(dtype, B, H, W, cip, Ho, Wo, cop, Cout, ops.fwd_taps(k, k, d, p), out_stride=s, tile_cfg=cfg)
+    ops.conv_igemm(desc, xd, wf, out)
+    torch.cuda.synchronize()
+    got = from_nhwc(out, Cout)
+    assert rel_err(got, ref) < TOL[dtype], "%s cfg %d" % (name, cfg)
+    if cop > Cout:   # padded channels are written as zeros
+        assert out[..., Cout:].float().abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_prologue_epilogue(dtype):
+    """relu(bn(x)) fused into the load (zero padding stays zero), bias, addend, BN statistics."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, Cin, Cout, H, W = 2, 64, 96, 13, 13
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    scale = torch.rand(Cin, generator=g) + 0.5
+    shift = torch.randn(Cin, generator=g) * 0.3
+    bias = torch.randn(Cout, generator=g)
+    add = torch.randn(B, Cout, H, W, generator=g)
+    xq = qround(x, dtype)
+    a = qround(F.relu(xq * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), dtype)
+    ref = F.conv2d(a, qround(w, dtype), bias, 1, 1, 1) + qround(add, dtype)
+    cip, cop = _pitch(Cin), _pitch(Cout)
+    out = torch.empty(B, H, W, cop, device=DEV, dtype=dtype)
+    stats = torch.zeros(2 * Cout, device=DEV)
+    wf, _ = pack_w(w, dtype, cip)
+    desc = ops.conv_desc(dtype, B, H, W, cip, H, W, cop, Cout, ops.fwd_taps(3, 3, 1, 1), relu_in=True)
+    ops.conv_igemm(desc, to_nhwc(x, cip, dtype), wf, out, in_scale=scale.to(DEV), in_shift=shift.to(DEV),
+                   bias=bias.to(DEV), addend=to_nhwc(add, cop, dtype), stats=stats)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(out, Cout), ref) < TOL[dtype]
+    s1 = ref.sum(dim=(0, 2, 3))
+    s2 = (ref * ref).sum(dim=(0, 2, 3))
+    assert rel_err(stats[:Cout].cpu(), s1) < 5 * TOL[dtype]
+    assert rel_err(stats[Cout:].cpu(), s2) < 5 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES[:-1], ids=[c[0] for c in CONV_CASES[:-1]])
+def test_conv_dgrad_and_wgrad(dtype, case):
+    ops = _ops()
+    name, B, Cin, Cout, H, W, k, s, d, p = case
+    g = torch.Generator().manual_seed(_seed(name) + 1)
+    x = qround(torch.randn(B, Cin, H, W, generator=g), dtype).requires_grad_(True)
+    w = qround(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p, d)
+    Ho, Wo = y.shape[2:]
+    dy = qround(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    cip, cop = _pitch(Cin), _pitch(Cout)
+    taps = ops.fwd_taps(k, k, d, p)
+    # ---- data gradient: implicit GEMM with transposed weights, negated taps, divisor = stride
+    _, wt = pack_w(w.detach(), dtype, cip, kp=cop)
+    dx = torch.empty(B, H, W, cip, device=DEV, dtype=dtype)
+    bdesc = ops.conv_desc(dtype, B, Ho, Wo, cop, H, W, cip, Cin, [(-a, -b) for a, b in taps], out_stride=1, div=s)
+    ops.conv_igemm(bdesc, to_nhwc(dy, cop, dtype), wt, dx)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dx, Cin), x.grad) < TOL[dtype], "dgrad " + name
+    # ---- weight gradient (fp32 master layout [K][T][C]), accumulated on top of a non-zero buffer
+    fdesc = ops.conv_desc(dtype, B, H, W, cip, Ho, Wo, cop, Cout, taps, out_stride=s)
+    dw = torch.ones(Cout, k * k, Cin, device=DEV)
+    ops.conv_wgrad(fdesc, to_nhwc(x.detach(), cip, dtype), to_nhwc(dy, cop, dtype), dw, Cin, Cin)
+    torch.cuda.synchronize()
+    got = (dw.cpu() - 1.0).view(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    assert rel_err(got, w.grad) < 2 * TOL[dtype], "wgrad " + name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wgrad_with_prologue_and_tile_cfgs(dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    B, Cin, Cout, H, W = 2, 64, 21, 11, 11
+    x = qround(torch.randn(B, Cin, H, W, generator=g), dtype)
+    scale = torch.rand(Cin, generator=g) + 0.5
+    shift = torch.randn(Cin, generator=g) * 0.3
+    a = qround(F.relu(x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)), dtype)
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    y = F.conv2d(a, w, None, 1, 2, 2)
+    dy = qround(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    cip, cop = _pitch(Cin), _pitch(Cout)
+    for cfg in (-1, 0, 1, 2):
+        desc = ops.conv_desc(dtype, B, H, W, cip, H, W, cop, Cout, ops.fwd_taps(3, 3, 2, 2), relu_in=True, tile_cfg=cfg)
+        dw = torch.zeros(Cout, 9, Cin, device=DEV)
+        ops.conv_wgrad(desc, to_nhwc(x, cip, dtype), to_nhwc(dy, cop, dtype), dw, Cin, Cin,
+                       in_scale=scale.to(DEV), in_shift=shift.to(DEV))
+        torch.cuda.synchronize()
+        got = dw.cpu().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        assert rel_err(got, w.grad) < 2 * TOL[dtype], "cfg %d" % cfg
+
+
+def test_aspp_multirate_as_one_launch():
+    """36 taps (4 dilation groups) in one implicit GEMM == sum of four dilated convs (deeplab_v2.py:81-85)."""
+    ops = _ops()
+    dtype = torch.float32
+    g = torch.Generator().manual_seed(11)
+    B, Cin, Cout, H, W = 2, 64, 21, 9, 9
+    rates = (1, 2, 3, 4)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    ws = [torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05 for _ in rates]
+    ref = sum(F.conv2d(x, w, None, 1, r, r) for w, r in zip(ws, rates))
+    cip, cop = _pitch(Cin), _pitch(Cout)
+    wf = torch.empty(Cout, 36, cip, device=DEV)
+    taps = []
+    for gi, (w, r) in enumerate(zip(ws, rates)):
+        ops.pack_weights(dtype, w.permute(0, 2, 3, 1).contiguous().to(DEV), Cout, 9, Cin, wf, cip, T_total=36, t_off=9 * gi)
+        taps += ops.fwd_taps(3, 3, r, r)
+    out = torch.empty(B, H, W, cop, device=DEV)
+    ops.conv_igemm(ops.conv_desc(dtype, B, H, W, cip, H, W, cop, Cout, taps), to_nhwc(x, cip, dtype), wf, out)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(out, Cout), ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [64, 256, 2048])
+def test_batchnorm_finalize_and_backward(dtype, C):
+    ops = _ops()
+    g = torch.Generator().manual_seed(C)
+    B, H, W = 2, 9, 7
+    y = qround(torch.randn(B, C, H, W, generator=g) * 2 + 0.5, dtype).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.2).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    z = F.relu(F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5))
+    dz = qround(torch.randn(z.shape, generator=g), dtype)
+    z.backward(dz)
+    M = B * H * W
+    yd = to_nhwc(y.detach(), C, dtype)
+    stats = torch.stack([y.detach().sum(dim=(0, 2, 3)), (y.detach() ** 2).sum(dim=(0, 2, 3))]).reshape(-1).to(DEV)
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    coef = ops.bn_finalize(stats, M, gamma.detach().to(DEV), beta.detach().to(DEV), rmd, rvd)
+    torch.cuda.synchronize()
+    assert rel_err(rmd.cpu(), rm) < 1e-5 and rel_err(rvd.cpu(), rv) < 1e-5
+    mean = y.detach().mean(dim=(0, 2, 3))
+    var = y.detach().var(dim=(0, 2, 3), unbiased=False)
+    assert rel_err(coef[:C].cpu(), mean) < 1e-4
+    assert rel_err(coef[C:2 * C].cpu(), (var + 1e-5).rsqrt()) < 1e-4
+    dgamma, dbeta = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dy = ops.bn_backward(to_nhwc(dz, C, dtype).view(M, C), yd.view(M, C), coef, M, True, dgamma, dbeta)
+    torch.cuda.synchronize()
+    tol = 1e-4 if dtype == torch.float32 else 1.5e-2
+    assert rel_err(from_nhwc(dy.view(B, H, W, C), C), y.grad) < tol
+    assert rel_err(dgamma.cpu(), gamma.grad) < tol
+    assert rel_err(dbeta.cpu(), beta.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_residual_join_and_relu_mask(dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    B, C, H, W = 2, 256, 9, 9
+    y = qround(torch.randn(B, C, H, W, generator=g), dtype)
+    r = qround(torch.randn(B, C, H, W, generator=g), dtype)
+    yc, rc = torch.randn(4 * C, generator=g), torch.randn(4 * C, generator=g)
+    aff = lambda t, c: t * c[2 * C:3 * C].view(1, -1, 1, 1) + c[3 * C:].view(1, -1, 1, 1)
+    for rcoef in (None, rc):
+        ref = F.relu(aff(y, yc) + (aff(r, rcoef) if rcoef is not None else r))
+        out = ops.residual_fwd(to_nhwc(y, C, dtype), yc.to(DEV), to_nhwc(r, C, dtype),
+                               rcoef.to(DEV) if rcoef is not None else None)
+        torch.cuda.synchronize()
+        assert rel_err(from_nhwc(out, C), ref) < TOL[dtype]
+    dout = qround(torch.randn(B, C, H, W, generator=g), dtype)
+    g1, g2 = ops.relu_mask(to_nhwc(dout, C, dtype), to_nhwc(ref, C, dtype), second=True)
+    torch.cuda.synchronize()
+    want = dout * (qround(ref, dtype) > 0)
+    assert torch.equal(from_nhwc(g1, C), want) and torch.equal(from_nhwc(g2, C), want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool_fused_bn_relu(dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    B, C, H, W = 2, 64, 17, 17
+    y = qround(torch.randn(B, C, H, W, generator=g), dtype)
+    coef = torch.randn(4 * C, generator=g)
+    z = F.relu(y * coef[2 * C:3 * C].view(1, -1, 1, 1) + coef[3 * C:].view(1, -1, 1, 1)).requires_grad_(True)
+    ref = F.max_pool2d(z, 3, 2, 1)
+    out, idx = ops.maxpool_fwd(to_nhwc(y, C, dtype), coef.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(out, C), qround(ref.detach(), dtype)) < TOL[dtype]
+    dp = qround(torch.randn(ref.shape, generator=g), dtype)
+    ref.backward(dp)
+    dz = ops.maxpool_bwd(to_nhwc(dp, C, dtype), idx, H, W)
+    torch.cuda.synchronize()
+    # gradients routed to zero-valued (relu-clamped) positions are killed by the following relu mask
+    mask = (z.detach() > 0).float()
+    assert rel_err(from_nhwc(dz, C) * mask, z.grad * mask) < (1e-6 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("size", [(5, 65), (3, 33)])
+def test_upsample_softmax_forward_backward(dtype, size):
+    ops = _ops()
+    h, H = size
+    g = torch.Generator().manual_seed(h)
+    B, C, Cp = 2, 21, 32
+    low = qround(torch.randn(B, C, h, h, generator=g) * 2, dtype).requires_grad_(True)
+    logits = F.interpolate(low, size=(H, H), mode="bilinear", align_corners=True)
+    prob = F.softmax(logits, dim=1)
+    gl, gp = torch.randn(logits.shape, generator=g), torch.randn(logits.shape, generator=g)
+    (logits * gl).sum().backward(retain_graph=True)
+    g_only_logits = low.grad.clone()
+    low.grad = None
+    ((logits * gl).sum() + (prob * gp).sum()).backward()
+    lowd = to_nhwc(low.detach(), Cp, dtype)
+    lg, pr = ops.upsample_softmax_fwd(lowd, C, H, H)
+    torch.cuda.synchronize()
+    assert rel_err(lg.cpu(), logits.detach()) < 1e-5
+    assert rel_err(pr.cpu(), prob.detach()) < 1e-5
+    tol = 1e-4 if dtype == torch.float32 else 8e-3
+    d1 = ops.upsample_softmax_bwd(dtype, gl.to(DEV), None, None, h, h, Cp)
+    d2 = ops.upsample_softmax_bwd(dtype, gl.to(DEV), gp.to(DEV), pr, h, h, Cp)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(d1, C), g_only_logits) < tol
+    assert rel_err(from_nhwc(d2, C), low.grad) < tol
+    assert d1[..., C:].float().abs().max().item() == 0.0
+
+
+def test_cross_entropy_and_mse_losses():
+    import torch_oracle as TO
+    from pixelssl_amd import functional as PF
+    g = torch.Generator().manual_seed(8)
+    N, C, H = 3, 21, 33
+    logits = (torch.randn(N, C, H, H, generator=g) * 3).requires_grad_(True)
+    gt = torch.randint(0, C, (N, 1, H, H), generator=g).float()
+    gt[0, 0, :5] = 255.0
+    gt[1, 0, :, ::3] = 255.0
+    ref = TO.sseg_criterion(logits, gt)
+    wgt = torch.tensor([0.2, 0.5, 0.3])
+    (ref * wgt).sum().backward()
+    ld = logits.detach().to(DEV).requires_grad_(True)
+    got = PF.cross_entropy_per_sample(ld, gt.to(DEV), 255)
+    (got * wgt.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    assert rel_err(got.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(ld.grad.cpu(), logits.grad) < 1e-5
+    # MSE on an odd-sized (unaligned) batch slice, gradient to the first operand only
+    a = torch.randn(4, C, H, H, generator=g).requires_grad_(True)
+    b = torch.randn(4, C, H, H, generator=g)
+    r = TO.mse_loss(a[1:], b[1:]) * 0.37
+    r.backward()
+    ad = a.detach().to(DEV).requires_grad_(True)
+    m = PF.mse_loss(ad[1:], b.to(DEV)[1:]) * 0.37
+    m.backward()
+    torch.cuda.synchronize()
+    assert abs(m.item() - r.item()) < 1e-5 * abs(r.item())
+    assert rel_err(ad.grad.cpu(), a.grad) < 1e-5
+
+
+def test_sgd_and_ema_flat_updates():
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    n = 100003
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    buf = torch.zeros(n)
+    pd, gd, bd = p.to(DEV), gr.to(DEV), buf.to(DEV)
+    ref_p = torch.nn.Parameter(p.clone())
+    opt = torch.optim.SGD([ref_p], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    for _ in range(3):
+        ref_p.grad = gr.clone()
+        opt.step()
+        ops.sgd_step(pd, gd, bd, 0.01, 0.9, 5e-4)
+    torch.cuda.synchronize()
+    assert rel_err(pd.cpu(), ref_p.detach()) < 1e-6
+    t, s = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    td = t.to(DEV)
+    ops.ema_update(td, s.to(DEV), 0.99)
+    torch.cuda.synchronize()
+    assert rel_err(td.cpu(), t * 0.99 + 0.01 * s) < 1e-6

@@ -1,0 +1,132 @@
+"""CPU-only checks of the host logic and the C-ABI surface (no kernel is launched here)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from pixelssl_amd import _lib
+    h = _lib.lib()
+    assert h.pxl_version() == 100
+    header = open(os.path.join(ROOT, "include", "pixelhip.h")).read()
+    declared = set(re.findall(r"\b(pxl_[a-z0-9_]+)\s*\(", header))
+    declared -= {"pxl_allreduce_fn"}
+    assert len(declared) >= 40
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), "libpixelhip.so does not export %s" % name
+        assert name in _lib.SIGNATURES, "ctypes binding misses %s" % name
+
+
+def test_argument_errors_are_reported_not_crashed():
+    from pixelssl_amd import _lib
+    h = _lib.lib()
+    d = _lib.ConvDesc()
+    d.dtype, d.Cin, d.ntaps, d.div, d.Kreal, d.Cout = 7, 64, 1, 1, 8, 8
+    assert h.pxl_conv_igemm(d, 1, 1, 1, None, None, None, None, None, None) == -1
+    assert b"dtype" in h.pxl_last_error()
+    with pytest.raises(_lib.PixelHipError):
+        _lib.check(h.pxl_mse_fwd(0, None, None, None, None))
+
+
+def test_engine_parameter_tree_matches_reference_names():
+    import torch_oracle as TO
+    from pixelssl_amd.engine import DeepLabV2Core
+    core = DeepLabV2Core(device="cpu", engine_dtype=torch.bfloat16)
+    sd = core.state_dict()
+    ref = TO.deeplabv2_param_shapes()
+    assert set(sd.keys()) == set(ref.keys())
+    for k, shape in ref.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert sum(p.numel() for p in core.parameters()) == 44048532
+    # parameters are views of ONE flat buffer, conv weights physically [K][kh][kw][C]
+    w = core.backbone.layer1._modules["0"].conv2.weight
+    assert w.is_contiguous(memory_format=torch.channels_last)
+    st = TO.init_deeplabv2_state(seed=3)
+    core.load_state_dict(st)
+    off = w._pxl_flat[1]
+    assert torch.equal(core.flat.params[off:off + w.numel()].view(64, 3, 3, 64),
+                       st["backbone.layer1.0.conv2.weight"].permute(0, 2, 3, 1))
+    groups = [list(core.get_1x_lr_params()), list(core.get_10x_lr_params())]
+    assert sum(p.numel() for p in groups[0]) == 42500160 and sum(p.numel() for p in groups[1]) == 1548372
+
+
+def test_plan_sizes_and_workspace_guards():
+    from pixelssl_amd.engine import DeepLabV2Core
+    from pixelssl_amd._lib import lib, check
+    core = DeepLabV2Core(device="cpu", engine_dtype=torch.float32)
+    h = lib()
+    assert h.pxl_net_arena_bytes(core._net) == 0          # not planned yet
+    check(h.pxl_net_plan(core._net, 2, 65, 65))
+    a65 = h.pxl_net_arena_bytes(core._net)
+    check(h.pxl_net_plan(core._net, 8, 513, 513))
+    a513 = h.pxl_net_arena_bytes(core._net)
+    assert 0 < a65 < a513 < 16 * 2 ** 30
+    c, hh, ww = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    check(h.pxl_net_latent_shape(core._net, ctypes.byref(c), ctypes.byref(hh), ctypes.byref(ww)))
+    assert (c.value, hh.value, ww.value) == (2048, 33, 33)
+    # a too-small arena is refused before anything is launched
+    rc = h.pxl_net_forward(core._net, 1, 1, None, 1, 1, None, 1, 16, 1, None)
+    assert rc == -4 and b"arena" in h.pxl_last_error()
+
+
+def test_product_path_refuses_cpu_tensors():
+    from pixelssl_amd import functional as PF, _lib
+    from pixelssl_amd.engine import DeepLabV2Core
+    with pytest.raises(_lib.PixelHipError):
+        PF.mse_loss(torch.zeros(4), torch.zeros(4))
+    core = DeepLabV2Core(device="cpu", engine_dtype=torch.float32)
+    with pytest.raises(_lib.PixelHipError):
+        core(torch.zeros(1, 3, 33, 33))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = ("import pixelssl_amd._lib as L; L.LIB_PATH=%r; L._lib=None\n"
+            "try:\n  L.lib()\nexcept L.PixelHipError as e:\n  print('LOUD', e)\n" % str(tmp_path / "nope.so"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert "LOUD" in out.stdout and "no CPU/PyTorch fallback" in out.stdout
+
+
+def test_polynomial_lr_matches_oracle_schedule():
+    import argparse
+    import torch_oracle as TO
+    from pixelssl_amd.nn import lrer
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([{"params": [p], "lr": 2.5e-4}, {"params": [torch.nn.Parameter(torch.zeros(1))], "lr": 2.5e-3}],
+                          lr=2.5e-4)
+    args = argparse.Namespace(power=-1, last_epoch=-1, epochs=2, iters_per_epoch=5)
+    sched = lrer.polynomiallr(args)(opt)
+    tr = TO.OracleTrainer({}, dict(max_iters=10))
+    for it in range(6):
+        tr.it = it
+        assert abs(opt.param_groups[0]["lr"] - tr._lrs()[0]) < 1e-12
+        assert abs(opt.param_groups[1]["lr"] - tr._lrs()[1]) < 1e-12
+        sched.step()
+
+
+def test_helpers_and_registry():
+    import pixelssl_amd as P
+    from pixelssl_amd.nn import func
+    assert P.SSL_ALGORITHMS == ["ssl_null", "ssl_mt"]
+    for name in P.SSL_ALGORITHMS:      # lookup convention of task_template/proxy.py:433
+        assert callable(P.ssl_algorithm.__dict__[name].__dict__[name])
+        assert callable(P.ssl_algorithm.__dict__[name].add_parser_arguments)
+    t = (torch.arange(12).view(6, 2),)
+    assert func.split_tensor_tuple(t, 0, 4)[0].shape == (4, 2)
+    assert func.split_tensor_tuple(t, 2, 3, reduce_dim=True)[0].shape == (2,)
+    assert func.sigmoid_rampup(3, 6) == pytest.approx(0.2865047968601901)
+    import argparse
+    parser = argparse.ArgumentParser()
+    P.nn.optimizer.add_parser_arguments(parser)
+    P.nn.lrer.add_parser_arguments(parser)
+    P.ssl_algorithm.ssl_mt.add_parser_arguments(parser)
+    P.sseg.model.add_parser_arguments(parser)
+    a = P.utils.cmd.parse_args(parser, {"lr": 0.00025, "cons_for_labeled": False, "ema_decay": 0.99})
+    assert a.lr == 0.00025 and a.cons_for_labeled is False and a.backbone == "resnet101"

@@ -1,0 +1,23 @@
+#!/bin/bash
+# One GPU-box session: parity tests, smoke, bench, rocprof.  Everything lands in gpurun_out/.
+# usage: tools/gpu_round.sh [stage ...]   stages: kernels net smoke bench prof
+set -u
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+OUT=gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+STAGES="${*:-kernels net smoke bench}"
+echo "stages: $STAGES" | tee $OUT/stages.txt
+rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/gpu.txt
+nproc >> $OUT/gpu.txt; lscpu | grep -E "Model name|^CPU\(s\)" >> $OUT/gpu.txt
+for s in $STAGES; do
+  case $s in
+    kernels) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q -x --tb=short -p no:cacheprovider > $OUT/test_kernels.log 2>&1; echo "kernels rc=$?" | tee -a $OUT/stages.txt; tail -30 $OUT/test_kernels.log;;
+    kernels_all) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=line -p no:cacheprovider > $OUT/test_kernels.log 2>&1; echo "kernels_all rc=$?" | tee -a $OUT/stages.txt; tail -60 $OUT/test_kernels.log;;
+    net) timeout 1200 python -m pytest tests/test_gpu_net.py -m gpu -q -s --tb=short -p no:cacheprovider > $OUT/test_net.log 2>&1; echo "net rc=$?" | tee -a $OUT/stages.txt; grep -vE "^\s*$" $OUT/test_net.log | tail -60;;
+    smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/stages.txt; tail -5 $OUT/smoke.log;;
+    bench) timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/bench.log 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/stages.txt; tail -3 $OUT/bench.log; tail -5 $OUT/bench.err;;
+    benchfast) timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench.log 2> $OUT/bench.err; echo "benchfast rc=$?" | tee -a $OUT/stages.txt; tail -3 $OUT/bench.log; tail -5 $OUT/bench.err;;
+    prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o mt -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $OLDPWD/$OUT/prof.log 2>&1); echo "prof rc=$?" | tee -a $OUT/stages.txt; find $OUT/prof -name "*stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f";;
+  esac
+done
