@@ -66,20 +66,24 @@ typedef struct pxl_conv_desc {
   int32_t div;          /* 1 or 2 */
   int32_t relu_in;      /* prologue: relu after the input affine */
   int32_t tile_cfg;     /* -1 = heuristic; otherwise forces a tile configuration (tests/tuning) */
+  int32_t stats_rep;    /* replicas of the [2*Kreal] statistics vector (0/1 = one); tile row % stats_rep */
+  int32_t split_k;      /* 0 = heuristic, 1 = off, >1 = forced number of K slices (needs workspace) */
   int16_t dy[64];
   int16_t dx[64];
 } pxl_conv_desc;
 
 /* out[m][n] = sum_{t,c} act(in)[m,t,c] * w[n][t][c]  (+ bias[n]) (+ addend[m][n]);
  * act(x) = relu?(x*in_scale[c] + in_shift[c]) applied to in-bounds taps only (zero padding stays 0);
- * stats (optional, [2*Kreal] fp32, caller-zeroed): per-channel sum and sum of squares of `out`
- * taken from the fp32 accumulators.
+ * stats (optional, [stats_rep][2*Kreal] fp32, caller-zeroed): per-channel sum and sum of squares of
+ * `out` taken from the fp32 accumulators, spread over stats_rep replicas (fold with pxl_bn_finalize).
+ * workspace (optional, >= M*Cout*4 bytes): enables split-K for launches that cannot fill the chip
+ * (long reductions with few output tiles, e.g. the 36-tap ASPP head); only without stats/addend.
  * Replaces: nn.Conv2d forward/backward-data at task/sseg/module/backbone/resnet.py:18-23,69,89,106,
  * module/deeplab_v2.py:76,81-85; the fused prologue/epilogue replaces SynchronizedBatchNorm2d +
  * nn.ReLU at resnet.py:33-41 (sync_batchnorm/batchnorm.py:48-78). */
 int pxl_conv_igemm(const pxl_conv_desc* desc, const void* in, const void* w, void* out,
                    const float* in_scale, const float* in_shift, const float* bias,
-                   const void* addend, float* stats, void* stream);
+                   const void* addend, float* stats, void* workspace, size_t ws_bytes, void* stream);
 
 /* dw[k][t][c] += sum_m dy[m][k] * act(in)[m,t,c]   (fp32, atomically accumulated: zero dw first
  * unless accumulating).  `desc` describes the FORWARD conv (in = its input, Ho/Wo/Cout = dy).
@@ -102,20 +106,23 @@ int pxl_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H, in
 /* BatchNorm (training-mode, cross-device statistics)                                          */
 /* ------------------------------------------------------------------------------------------ */
 
-/* stats [2C] (sum, sumsq over `count` elements per channel; all-reduced by the caller for SyncBN)
+/* stats [nrep][2C] (sum, sumsq over `count` elements per channel; for SyncBN the caller folds the
+ * replicas with pxl_bn_fold_replicas, all-reduces the [2C] vector and passes nrep = 1)
  * -> coef [4C] = mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; updates running stats
  * (momentum, unbiased variance).  training=0: coef from the running statistics.
  * clamp_var=1 selects the reference's multi-device formula clamp(var,eps)^-1/2
  * (sync_batchnorm/batchnorm.py:125) instead of (var+eps)^-1/2 (F.batch_norm, :50-53). */
-int pxl_bn_finalize(int C, const float* stats, float count, const float* gamma, const float* beta,
+int pxl_bn_finalize(int C, const float* stats, int nrep, float count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, int training,
                     int clamp_var, float* coef, void* stream);
-/* sums [2C] (caller-zeroed) += sum dz', sum dz'*xhat with dz' = dz * (relu ? bn(y) > 0 : 1) */
+/* buf[0][i] = sum_r buf[r][i], i < n */
+int pxl_bn_fold_replicas(int n, int nrep, float* buf, void* stream);
+/* sums [nrep][2C] (caller-zeroed) += sum dz', sum dz'*xhat with dz' = dz * (relu ? bn(y) > 0 : 1) */
 int pxl_bn_bwd_reduce(int dtype, int M, int C, const void* dz, const void* y, const float* coef, int relu,
-                      float* sums, void* stream);
-/* bcoef [2C] = sums / count ; dgamma += sum dz'*xhat ; dbeta += sum dz' */
-int pxl_bn_bwd_finalize(int C, const float* sums, float count, float* dgamma, float* dbeta, float* bcoef,
-                        void* stream);
+                      float* sums, int nrep, void* stream);
+/* bcoef [2C] = fold(sums) / count ; dgamma += sum dz'*xhat ; dbeta += sum dz' */
+int pxl_bn_bwd_finalize(int C, const float* sums, int nrep, float count, float* dgamma, float* dbeta,
+                        float* bcoef, void* stream);
 /* dy = scale * (dz' - bcoef0 - xhat*bcoef1)  -- gradient w.r.t. the raw conv output (in place allowed) */
 int pxl_bn_bwd_apply(int dtype, int M, int C, const void* dz, const void* y, const float* coef,
                      const float* bcoef, int relu, void* dy, void* stream);

@@ -34,8 +34,12 @@ BN_MOMENTUM = 0.1   # same
 # Architecture tables
 # -----------------------------------------------------------------------------
 
-def resnet101_os16_table():
-    """Layer table of the reference backbone.
+RESNET101 = (3, 4, 23, 3)
+
+
+def resnet101_os16_table(layers=RESNET101):
+    """Layer table of the reference backbone (`layers` = blocks per stage; the reference's ResNet101 is
+    (3, 4, 23, 3), shallower tuples are used by the tests to bound numeric amplification).
 
     Follows task/sseg/module/backbone/resnet.py:58-66 (os16: strides 1,2,2,1;
     dilations 1,1,1,2), :87-100 (_make_layer), :102-119 (_make_MG_unit with
@@ -46,10 +50,10 @@ def resnet101_os16_table():
     """
     stages = []
     cin = 64
-    plan = [("layer1", 64, 3, 1, [1, 1, 1]),
-            ("layer2", 128, 4, 2, [1, 1, 1, 1]),
-            ("layer3", 256, 23, 2, [1] * 23),
-            ("layer4", 512, 3, 1, [2, 4, 8])]   # dilation 2 x multi-grid (1,2,4)
+    plan = [("layer1", 64, layers[0], 1, [1] * layers[0]),
+            ("layer2", 128, layers[1], 2, [1] * layers[1]),
+            ("layer3", 256, layers[2], 2, [1] * layers[2]),
+            ("layer4", 512, 3, 1, [2, 4, 8])]   # MG unit: always 3 blocks, dilation 2 x multi-grid (1,2,4)
     for lname, planes, nblk, stride, dils in plan:
         blocks = []
         for b in range(nblk):
@@ -65,7 +69,7 @@ def resnet101_os16_table():
 ASPP_RATES = (6, 12, 18, 24)   # task/sseg/module/deeplab_v2.py:23
 
 
-def deeplabv2_param_shapes(num_classes=21):
+def deeplabv2_param_shapes(num_classes=21, layers=RESNET101):
     """OrderedDict name -> shape for every parameter and buffer, in the
     reference's state_dict order and naming (prefix-free: 'backbone.conv1.weight')."""
     sd = OrderedDict()
@@ -79,7 +83,7 @@ def deeplabv2_param_shapes(num_classes=21):
 
     sd["backbone.conv1.weight"] = (64, 3, 7, 7)
     bn("backbone.bn1", 64)
-    for stage in resnet101_os16_table():
+    for stage in resnet101_os16_table(layers):
         for blk in stage:
             p = "backbone." + blk["name"]
             pl = blk["planes"]
@@ -103,14 +107,14 @@ def is_buffer(name):
         or name.endswith("num_batches_tracked")
 
 
-def init_deeplabv2_state(num_classes=21, seed=0):
+def init_deeplabv2_state(num_classes=21, seed=0, layers=RESNET101):
     """Random init with the reference's distributions (not its RNG stream):
     conv ~ N(0, sqrt(2/(k*k*cout))) resnet.py:133-137; BN gamma=1 beta=0 :138-143;
     ASPP weight ~ N(0, 0.01), bias = torch Conv2d default U(-1/sqrt(fan_in), ..)
     deeplab_v2.py:76-79."""
     g = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
-    for name, shape in deeplabv2_param_shapes(num_classes).items():
+    for name, shape in deeplabv2_param_shapes(num_classes, layers).items():
         if name.endswith("num_batches_tracked"):
             sd[name] = torch.zeros((), dtype=torch.long)
         elif name.endswith("running_mean"):
@@ -153,12 +157,12 @@ def _bn(sd, prefix, x, train):
                         train, BN_MOMENTUM, BN_EPS)
 
 
-def resnet_forward(sd, x, train=True, prefix="backbone"):
+def resnet_forward(sd, x, train=True, prefix="backbone", layers=RESNET101):
     """task/sseg/module/backbone/resnet.py:121-131 (+ Bottleneck.forward :30-50)."""
     h = F.conv2d(x, sd[prefix + ".conv1.weight"], None, stride=2, padding=3)
     h = F.relu(_bn(sd, prefix + ".bn1", h, train))
     h = F.max_pool2d(h, kernel_size=3, stride=2, padding=1)
-    for stage in resnet101_os16_table():
+    for stage in resnet101_os16_table(layers):
         for blk in stage:
             p = prefix + "." + blk["name"]
             o = F.conv2d(h, sd[p + ".conv1.weight"])
@@ -188,12 +192,12 @@ def aspp_forward(sd, feat, prefix="classifier"):
     return out
 
 
-def deeplabv2_forward(sd, x, train=True):
+def deeplabv2_forward(sd, x, train=True, layers=RESNET101):
     """DeepLabV2.forward (task/sseg/module/deeplab_v2.py:29-33) followed by the
     softmax of DeepLab.forward (task/sseg/model.py:59-65).
 
     Returns (logits NCHW, softmax NCHW, latent NCHW, lowres_logits)."""
-    feat = resnet_forward(sd, x, train)
+    feat = resnet_forward(sd, x, train, layers=layers)
     low = aspp_forward(sd, feat)
     logits = F.interpolate(low, size=x.shape[2:], mode="bilinear", align_corners=True)
     return logits, F.softmax(logits, dim=1), feat, low

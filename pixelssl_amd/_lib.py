@@ -24,6 +24,7 @@ class ConvDesc(C.Structure):
                 ("Cin", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
                 ("Kreal", C.c_int32), ("ntaps", C.c_int32), ("out_stride", C.c_int32),
                 ("div", C.c_int32), ("relu_in", C.c_int32), ("tile_cfg", C.c_int32),
+                ("stats_rep", C.c_int32), ("split_k", C.c_int32),
                 ("dy", C.c_int16 * 64), ("dx", C.c_int16 * 64)]
 
 
@@ -54,14 +55,15 @@ _Z = C.c_size_t
 SIGNATURES = {
     "pxl_last_error": (C.c_char_p, []),
     "pxl_version": (_I, []),
-    "pxl_conv_igemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pxl_conv_igemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "pxl_conv_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _I, _P]),
     "pxl_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P]),
     "pxl_nchw_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "pxl_nhwc_to_nchw": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "pxl_bn_finalize": (_I, [_I, _P, _F, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P]),
-    "pxl_bn_bwd_reduce": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _P]),
-    "pxl_bn_bwd_finalize": (_I, [_I, _P, _F, _P, _P, _P, _P]),
+    "pxl_bn_finalize": (_I, [_I, _P, _I, _F, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P]),
+    "pxl_bn_fold_replicas": (_I, [_I, _I, _P, _P]),
+    "pxl_bn_bwd_reduce": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
+    "pxl_bn_bwd_finalize": (_I, [_I, _P, _I, _F, _P, _P, _P, _P]),
     "pxl_bn_bwd_apply": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "pxl_residual_fwd": (_I, [_I, _L, _I, _P, _P, _P, _P, _P, _P]),
     "pxl_relu_mask": (_I, [_I, _L, _P, _P, _P, _P, _P]),

@@ -31,6 +31,9 @@ struct ConvArgs {
   const float* bias;
   const void* addend;
   float* stats;
+  float* ws;       // split-K fp32 accumulation buffer [M][Cout] (pre-zeroed), nullptr when splitk == 1
+  int stats_rep;   // replicas of the [2*Kreal] statistics vector (spreads same-address atomics)
+  int splitk, nk_per;
   int B, Hi, Wi, Cin;
   int Ho, Wo, Cout, Kreal;
   int ntaps, so, div_shift, div_mask, relu_in;
@@ -119,9 +122,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       a_base[i] = 0;
     }
   }
-  // k cursor of this thread's chunk column: (tap, channel)
-  int kt = 0, kc = chunk * EPC;
-  while (kc >= p.Cin) { kc -= p.Cin; ++kt; }
+  // split-K slice of this block and the k cursor of this thread's chunk column: (tap, channel)
+  const int ks_begin = blockIdx.y * p.nk_per;
+  const int ks_end = min(p.nk, ks_begin + p.nk_per);
+  int kt, kc;
+  {
+    const int kidx0 = ks_begin * BK + chunk * EPC;
+    kt = kidx0 / p.Cin;
+    kc = kidx0 - kt * p.Cin;
+  }
 
   const T* __restrict__ gin = reinterpret_cast<const T*>(p.in);
   const T* __restrict__ gw = reinterpret_cast<const T*>(p.w);
@@ -199,15 +208,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   __syncthreads();   // taps / affine visible
-  load_tiles(0);
+  load_tiles(ks_begin);
   store_tiles(0);
   __syncthreads();
 
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
-  for (int ks = 0; ks < p.nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < p.nk) load_tiles(ks + 1);
+  for (int ks = ks_begin; ks < ks_end; ++ks) {
+    const int buf = (ks - ks_begin) & 1;
+    if (ks + 1 < ks_end) load_tiles(ks + 1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int ch = fhalf + 2 * kk;
@@ -227,8 +236,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[i], fb[j], acc[i][j]);
     }
-    if (ks + 1 < p.nk) store_tiles(buf ^ 1);
+    if (ks + 1 < ks_end) store_tiles(buf ^ 1);
     __syncthreads();
+  }
+
+  if (p.splitk > 1) {
+    // partial sums of this K slice -> fp32 workspace; bias / conversion happen in splitk_finish_kernel
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + frow;
+      if (n >= p.Kreal) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+          if (m < p.M) atomicAdd(p.ws + (size_t)m * p.Cout + n, acc[i][j][r]);
+        }
+    }
+    return;
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
@@ -259,29 +285,65 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
       if (fhalf == 0 && n < p.Kreal) {
-        atomicAdd(p.stats + n, s1);
-        atomicAdd(p.stats + p.Kreal + n, s2);
+        float* rep = p.stats + (size_t)(tm % p.stats_rep) * 2 * p.Kreal;
+        atomicAdd(rep + n, s1);
+        atomicAdd(rep + p.Kreal + n, s2);
       }
     }
   }
 }
 
+// out[m][n] = T(ws[m][n] + bias[n]) for n < Kreal, 0 for padded channels
+template <typename T>
+__global__ void splitk_finish_kernel(long total, int Cout, int Kreal, const float* __restrict__ ws,
+                                     const float* __restrict__ bias, T* __restrict__ out) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % Cout);
+    float v = 0.f;
+    if (n < Kreal) v = ws[i] + (bias ? bias[n] : 0.f);
+    out[i] = from_f<T>(v);
+  }
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
-int launch_cfg(const ConvArgs& a, hipStream_t stream) {
+int launch_cfg(const ConvArgs& a, int want_split, size_t ws_bytes, hipStream_t stream) {
   ConvArgs p = a;
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.Cout, BN);
   constexpr int BK = 4 * Elem<T>::EPC;
   p.nk = cdiv(p.Ktot, BK);
-  const size_t smem = 2 * (BM + BN) * 64 + 256 + (p.in_scale ? 2 * (size_t)p.Cin * 4 : 0);
   const int grid = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN>), dim3(grid), dim3(256), smem, stream, p);
+  // split-K: only for launches that cannot fill the chip and have a long reduction (ASPP: 69 tiles, K = 73728)
+  int splitk = 1;
+  const bool can_split = p.ws != nullptr && p.stats == nullptr && p.addend == nullptr &&
+                         ws_bytes >= (size_t)p.M * p.Cout * sizeof(float);
+  if (can_split) {
+    if (want_split > 1) splitk = want_split;
+    else if (want_split <= 0 && grid < 200 && p.nk >= 64) splitk = min(cdiv(640, grid), p.nk / 16);
+    if (splitk > p.nk) splitk = p.nk;
+    if (splitk < 1) splitk = 1;
+  }
+  p.nk_per = cdiv(p.nk, splitk);
+  splitk = cdiv(p.nk, p.nk_per);
+  p.splitk = splitk;
+  if (splitk > 1) PXL_CHECK_HIP(hipMemsetAsync(p.ws, 0, (size_t)p.M * p.Cout * sizeof(float), stream));
+  else p.ws = nullptr;
+  const size_t smem = 2 * (BM + BN) * 64 + 256 + (p.in_scale ? 2 * (size_t)p.Cin * 4 : 0);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN>), dim3(grid, splitk), dim3(256), smem, stream, p);
   PXL_LAUNCH_CHECK();
+  if (splitk > 1) {
+    const long total = (long)p.M * p.Cout;
+    long g = (total + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((int)g), dim3(256), 0, stream, total, p.Cout, p.Kreal, p.ws,
+                       p.bias, reinterpret_cast<T*>(p.out));
+    PXL_LAUNCH_CHECK();
+  }
   return PXL_OK;
 }
 
 template <typename T>
-int launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
+int launch_conv(const ConvArgs& a, int force_cfg, int want_split, size_t ws_bytes, hipStream_t stream) {
   const int M = a.M, N = a.Cout;
   int cfg = force_cfg;
   if (cfg < 0) {
@@ -296,10 +358,10 @@ int launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
     }
   }
   switch (cfg) {
-    case 0: return launch_cfg<T, 128, 128, 2, 2>(a, stream);
-    case 1: return launch_cfg<T, 128, 64, 2, 2>(a, stream);
-    case 2: return launch_cfg<T, 64, 64, 2, 2>(a, stream);
-    case 3: return launch_cfg<T, 128, 32, 4, 1>(a, stream);
+    case 0: return launch_cfg<T, 128, 128, 2, 2>(a, want_split, ws_bytes, stream);
+    case 1: return launch_cfg<T, 128, 64, 2, 2>(a, want_split, ws_bytes, stream);
+    case 2: return launch_cfg<T, 64, 64, 2, 2>(a, want_split, ws_bytes, stream);
+    case 3: return launch_cfg<T, 128, 32, 4, 1>(a, want_split, ws_bytes, stream);
     default: return pxl_set_error(PXL_ERR_ARG, "conv_igemm: unknown tile config %d", cfg);
   }
 }
@@ -308,7 +370,8 @@ int launch_conv(const ConvArgs& a, int force_cfg, hipStream_t stream) {
 
 extern "C" int pxl_conv_igemm(const pxl_conv_desc* d, const void* in, const void* w, void* out,
                               const float* in_scale, const float* in_shift, const float* bias,
-                              const void* addend, float* stats, void* stream) {
+                              const void* addend, float* stats, void* workspace, size_t ws_bytes,
+                              void* stream) {
   PXL_REQUIRE(d && in && w && out, "conv_igemm: null argument");
   PXL_REQUIRE(d->dtype == PXL_F32 || d->dtype == PXL_BF16, "conv_igemm: bad dtype %d", d->dtype);
   const int epc = d->dtype == PXL_F32 ? 4 : 8;
@@ -322,6 +385,9 @@ extern "C" int pxl_conv_igemm(const pxl_conv_desc* d, const void* in, const void
   ConvArgs a;
   a.in = in; a.w = w; a.out = out;
   a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.addend = addend; a.stats = stats;
+  a.ws = reinterpret_cast<float*>(workspace);
+  a.stats_rep = d->stats_rep >= 1 ? d->stats_rep : 1;
+  a.splitk = 1; a.nk_per = 0;
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.Kreal = d->Kreal;
   a.ntaps = d->ntaps; a.so = d->out_stride;
@@ -333,6 +399,6 @@ extern "C" int pxl_conv_igemm(const pxl_conv_desc* d, const void* in, const void
     a.taps[t] = t < d->ntaps ? (((int)d->dy[t]) << 16) | (((int)d->dx[t]) & 0xffff) : 0;
   a.nk = 0; a.tiles_m = a.tiles_n = 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d->dtype == PXL_F32) return launch_conv<float>(a, d->tile_cfg, s);
-  return launch_conv<bf16_t>(a, d->tile_cfg, s);
+  if (d->dtype == PXL_F32) return launch_conv<float>(a, d->tile_cfg, d->split_k, ws_bytes, s);
+  return launch_conv<bf16_t>(a, d->tile_cfg, d->split_k, ws_bytes, s);
 }

@@ -13,28 +13,38 @@ inline int grid_for(long n, int block = 256) {
   return (int)g;
 }
 
+// Per-channel-affine element-wise kernels keep their channel chunk FIXED per thread and walk rows, so the
+// per-channel coefficients are loaded once into registers (not once per element).
 template <typename T>
-__global__ __launch_bounds__(256) void residual_fwd_kernel(long nchunks, int C, const T* __restrict__ y,
+__global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T* __restrict__ y,
                                                            const float* __restrict__ ycoef,
                                                            const T* __restrict__ res,
                                                            const float* __restrict__ rcoef,
                                                            T* __restrict__ out) {
   constexpr int EPC = Elem<T>::EPC;
   const int cpr = C / EPC;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % cpr) * EPC;
-    float fy[EPC], fr[EPC], o[EPC];
-    Chunk<T>::unpack(reinterpret_cast<const uint4*>(y)[i], fy);
-    Chunk<T>::unpack(reinterpret_cast<const uint4*>(res)[i], fr);
+  const int cpb = cpr < 256 ? cpr : 256;     // chunk columns per block pass
+  const int rpb = 256 / cpb;                 // rows in flight per block
+  const int ccol = threadIdx.x % cpb, rlane = threadIdx.x / cpb;
+  for (int c0 = 0; c0 < cpr; c0 += cpb) {
+    const int cc = c0 + ccol;
+    if (cc >= cpr || rlane >= rpb) continue;
+    float ys[EPC], yb[EPC], rs[EPC], rb[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      const int c = c0 + e;
-      float v = fy[e] * ycoef[2 * C + c] + ycoef[3 * C + c];
-      float r = fr[e];
-      if (rcoef != nullptr) r = r * rcoef[2 * C + c] + rcoef[3 * C + c];
-      o[e] = fmaxf(v + r, 0.f);
+      const int c = cc * EPC + e;
+      ys[e] = ycoef[2 * C + c]; yb[e] = ycoef[3 * C + c];
+      rs[e] = rcoef ? rcoef[2 * C + c] : 1.f; rb[e] = rcoef ? rcoef[3 * C + c] : 0.f;
     }
-    reinterpret_cast<uint4*>(out)[i] = Chunk<T>::pack(o);
+    for (int m = blockIdx.x * rpb + rlane; m < M; m += gridDim.x * rpb) {
+      const size_t o = (size_t)m * C + cc * EPC;
+      float fy[EPC], fr[EPC], v[EPC];
+      Chunk<T>::unpack(*reinterpret_cast<const uint4*>(y + o), fy);
+      Chunk<T>::unpack(*reinterpret_cast<const uint4*>(res + o), fr);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] = fmaxf(fy[e] * ys[e] + yb[e] + (fr[e] * rs[e] + rb[e]), 0.f);
+      *reinterpret_cast<uint4*>(out + o) = Chunk<T>::pack(v);
+    }
   }
 }
 
@@ -183,19 +193,27 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(int B, int Hi, int Wi,
 template <typename T> static const T* cp(const void* p) { return reinterpret_cast<const T*>(p); }
 template <typename T> static T* mp(void* p) { return reinterpret_cast<T*>(p); }
 
+inline int row_grid(long M, int C, int epc) {
+  const int cpr = C / epc;
+  const int rpb = 256 / (cpr < 256 ? cpr : 256);
+  long g = (M + rpb - 1) / rpb;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
 extern "C" int pxl_residual_fwd(int dtype, long M, int C, const void* y, const float* ycoef, const void* res,
                                 const float* rcoef, void* out, void* stream) {
   PXL_REQUIRE(y && ycoef && res && out, "residual_fwd: null argument");
   PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "residual_fwd: bad dtype");
   const int epc = dtype == PXL_F32 ? 4 : 8;
   PXL_REQUIRE(C % epc == 0, "residual_fwd: C=%d must be a multiple of %d", C, epc);
-  const long nchunks = M * (C / epc);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(residual_fwd_kernel<float>, dim3(grid_for(nchunks)), dim3(256), 0, s, nchunks, C,
+    hipLaunchKernelGGL(residual_fwd_kernel<float>, dim3(row_grid(M, C, epc)), dim3(256), 0, s, (int)M, C,
                        cp<float>(y), ycoef, cp<float>(res), rcoef, mp<float>(out));
   else
-    hipLaunchKernelGGL(residual_fwd_kernel<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, s, nchunks, C,
+    hipLaunchKernelGGL(residual_fwd_kernel<bf16_t>, dim3(row_grid(M, C, epc)), dim3(256), 0, s, (int)M, C,
                        cp<bf16_t>(y), ycoef, cp<bf16_t>(res), rcoef, mp<bf16_t>(out));
   PXL_LAUNCH_CHECK();
   return PXL_OK;

@@ -29,6 +29,7 @@ int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, v
 namespace {
 
 constexpr size_t ALIGN = 256;
+constexpr int STATS_REP = 32;   // replicas of every BN statistics vector (atomic-contention spreading)
 inline size_t align_up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
 inline int pitch_of(int c) { return c <= 8 ? 8 : (c + 31) / 32 * 32; }
 
@@ -60,6 +61,7 @@ struct OpInfo {
   pxl_conv_desc grp[4];    // per-group forward geometry (wgrad)
   size_t wf_off = 0, wt_off = 0, bias_off = 0;   // packed buffer offsets
   size_t idx_off = 0;      // arena: maxpool argmax
+  size_t ws_off = 0, ws_bytes = 0;               // arena: split-K fp32 workspace (small-N, long-K convs)
 };
 
 }  // namespace
@@ -103,6 +105,8 @@ int build_conv_descs(pxl_net* n, OpInfo& op, const TensorInfo& tin, const Tensor
   f.ntaps = op.ntaps; f.out_stride = d.stride; f.div = 1;
   f.relu_in = d.bn_in0 >= 0 ? 1 : 0;
   f.tile_cfg = -1;
+  f.stats_rep = STATS_REP;
+  f.split_k = 0;
   for (int g = 0; g < d.ngroups; ++g)
     for (int r = 0; r < d.kh; ++r)
       for (int s = 0; s < d.kw; ++s) {
@@ -115,7 +119,7 @@ int build_conv_descs(pxl_net* n, OpInfo& op, const TensorInfo& tin, const Tensor
   pxl_conv_desc b = f;
   b.Hi = tout.H; b.Wi = tout.W; b.Cin = tout.Cp;
   b.Ho = tin.H; b.Wo = tin.W; b.Cout = tin.Cp; b.Kreal = d.cin;
-  b.out_stride = 1; b.div = d.stride; b.relu_in = 0;
+  b.out_stride = 1; b.div = d.stride; b.relu_in = 0; b.stats_rep = 1;
   for (int t = 0; t < op.ntaps; ++t) { b.dy[t] = (int16_t)(-f.dy[t]); b.dx[t] = (int16_t)(-f.dx[t]); }
   op.bwd = b;
   for (int g = 0; g < d.ngroups; ++g) {
@@ -242,11 +246,11 @@ extern "C" int pxl_net_plan(pxl_net* n, int B, int H, int W) {
   size_t arena = 0, scratch = 0, packed = 0;
   // BN statistics first (contiguous -> one memset per pass)
   n->stats_region_off = arena;
-  for (auto& b : n->bns) { b.stats_off = arena; arena += align_up(2 * (size_t)b.d.C * 4); }
+  for (auto& b : n->bns) { b.stats_off = arena; arena += align_up(STATS_REP * 2 * (size_t)b.d.C * 4); }
   n->stats_region_bytes = arena - n->stats_region_off;
   for (auto& b : n->bns) { b.coef_off = arena; arena += align_up(4 * (size_t)b.d.C * 4); }
   n->bsum_region_off = scratch;
-  for (auto& b : n->bns) { b.bsum_off = scratch; scratch += align_up(2 * (size_t)b.d.C * 4); }
+  for (auto& b : n->bns) { b.bsum_off = scratch; scratch += align_up(STATS_REP * 2 * (size_t)b.d.C * 4); }
   n->bsum_region_bytes = scratch - n->bsum_region_off;
   for (auto& b : n->bns) { b.bcoef_off = scratch; scratch += align_up(2 * (size_t)b.d.C * 4); }
 
@@ -284,6 +288,10 @@ extern "C" int pxl_net_plan(pxl_net* n, int B, int H, int W) {
         op.wf_off = packed; packed += align_up((size_t)d.cout * op.ntaps * tin.Cp * n->esize);
         if (d.need_dgrad) { op.wt_off = packed; packed += align_up((size_t)tin.Cp * op.ntaps * tout.Cp * n->esize); }
         if (d.b_off[0] >= 0) { op.bias_off = packed; packed += align_up((size_t)d.cout * 4); }
+        if (d.bn_out < 0 && tout.Cp <= 32) {     // few output tiles + long reduction: allow split-K
+          op.ws_bytes = align_up((size_t)B * ho * wo * tout.Cp * 4);
+          op.ws_off = arena; arena += op.ws_bytes;
+        }
         if (d.bn_out >= 0) {
           PXL_REQUIRE(n->bns[d.bn_out].d.C == d.cout, "net_plan: BN %d has %d channels, conv %zu has %d", d.bn_out,
                       n->bns[d.bn_out].d.C, i, d.cout);
@@ -389,16 +397,20 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
         {
           Timed t(n, s, 0, conv_flops(n, d, tout));
           rc = pxl_conv_igemm(&op.fwd, at(arena, tin.off), at(packed, op.wf_off), at(arena, tout.off), sc, sh, bias,
-                              nullptr, stats, stream);
+                              nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr, op.ws_bytes, stream);
         }
         if (rc != PXL_OK) return rc;
         if (d.bn_out >= 0) {
           BnInfo& b = n->bns[d.bn_out];
+          int nrep = STATS_REP;
           if (training && n->sync && n->world > 1) {
+            rc = pxl_bn_fold_replicas(2 * b.d.C, STATS_REP, fat(arena, b.stats_off), stream);
+            if (rc != PXL_OK) return rc;
             rc = n->sync(n->sync_user, fat(arena, b.stats_off), 2 * b.d.C, stream);
             if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_forward: SyncBN all-reduce hook failed (%d)", rc);
+            nrep = 1;
           }
-          rc = pxl_bn_finalize(b.d.C, fat(arena, b.stats_off), (float)b.M * n->world, params + b.d.gamma_off,
+          rc = pxl_bn_finalize(b.d.C, fat(arena, b.stats_off), nrep, (float)b.M * n->world, params + b.d.gamma_off,
                                params + b.d.beta_off, running ? running + b.d.rmean_off : nullptr,
                                running ? running + b.d.rvar_off : nullptr, b.d.momentum, b.d.eps, training,
                                n->world > 1 ? 1 : 0, fat(arena, b.coef_off), stream);
@@ -515,13 +527,18 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         if (d.bn_out >= 0) {
           BnInfo& b = n->bns[d.bn_out];
           const float* coef = fat(arena, b.coef_off);
-          rc = pxl_bn_bwd_reduce(dt, M, tout.Cp, dy, at(arena, tout.off), coef, b.relu, fat(scratch, b.bsum_off), stream);
+          rc = pxl_bn_bwd_reduce(dt, M, tout.Cp, dy, at(arena, tout.off), coef, b.relu, fat(scratch, b.bsum_off),
+                                 STATS_REP, stream);
           if (rc != PXL_OK) return rc;
+          int nrep = STATS_REP;
           if (n->sync && n->world > 1) {
+            rc = pxl_bn_fold_replicas(2 * b.d.C, STATS_REP, fat(scratch, b.bsum_off), stream);
+            if (rc != PXL_OK) return rc;
             rc = n->sync(n->sync_user, fat(scratch, b.bsum_off), 2 * b.d.C, stream);
             if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_backward: SyncBN all-reduce hook failed (%d)", rc);
+            nrep = 1;
           }
-          rc = pxl_bn_bwd_finalize(b.d.C, fat(scratch, b.bsum_off), (float)b.M * n->world, grads + b.d.gamma_off,
+          rc = pxl_bn_bwd_finalize(b.d.C, fat(scratch, b.bsum_off), nrep, (float)b.M * n->world, grads + b.d.gamma_off,
                                    grads + b.d.beta_off, fat(scratch, b.bcoef_off), stream);
           if (rc != PXL_OK) return rc;
           rc = pxl_bn_bwd_apply(dt, M, tout.Cp, dy, at(arena, tout.off), coef, fat(scratch, b.bcoef_off), b.relu, dy, stream);
@@ -548,7 +565,7 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
           void* din = at(scratch, tin.goff);
           Timed t(n, s, 0, conv_flops(n, d, tout));
           rc = pxl_conv_igemm(&op.bwd, dy, at(packed, op.wt_off), din, nullptr, nullptr, nullptr,
-                              written[d.in0] ? din : nullptr, nullptr, stream);
+                              written[d.in0] ? din : nullptr, nullptr, nullptr, 0, stream);
           written[d.in0] = 1;
         }
         break;

@@ -235,6 +235,9 @@ class SegNetCore(nn.Module):
         s.allocate()
         pviews, rviews = s.param_views(), s.running_views()
         self._param_list = []
+        nbn = sum(1 for k in pb.modules.values() if k == "bn")
+        self._nbt = torch.zeros(max(nbn, 1), dtype=torch.long, device=self._device)   # all counters, one buffer
+        bn_index = 0
         for dotted, kind in pb.modules.items():
             leaf = SynchronizedBatchNorm2d() if kind == "bn" else _Leaf()
             for attr in ("weight", "bias"):
@@ -250,7 +253,8 @@ class SegNetCore(nn.Module):
             if kind == "bn":
                 leaf.register_buffer("running_mean", rviews[dotted + ".running_mean"])
                 leaf.register_buffer("running_var", rviews[dotted + ".running_var"])
-                leaf.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long, device=self._device))
+                leaf.register_buffer("num_batches_tracked", self._nbt[bn_index])
+                bn_index += 1
             self._attach(dotted, leaf)
         ops = (Op * len(pb.ops))(*pb.ops)
         bns = (BnDesc * len(pb.bns))(*pb.bns)
@@ -343,8 +347,7 @@ class SegNetCore(nn.Module):
                                     ptr(x), ptr(logits), ptr(prob), ptr(arena), arena.numel(), int(training),
                                     stream_ptr()))
         if training:
-            for m in self._bn_leaves():
-                m.num_batches_tracked += 1
+            self._nbt += 1          # every BN's num_batches_tracked is a view of this buffer
         return logits, prob
 
     def _bn_leaves(self):
@@ -436,10 +439,14 @@ class DeepLabV2Core(SegNetCore):
     def __init__(self, backbone="resnet101", output_stride=16, num_classes=21, device="cuda",
                  engine_dtype=torch.float32, freeze_bn=False):
         super().__init__(device, engine_dtype, num_classes)
-        if backbone not in RESNET_LAYERS:
+        if isinstance(backbone, (tuple, list)):
+            layers = tuple(backbone)           # blocks per stage (tests use shallow trunks)
+        elif backbone in RESNET_LAYERS:
+            layers = RESNET_LAYERS[backbone]
+        else:
             raise NotImplementedError("backbone %r" % backbone)
         pb = self._pb
-        feat, c = build_resnet_trunk(pb, "backbone", RESNET_LAYERS[backbone], output_stride)
+        feat, c = build_resnet_trunk(pb, "backbone", layers, output_stride)
         names = ["classifier.conv2d_list.%d" % i for i in range(len(ASPP_RATES))]
         low = pb.conv(names, feat, -1, c, num_classes, 3, 1, list(ASPP_RATES), list(ASPP_RATES), bias=True)
         pb.head(low, feat)

@@ -16,13 +16,14 @@ def _require_cuda(*ts):
 
 
 def conv_desc(dtype, B, Hi, Wi, Cin_p, Ho, Wo, Cout_p, Kreal, taps, out_stride=1, div=1, relu_in=False,
-              tile_cfg=-1):
+              tile_cfg=-1, stats_rep=1, split_k=0):
     d = ConvDesc()
     d.dtype = dtype_code(dtype)
     d.B, d.Hi, d.Wi, d.Cin = B, Hi, Wi, Cin_p
     d.Ho, d.Wo, d.Cout, d.Kreal = Ho, Wo, Cout_p, Kreal
     d.ntaps = len(taps)
     d.out_stride, d.div, d.relu_in, d.tile_cfg = out_stride, div, int(relu_in), tile_cfg
+    d.stats_rep, d.split_k = stats_rep, split_k
     for i, (dy, dx) in enumerate(taps):
         d.dy[i], d.dx[i] = dy, dx
     return d
@@ -32,10 +33,12 @@ def fwd_taps(kh, kw, dil, pad):
     return [(r * dil - pad, s * dil - pad) for r in range(kh) for s in range(kw)]
 
 
-def conv_igemm(desc, x, w, out, in_scale=None, in_shift=None, bias=None, addend=None, stats=None):
+def conv_igemm(desc, x, w, out, in_scale=None, in_shift=None, bias=None, addend=None, stats=None, workspace=None):
     _require_cuda(x, w, out)
     check(lib().pxl_conv_igemm(desc, ptr(x), ptr(w), ptr(out), ptr(in_scale), ptr(in_shift), ptr(bias),
-                               ptr(addend), ptr(stats), stream_ptr()))
+                               ptr(addend), ptr(stats), ptr(workspace),
+                               workspace.numel() * workspace.element_size() if workspace is not None else 0,
+                               stream_ptr()))
     return out
 
 
@@ -68,23 +71,25 @@ def nhwc_to_nchw(x, C):
     return y
 
 
-def bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5, training=True, clamp_var=False):
+def bn_finalize(stats, count, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5, training=True, clamp_var=False,
+                nrep=1):
     Cc = gamma.numel()
     coef = torch.empty(4 * Cc, device=gamma.device, dtype=torch.float32)
-    check(lib().pxl_bn_finalize(Cc, ptr(stats), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+    check(lib().pxl_bn_finalize(Cc, ptr(stats), nrep, float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
                                 momentum, eps, int(training), int(clamp_var), ptr(coef), stream_ptr()))
     return coef
 
 
-def bn_backward(dz, y, coef, count, relu, dgamma, dbeta):
+def bn_backward(dz, y, coef, count, relu, dgamma, dbeta, nrep=4):
     """dz,y: [M,C] engine dtype.  Returns dy (new tensor); accumulates dgamma/dbeta."""
     M, Cc = dz.shape[0], dz.shape[1]
     code = dtype_code(dz.dtype)
-    sums = torch.zeros(2 * Cc, device=dz.device, dtype=torch.float32)
+    sums = torch.zeros(nrep * 2 * Cc, device=dz.device, dtype=torch.float32)
     bcoef = torch.empty(2 * Cc, device=dz.device, dtype=torch.float32)
     dy = torch.empty_like(dz)
-    check(lib().pxl_bn_bwd_reduce(code, M, Cc, ptr(dz), ptr(y), ptr(coef), int(relu), ptr(sums), stream_ptr()))
-    check(lib().pxl_bn_bwd_finalize(Cc, ptr(sums), float(count), ptr(dgamma), ptr(dbeta), ptr(bcoef), stream_ptr()))
+    check(lib().pxl_bn_bwd_reduce(code, M, Cc, ptr(dz), ptr(y), ptr(coef), int(relu), ptr(sums), nrep, stream_ptr()))
+    check(lib().pxl_bn_bwd_finalize(Cc, ptr(sums), nrep, float(count), ptr(dgamma), ptr(dbeta), ptr(bcoef),
+                                    stream_ptr()))
     check(lib().pxl_bn_bwd_apply(code, M, Cc, ptr(dz), ptr(y), ptr(coef), ptr(bcoef), int(relu), ptr(dy),
                                  stream_ptr()))
     return dy

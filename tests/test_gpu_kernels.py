@@ -114,17 +114,20 @@ def test_conv_prologue_epilogue(dtype):
     ref = F.conv2d(a, qround(w, dtype), bias, 1, 1, 1) + qround(add, dtype)
     cip, cop = _pitch(Cin), _pitch(Cout)
     out = torch.empty(B, H, W, cop, device=DEV, dtype=dtype)
-    stats = torch.zeros(2 * Cout, device=DEV)
+    nrep = 3
+    stats = torch.zeros(nrep, 2 * Cout, device=DEV)
     wf, _ = pack_w(w, dtype, cip)
-    desc = ops.conv_desc(dtype, B, H, W, cip, H, W, cop, Cout, ops.fwd_taps(3, 3, 1, 1), relu_in=True)
+    desc = ops.conv_desc(dtype, B, H, W, cip, H, W, cop, Cout, ops.fwd_taps(3, 3, 1, 1), relu_in=True, stats_rep=nrep)
     ops.conv_igemm(desc, to_nhwc(x, cip, dtype), wf, out, in_scale=scale.to(DEV), in_shift=shift.to(DEV),
                    bias=bias.to(DEV), addend=to_nhwc(add, cop, dtype), stats=stats)
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(out, Cout), ref) < TOL[dtype]
     s1 = ref.sum(dim=(0, 2, 3))
     s2 = (ref * ref).sum(dim=(0, 2, 3))
-    assert rel_err(stats[:Cout].cpu(), s1) < 5 * TOL[dtype]
-    assert rel_err(stats[Cout:].cpu(), s2) < 5 * TOL[dtype]
+    folded = stats.sum(0).cpu()
+    assert rel_err(folded[:Cout], s1) < 5 * TOL[dtype]
+    assert rel_err(folded[Cout:], s2) < 5 * TOL[dtype]
+    assert (stats.abs().sum(1) > 0).all()          # every replica received some tiles
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -201,6 +204,21 @@ def test_aspp_multirate_as_one_launch():
     ops.conv_igemm(ops.conv_desc(dtype, B, H, W, cip, H, W, cop, Cout, taps), to_nhwc(x, cip, dtype), wf, out)
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(out, Cout), ref) < 2e-5
+    # split-K over the 36 taps (few output tiles, long reduction) with bias, bf16 and fp32
+    bias = torch.randn(Cout, generator=g)
+    for dt in (torch.float32, torch.bfloat16):
+        wf2 = torch.empty(Cout, 36, cip, device=DEV, dtype=dt)
+        for gi, w in enumerate(ws):
+            ops.pack_weights(dt, w.permute(0, 2, 3, 1).contiguous().to(DEV), Cout, 9, Cin, wf2, cip, T_total=36, t_off=9 * gi)
+        ref2 = sum(F.conv2d(qround(x, dt), qround(w, dt), None, 1, r, r) for w, r in zip(ws, rates)) + bias.view(1, -1, 1, 1)
+        for sk in (0, 1, 5):
+            o2 = torch.full((B, H, W, cop), 3.0, device=DEV, dtype=dt)
+            wsb = torch.empty(B * H * W * cop, device=DEV, dtype=torch.float32)
+            ops.conv_igemm(ops.conv_desc(dt, B, H, W, cip, H, W, cop, Cout, taps, split_k=sk), to_nhwc(x, cip, dt), wf2, o2,
+                           bias=bias.to(DEV), workspace=wsb)
+            torch.cuda.synchronize()
+            assert rel_err(from_nhwc(o2, Cout), ref2) < TOL[dt], (dt, sk)
+            assert o2[..., Cout:].float().abs().max().item() == 0.0
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -30,7 +30,7 @@ def test_argument_errors_are_reported_not_crashed():
     h = _lib.lib()
     d = _lib.ConvDesc()
     d.dtype, d.Cin, d.ntaps, d.div, d.Kreal, d.Cout = 7, 64, 1, 1, 8, 8
-    assert h.pxl_conv_igemm(d, 1, 1, 1, None, None, None, None, None, None) == -1
+    assert h.pxl_conv_igemm(d, 1, 1, 1, None, None, None, None, None, None, 0, None) == -1
     assert b"dtype" in h.pxl_last_error()
     with pytest.raises(_lib.PixelHipError):
         _lib.check(h.pxl_mse_fwd(0, None, None, None, None))
