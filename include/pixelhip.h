@@ -120,9 +120,10 @@ int pxl_bn_fold_replicas(int n, int nrep, float* buf, void* stream);
 /* sums [nrep][2C] (caller-zeroed) += sum dz', sum dz'*xhat with dz' = dz * (relu ? bn(y) > 0 : 1) */
 int pxl_bn_bwd_reduce(int dtype, int M, int C, const void* dz, const void* y, const float* coef, int relu,
                       float* sums, int nrep, void* stream);
-/* bcoef [2C] = fold(sums) / count ; dgamma += sum dz'*xhat ; dbeta += sum dz' */
+/* bcoef [2C] = fold(sums) / count (zeros when training == 0: eval-mode BN is a fixed affine);
+ * dgamma += sum dz'*xhat ; dbeta += sum dz' */
 int pxl_bn_bwd_finalize(int C, const float* sums, int nrep, float count, float* dgamma, float* dbeta,
-                        float* bcoef, void* stream);
+                        float* bcoef, int training, void* stream);
 /* dy = scale * (dz' - bcoef0 - xhat*bcoef1)  -- gradient w.r.t. the raw conv output (in place allowed) */
 int pxl_bn_bwd_apply(int dtype, int M, int C, const void* dz, const void* y, const float* coef,
                      const float* bcoef, int relu, void* dy, void* stream);
@@ -242,10 +243,11 @@ int pxl_net_forward(pxl_net* net, const float* params, const void* packed, float
 /* latent (backbone feature, NCHW fp32 [B,2048,h,w]) of the last forward held in `arena` */
 int pxl_net_latent(pxl_net* net, const void* arena, float* latent, void* stream);
 int pxl_net_latent_shape(const pxl_net* net, int* C, int* h, int* w);
-/* accumulates parameter gradients into `grads` (same layout as params; caller zeroes when needed) */
+/* accumulates parameter gradients into `grads` (same layout as params; caller zeroes when needed);
+ * `training` must equal the flag of the forward pass that filled `arena` */
 int pxl_net_backward(pxl_net* net, const float* params, const void* packed, const float* dlogits,
                      const float* dprob, const float* prob, float* grads, void* arena, size_t arena_bytes,
-                     void* scratch, size_t scratch_bytes, void* stream);
+                     void* scratch, size_t scratch_bytes, int training, void* stream);
 
 /* Measurement aid (bench.py roofline leg): bracket every contraction launch of this net with HIP
  * events on the launch stream.  kind 0 = implicit-GEMM conv (forward + data gradient), 1 = weight

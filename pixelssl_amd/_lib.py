@@ -63,7 +63,7 @@ SIGNATURES = {
     "pxl_bn_finalize": (_I, [_I, _P, _I, _F, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P]),
     "pxl_bn_fold_replicas": (_I, [_I, _I, _P, _P]),
     "pxl_bn_bwd_reduce": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
-    "pxl_bn_bwd_finalize": (_I, [_I, _P, _I, _F, _P, _P, _P, _P]),
+    "pxl_bn_bwd_finalize": (_I, [_I, _P, _I, _F, _P, _P, _P, _I, _P]),
     "pxl_bn_bwd_apply": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "pxl_residual_fwd": (_I, [_I, _L, _I, _P, _P, _P, _P, _P, _P]),
     "pxl_relu_mask": (_I, [_I, _L, _P, _P, _P, _P, _P]),
@@ -95,7 +95,7 @@ SIGNATURES = {
     "pxl_net_latent_shape": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "pxl_net_profile": (_I, [_P, _I]),
     "pxl_net_profile_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
-    "pxl_net_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
+    "pxl_net_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
 }
 
 _lib = None

@@ -121,13 +121,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int M, int C, const 
 // bcoef[0..C) = sum dzh / count ; bcoef[C..2C) = sum dzh*xhat / count ; accumulates dgamma, dbeta.
 __global__ void bn_bwd_finalize_kernel(int C, const float* __restrict__ sums, int nrep, float total_count,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ bcoef) {
+                                       float* __restrict__ bcoef, int training) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float s1 = 0.f, s2 = 0.f;
   for (int r = 0; r < nrep; ++r) { s1 += sums[(size_t)r * 2 * C + c]; s2 += sums[(size_t)r * 2 * C + C + c]; }
-  bcoef[c] = s1 / total_count;
-  bcoef[C + c] = s2 / total_count;
+  // eval-mode BN (running statistics, freeze_bn) is a fixed affine: no batch-mean terms in dy
+  bcoef[c] = training ? s1 / total_count : 0.f;
+  bcoef[C + c] = training ? s2 / total_count : 0.f;
   if (dgamma) dgamma[c] += s2;
   if (dbeta) dbeta[c] += s1;
 }
@@ -223,10 +224,10 @@ extern "C" int pxl_bn_bwd_reduce(int dtype, int M, int C, const void* dz, const 
 }
 
 extern "C" int pxl_bn_bwd_finalize(int C, const float* sums, int nrep, float count, float* dgamma, float* dbeta,
-                                   float* bcoef, void* stream) {
+                                   float* bcoef, int training, void* stream) {
   PXL_REQUIRE(C > 0 && sums && bcoef && nrep >= 1, "bn_bwd_finalize: bad argument");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), C, sums, nrep, count, dgamma, dbeta, bcoef);
+                     reinterpret_cast<hipStream_t>(stream), C, sums, nrep, count, dgamma, dbeta, bcoef, training);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

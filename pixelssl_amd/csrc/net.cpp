@@ -467,7 +467,8 @@ extern "C" int pxl_net_latent(pxl_net* n, const void* arena, float* latent, void
 
 extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* packed, const float* dlogits,
                                 const float* dprob, const float* prob, float* grads, void* arena,
-                                size_t arena_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+                                size_t arena_bytes, void* scratch, size_t scratch_bytes, int training,
+                                void* stream) {
   PXL_REQUIRE(n && n->planned && params && packed && grads && arena && scratch, "net_backward: bad argument");
   PXL_REQUIRE(dlogits || dprob, "net_backward: no incoming gradient");
   if (arena_bytes < n->arena_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_backward: arena too small");
@@ -531,7 +532,7 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
                                  STATS_REP, stream);
           if (rc != PXL_OK) return rc;
           int nrep = STATS_REP;
-          if (n->sync && n->world > 1) {
+          if (training && n->sync && n->world > 1) {
             rc = pxl_bn_fold_replicas(2 * b.d.C, STATS_REP, fat(scratch, b.bsum_off), stream);
             if (rc != PXL_OK) return rc;
             rc = n->sync(n->sync_user, fat(scratch, b.bsum_off), 2 * b.d.C, stream);
@@ -539,7 +540,7 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
             nrep = 1;
           }
           rc = pxl_bn_bwd_finalize(b.d.C, fat(scratch, b.bsum_off), nrep, (float)b.M * n->world, grads + b.d.gamma_off,
-                                   grads + b.d.beta_off, fat(scratch, b.bcoef_off), stream);
+                                   grads + b.d.beta_off, fat(scratch, b.bcoef_off), training, stream);
           if (rc != PXL_OK) return rc;
           rc = pxl_bn_bwd_apply(dt, M, tout.Cp, dy, at(arena, tout.off), coef, fat(scratch, b.bcoef_off), b.relu, dy, stream);
           if (rc != PXL_OK) return rc;

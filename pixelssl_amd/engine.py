@@ -405,6 +405,7 @@ class _SegNetFn(torch.autograd.Function):
     def forward(ctx, x, anchor, core, arena):
         logits, prob = core._forward_raw(x, arena)
         ctx.core, ctx.arena = core, arena
+        ctx.bn_training = bool(core.training and not core.freeze_bn)
         ctx.save_for_backward(prob)
         ctx.set_materialize_grads(False)
         return logits, prob
@@ -423,7 +424,7 @@ class _SegNetFn(torch.autograd.Function):
         s = core._store
         check(lib().pxl_net_backward(core._net, ptr(s.params), ptr(core._packed), ptr(dlogits), ptr(dprob), ptr(prob),
                                      ptr(s.grads), ptr(ctx.arena), ctx.arena.numel(), ptr(core._scratch),
-                                     core._scratch.numel(), stream_ptr()))
+                                     core._scratch.numel(), int(ctx.bn_training), stream_ptr()))
         hook = getattr(core, "_post_backward_hook", None)
         if hook is not None:
             hook(core)

@@ -88,7 +88,7 @@ def bn_backward(dz, y, coef, count, relu, dgamma, dbeta, nrep=4):
     bcoef = torch.empty(2 * Cc, device=dz.device, dtype=torch.float32)
     dy = torch.empty_like(dz)
     check(lib().pxl_bn_bwd_reduce(code, M, Cc, ptr(dz), ptr(y), ptr(coef), int(relu), ptr(sums), nrep, stream_ptr()))
-    check(lib().pxl_bn_bwd_finalize(Cc, ptr(sums), nrep, float(count), ptr(dgamma), ptr(dbeta), ptr(bcoef),
+    check(lib().pxl_bn_bwd_finalize(Cc, ptr(sums), nrep, float(count), ptr(dgamma), ptr(dbeta), ptr(bcoef), 1,
                                     stream_ptr()))
     check(lib().pxl_bn_bwd_apply(code, M, Cc, ptr(dz), ptr(y), ptr(coef), ptr(bcoef), int(relu), ptr(dy),
                                  stream_ptr()))
