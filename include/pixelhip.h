@@ -98,6 +98,17 @@ int pxl_conv_wgrad(const pxl_conv_desc* desc, const void* in, const float* in_sc
 int pxl_pack_weights(int dtype, const float* w, int K, int T, int C, void* wf, int Cp, int T_total,
                      int t_off, void* wt, int Kp, void* stream);
 
+/* batched form: params + src_off (floats) -> packed + wf_off / wt_off (bytes; wt_off < 0 = no dgrad operand) */
+typedef struct pxl_pack_item {
+  int64_t src_off;      /* floats, into params */
+  int64_t wf_off;       /* bytes, into packed  */
+  int64_t wt_off;       /* bytes, into packed; -1 = none */
+  int32_t K, T, C;      /* master tensor [K][T][C] */
+  int32_t Cp, T_total, t_off, Kp;
+} pxl_pack_item;
+int pxl_pack_weights_batched(int dtype, const float* params, void* packed, const pxl_pack_item* items, int n,
+                             void* stream);
+
 /* layout conversion at the API edge: NCHW fp32 <-> NHWC engine dtype (channel pitch Cp >= C) */
 int pxl_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W, int Cp, void* stream);
 int pxl_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H, int W, int Cp, void* stream);
@@ -234,6 +245,10 @@ size_t pxl_net_packed_bytes(const pxl_net* net);     /* persistent packed-weight
 size_t pxl_net_arena_bytes(const pxl_net* net);      /* activations saved between fwd and bwd      */
 size_t pxl_net_scratch_bytes(const pxl_net* net);    /* backward gradient buffers                  */
 int pxl_net_set_sync(pxl_net* net, pxl_allreduce_fn fn, void* user, int world_size);
+/* autotune: time every tile configuration of every contraction on the planned shapes and keep the
+ * fastest (call once after plan + pack; clobbers arena / scratch / grads contents; synchronises) */
+int pxl_net_tune(pxl_net* net, const float* params, const void* packed, float* grads, void* arena,
+                 size_t arena_bytes, void* scratch, size_t scratch_bytes, void* stream);
 /* repack params -> packed (call after every parameter update) */
 int pxl_net_pack(pxl_net* net, const float* params, void* packed, void* stream);
 /* x NCHW fp32 [B,3,H,W] -> logits/prob NCHW fp32 [B,classes,H,W]; training selects batch statistics

@@ -37,6 +37,12 @@ class Op(C.Structure):
                 ("need_dgrad", C.c_int32)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("src_off", C.c_int64), ("wf_off", C.c_int64), ("wt_off", C.c_int64), ("K", C.c_int32),
+                ("T", C.c_int32), ("C", C.c_int32), ("Cp", C.c_int32), ("T_total", C.c_int32),
+                ("t_off", C.c_int32), ("Kp", C.c_int32)]
+
+
 class BnDesc(C.Structure):
     _fields_ = [("C", C.c_int32), ("gamma_off", C.c_int32), ("beta_off", C.c_int32),
                 ("rmean_off", C.c_int32), ("rvar_off", C.c_int32), ("eps", C.c_float),
@@ -58,6 +64,7 @@ SIGNATURES = {
     "pxl_conv_igemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "pxl_conv_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _I, _P]),
     "pxl_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P]),
+    "pxl_pack_weights_batched": (_I, [_I, _P, _P, C.POINTER(PackItem), _I, _P]),
     "pxl_nchw_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "pxl_nhwc_to_nchw": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "pxl_bn_finalize": (_I, [_I, _P, _I, _F, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P]),
@@ -89,6 +96,7 @@ SIGNATURES = {
     "pxl_net_arena_bytes": (_Z, [_P]),
     "pxl_net_scratch_bytes": (_Z, [_P]),
     "pxl_net_set_sync": (_I, [_P, ALLREDUCE_FN, _P, _I]),
+    "pxl_net_tune": (_I, [_P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
     "pxl_net_pack": (_I, [_P, _P, _P, _P]),
     "pxl_net_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
     "pxl_net_latent": (_I, [_P, _P, _P, _P]),

@@ -64,6 +64,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+  constexpr int PF = 3;                      // register prefetch stages (tiles in flight)
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BK = 4 * EPC;                // elements per 64-byte row slice
   constexpr int RA = (BM + 63) / 64;         // A rows per thread
@@ -135,9 +136,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   const T* __restrict__ gin = reinterpret_cast<const T*>(p.in);
   const T* __restrict__ gw = reinterpret_cast<const T*>(p.w);
 
-  uint4 ra[RA], rb[RB];
+  // PF register stages: tiles k+1 .. k+PF are in flight while tile k is multiplied, so a block keeps
+  // PF global-load batches outstanding (the M = 8712 layers run ~2 blocks per CU and are latency-bound
+  // with a single stage).  The prologue transform is applied when a stage is written to LDS, never at
+  // issue time, so it does not serialise the load.
+  uint4 ra[PF][RA], rb[PF][RB];
+  int st_ok[PF], st_kc[PF];
 
-  auto load_tiles = [&](int kstep) {
+  auto issue_loads = [&](int kstep, uint4 (&qa)[RA], uint4 (&qb)[RB], int& okmask, int& kc_saved) {
     const bool kvalid = kt < p.ntaps;
     int dy = 0, dx = 0;
     if (kvalid) {
@@ -145,6 +151,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       dy = tp >> 16;
       dx = (int)(short)(tp & 0xffff);
     }
+    okmask = 0;
+    kc_saved = kc;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const int ny = a_iy0[i] + dy, nx = a_ix0[i] + dx;
@@ -156,18 +164,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       if (ok) {
         const size_t off = ((size_t)(a_base[i] + iy * p.Wi + ix)) * p.Cin + kc;
         v = *reinterpret_cast<const uint4*>(gin + off);
-        if (has_aff) {
-          float f[EPC];
-          Chunk<T>::unpack(v, f);
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) {
-            float z = f[e] * sAff[kc + e] + sAff[p.Cin + kc + e];
-            f[e] = p.relu_in ? fmaxf(z, 0.f) : z;
-          }
-          v = Chunk<T>::pack(f);
-        }
+        okmask |= 1 << i;
       }
-      ra[i] = v;
+      qa[i] = v;
     }
     const int kidx = kstep * BK + chunk * EPC;
 #pragma unroll
@@ -177,25 +176,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (row < BN && n < p.Kreal && kvalid)
         v = *reinterpret_cast<const uint4*>(gw + (size_t)n * p.Ktot + kidx);
-      rb[i] = v;
+      qb[i] = v;
     }
     // advance the k cursor by one K step
     kc += BK;
     while (kc >= p.Cin) { kc -= p.Cin; ++kt; }
   };
 
-  auto store_tiles = [&](int buf) {
+  auto store_stage = [&](int buf, uint4 (&qa)[RA], uint4 (&qb)[RB], int okmask, int kc_saved) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const int row = lrow + 64 * i;
+      uint4 v = qa[i];
+      if (has_aff && ((okmask >> i) & 1)) {
+        float f[EPC];
+        Chunk<T>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float z = f[e] * sAff[kc_saved + e] + sAff[p.Cin + kc_saved + e];
+          f[e] = p.relu_in ? fmaxf(z, 0.f) : z;
+        }
+        v = Chunk<T>::pack(f);
+      }
       if (row < BM)
-        *reinterpret_cast<uint4*>(sA + (buf * BM + row) * 64 + swz(row, chunk) * 16) = ra[i];
+        *reinterpret_cast<uint4*>(sA + (buf * BM + row) * 64 + swz(row, chunk) * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int row = lrow + 64 * i;
       if (row < BN)
-        *reinterpret_cast<uint4*>(sB + (buf * BN + row) * 64 + swz(row, chunk) * 16) = rb[i];
+        *reinterpret_cast<uint4*>(sB + (buf * BN + row) * 64 + swz(row, chunk) * 16) = qb[i];
     }
   };
 
@@ -208,36 +218,49 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   __syncthreads();   // taps / affine visible
-  load_tiles(ks_begin);
-  store_tiles(0);
+  // prologue: tile 0 -> LDS buffer 0; tiles 1..PF in flight in stages 1..PF-1, 0
+  issue_loads(ks_begin, ra[0], rb[0], st_ok[0], st_kc[0]);
+  store_stage(0, ra[0], rb[0], st_ok[0], st_kc[0]);
+#pragma unroll
+  for (int u = 1; u <= PF; ++u)
+    if (ks_begin + u < ks_end) issue_loads(ks_begin + u, ra[u % PF], rb[u % PF], st_ok[u % PF], st_kc[u % PF]);
   __syncthreads();
 
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
-  for (int ks = ks_begin; ks < ks_end; ++ks) {
-    const int buf = (ks - ks_begin) & 1;
-    if (ks + 1 < ks_end) load_tiles(ks + 1);
+  for (int ks0 = ks_begin; ks0 < ks_end; ks0 += PF) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ch = fhalf + 2 * kk;
-      uint4 fa[TM], fb[TN];
+    for (int u = 0; u < PF; ++u) {
+      const int ks = ks0 + u;             // tile index; its successor lives in stage (u+1)%PF
+      if (ks < ks_end) {
+        const int buf = (ks - ks_begin) & 1;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = (wm * TM + i) * 32 + frow;
-        fa[i] = *reinterpret_cast<const uint4*>(sA + (buf * BM + row) * 64 + swz(row, ch) * 16);
+        for (int kk = 0; kk < 2; ++kk) {
+          const int ch = fhalf + 2 * kk;
+          uint4 fa[TM], fb[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int row = (wm * TM + i) * 32 + frow;
+            fa[i] = *reinterpret_cast<const uint4*>(sA + (buf * BM + row) * 64 + swz(row, ch) * 16);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int row = (wn * TN + j) * 32 + frow;
+            fb[j] = *reinterpret_cast<const uint4*>(sB + (buf * BN + row) * 64 + swz(row, ch) * 16);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+        const int nx = (u + 1) % PF;      // static after unrolling (checked: no scratch in the resource report)
+        if (ks + 1 < ks_end) {
+          store_stage(buf ^ 1, ra[nx], rb[nx], st_ok[nx], st_kc[nx]);
+          if (ks + 1 + PF < ks_end) issue_loads(ks + 1 + PF, ra[nx], rb[nx], st_ok[nx], st_kc[nx]);
+        }
+        __syncthreads();
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = (wn * TN + j) * 32 + frow;
-        fb[j] = *reinterpret_cast<const uint4*>(sB + (buf * BN + row) * 64 + swz(row, ch) * 16);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[i], fb[j], acc[i][j]);
     }
-    if (ks + 1 < ks_end) store_tiles(buf ^ 1);
-    __syncthreads();
   }
 
   if (p.splitk > 1) {

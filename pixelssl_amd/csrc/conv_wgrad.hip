@@ -74,6 +74,7 @@ __device__ __forceinline__ void store_task(unsigned char* base, int pq, int cc, 
 
 template <typename T, int BMK, int BNC, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+  constexpr int PF = 3;                       // register prefetch stages
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BKP = WLayout<T>::BKP;
   constexpr int PQ = BKP / 4;                 // pixel quads per K step
@@ -155,12 +156,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     }
   }
 
-  uint4 stage[NT][4];
+  // PF register stages in flight (see conv_igemm.hip); the fused activation of the `in` operand is
+  // applied when a stage is written to LDS so the loads are never waited for at issue time.
+  uint4 stage[PF][NT][4];
+  int st_ok[PF][NT];
 
-  auto load_tiles = [&](int ks) {
+  auto issue_loads = [&](int ks, uint4 (&q)[NT][4], int (&okm)[NT]) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int mq = m_begin + ks * BKP + t_pq[i] * 4;
+      okm[i] = 0;
       if (t_kind[i] == 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
           uint4 v = make_uint4(0, 0, 0, 0);
           if (t_colok[i] && m < m_end)
             v = *reinterpret_cast<const uint4*>(gdy + (size_t)m * p.Cout + t_col[i]);
-          stage[i][j] = v;
+          q[i][j] = v;
         }
       } else if (t_kind[i] == 1) {
         int b = t_b[i], oy = t_oy[i], ox = t_ox[i];
@@ -181,18 +186,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
           uint4 v = make_uint4(0, 0, 0, 0);
           if (ok) {
             v = *reinterpret_cast<const uint4*>(gin + ((size_t)((b * p.Hi + iy) * p.Wi + ix)) * p.Cin + t_col[i]);
-            if (has_aff) {
-              float f[EPC];
-              Chunk<T>::unpack(v, f);
-#pragma unroll
-              for (int e = 0; e < EPC; ++e) {
-                float z = f[e] * sAff[t_col[i] + e] + sAff[p.Cin + t_col[i] + e];
-                f[e] = p.relu_in ? fmaxf(z, 0.f) : z;
-              }
-              v = Chunk<T>::pack(f);
-            }
+            okm[i] |= 1 << j;
           }
-          stage[i][j] = v;
+          q[i][j] = v;
           if (++ox == p.Wo) { ox = 0; if (++oy == p.Ho) { oy = 0; ++b; } }
         }
         // advance the task's first pixel by one K step (BKP pixels)
@@ -203,11 +199,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     }
   };
 
-  auto store_tiles = [&](int buf) {
+  auto store_stage = [&](int buf, uint4 (&q)[NT][4], int (&okm)[NT]) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      if (t_kind[i] == 0) store_task<T, BMK>(sA + buf * ABYTES, t_pq[i], t_cc[i], stage[i]);
-      else if (t_kind[i] == 1) store_task<T, BNC>(sB + buf * BBYTES, t_pq[i], t_cc[i], stage[i]);
+      if (t_kind[i] == 0) {
+        store_task<T, BMK>(sA + buf * ABYTES, t_pq[i], t_cc[i], q[i]);
+      } else if (t_kind[i] == 1) {
+        if (has_aff) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if ((okm[i] >> j) & 1) {
+              float f[EPC];
+              Chunk<T>::unpack(q[i][j], f);
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) {
+                float z = f[e] * sAff[t_col[i] + e] + sAff[p.Cin + t_col[i] + e];
+                f[e] = p.relu_in ? fmaxf(z, 0.f) : z;
+              }
+              q[i][j] = Chunk<T>::pack(f);
+            }
+          }
+        }
+        store_task<T, BNC>(sB + buf * BBYTES, t_pq[i], t_cc[i], q[i]);
+      }
     }
   };
 
@@ -221,64 +235,76 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 
   __syncthreads();
   if (nks > 0) {
-    load_tiles(0);
-    store_tiles(0);
+    issue_loads(0, stage[0], st_ok[0]);
+    store_stage(0, stage[0], st_ok[0]);
+#pragma unroll
+    for (int u = 1; u <= PF; ++u)
+      if (u < nks) issue_loads(u, stage[u % PF], st_ok[u % PF]);
   }
   __syncthreads();
 
   const int frow = lane & 31, fhalf = lane >> 5;
-  for (int ks = 0; ks < nks; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nks) load_tiles(ks + 1);
-    const unsigned char* a = sA + buf * ABYTES;
-    const unsigned char* b = sB + buf * BBYTES;
-    if constexpr (sizeof(T) == 4) {
+  for (int ks0 = 0; ks0 < nks; ks0 += PF) {
 #pragma unroll
-      for (int e = 0; e < BKP / 2; ++e) {
-        const int pix = 2 * e + fhalf;
-        float fa[TM], fb[TN];
+    for (int u = 0; u < PF; ++u) {
+      const int ks = ks0 + u;
+      if (ks < nks) {
+        const int buf = ks & 1;
+        const unsigned char* a = sA + buf * ABYTES;
+        const unsigned char* b = sB + buf * BBYTES;
+        if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-          fa[i] = *reinterpret_cast<const float*>(a + (pix * BMK + (wm * TM + i) * 32 + frow) * 4);
+          for (int e = 0; e < BKP / 2; ++e) {
+            const int pix = 2 * e + fhalf;
+            float fa[TM], fb[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          fb[j] = *reinterpret_cast<const float*>(b + (pix * BNC + (wn * TN + j) * 32 + frow) * 4);
+            for (int i = 0; i < TM; ++i)
+              fa[i] = *reinterpret_cast<const float*>(a + (pix * BMK + (wm * TM + i) * 32 + frow) * 4);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int j = 0; j < TN; ++j)
+              fb[j] = *reinterpret_cast<const float*>(b + (pix * BNC + (wn * TN + j) * 32 + frow) * 4);
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
-    } else {
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int kk = 0; kk < BKP / 16; ++kk) {
-        const int q0 = 4 * kk + 2 * fhalf;
-        uint4 fa[TM], fb[TN];
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          }
+        } else {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int ch = (wm * TM + i) * 32 + frow;
-          const uint2 lo = *reinterpret_cast<const uint2*>(a + (q0 * (BMK / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
-          const uint2 hi = *reinterpret_cast<const uint2*>(a + ((q0 + 1) * (BMK / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
-          fa[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          for (int kk = 0; kk < BKP / 16; ++kk) {
+            const int q0 = 4 * kk + 2 * fhalf;
+            uint4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              const int ch = (wm * TM + i) * 32 + frow;
+              const uint2 lo = *reinterpret_cast<const uint2*>(a + (q0 * (BMK / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
+              const uint2 hi = *reinterpret_cast<const uint2*>(a + ((q0 + 1) * (BMK / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
+              fa[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const int ch = (wn * TN + j) * 32 + frow;
+              const uint2 lo = *reinterpret_cast<const uint2*>(b + (q0 * (BNC / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
+              const uint2 hi = *reinterpret_cast<const uint2*>(b + ((q0 + 1) * (BNC / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
+              fb[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                    __builtin_bit_cast(bf16x8, fb[j]),
+                                                                    acc[i][j], 0, 0, 0);
+          }
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int ch = (wn * TN + j) * 32 + frow;
-          const uint2 lo = *reinterpret_cast<const uint2*>(b + (q0 * (BNC / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
-          const uint2 hi = *reinterpret_cast<const uint2*>(b + ((q0 + 1) * (BNC / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
-          fb[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const int nx = (u + 1) % PF;      // static after unrolling
+        if (ks + 1 < nks) {
+          store_stage(buf ^ 1, stage[nx], st_ok[nx]);
+          if (ks + 1 + PF < nks) issue_loads(ks + 1 + PF, stage[nx], st_ok[nx]);
         }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                                __builtin_bit_cast(bf16x8, fb[j]),
-                                                                acc[i][j], 0, 0, 0);
+        __syncthreads();
       }
     }
-    if (ks + 1 < nks) store_tiles(buf ^ 1);
-    __syncthreads();
   }
 
   // ---- epilogue: rows = out channel k (A operand index), cols = (tap, c)

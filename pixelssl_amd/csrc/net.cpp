@@ -343,6 +343,7 @@ extern "C" size_t pxl_net_scratch_bytes(const pxl_net* n) { return n && n->plann
 
 extern "C" int pxl_net_pack(pxl_net* n, const float* params, void* packed, void* stream) {
   PXL_REQUIRE(n && n->planned && params && packed, "net_pack: bad argument (plan first)");
+  std::vector<pxl_pack_item> items;
   for (auto& op : n->ops) {
     const pxl_op& d = op.d;
     if (d.kind != PXL_OP_CONV) continue;
@@ -350,9 +351,13 @@ extern "C" int pxl_net_pack(pxl_net* n, const float* params, void* packed, void*
     const TensorInfo& tout = n->tensors[d.out];
     const int tpg = d.kh * d.kw;
     for (int g = 0; g < d.ngroups; ++g) {
-      int rc = pxl_pack_weights(n->dtype, params + d.w_off[g], d.cout, tpg, d.cin, at(packed, op.wf_off), tin.Cp,
-                                op.ntaps, g * tpg, d.need_dgrad ? at(packed, op.wt_off) : nullptr, tout.Cp, stream);
-      if (rc != PXL_OK) return rc;
+      pxl_pack_item it;
+      it.src_off = d.w_off[g];
+      it.wf_off = (int64_t)op.wf_off;
+      it.wt_off = d.need_dgrad ? (int64_t)op.wt_off : -1;
+      it.K = d.cout; it.T = tpg; it.C = d.cin;
+      it.Cp = tin.Cp; it.T_total = op.ntaps; it.t_off = g * tpg; it.Kp = tout.Cp;
+      items.push_back(it);
     }
     if (d.b_off[0] >= 0) {
       const float* b[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -361,6 +366,100 @@ extern "C" int pxl_net_pack(pxl_net* n, const float* params, void* packed, void*
       if (rc != PXL_OK) return rc;
     }
   }
+  return pxl_pack_weights_batched(n->dtype, params, packed, items.data(), (int)items.size(), stream);
+}
+
+namespace {
+// median-free quick timer: one warm-up + `reps` timed launches, returns the best time in ms (< 0 on error)
+template <typename F>
+float time_launch(F&& fn, hipStream_t s, hipEvent_t a, hipEvent_t b, int reps) {
+  if (fn() != PXL_OK) return -1.f;
+  float best = 1e30f;
+  for (int r = 0; r < reps; ++r) {
+    if (hipEventRecord(a, s) != hipSuccess) return -1.f;
+    if (fn() != PXL_OK) return -1.f;
+    if (hipEventRecord(b, s) != hipSuccess) return -1.f;
+    if (hipEventSynchronize(b) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.f;
+    if (ms < best) best = ms;
+  }
+  return best;
+}
+}  // namespace
+
+// "Measure, don't guess": time every tile configuration of every contraction on the planned shapes and
+// keep the fastest.  Results do not depend on the choice (same per-element reduction order for
+// forward/dgrad; wgrad differs only in fp32 atomic order).  Clobbers arena/scratch/grads contents.
+extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed, float* grads, void* arena,
+                            size_t arena_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+  PXL_REQUIRE(n && n->planned && params && packed && grads && arena && scratch, "net_tune: bad argument (plan first)");
+  if (arena_bytes < n->arena_bytes || scratch_bytes < n->scratch_bytes)
+    return pxl_set_error(PXL_ERR_WORKSPACE, "net_tune: arena/scratch too small");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipEvent_t a, b;
+  PXL_CHECK_HIP(hipEventCreate(&a));
+  PXL_CHECK_HIP(hipEventCreate(&b));
+  const int reps = 3;
+  int rc_all = PXL_OK;
+  for (auto& op : n->ops) {
+    const pxl_op& d = op.d;
+    if (d.kind != PXL_OP_CONV) continue;
+    const TensorInfo& tin = n->tensors[d.in0];
+    const TensorInfo& tout = n->tensors[d.out];
+    const float* sc = nullptr; const float* sh = nullptr;
+    if (d.bn_in0 >= 0) {
+      const BnInfo& bi = n->bns[d.bn_in0];
+      sc = fat(arena, bi.coef_off) + 2 * bi.d.C;
+      sh = fat(arena, bi.coef_off) + 3 * bi.d.C;
+    }
+    float* stats = d.bn_out >= 0 ? fat(arena, n->bns[d.bn_out].stats_off) : nullptr;
+    const float* bias = d.b_off[0] >= 0 ? fat(packed, op.bias_off) : nullptr;
+    // forward
+    {
+      int best_cfg = -1; float best = 1e30f;
+      for (int cfg = 0; cfg < 4; ++cfg) {
+        if (cfg == 3 && tout.Cp > 64) continue;
+        pxl_conv_desc q = op.fwd; q.tile_cfg = cfg;
+        float t = time_launch([&]() { return pxl_conv_igemm(&q, at(arena, tin.off), at(packed, op.wf_off), at(arena, tout.off),
+                                                            sc, sh, bias, nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr,
+                                                            op.ws_bytes, stream); }, s, a, b, reps);
+        if (t < 0) { rc_all = PXL_ERR_HIP; continue; }
+        if (t < best) { best = t; best_cfg = cfg; }
+      }
+      op.fwd.tile_cfg = best_cfg;
+    }
+    // data gradient
+    if (d.need_dgrad) {
+      int best_cfg = -1; float best = 1e30f;
+      for (int cfg = 0; cfg < 4; ++cfg) {
+        if (cfg == 3 && tin.Cp > 64) continue;
+        pxl_conv_desc q = op.bwd; q.tile_cfg = cfg;
+        float t = time_launch([&]() { return pxl_conv_igemm(&q, at(scratch, tout.goff), at(packed, op.wt_off), at(scratch, tin.goff),
+                                                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream); },
+                              s, a, b, reps);
+        if (t < 0) { rc_all = PXL_ERR_HIP; continue; }
+        if (t < best) { best = t; best_cfg = cfg; }
+      }
+      op.bwd.tile_cfg = best_cfg;
+    }
+    // weight gradient (per tap group)
+    for (int g = 0; g < d.ngroups; ++g) {
+      int best_cfg = -1; float best = 1e30f;
+      for (int cfg = 0; cfg < 3; ++cfg) {
+        if (cfg == 2 && d.cout > 64) continue;
+        pxl_conv_desc q = op.grp[g]; q.tile_cfg = cfg;
+        float t = time_launch([&]() { return pxl_conv_wgrad(&q, at(arena, tin.off), sc, sh, at(scratch, tout.goff),
+                                                            grads + d.w_off[g], d.cin, d.cin, stream); }, s, a, b, reps);
+        if (t < 0) { rc_all = PXL_ERR_HIP; continue; }
+        if (t < best) { best = t; best_cfg = cfg; }
+      }
+      op.grp[g].tile_cfg = best_cfg;
+    }
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  if (rc_all != PXL_OK) return pxl_set_error(rc_all, "net_tune: a candidate launch failed: %s", pxl_last_error());
   return PXL_OK;
 }
 

@@ -38,6 +38,69 @@ __global__ void pack_t_kernel(const float* __restrict__ w, int K, int Tn, int C,
   }
 }
 
+// ---- batched variants: one launch packs up to 64 weight tensors (the executor repacks ~110 convs after
+// every optimizer / EMA step; per-tensor launches cost ~430 launches per step)
+struct PackBatch {
+  int n;
+  pxl_pack_item it[64];
+  int start[65];        // first block of each item
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_fwd_batched_kernel(const float* __restrict__ params,
+                                                               unsigned char* __restrict__ packed, const PackBatch b) {
+  int lo = 0, hi = b.n - 1;
+  while (lo < hi) {                       // last item with start <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (b.start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const pxl_pack_item it = b.it[lo];
+  const float* __restrict__ w = params + it.src_off;
+  T* __restrict__ wf = reinterpret_cast<T*>(packed + it.wf_off);
+  const long total = (long)it.K * it.T * it.Cp;
+  const long i0 = ((long)blockIdx.x - b.start[lo]) * 2048 + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const long i = i0 + r * 256;
+    if (i >= total) break;
+    const int c = (int)(i % it.Cp);
+    const long kt = i / it.Cp;
+    const int t = (int)(kt % it.T);
+    const int k = (int)(kt / it.T);
+    const float v = c < it.C ? w[((long)k * it.T + t) * it.C + c] : 0.f;
+    wf[((long)k * it.T_total + it.t_off + t) * it.Cp + c] = from_f<T>(v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_t_batched_kernel(const float* __restrict__ params,
+                                                             unsigned char* __restrict__ packed, const PackBatch b) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = b.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (b.start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const pxl_pack_item it = b.it[lo];
+  const float* __restrict__ w = params + it.src_off;
+  T* __restrict__ wt = reinterpret_cast<T*>(packed + it.wt_off);
+  int rem = (int)blockIdx.x - b.start[lo];
+  const int tc = (it.C + 31) / 32, tk = (it.Kp + 31) / 32;
+  const int c0 = (rem % tc) * 32; rem /= tc;
+  const int k0 = (rem % tk) * 32;
+  const int t = rem / tk;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, c = c0 + tx;
+    tile[r][tx] = (k < it.K && c < it.C) ? w[((long)k * it.T + t) * it.C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, k = k0 + tx;
+    if (c < it.C && k < it.Kp) wt[((long)c * it.T_total + it.t_off + t) * it.Kp + k] = from_f<T>(tile[tx][r]);
+  }
+}
+
 // x NCHW fp32 [B][C][H][W] -> NHWC [B][H][W][Cp] (zero padded channels)
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C,
@@ -109,6 +172,47 @@ extern "C" int pxl_pack_weights(int dtype, const float* w, int K, int T, int C, 
   if (dtype == PXL_BF16)
     return pack_weights_impl<bf16_t>(w, K, T, C, (bf16_t*)wf, Cp, T_total, t_off, (bf16_t*)wt, Kp, s);
   return pxl_set_error(PXL_ERR_ARG, "pack_weights: bad dtype %d", dtype);
+}
+
+extern "C" int pxl_pack_weights_batched(int dtype, const float* params, void* packed, const pxl_pack_item* items,
+                                        int n, void* stream) {
+  PXL_REQUIRE(params && packed && items && n >= 0, "pack_weights_batched: bad argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "pack_weights_batched: bad dtype %d", dtype);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  unsigned char* pk = reinterpret_cast<unsigned char*>(packed);
+  for (int base = 0; base < n; base += 64) {
+    const int cnt = n - base < 64 ? n - base : 64;
+    PackBatch f, t;
+    f.n = cnt; t.n = 0;
+    int fb = 0, tb = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const pxl_pack_item& it = items[base + i];
+      PXL_REQUIRE(it.Cp >= it.C && it.t_off + it.T <= it.T_total, "pack_weights_batched: bad padding in item %d", base + i);
+      f.it[i] = it;
+      f.start[i] = fb;
+      fb += (int)(((long)it.K * it.T * it.Cp + 2047) / 2048);
+      if (it.wt_off >= 0) {
+        PXL_REQUIRE(it.Kp >= it.K, "pack_weights_batched: bad Kp in item %d", base + i);
+        t.it[t.n] = it;
+        t.start[t.n] = tb;
+        tb += ((it.C + 31) / 32) * ((it.Kp + 31) / 32) * it.T;
+        ++t.n;
+      }
+    }
+    f.start[cnt] = fb;
+    t.start[t.n] = tb;
+    if (fb > 0) {
+      if (dtype == PXL_F32) hipLaunchKernelGGL(pack_fwd_batched_kernel<float>, dim3(fb), dim3(256), 0, s, params, pk, f);
+      else hipLaunchKernelGGL(pack_fwd_batched_kernel<bf16_t>, dim3(fb), dim3(256), 0, s, params, pk, f);
+      PXL_LAUNCH_CHECK();
+    }
+    if (tb > 0) {
+      if (dtype == PXL_F32) hipLaunchKernelGGL(pack_t_batched_kernel<float>, dim3(tb), dim3(256), 0, s, params, pk, t);
+      else hipLaunchKernelGGL(pack_t_batched_kernel<bf16_t>, dim3(tb), dim3(256), 0, s, params, pk, t);
+      PXL_LAUNCH_CHECK();
+    }
+  }
+  return PXL_OK;
 }
 
 extern "C" int pxl_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W, int Cp,

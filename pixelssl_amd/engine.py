@@ -10,6 +10,7 @@ Design (MI355X-first):
   * the network itself is a layer program interpreted by libpixelhip (csrc/net.cpp).
 """
 import ctypes
+import os
 from collections import OrderedDict
 
 import torch
@@ -228,6 +229,7 @@ class SegNetCore(nn.Module):
         self._sync_cb = None
         self._anchor = None
         self.freeze_bn = False
+        self.autotune = os.environ.get("PXL_AUTOTUNE", "1") != "0"
 
     # -- construction -----------------------------------------------------------------------
     def _finalize(self):
@@ -318,12 +320,24 @@ class SegNetCore(nn.Module):
         self._scratch = torch.empty(lib().pxl_net_scratch_bytes(self._net), device=dev, dtype=torch.uint8)
         self._arena_bytes = lib().pxl_net_arena_bytes(self._net)
         self._eval_arena = None
+        self._tuned = False
 
     def _ensure_packed(self):
         v = self._store.version()
         if self._packed_version != v:
             check(lib().pxl_net_pack(self._net, ptr(self._store.params), ptr(self._packed), stream_ptr()))
             self._packed_version = v
+        if not self._tuned and self.autotune:
+            # per-shape tile selection, measured on this GPU (csrc/net.cpp: pxl_net_tune)
+            arena = torch.zeros(self._arena_bytes, device=self._device, dtype=torch.uint8)
+            self._scratch.zero_()
+            keep = self._store.grads.clone()
+            check(lib().pxl_net_tune(self._net, ptr(self._store.params), ptr(self._packed), ptr(self._store.grads),
+                                     ptr(arena), arena.numel(), ptr(self._scratch), self._scratch.numel(),
+                                     stream_ptr()))
+            self._store.grads.copy_(keep)
+            del arena
+        self._tuned = True
 
     def set_sync(self, callback, world_size):
         """callback(buf_ptr:int, n:int, stream:int) -> int ; installs the SyncBN statistics hook."""

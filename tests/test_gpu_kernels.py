@@ -377,3 +377,38 @@ def test_sgd_and_ema_flat_updates():
     ops.ema_update(td, s.to(DEV), 0.99)
     torch.cuda.synchronize()
     assert rel_err(td.cpu(), t * 0.99 + 0.01 * s) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_pack_equals_per_tensor_pack(dtype):
+    """pxl_pack_weights_batched (one launch for many tensors) == pxl_pack_weights per tensor, bit for bit."""
+    import ctypes
+    from pixelssl_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    shapes = [(64, 49, 3, 8, 49, 0, 0), (21, 9, 40, 64, 36, 9, 32), (21, 9, 40, 64, 36, 27, 32), (96, 1, 72, 96, 1, 0, 96),
+              (33, 16, 24, 32, 16, 0, 64)]                      # K, T, C, Cp, T_total, t_off, Kp (0 = no dgrad operand)
+    flat = torch.randn(sum(k * t * c for k, t, c, *_ in shapes) + 64, generator=g).to(DEV)
+    es = 4 if dtype == torch.float32 else 2
+    items, off, boff, singles = [], 0, 0, []
+    for k, t, c, cp, tt, to, kp in shapes:
+        it = _lib.PackItem()
+        it.src_off, it.K, it.T, it.C, it.Cp, it.T_total, it.t_off, it.Kp = off, k, t, c, cp, tt, to, kp
+        it.wf_off = boff
+        boff += (k * tt * cp * es + 255) // 256 * 256
+        it.wt_off = boff if kp else -1
+        boff += (c * tt * kp * es + 255) // 256 * 256 if kp else 0
+        items.append(it)
+        off += k * t * c
+    packed = torch.zeros(boff, device=DEV, dtype=torch.uint8)
+    ref = torch.zeros_like(packed)
+    arr = (_lib.PackItem * len(items))(*items)
+    _lib.check(_lib.lib().pxl_pack_weights_batched(_lib.dtype_code(dtype), flat.data_ptr(), packed.data_ptr(), arr, len(items),
+                                                   _lib.stream_ptr()))
+    for it in items:
+        wf = ref[it.wf_off:].view(dtype)
+        wt = ref[it.wt_off:].view(dtype) if it.wt_off >= 0 else None
+        ops.pack_weights(dtype, flat[it.src_off:], it.K, it.T, it.C, wf, it.Cp, T_total=it.T_total, t_off=it.t_off, wt=wt,
+                         Kp=it.Kp)
+    torch.cuda.synchronize()
+    assert torch.equal(packed, ref)
