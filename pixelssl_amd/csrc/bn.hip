@@ -24,6 +24,7 @@ __global__ void bn_finalize_kernel(int C, const float* __restrict__ stats, int n
   float mean, var;
   if (training) {
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
     for (int r = 0; r < nrep; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
     mean = s1 / total_count;
     var = s2 / total_count - mean * mean;

@@ -12,12 +12,11 @@
 //
 // Mapping to CDNA4: 256 threads = 4 waves (2x2 or 4x1), each wave owns 32x32 MFMA tiles
 // (v_mfma_f32_32x32x16_bf16 for bf16, v_mfma_f32_32x32x2_f32 for the exact-fp32 parity
-// mode).  K is walked in 64-byte slices per row (32 bf16 / 16 fp32); global loads are
-// 16 B per lane along the channel axis (NHWC => coalesced), register-staged so that
-// the prologue can run, written to a double-buffered, XOR-swizzled LDS image
-// ([rows][4 x 16 B], chunk ^= (row>>2)&3 -> conflict-free ds_read_b128 for the 32-row
-// fragment pattern), one barrier per K step.  blockIdx is remapped so that tiles sharing
-// an A row-panel run on the same XCD (shared L2).
+// mode).  K is walked in 64- or 128-byte slices per row; global loads are 16 B per lane along
+// the channel axis (NHWC => coalesced), register-staged (2-3 tiles in flight) so that the
+// prologue can run, written to a double-buffered, XOR-swizzled LDS image (conflict-free
+// ds_read_b128 for the 32-row fragment pattern), one barrier per K step.  blockIdx is remapped
+// so that tiles sharing an A row-panel run on the same XCD (shared L2).
 #include "common.h"
 
 namespace {
@@ -60,26 +59,35 @@ template <> struct Mfma<float> {
   }
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+// XOR swizzle of the 16-byte chunk index so that the ds_read_b128 of a 32-row MFMA fragment is
+// conflict-free: 64-byte rows (4 chunks) -> chunk ^ (row>>2)&3 ; 128-byte rows (8 chunks) -> chunk ^ (row>>1)&7
+template <int CH> __device__ __forceinline__ int swz(int row, int chunk) {
+  if constexpr (CH == 4) return chunk ^ ((row >> 2) & 3);
+  else return chunk ^ ((row >> 1) & 7);
+}
 
-template <typename T, int BM, int BN, int WM, int WN>
+// BKB   = bytes of K per row slice and K step (64 or 128)
+// SIMPLE = 1x1 / stride 1 / no padding: A(m, c) = in[m][c], no tap table, no bounds logic
+template <typename T, int BM, int BN, int WM, int WN, int BKB, bool SIMPLE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
-  constexpr int PF = 3;                      // register prefetch stages (tiles in flight)
   constexpr int EPC = Elem<T>::EPC;
-  constexpr int BK = 4 * EPC;                // elements per 64-byte row slice
-  constexpr int RA = (BM + 63) / 64;         // A rows per thread
-  constexpr int RB = (BN + 63) / 64;         // B rows per thread
+  constexpr int CH = BKB / 16;               // 16-byte chunks per row slice
+  constexpr int BK = CH * EPC;               // elements per K step
+  constexpr int RP = 256 / CH;               // rows covered by one pass of the 256 loader threads
+  constexpr int RA = (BM + RP - 1) / RP;     // A chunks per thread per K step
+  constexpr int RB = (BN + RP - 1) / RP;
+  constexpr int PF = (RA + RB) >= 8 ? 2 : 3; // register prefetch stages (tiles in flight)
   constexpr int TM = BM / (32 * WM);         // 32x32 tiles per wave along M
   constexpr int TN = BN / (32 * WN);
   static_assert(WM * WN == 4, "4 waves");
   static_assert(TM >= 1 && TN >= 1, "tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // layout: [2][BM][64B] A | [2][BN][64B] B | taps[64] int | affine [2*Cin] float
+  // layout: [2][BM][BKB] A | [2][BN][BKB] B | taps[64] int | affine [2*Cin] float
   unsigned char* sA = smem;
-  unsigned char* sB = smem + 2 * BM * 64;
-  int* sTaps = reinterpret_cast<int*>(smem + 2 * (BM + BN) * 64);
-  float* sAff = reinterpret_cast<float*>(smem + 2 * (BM + BN) * 64 + 256);
+  unsigned char* sB = smem + 2 * BM * BKB;
+  int* sTaps = reinterpret_cast<int*>(smem + 2 * (BM + BN) * BKB);
+  float* sAff = reinterpret_cast<float*>(smem + 2 * (BM + BN) * BKB + 256);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   const bool has_aff = p.in_scale != nullptr;
-  if (tid < 64) sTaps[tid] = p.taps[tid];
+  if (!SIMPLE && tid < 64) sTaps[tid] = p.taps[tid];
   if (has_aff) {
     for (int i = tid; i < p.Cin; i += 256) {
       sAff[i] = p.in_scale[i];
@@ -101,15 +109,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   }
 
   // ---- per-thread load coordinates
-  const int chunk = tid & 3;
-  const int lrow = tid >> 2;                 // 0..63
-  int a_iy0[RA], a_ix0[RA], a_base[RA];
+  const int chunk = tid % CH;
+  const int lrow = tid / CH;                 // 0..RP-1
+  int a_iy0[RA], a_ix0[RA], a_base[RA];      // SIMPLE: a_base = pixel index (or -1), others unused
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    const int row = lrow + 64 * i;
+    const int row = lrow + RP * i;
     const int m = m0 + row;
-    if (row < BM && m < p.M) {
+    if (SIMPLE) {
+      a_base[i] = (row < BM && m < p.M) ? m : -1;
+      a_iy0[i] = a_ix0[i] = 0;
+    } else if (row < BM && m < p.M) {
       const int b = m / HoWo;
       const int r = m - b * HoWo;
       const int oy = r / p.Wo;
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   auto issue_loads = [&](int kstep, uint4 (&qa)[RA], uint4 (&qb)[RB], int& okmask, int& kc_saved) {
     const bool kvalid = kt < p.ntaps;
     int dy = 0, dx = 0;
-    if (kvalid) {
+    if (!SIMPLE && kvalid) {
       const int tp = sTaps[kt];
       dy = tp >> 16;
       dx = (int)(short)(tp & 0xffff);
@@ -155,14 +166,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     kc_saved = kc;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int ny = a_iy0[i] + dy, nx = a_ix0[i] + dx;
-      const int iy = ny >> p.div_shift, ix = nx >> p.div_shift;
-      const bool ok = kvalid && ((ny & p.div_mask) == 0) && ((nx & p.div_mask) == 0) &&
-                      ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi) &&
-                      (ny >= 0) && (nx >= 0);
+      bool ok;
+      size_t off;
+      if (SIMPLE) {
+        ok = kvalid && a_base[i] >= 0;
+        off = (size_t)a_base[i] * p.Cin + kc;
+      } else {
+        const int ny = a_iy0[i] + dy, nx = a_ix0[i] + dx;
+        const int iy = ny >> p.div_shift, ix = nx >> p.div_shift;
+        ok = kvalid && ((ny & p.div_mask) == 0) && ((nx & p.div_mask) == 0) &&
+             ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi) && (ny >= 0) && (nx >= 0);
+        off = ((size_t)(a_base[i] + iy * p.Wi + ix)) * p.Cin + kc;
+      }
       uint4 v = make_uint4(0, 0, 0, 0);
       if (ok) {
-        const size_t off = ((size_t)(a_base[i] + iy * p.Wi + ix)) * p.Cin + kc;
         v = *reinterpret_cast<const uint4*>(gin + off);
         okmask |= 1 << i;
       }
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int kidx = kstep * BK + chunk * EPC;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const int row = lrow + 64 * i;
+      const int row = lrow + RP * i;
       const int n = n0 + row;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (row < BN && n < p.Kreal && kvalid)
@@ -186,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   auto store_stage = [&](int buf, uint4 (&qa)[RA], uint4 (&qb)[RB], int okmask, int kc_saved) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int row = lrow + 64 * i;
+      const int row = lrow + RP * i;
       uint4 v = qa[i];
       if (has_aff && ((okmask >> i) & 1)) {
         float f[EPC];
@@ -199,13 +216,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         v = Chunk<T>::pack(f);
       }
       if (row < BM)
-        *reinterpret_cast<uint4*>(sA + (buf * BM + row) * 64 + swz(row, chunk) * 16) = v;
+        *reinterpret_cast<uint4*>(sA + (buf * BM + row) * BKB + swz<CH>(row, chunk) * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const int row = lrow + 64 * i;
+      const int row = lrow + RP * i;
       if (row < BN)
-        *reinterpret_cast<uint4*>(sB + (buf * BN + row) * 64 + swz(row, chunk) * 16) = qb[i];
+        *reinterpret_cast<uint4*>(sB + (buf * BN + row) * BKB + swz<CH>(row, chunk) * 16) = qb[i];
     }
   };
 
@@ -235,18 +252,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       if (ks < ks_end) {
         const int buf = (ks - ks_begin) & 1;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < CH / 2; ++kk) {
           const int ch = fhalf + 2 * kk;
           uint4 fa[TM], fb[TN];
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             const int row = (wm * TM + i) * 32 + frow;
-            fa[i] = *reinterpret_cast<const uint4*>(sA + (buf * BM + row) * 64 + swz(row, ch) * 16);
+            fa[i] = *reinterpret_cast<const uint4*>(sA + (buf * BM + row) * BKB + swz<CH>(row, ch) * 16);
           }
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const int row = (wn * TN + j) * 32 + frow;
-            fb[j] = *reinterpret_cast<const uint4*>(sB + (buf * BN + row) * 64 + swz(row, ch) * 16);
+            fb[j] = *reinterpret_cast<const uint4*>(sB + (buf * BN + row) * BKB + swz<CH>(row, ch) * 16);
           }
 #pragma unroll
           for (int i = 0; i < TM; ++i)
@@ -328,12 +345,12 @@ __global__ void splitk_finish_kernel(long total, int Cout, int Kreal, const floa
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_cfg(const ConvArgs& a, int want_split, size_t ws_bytes, hipStream_t stream) {
+template <typename T, int BM, int BN, int WM, int WN, int BKB>
+int launch_cfg(const ConvArgs& a, int want_split, size_t ws_bytes, bool simple, hipStream_t stream) {
   ConvArgs p = a;
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.Cout, BN);
-  constexpr int BK = 4 * Elem<T>::EPC;
+  constexpr int BK = (BKB / 16) * Elem<T>::EPC;
   p.nk = cdiv(p.Ktot, BK);
   const int grid = p.tiles_m * p.tiles_n;
   // split-K: only for launches that cannot fill the chip and have a long reduction (ASPP: 69 tiles, K = 73728)
@@ -351,8 +368,21 @@ int launch_cfg(const ConvArgs& a, int want_split, size_t ws_bytes, hipStream_t s
   p.splitk = splitk;
   if (splitk > 1) PXL_CHECK_HIP(hipMemsetAsync(p.ws, 0, (size_t)p.M * p.Cout * sizeof(float), stream));
   else p.ws = nullptr;
-  const size_t smem = 2 * (BM + BN) * 64 + 256 + (p.in_scale ? 2 * (size_t)p.Cin * 4 : 0);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN>), dim3(grid, splitk), dim3(256), smem, stream, p);
+  const size_t smem = 2 * (BM + BN) * BKB + 256 + (p.in_scale ? 2 * (size_t)p.Cin * 4 : 0);
+  if (smem > 64 * 1024) {
+    static bool raised[2] = {false, false};     // opt in once per instantiation to > 64 KiB of dynamic LDS
+    if (!raised[simple ? 1 : 0]) {
+      if (simple) PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, WM, WN, BKB, true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      else PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, WM, WN, BKB, false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised[simple ? 1 : 0] = true;
+    }
+  }
+  if (simple)
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, BKB, true>), dim3(grid, splitk), dim3(256), smem, stream, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, BKB, false>), dim3(grid, splitk), dim3(256), smem, stream, p);
   PXL_LAUNCH_CHECK();
   if (splitk > 1) {
     const long total = (long)p.M * p.Cout;
@@ -365,26 +395,32 @@ int launch_cfg(const ConvArgs& a, int want_split, size_t ws_bytes, hipStream_t s
   return PXL_OK;
 }
 
+// tile configurations: 0-3 walk K in 64-byte slices, 4-7 in 128-byte slices (half the barriers and
+// address arithmetic per MFMA, twice the LDS)
 template <typename T>
-int launch_conv(const ConvArgs& a, int force_cfg, int want_split, size_t ws_bytes, hipStream_t stream) {
+int launch_conv(const ConvArgs& a, int force_cfg, int want_split, size_t ws_bytes, bool simple, hipStream_t stream) {
   const int M = a.M, N = a.Cout;
   int cfg = force_cfg;
   if (cfg < 0) {
-    if (N <= 32) cfg = 3;
-    else if (N <= 64) cfg = (cdiv(M, 128) >= 512) ? 1 : 2;
+    if (N <= 32) cfg = 7;
+    else if (N <= 64) cfg = (cdiv(M, 128) >= 512) ? 5 : 6;
     else {
       const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
       const long t12864 = (long)cdiv(M, 128) * cdiv(N, 64);
-      if (t128 >= 512) cfg = 0;
-      else if (t12864 >= 512) cfg = 1;
-      else cfg = 2;
+      if (t128 >= 512) cfg = 4;
+      else if (t12864 >= 512) cfg = 5;
+      else cfg = 6;
     }
   }
   switch (cfg) {
-    case 0: return launch_cfg<T, 128, 128, 2, 2>(a, want_split, ws_bytes, stream);
-    case 1: return launch_cfg<T, 128, 64, 2, 2>(a, want_split, ws_bytes, stream);
-    case 2: return launch_cfg<T, 64, 64, 2, 2>(a, want_split, ws_bytes, stream);
-    case 3: return launch_cfg<T, 128, 32, 4, 1>(a, want_split, ws_bytes, stream);
+    case 0: return launch_cfg<T, 128, 128, 2, 2, 64>(a, want_split, ws_bytes, simple, stream);
+    case 1: return launch_cfg<T, 128, 64, 2, 2, 64>(a, want_split, ws_bytes, simple, stream);
+    case 2: return launch_cfg<T, 64, 64, 2, 2, 64>(a, want_split, ws_bytes, simple, stream);
+    case 3: return launch_cfg<T, 128, 32, 4, 1, 64>(a, want_split, ws_bytes, simple, stream);
+    case 4: return launch_cfg<T, 128, 128, 2, 2, 128>(a, want_split, ws_bytes, simple, stream);
+    case 5: return launch_cfg<T, 128, 64, 2, 2, 128>(a, want_split, ws_bytes, simple, stream);
+    case 6: return launch_cfg<T, 64, 64, 2, 2, 128>(a, want_split, ws_bytes, simple, stream);
+    case 7: return launch_cfg<T, 128, 32, 4, 1, 128>(a, want_split, ws_bytes, simple, stream);
     default: return pxl_set_error(PXL_ERR_ARG, "conv_igemm: unknown tile config %d", cfg);
   }
 }
@@ -422,6 +458,9 @@ extern "C" int pxl_conv_igemm(const pxl_conv_desc* d, const void* in, const void
     a.taps[t] = t < d->ntaps ? (((int)d->dy[t]) << 16) | (((int)d->dx[t]) & 0xffff) : 0;
   a.nk = 0; a.tiles_m = a.tiles_n = 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d->dtype == PXL_F32) return launch_conv<float>(a, d->tile_cfg, d->split_k, ws_bytes, s);
-  return launch_conv<bf16_t>(a, d->tile_cfg, d->split_k, ws_bytes, s);
+  // 1x1 / stride 1 / unpadded convolutions (and their data gradients) skip the whole gather logic
+  const bool simple = d->ntaps == 1 && d->out_stride == 1 && d->div == 1 && d->dy[0] == 0 && d->dx[0] == 0 &&
+                      d->Hi == d->Ho && d->Wi == d->Wo;
+  if (d->dtype == PXL_F32) return launch_conv<float>(a, d->tile_cfg, d->split_k, ws_bytes, simple, s);
+  return launch_conv<bf16_t>(a, d->tile_cfg, d->split_k, ws_bytes, simple, s);
 }

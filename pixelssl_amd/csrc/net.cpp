@@ -418,8 +418,8 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
     // forward
     {
       int best_cfg = -1; float best = 1e30f;
-      for (int cfg = 0; cfg < 4; ++cfg) {
-        if (cfg == 3 && tout.Cp > 64) continue;
+      for (int cfg = 0; cfg < 8; ++cfg) {
+        if ((cfg & 3) == 3 && tout.Cp > 64) continue;
         pxl_conv_desc q = op.fwd; q.tile_cfg = cfg;
         float t = time_launch([&]() { return pxl_conv_igemm(&q, at(arena, tin.off), at(packed, op.wf_off), at(arena, tout.off),
                                                             sc, sh, bias, nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr,
@@ -432,8 +432,8 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
     // data gradient
     if (d.need_dgrad) {
       int best_cfg = -1; float best = 1e30f;
-      for (int cfg = 0; cfg < 4; ++cfg) {
-        if (cfg == 3 && tin.Cp > 64) continue;
+      for (int cfg = 0; cfg < 8; ++cfg) {
+        if ((cfg & 3) == 3 && tin.Cp > 64) continue;
         pxl_conv_desc q = op.bwd; q.tile_cfg = cfg;
         float t = time_launch([&]() { return pxl_conv_igemm(&q, at(scratch, tout.goff), at(packed, op.wt_off), at(scratch, tin.goff),
                                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream); },

@@ -75,7 +75,7 @@ def _pitch(c):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7])
 def test_conv_forward(dtype, case, cfg):
     ops = _ops()
     name, B, Cin, Cout, H, W, k, s, d, p = case
