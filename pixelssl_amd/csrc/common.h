@@ -99,6 +99,14 @@ __device__ __forceinline__ float wave_max(float v) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// branch-free q = m / d, r = m % d for 0 <= m < 2^24 (pixel indices) using a float reciprocal
+__device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, int& r) {
+  q = (int)((float)m * inv_d);
+  r = m - q * d;
+  if (r >= d) { ++q; r -= d; }
+  if (r < 0) { --q; r += d; }
+}
+
 // XCD-aware bijective remap of a linear block id (guide T1): consecutive logical
 // tiles land on the same XCD (= same L2).  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

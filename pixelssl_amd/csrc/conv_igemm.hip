@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   int st_ok[PF], st_kc[PF];
 
   auto issue_loads = [&](int kstep, uint4 (&qa)[RA], uint4 (&qb)[RB], int& okmask, int& kc_saved) {
-    const bool kvalid = kt < p.ntaps;
+    const bool kvalid = kt < p.ntaps && kstep < ks_end;
     int dy = 0, dx = 0;
     if (!SIMPLE && kvalid) {
       const int tp = sTaps[kt];
@@ -164,6 +164,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     }
     okmask = 0;
     kc_saved = kc;
+    // Loads are UNCONDITIONAL (invalid lanes read element 0 and are zeroed when the stage is written to
+    // LDS): a branch around a load makes hipcc wait vmcnt(0) right behind it, which serialises every
+    // load of the stage (measured: 39 vmcnt(0) per loop body, 4-6x slower).
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       bool ok;
@@ -178,34 +181,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
              ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi) && (ny >= 0) && (nx >= 0);
         off = ((size_t)(a_base[i] + iy * p.Wi + ix)) * p.Cin + kc;
       }
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        v = *reinterpret_cast<const uint4*>(gin + off);
-        okmask |= 1 << i;
-      }
-      qa[i] = v;
+      qa[i] = *reinterpret_cast<const uint4*>(gin + (ok ? off : (size_t)0));
+      okmask |= (ok ? 1 : 0) << i;
     }
     const int kidx = kstep * BK + chunk * EPC;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int row = lrow + RP * i;
       const int n = n0 + row;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (row < BN && n < p.Kreal && kvalid)
-        v = *reinterpret_cast<const uint4*>(gw + (size_t)n * p.Ktot + kidx);
-      qb[i] = v;
+      const bool ok = row < BN && n < p.Kreal && kvalid;
+      qb[i] = *reinterpret_cast<const uint4*>(gw + (ok ? (size_t)n * p.Ktot + kidx : (size_t)0));
+      okmask |= (ok ? 1 : 0) << (16 + i);
     }
-    // advance the k cursor by one K step
-    kc += BK;
-    while (kc >= p.Cin) { kc -= p.Cin; ++kt; }
+    // advance the k cursor by one K step (no data-dependent loop: hipcc drains vmcnt at loop headers)
+    if (p.Cin >= BK) {                       // block-uniform: at most one tap boundary per step
+      kc += BK;
+      const bool wrap = kc >= p.Cin;
+      kc = wrap ? kc - p.Cin : kc;
+      kt = wrap ? kt + 1 : kt;
+    } else {                                 // tiny Cin (7x7 stem): several taps per K step
+      const int kl = (kstep + 1) * BK + chunk * EPC;
+      kt = kl / p.Cin;
+      kc = kl - kt * p.Cin;
+    }
   };
 
   auto store_stage = [&](int buf, uint4 (&qa)[RA], uint4 (&qb)[RB], int okmask, int kc_saved) {
+    const uint4 zero = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const int row = lrow + RP * i;
       uint4 v = qa[i];
-      if (has_aff && ((okmask >> i) & 1)) {
+      if (has_aff) {                        // block-uniform branch; the per-lane validity is a select below
         float f[EPC];
         Chunk<T>::unpack(v, f);
 #pragma unroll
@@ -215,14 +222,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         }
         v = Chunk<T>::pack(f);
       }
+      if (!((okmask >> i) & 1)) v = zero;   // zero padding / ragged edges stay exactly 0
       if (row < BM)
         *reinterpret_cast<uint4*>(sA + (buf * BM + row) * BKB + swz<CH>(row, chunk) * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int row = lrow + RP * i;
+      const uint4 v = ((okmask >> (16 + i)) & 1) ? qb[i] : zero;
       if (row < BN)
-        *reinterpret_cast<uint4*>(sB + (buf * BN + row) * BKB + swz<CH>(row, chunk) * 16) = qb[i];
+        *reinterpret_cast<uint4*>(sB + (buf * BN + row) * BKB + swz<CH>(row, chunk) * 16) = v;
     }
   };
 
@@ -235,48 +244,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   __syncthreads();   // taps / affine visible
-  // prologue: tile 0 -> LDS buffer 0; tiles 1..PF in flight in stages 1..PF-1, 0
+  // prologue: tile 0 -> LDS buffer 0; tiles 1..PF in flight in stages 1..PF-1, 0.  Tiles past ks_end are
+  // all-zero (kvalid false), so the steady-state loop has NO conditionals: its trip count is rounded up
+  // to a multiple of PF and the padding iterations multiply zero tiles.
   issue_loads(ks_begin, ra[0], rb[0], st_ok[0], st_kc[0]);
   store_stage(0, ra[0], rb[0], st_ok[0], st_kc[0]);
 #pragma unroll
-  for (int u = 1; u <= PF; ++u)
-    if (ks_begin + u < ks_end) issue_loads(ks_begin + u, ra[u % PF], rb[u % PF], st_ok[u % PF], st_kc[u % PF]);
+  for (int u = 1; u <= PF; ++u) issue_loads(ks_begin + u, ra[u % PF], rb[u % PF], st_ok[u % PF], st_kc[u % PF]);
   __syncthreads();
 
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
-  for (int ks0 = ks_begin; ks0 < ks_end; ks0 += PF) {
+  const int nsteps = (ks_end - ks_begin + PF - 1) / PF * PF;
+  for (int j0 = 0; j0 < nsteps; j0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      const int ks = ks0 + u;             // tile index; its successor lives in stage (u+1)%PF
-      if (ks < ks_end) {
-        const int buf = (ks - ks_begin) & 1;
+      const int j = j0 + u;               // tile index relative to ks_begin; successor lives in stage (u+1)%PF
+      const int buf = j & 1;
 #pragma unroll
-        for (int kk = 0; kk < CH / 2; ++kk) {
-          const int ch = fhalf + 2 * kk;
-          uint4 fa[TM], fb[TN];
+      for (int kk = 0; kk < CH / 2; ++kk) {
+        const int ch = fhalf + 2 * kk;
+        uint4 fa[TM], fb[TN];
 #pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const int row = (wm * TM + i) * 32 + frow;
-            fa[i] = *reinterpret_cast<const uint4*>(sA + (buf * BM + row) * BKB + swz<CH>(row, ch) * 16);
-          }
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int row = (wn * TN + j) * 32 + frow;
-            fb[j] = *reinterpret_cast<const uint4*>(sB + (buf * BN + row) * BKB + swz<CH>(row, ch) * 16);
-          }
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+        for (int i = 0; i < TM; ++i) {
+          const int row = (wm * TM + i) * 32 + frow;
+          fa[i] = *reinterpret_cast<const uint4*>(sA + (buf * BM + row) * BKB + swz<CH>(row, ch) * 16);
         }
-        const int nx = (u + 1) % PF;      // static after unrolling (checked: no scratch in the resource report)
-        if (ks + 1 < ks_end) {
-          store_stage(buf ^ 1, ra[nx], rb[nx], st_ok[nx], st_kc[nx]);
-          if (ks + 1 + PF < ks_end) issue_loads(ks + 1 + PF, ra[nx], rb[nx], st_ok[nx], st_kc[nx]);
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+          const int row = (wn * TN + jn) * 32 + frow;
+          fb[jn] = *reinterpret_cast<const uint4*>(sB + (buf * BN + row) * BKB + swz<CH>(row, ch) * 16);
         }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) Mfma<T>::run(fa[i], fb[jn], acc[i][jn]);
       }
+      const int nx = (u + 1) % PF;        // static after unrolling (checked: no scratch in the resource report)
+      store_stage(buf ^ 1, ra[nx], rb[nx], st_ok[nx], st_kc[nx]);
+      issue_loads(ks_begin + j + 1 + PF, ra[nx], rb[nx], st_ok[nx], st_kc[nx]);
+      __syncthreads();
     }
   }
 

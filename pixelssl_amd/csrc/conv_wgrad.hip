@@ -31,6 +31,7 @@ struct WgradArgs {
   int ntaps, so, relu_in;
   int M, m_per_split;
   int Ng;          // ntaps*Cin (GEMM columns)
+  float inv_wo, inv_howo;
   int tiles_k, tiles_c;
   int taps[64];
 };
@@ -118,13 +119,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   int t_kind[NT], t_pq[NT], t_cc[NT];          // 0 = dY, 1 = act, 2 = idle
   int t_col[NT];                               // dY: channel offset ; act: channel c
   int t_dy[NT], t_dx[NT];                      // act: tap offsets
-  int t_b[NT], t_oy[NT], t_ox[NT];             // act: position of the task's first pixel
   bool t_colok[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int task = tid + 256 * i;
     t_dy[i] = t_dx[i] = 0;
-    t_b[i] = t_oy[i] = t_ox[i] = 0;
     if (task < NA) {
       t_kind[i] = 0;
       t_pq[i] = task / CA;
@@ -143,12 +142,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       const int tp = p.taps[t];
       t_dy[i] = tp >> 16;
       t_dx[i] = (int)(short)(tp & 0xffff);
-      const int m = m_begin + t_pq[i] * 4;
-      const int b = m / HoWo;
-      const int r = m - b * HoWo;
-      t_b[i] = b;
-      t_oy[i] = r / p.Wo;
-      t_ox[i] = r - t_oy[i] * p.Wo;
     } else {
       t_kind[i] = 2;
       t_pq[i] = t_cc[i] = t_col[i] = 0;
@@ -161,64 +154,71 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   uint4 stage[PF][NT][4];
   int st_ok[PF][NT];
 
+  // Loads are unconditional (invalid lanes read element 0 and are zeroed at store time): a branch around a
+  // load makes hipcc emit vmcnt(0) behind it and serialises the whole stage (see conv_igemm.hip).
   auto issue_loads = [&](int ks, uint4 (&q)[NT][4], int (&okm)[NT]) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int mq = m_begin + ks * BKP + t_pq[i] * 4;
       okm[i] = 0;
-      if (t_kind[i] == 0) {
+      if (t_kind[i] == 0) {                     // wave-uniform for the 128x128 tile (tasks 0..127 / 128..255)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int m = mq + j;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (t_colok[i] && m < m_end)
-            v = *reinterpret_cast<const uint4*>(gdy + (size_t)m * p.Cout + t_col[i]);
-          q[i][j] = v;
+          const bool ok = t_colok[i] && m < m_end;
+          q[i][j] = *reinterpret_cast<const uint4*>(gdy + (ok ? (size_t)m * p.Cout + t_col[i] : (size_t)0));
+          okm[i] |= (ok ? 1 : 0) << j;
         }
       } else if (t_kind[i] == 1) {
-        int b = t_b[i], oy = t_oy[i], ox = t_ox[i];
+        int b, r, oy, ox;
+        fast_divmod(mq, HoWo, p.inv_howo, b, r);
+        fast_divmod(r, p.Wo, p.inv_wo, oy, ox);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int m = mq + j;
           const int iy = oy * p.so + t_dy[i], ix = ox * p.so + t_dx[i];
           const bool ok = t_colok[i] && m < m_end && ((unsigned)iy < (unsigned)p.Hi) &&
                           ((unsigned)ix < (unsigned)p.Wi);
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (ok) {
-            v = *reinterpret_cast<const uint4*>(gin + ((size_t)((b * p.Hi + iy) * p.Wi + ix)) * p.Cin + t_col[i]);
-            okm[i] |= 1 << j;
-          }
-          q[i][j] = v;
-          if (++ox == p.Wo) { ox = 0; if (++oy == p.Ho) { oy = 0; ++b; } }
+          const size_t off = ((size_t)((b * p.Hi + iy) * p.Wi + ix)) * p.Cin + t_col[i];
+          q[i][j] = *reinterpret_cast<const uint4*>(gin + (ok ? off : (size_t)0));
+          okm[i] |= (ok ? 1 : 0) << j;
+          // next pixel (branch-free wrap)
+          ++ox;
+          const bool wx = ox == p.Wo;
+          ox = wx ? 0 : ox;
+          oy = wx ? oy + 1 : oy;
+          const bool wy = oy == p.Ho;
+          oy = wy ? 0 : oy;
+          b = wy ? b + 1 : b;
         }
-        // advance the task's first pixel by one K step (BKP pixels)
-        int nox = t_ox[i] + BKP, noy = t_oy[i], nb = t_b[i];
-        while (nox >= p.Wo) { nox -= p.Wo; if (++noy == p.Ho) { noy = 0; ++nb; } }
-        t_ox[i] = nox; t_oy[i] = noy; t_b[i] = nb;
       }
     }
   };
 
   auto store_stage = [&](int buf, uint4 (&q)[NT][4], int (&okm)[NT]) {
+    const uint4 zero = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       if (t_kind[i] == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!((okm[i] >> j) & 1)) q[i][j] = zero;
         store_task<T, BMK>(sA + buf * ABYTES, t_pq[i], t_cc[i], q[i]);
       } else if (t_kind[i] == 1) {
-        if (has_aff) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if ((okm[i] >> j) & 1) {
-              float f[EPC];
-              Chunk<T>::unpack(q[i][j], f);
+        for (int j = 0; j < 4; ++j) {
+          uint4 v = q[i][j];
+          if (has_aff) {
+            float f[EPC];
+            Chunk<T>::unpack(v, f);
 #pragma unroll
-              for (int e = 0; e < EPC; ++e) {
-                float z = f[e] * sAff[t_col[i] + e] + sAff[p.Cin + t_col[i] + e];
-                f[e] = p.relu_in ? fmaxf(z, 0.f) : z;
-              }
-              q[i][j] = Chunk<T>::pack(f);
+            for (int e = 0; e < EPC; ++e) {
+              float z = f[e] * sAff[t_col[i] + e] + sAff[p.Cin + t_col[i] + e];
+              f[e] = p.relu_in ? fmaxf(z, 0.f) : z;
             }
+            v = Chunk<T>::pack(f);
           }
+          q[i][j] = ((okm[i] >> j) & 1) ? v : zero;
         }
         store_task<T, BNC>(sB + buf * BBYTES, t_pq[i], t_cc[i], q[i]);
       }
@@ -234,76 +234,72 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   __syncthreads();
-  if (nks > 0) {
-    issue_loads(0, stage[0], st_ok[0]);
-    store_stage(0, stage[0], st_ok[0]);
+  // tiles past nks are all-zero (m >= m_end), so the loop below runs without conditionals for a trip count
+  // rounded up to a multiple of PF (see conv_igemm.hip)
+  issue_loads(0, stage[0], st_ok[0]);
+  store_stage(0, stage[0], st_ok[0]);
 #pragma unroll
-    for (int u = 1; u <= PF; ++u)
-      if (u < nks) issue_loads(u, stage[u % PF], st_ok[u % PF]);
-  }
+  for (int u = 1; u <= PF; ++u) issue_loads(u, stage[u % PF], st_ok[u % PF]);
   __syncthreads();
 
   const int frow = lane & 31, fhalf = lane >> 5;
-  for (int ks0 = 0; ks0 < nks; ks0 += PF) {
+  const int nsteps = (nks + PF - 1) / PF * PF;
+  for (int ks0 = 0; ks0 < nsteps; ks0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int ks = ks0 + u;
-      if (ks < nks) {
-        const int buf = ks & 1;
-        const unsigned char* a = sA + buf * ABYTES;
-        const unsigned char* b = sB + buf * BBYTES;
-        if constexpr (sizeof(T) == 4) {
+      const int buf = ks & 1;
+      const unsigned char* a = sA + buf * ABYTES;
+      const unsigned char* b = sB + buf * BBYTES;
+      if constexpr (sizeof(T) == 4) {
 #pragma unroll
-          for (int e = 0; e < BKP / 2; ++e) {
-            const int pix = 2 * e + fhalf;
-            float fa[TM], fb[TN];
+        for (int e = 0; e < BKP / 2; ++e) {
+          const int pix = 2 * e + fhalf;
+          float fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-              fa[i] = *reinterpret_cast<const float*>(a + (pix * BMK + (wm * TM + i) * 32 + frow) * 4);
+          for (int i = 0; i < TM; ++i)
+            fa[i] = *reinterpret_cast<const float*>(a + (pix * BMK + (wm * TM + i) * 32 + frow) * 4);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            fb[j] = *reinterpret_cast<const float*>(b + (pix * BNC + (wn * TN + j) * 32 + frow) * 4);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              fb[j] = *reinterpret_cast<const float*>(b + (pix * BNC + (wn * TN + j) * 32 + frow) * 4);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-          }
-        } else {
-#pragma unroll
-          for (int kk = 0; kk < BKP / 16; ++kk) {
-            const int q0 = 4 * kk + 2 * fhalf;
-            uint4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-              const int ch = (wm * TM + i) * 32 + frow;
-              const uint2 lo = *reinterpret_cast<const uint2*>(a + (q0 * (BMK / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
-              const uint2 hi = *reinterpret_cast<const uint2*>(a + ((q0 + 1) * (BMK / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
-              fa[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const int ch = (wn * TN + j) * 32 + frow;
-              const uint2 lo = *reinterpret_cast<const uint2*>(b + (q0 * (BNC / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
-              const uint2 hi = *reinterpret_cast<const uint2*>(b + ((q0 + 1) * (BNC / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
-              fb[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                                    __builtin_bit_cast(bf16x8, fb[j]),
-                                                                    acc[i][j], 0, 0, 0);
-          }
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        const int nx = (u + 1) % PF;      // static after unrolling
-        if (ks + 1 < nks) {
-          store_stage(buf ^ 1, stage[nx], st_ok[nx]);
-          if (ks + 1 + PF < nks) issue_loads(ks + 1 + PF, stage[nx], st_ok[nx]);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < BKP / 16; ++kk) {
+          const int q0 = 4 * kk + 2 * fhalf;
+          uint4 fa[TM], fb[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int ch = (wm * TM + i) * 32 + frow;
+            const uint2 lo = *reinterpret_cast<const uint2*>(a + (q0 * (BMK / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
+            const uint2 hi = *reinterpret_cast<const uint2*>(a + ((q0 + 1) * (BMK / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
+            fa[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int ch = (wn * TN + j) * 32 + frow;
+            const uint2 lo = *reinterpret_cast<const uint2*>(b + (q0 * (BNC / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
+            const uint2 hi = *reinterpret_cast<const uint2*>(b + ((q0 + 1) * (BNC / 8) + (ch >> 3)) * 80 + (ch & 7) * 8);
+            fb[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                  __builtin_bit_cast(bf16x8, fb[j]),
+                                                                  acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
       }
+      const int nx = (u + 1) % PF;      // static after unrolling
+      store_stage(buf ^ 1, stage[nx], st_ok[nx]);
+      issue_loads(ks + 1 + PF, stage[nx], st_ok[nx]);
+      __syncthreads();
     }
   }
 
@@ -388,6 +384,8 @@ extern "C" int pxl_conv_wgrad(const pxl_conv_desc* d, const void* in, const floa
   a.ntaps = d->ntaps; a.so = d->out_stride; a.relu_in = d->relu_in;
   a.M = d->B * d->Ho * d->Wo; a.m_per_split = 0;
   a.Ng = d->ntaps * d->Cin; a.tiles_k = a.tiles_c = 0;
+  a.inv_wo = 1.0f / (float)d->Wo; a.inv_howo = 1.0f / (float)(d->Ho * d->Wo);
+  PXL_REQUIRE((long)d->B * d->Ho * d->Wo < (1L << 24), "conv_wgrad: more than 2^24 output pixels");
   for (int t = 0; t < 64; ++t)
     a.taps[t] = t < d->ntaps ? (((int)d->dy[t]) << 16) | (((int)d->dx[t]) & 0xffff) : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
