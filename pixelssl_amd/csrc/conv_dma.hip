@@ -1,0 +1,419 @@
+// LDS-DMA implicit-GEMM convolution for gfx950 (bf16, NHWC, channel pitch % 64 == 0).
+//
+//   out[m][n] = sum_{t,c} in[pix(m,t)][c] * w[n][t][c]        m = (b,oy,ox), n = out channel
+//
+// This is the fast path behind pxl_conv_igemm for plain (already activated) bf16 inputs: forward
+// 1x1 / 3x3 / atrous / strided convolutions and the data gradients of stride-1 convolutions.
+// Differences to conv_igemm.hip (which stays the generic / fp32-parity kernel):
+//   * tiles go HBM/L2 -> LDS directly (`buffer_load_dwordx4 ... lds`), 1 KiB per wave-instruction,
+//     no register staging and no per-element VALU in the K loop.  Zero padding, ragged M and padded
+//     output channels are lanes whose buffer offset is out of range: the buffer descriptor makes
+//     the DMA write zeros (probed on MI355X: tools/probes/probe_tr.hip).
+//   * a K step is 64 channels (128-byte rows) of ONE tap; the per-lane gather offset only changes
+//     at a tap boundary, the walk inside a tap is the scalar soffset.
+//   * NST-deep LDS ring, one raw s_barrier per K step, counted `s_waitcnt vmcnt(N)` so that NST-2
+//     tiles stay in flight across the barrier (a __syncthreads() would drain them).
+//   * 16-byte XOR swizzle applied on the SOURCE side (lane -> chunk) and on the fragment read, LDS
+//     image stays lane-linear as the DMA requires.
+//   * MFMA roles are swapped (A = weights, B = activations) so that a lane's accumulator quads are
+//     4 consecutive output channels: the epilogue packs them, stages the tile through LDS
+//     (ds_write_b64) and stores full 16-byte row segments; bias / addend / BN statistics are applied
+//     on that coalesced read-back pass.
+#include "common.h"
+
+namespace {
+
+struct DmaArgs {
+  const void* in;
+  const void* w;
+  void* out;
+  const float* bias;
+  const void* addend;
+  float* stats;
+  int stats_rep;
+  int B, Hi, Wi, Cin;
+  int Ho, Wo, Cout, Kreal;
+  int ntaps, so;
+  int M, Ktot, nk;
+  int tiles_m, tiles_n;
+  unsigned in_bytes, w_bytes;
+  int taps[64];      // (dy << 16) | (dx & 0xffff)
+};
+
+constexpr unsigned OOB = 0x80000000u;
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds, 16, (int)voff, (int)soff, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Fragment reads are inline asm on purpose: for a C++ LDS load hipcc's waitcnt pass assumes it may alias
+// every LDS-DMA in flight and puts `s_waitcnt vmcnt(0)` in front of the first ds_read of each K step, which
+// drains the ring.  The ordering that is actually needed (this wave's counted vmcnt + the barrier) is
+// written out in the loop below.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF> __device__ __forceinline__ u32x4 lds_read128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+// `s_waitcnt lgkmcnt(N)` with the fragments of ONE k-chunk and the accumulators threaded through it.  To the
+// compiler an MFMA is pure register code, which it schedules freely around a bare wait statement (a "memory"
+// clobber does not order it).  "+v"(fragments): the MFMAs of this k-chunk cannot move above the wait that makes
+// their operands valid.  "+a"(accumulators): the MFMAs of the previous k-chunk cannot sink below it, so they
+// overlap the LDS reads that are still outstanding.  The statement touches none of these registers.
+template <int N, int TMI, int TNI>
+__device__ __forceinline__ void wait_chunk(u32x4 (&fa)[TMI], u32x4 (&fw)[TNI], f32x16 (&acc)[TNI][TMI]) {
+  if constexpr (TMI == 1 && TNI == 1)
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fa[0]), "+v"(fw[0]), "+a"(acc[0][0]) : "n"(N));
+  else if constexpr (TMI == 2 && TNI == 1)
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fw[0]), "+a"(acc[0][0]), "+a"(acc[0][1]) : "n"(N));
+  else if constexpr (TMI == 1 && TNI == 2)
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fa[0]), "+v"(fw[0]), "+v"(fw[1]), "+a"(acc[0][0]), "+a"(acc[1][0]) : "n"(N));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(fa[0]), "+v"(fa[1]), "+v"(fw[0]), "+v"(fw[1]), "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]),
+                   "+a"(acc[1][1])
+                 : "n"(N));
+}
+template <int I, int N, int STRIDE, int BASE> struct FragLoad {
+  static __device__ __forceinline__ void run(u32x4 (&f)[N], unsigned addr) {
+    f[I] = lds_read128<BASE + I * STRIDE>(addr);
+    if constexpr (I + 1 < N) FragLoad<I + 1, N, STRIDE, BASE>::run(f, addr);
+  }
+};
+
+// BM x BN output tile (pixels x channels), 4 waves as WM x WN, NST LDS stages, GATHER = taps / padding logic
+template <int BM, int BN, int WM, int WN, int NST, bool GATHER>
+__global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
+  constexpr int TMI = BM / WM / 32;          // 32-pixel tiles per wave
+  constexpr int TNI = BN / WN / 32;          // 32-channel tiles per wave
+  constexpr int LA = BM / 32, LB = BN / 32;  // DMA instructions per wave per K step
+  constexpr int SB = (BM + BN) * 128;        // bytes per stage
+  constexpr int TP = BN * 2 + 16;            // epilogue staging row pitch (bank-conflict-free ds_write_b64)
+  constexpr int TPR = BN / 8;                // threads per output row on the read-back pass
+  constexpr int RPP = 256 / TPR;             // rows per pass
+  constexpr int NPASS = BM / RPP;
+  static_assert(WM * WN == 4 && TMI >= 1 && TNI >= 1 && TMI <= 2 && TNI <= 2, "tile");
+  static_assert(NST * SB >= BM * TP + 4 * BN * 8, "epilogue staging must fit in the ring");
+
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  // ---- loader coordinates: DMA instruction g = wave + 4*q covers tile rows 8g .. 8g+7, lane -> (row, 16-byte slot)
+  const int lrow = lane >> 3, lslot = lane & 7;
+  unsigned voffA[LA], voffB[LB];
+  int a_pix[LA], a_iy[LA], a_ix[LA];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int q = 0; q < LA; ++q) {
+    const int row = (wave + 4 * q) * 8 + lrow;
+    const int chunk = lslot ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    if (m < p.M) {
+      const int b = m / HoWo;
+      const int r = m - b * HoWo;
+      const int oy = r / p.Wo;
+      const int ox = r - oy * p.Wo;
+      a_iy[q] = oy * p.so;
+      a_ix[q] = ox * p.so;
+      a_pix[q] = ((b * p.Hi + a_iy[q]) * p.Wi + a_ix[q]) * p.Cin * 2 + chunk * 16;
+      voffA[q] = (unsigned)a_pix[q];
+    } else {
+      a_iy[q] = -(1 << 20);
+      a_ix[q] = 0;
+      a_pix[q] = 0;
+      voffA[q] = OOB;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < LB; ++q) {
+    const int row = (wave + 4 * q) * 8 + lrow;
+    const int chunk = lslot ^ ((row >> 1) & 7);
+    const int n = n0 + row;
+    voffB[q] = n < p.Kreal ? (unsigned)(n * p.Ktot * 2 + chunk * 16) : OOB;
+  }
+
+  // ---- load cursor: tap t, byte offset kcb inside the pixel's channel vector, kwb inside the weight row
+  int ld_t = 0;
+  unsigned kcb = 0, kwb = 0;
+  const unsigned cin_bytes = (unsigned)p.Cin * 2;
+  auto set_tap = [&](int t) {
+    if constexpr (GATHER) {
+      const int tp = p.taps[min(t, p.ntaps - 1)];
+      const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
+      const int tapoff = (dy * p.Wi + dx) * p.Cin * 2;
+#pragma unroll
+      for (int q = 0; q < LA; ++q) {
+        const int iy = a_iy[q] + dy, ix = a_ix[q] + dx;
+        const bool ok = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
+        voffA[q] = ok ? (unsigned)(a_pix[q] + tapoff) : OOB;
+      }
+    }
+  };
+  auto issue = [&](int stage) {
+    unsigned char* sa = smem + stage * SB + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < LA; ++q) dma16(r_in, sa + q * 4096, voffA[q], kcb);
+    unsigned char* sb = smem + stage * SB + BM * 128 + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < LB; ++q) dma16(r_w, sb + q * 4096, voffB[q], kwb);
+    kwb += 128;
+    kcb += 128;
+    if (kcb == cin_bytes) {      // block-uniform: next tap
+      kcb = 0;
+      ++ld_t;
+      set_tap(ld_t);
+    }
+  };
+
+  f32x16 acc[TNI][TMI];
+#pragma unroll
+  for (int j = 0; j < TNI; ++j)
+#pragma unroll
+    for (int i = 0; i < TMI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  // fragment read offsets: row (lane & 31) of a 32-row tile, 16-byte chunk 2*kk + (lane >> 5), swizzled
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int fx = (frow >> 1) & 7;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const unsigned f = frow * 128 + (((2 * kk + fhalf) ^ fx) << 4);
+    aoff[kk] = f + wm * TMI * 4096;
+    boff[kk] = f + wn * TNI * 4096;
+  }
+
+  set_tap(0);
+  // ---- prologue: NST-1 tiles in flight
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) issue(s);
+
+  int st_c = 0;               // stage being multiplied
+  int st_l = NST - 1;         // stage being filled
+  for (int ks = 0; ks < p.nk; ++ks) {
+    wait_vmcnt<(NST - 2) * (LA + LB)>();      // this wave's share of tile ks has landed
+    __builtin_amdgcn_s_barrier();             // ... everyone's has; stage st_l is no longer being read
+    issue(st_l);
+    // all 4*(TMI+TNI) fragment reads of the step are issued up front (LDS returns in order), the MFMAs of
+    // k-chunk kk start as soon as its own reads are back: lgkmcnt counts the reads still outstanding
+    const unsigned sbase = lds0 + st_c * SB;
+    u32x4 fa[4][TMI], fw[4][TNI];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      FragLoad<0, TMI, 4096, 0>::run(fa[kk], sbase + aoff[kk]);
+      FragLoad<0, TNI, 4096, BM * 128>::run(fw[kk], sbase + boff[kk]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk == 0) wait_chunk<3 * (TMI + TNI)>(fa[0], fw[0], acc);
+      if (kk == 1) wait_chunk<2 * (TMI + TNI)>(fa[1], fw[1], acc);
+      if (kk == 2) wait_chunk<1 * (TMI + TNI)>(fa[2], fw[2], acc);
+      if (kk == 3) wait_chunk<0>(fa[3], fw[3], acc);
+#pragma unroll
+      for (int j = 0; j < TNI; ++j)
+#pragma unroll
+        for (int i = 0; i < TMI; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[kk][j]),
+                                                              __builtin_bit_cast(bf16x8, fa[kk][i]), acc[j][i], 0, 0, 0);
+    }
+    st_c = st_c + 1 == NST ? 0 : st_c + 1;
+    st_l = st_l + 1 == NST ? 0 : st_l + 1;
+  }
+  wait_vmcnt<0>();                 // the tail DMAs (tiles past nk) must not land in the staging area
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue 1: accumulators -> bf16 tile T[m][n] in LDS.  C/D layout of the 32x32 MFMA with swapped
+  // roles: column (lane & 31) = pixel, rows (r&3) + 8*(r>>2) + 4*(lane>>5) = channel
+  unsigned char* T = smem;
+#pragma unroll
+  for (int j = 0; j < TNI; ++j)
+#pragma unroll
+    for (int i = 0; i < TMI; ++i) {
+      const int ml = (wm * TMI + i) * 32 + frow;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = (wn * TNI + j) * 32 + 8 * g + 4 * fhalf;
+        uint2 v;
+        v.x = pack_bf2(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1]);
+        v.y = pack_bf2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+        *reinterpret_cast<uint2*>(T + ml * TP + nl * 2) = v;
+      }
+    }
+  __syncthreads();
+
+  // ---- epilogue 2: coalesced read-back, bias / addend / statistics, 16-byte stores
+  const int ec = tid % TPR;                  // 8-channel chunk of this thread
+  const int er = tid / TPR;
+  const int n = n0 + ec * 8;
+  const bool ncol = n < p.Cout;
+  bf16_t* __restrict__ gout = reinterpret_cast<bf16_t*>(p.out);
+  const bf16_t* __restrict__ gadd = reinterpret_cast<const bf16_t*>(p.addend);
+  const bool has_bias = p.bias != nullptr;
+  const bool has_add = gadd != nullptr;
+  const bool has_stats = p.stats != nullptr;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = (has_bias && n + e < p.Kreal) ? p.bias[n + e] : 0.f;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int ml = ps * RPP + er;
+    const int m = m0 + ml;
+    uint4 v = *reinterpret_cast<const uint4*>(T + ml * TP + ec * 16);
+    if (m < p.M && ncol) {
+      const size_t o = (size_t)m * p.Cout + n;
+      if (has_bias || has_add || has_stats) {
+        float f[8];
+        Chunk<bf16_t>::unpack(v, f);
+        if (has_bias || has_add) {
+          if (has_add) {
+            float ad[8];
+            Chunk<bf16_t>::unpack(*reinterpret_cast<const uint4*>(gadd + o), ad);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += ad[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += bv[e];
+          v = Chunk<bf16_t>::pack(f);
+          if (has_stats) Chunk<bf16_t>::unpack(v, f);     // statistics of the stored (rounded) values
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s1[e] += f[e];
+          s2[e] += f[e] * f[e];
+        }
+      }
+      *reinterpret_cast<uint4*>(gout + o) = v;
+    }
+  }
+  if (has_stats) {
+    // reduce over the threads that share a channel chunk: lanes ec + TPR*k inside the wave, then the 4 waves
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = TPR; o < 64; o <<= 1) {
+        s1[e] += __shfl_xor(s1[e], o, 64);
+        s2[e] += __shfl_xor(s2[e], o, 64);
+      }
+    }
+    float* red = reinterpret_cast<float*>(smem + BM * TP);     // [4 waves][2][BN]
+    if (lane < TPR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * 2 + 0) * BN + ec * 8 + e] = s1[e];
+        red[(wave * 2 + 1) * BN + ec * 8 + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, c = tid % BN;
+      const float v = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c] +
+                      red[(2 * 2 + which) * BN + c] + red[(3 * 2 + which) * BN + c];
+      if (n0 + c < p.Kreal) {
+        float* rep = p.stats + (size_t)(tm % p.stats_rep) * 2 * p.Kreal;
+        atomicAdd(rep + which * p.Kreal + n0 + c, v);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NST>
+int launch_dma(const DmaArgs& a, bool gather, hipStream_t stream) {
+  DmaArgs p = a;
+  p.tiles_m = cdiv(p.M, BM);
+  p.tiles_n = cdiv(p.Cout, BN);
+  const int grid = p.tiles_m * p.tiles_n;
+  constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
+  static bool raised[2] = {false, false};
+  if (!raised[gather ? 1 : 0]) {
+    if (gather) PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised[gather ? 1 : 0] = true;
+  }
+  if (gather)
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, true>), dim3(grid), dim3(256), smem, stream, p);
+  else
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, false>), dim3(grid), dim3(256), smem, stream, p);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+}  // namespace
+
+// 1 if the descriptor / operand combination can run on the LDS-DMA kernel
+extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_scale, const void* workspace) {
+  (void)workspace;
+  if (d->dtype != PXL_BF16 || in_scale != nullptr) return 0;
+  if (d->Cin % 64 != 0 || d->Cout % 8 != 0 || d->div != 1) return 0;
+  if (d->split_k > 1) return 0;
+  if ((long)d->Kreal * d->ntaps * d->Cin * 2 >= (1L << 31)) return 0;
+  return 1;
+}
+
+// tile configurations 8..: 8 = 128x128, 9 = 128(pixels)x64, 10 = 64x128, 11 = 64x64 ; +4 = one more LDS stage
+extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
+                            const void* addend, float* stats, void* stream) {
+  DmaArgs a;
+  a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = addend; a.stats = stats;
+  a.stats_rep = d->stats_rep >= 1 ? d->stats_rep : 1;
+  a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.Kreal = d->Kreal;
+  a.ntaps = d->ntaps; a.so = d->out_stride;
+  a.M = d->B * d->Ho * d->Wo;
+  a.Ktot = d->ntaps * d->Cin;
+  a.nk = a.Ktot / 64;
+  a.tiles_m = a.tiles_n = 0;
+  a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->Cin * 2);
+  a.w_bytes = (unsigned)((size_t)d->Kreal * a.Ktot * 2);
+  for (int t = 0; t < 64; ++t)
+    a.taps[t] = t < d->ntaps ? (((int)d->dy[t]) << 16) | (((int)d->dx[t]) & 0xffff) : 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // taps at offset (0,0) only and every output pixel inside the input: no bounds logic at all
+  bool gather = false;
+  for (int t = 0; t < d->ntaps; ++t) gather |= d->dy[t] != 0 || d->dx[t] != 0;
+  gather |= d->ntaps != 1;
+  gather |= (d->Ho - 1) * d->out_stride >= d->Hi || (d->Wo - 1) * d->out_stride >= d->Wi;
+  int cfg = d->tile_cfg;
+  if (cfg < 8) {
+    const long t128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 128);
+    if (a.Cout <= 64) cfg = 9;
+    else if (t128 >= 384) cfg = 8;
+    else cfg = 9;
+  }
+  switch (cfg) {
+    case 8: return launch_dma<128, 128, 2, 2, 3>(a, gather, s);
+    case 9: return launch_dma<128, 64, 2, 2, 3>(a, gather, s);
+    case 10: return launch_dma<64, 128, 2, 2, 3>(a, gather, s);
+    case 11: return launch_dma<64, 64, 2, 2, 3>(a, gather, s);
+    case 12: return launch_dma<128, 128, 2, 2, 4>(a, gather, s);
+    case 13: return launch_dma<128, 64, 2, 2, 4>(a, gather, s);
+    case 14: return launch_dma<64, 128, 2, 2, 4>(a, gather, s);
+    case 15: return launch_dma<64, 64, 2, 2, 4>(a, gather, s);
+    default: return pxl_set_error(PXL_ERR_ARG, "conv_dma: unknown tile config %d", cfg);
+  }
+}

@@ -434,6 +434,10 @@ int launch_conv(const ConvArgs& a, int force_cfg, int want_split, size_t ws_byte
 
 }  // namespace
 
+extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_scale, const void* workspace);
+extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
+                            const void* addend, float* stats, void* stream);
+
 extern "C" int pxl_conv_igemm(const pxl_conv_desc* d, const void* in, const void* w, void* out,
                               const float* in_scale, const float* in_shift, const float* bias,
                               const void* addend, float* stats, void* workspace, size_t ws_bytes,
@@ -448,6 +452,11 @@ extern "C" int pxl_conv_igemm(const pxl_conv_desc* d, const void* in, const void
   PXL_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv_igemm: scale/shift must come together");
   PXL_REQUIRE((long)d->B * d->Hi * d->Wi * d->Cin < (1L << 31) && (long)d->B * d->Ho * d->Wo * d->Cout < (1L << 31),
               "conv_igemm: tensor too large for 32-bit indexing");
+  // plain bf16 operands take the LDS-DMA kernel (conv_dma.hip); tile_cfg 0..7 forces this generic kernel
+  if (d->tile_cfg < 0 || d->tile_cfg >= 8) {
+    if (pxl_conv_dma_eligible(d, in_scale, workspace)) return pxl_conv_dma(d, in, w, out, bias, addend, stats, stream);
+    PXL_REQUIRE(d->tile_cfg < 8, "conv_igemm: tile config %d needs plain bf16 operands with Cin %% 64 == 0", d->tile_cfg);
+  }
   ConvArgs a;
   a.in = in; a.w = w; a.out = out;
   a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.addend = addend; a.stats = stats;

@@ -97,6 +97,69 @@ def test_conv_forward(dtype, case, cfg):
         assert out[..., Cout:].float().abs().max().item() == 0.0
 
 
+DMA_CASES = [
+    # name, B, Cin, Cout, H, W, k, stride, dil, pad   (Cin % 64 == 0: the LDS-DMA kernel, conv_dma.hip)
+    ("dma_1x1", 2, 64, 256, 17, 17, 1, 1, 1, 0),
+    ("dma_1x1_k256", 3, 256, 72, 9, 13, 1, 1, 1, 0),
+    ("dma_1x1_s2", 2, 128, 160, 17, 17, 1, 2, 1, 0),
+    ("dma_3x3", 2, 64, 64, 17, 17, 3, 1, 1, 1),
+    ("dma_3x3_s2", 2, 64, 96, 17, 17, 3, 2, 1, 1),
+    ("dma_3x3_d2", 2, 128, 128, 9, 9, 3, 1, 2, 2),
+    ("dma_3x3_d4_wide", 1, 64, 288, 9, 9, 3, 1, 4, 4),
+    ("dma_4x4_s2", 2, 64, 64, 33, 33, 4, 2, 1, 1),
+    ("dma_tiny_m", 1, 192, 40, 3, 5, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", DMA_CASES, ids=[c[0] for c in DMA_CASES])
+@pytest.mark.parametrize("cfg", [-1, 8, 9, 10, 11, 12, 13, 14, 15])
+def test_conv_dma_forward_and_dgrad(case, cfg):
+    """LDS-DMA kernel: forward (every tile configuration, 3- and 4-stage rings), bias + addend + BN statistics
+    on the coalesced read-back pass, and the data gradient of stride-1 convolutions."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    name, B, Cin, Cout, H, W, k, s, d, p = case
+    g = torch.Generator().manual_seed(_seed(name) + 7)
+    x = qround(torch.randn(B, Cin, H, W, generator=g), dtype).requires_grad_(True)
+    w = qround(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype).requires_grad_(True)
+    bias = torch.randn(Cout, generator=g)
+    y0 = F.conv2d(x, w, None, s, p, d)
+    Ho, Wo = y0.shape[2:]
+    add = qround(torch.randn(B, Cout, Ho, Wo, generator=g), dtype)
+    cip, cop = _pitch(Cin), _pitch(Cout)
+    taps = ops.fwd_taps(k, k, d, p)
+    xd = to_nhwc(x.detach(), cip, dtype)
+    wf, wt = pack_w(w.detach(), dtype, cip, kp=cop)
+    # plain forward
+    out = torch.full((B, Ho, Wo, cop), 7.0, device=DEV, dtype=dtype)
+    desc = ops.conv_desc(dtype, B, H, W, cip, Ho, Wo, cop, Cout, taps, out_stride=s, tile_cfg=cfg, stats_rep=3)
+    ops.conv_igemm(desc, xd, wf, out)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(out, Cout), y0.detach()) < TOL[dtype], "%s cfg %d" % (name, cfg)
+    if cop > Cout:
+        assert out[..., Cout:].float().abs().max().item() == 0.0
+    # bias + addend + statistics
+    ref = qround(qround(y0.detach(), dtype) + add + bias.view(1, -1, 1, 1), dtype)
+    stats = torch.zeros(3, 2 * Cout, device=DEV)
+    out2 = torch.empty(B, Ho, Wo, cop, device=DEV, dtype=dtype)
+    ops.conv_igemm(desc, xd, wf, out2, bias=bias.to(DEV), addend=to_nhwc(add, cop, dtype), stats=stats)
+    torch.cuda.synchronize()
+    got = from_nhwc(out2, Cout)
+    assert rel_err(got, ref) < TOL[dtype], "%s cfg %d epilogue" % (name, cfg)
+    folded = stats.sum(0).cpu()
+    assert rel_err(folded[:Cout], got.sum(dim=(0, 2, 3))) < 1e-4          # statistics of the STORED values
+    assert rel_err(folded[Cout:], (got * got).sum(dim=(0, 2, 3))) < 1e-4
+    # data gradient (stride-1 convolutions run on the DMA kernel, strided ones on the generic kernel)
+    dy = qround(torch.randn(y0.shape, generator=g), dtype)
+    y0.backward(dy)
+    dx = torch.empty(B, H, W, cip, device=DEV, dtype=dtype)
+    bdesc = ops.conv_desc(dtype, B, Ho, Wo, cop, H, W, cip, Cin, [(-a, -b) for a, b in taps], out_stride=1, div=s,
+                          tile_cfg=cfg if s == 1 else -1)
+    ops.conv_igemm(bdesc, to_nhwc(dy, cop, dtype), wt, dx)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dx, Cin), x.grad) < TOL[dtype], "dgrad %s cfg %d" % (name, cfg)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_prologue_epilogue(dtype):
     """relu(bn(x)) fused into the load (zero padding stays zero), bias, addend, BN statistics."""

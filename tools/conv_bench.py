@@ -101,7 +101,9 @@ def main():
                                          out_stride=1, div=s, tile_cfg=cfg)
                     fn = lambda: ops.conv_igemm(desc, y, wt, x)
                 else:
-                    desc = ops.conv_desc(dtype, B, H, H, cip, Ho, Ho, cop, cout, taps, out_stride=s, tile_cfg=min(cfg, 2) if cfg >= 0 else -1)
+                    if cfg > 2:
+                        continue
+                    desc = ops.conv_desc(dtype, B, H, H, cip, Ho, Ho, cop, cout, taps, out_stride=s, tile_cfg=cfg)
                     fn = lambda: ops.conv_wgrad(desc, x, y, dw, cin, cin)
                 try:
                     t = timeit(fn, a.iters)
