@@ -126,6 +126,10 @@ int pxl_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H, in
 int pxl_bn_finalize(int C, const float* stats, int nrep, float count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, int training,
                     int clamp_var, float* coef, void* stream);
+/* z = relu?(y*scale + shift) with (scale, shift) = coef[2C..4C): the activated tensor.  The bf16 engine
+ * materialises it once per BN so that the LDS-DMA contraction kernels read plain operands
+ * (SynchronizedBatchNorm2d + nn.ReLU at resnet.py:33-41). */
+int pxl_bn_apply_fwd(int dtype, long M, int C, const void* y, const float* coef, int relu, void* z, void* stream);
 /* buf[0][i] = sum_r buf[r][i], i < n */
 int pxl_bn_fold_replicas(int n, int nrep, float* buf, void* stream);
 /* sums [nrep][2C] (caller-zeroed) += sum dz', sum dz'*xhat with dz' = dz * (relu ? bn(y) > 0 : 1) */

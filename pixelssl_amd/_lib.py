@@ -68,6 +68,7 @@ SIGNATURES = {
     "pxl_nchw_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "pxl_nhwc_to_nchw": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "pxl_bn_finalize": (_I, [_I, _P, _I, _F, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P]),
+    "pxl_bn_apply_fwd": (_I, [_I, _L, _I, _P, _P, _I, _P, _P]),
     "pxl_bn_fold_replicas": (_I, [_I, _I, _P, _P]),
     "pxl_bn_bwd_reduce": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
     "pxl_bn_bwd_finalize": (_I, [_I, _P, _I, _F, _P, _P, _P, _I, _P]),

@@ -375,7 +375,8 @@ extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_sca
   return 1;
 }
 
-// tile configurations 8..: 8 = 128x128, 9 = 128(pixels)x64, 10 = 64x128, 11 = 64x64 ; +4 = one more LDS stage
+// tile configurations 8..: 8 = 128x128, 9 = 128(pixels)x64, 10 = 64x128, 11 = 64x64 with a 3-stage LDS ring;
+// 12..15 the same with 4 stages, 16..19 with 2 stages (more blocks per CU)
 extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
                             const void* addend, float* stats, void* stream) {
   DmaArgs a;
@@ -414,6 +415,10 @@ extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* 
     case 13: return launch_dma<128, 64, 2, 2, 4>(a, gather, s);
     case 14: return launch_dma<64, 128, 2, 2, 4>(a, gather, s);
     case 15: return launch_dma<64, 64, 2, 2, 4>(a, gather, s);
+    case 16: return launch_dma<128, 128, 2, 2, 2>(a, gather, s);
+    case 17: return launch_dma<128, 64, 2, 2, 2>(a, gather, s);
+    case 18: return launch_dma<64, 128, 2, 2, 2>(a, gather, s);
+    case 19: return launch_dma<64, 64, 2, 2, 2>(a, gather, s);
     default: return pxl_set_error(PXL_ERR_ARG, "conv_dma: unknown tile config %d", cfg);
   }
 }

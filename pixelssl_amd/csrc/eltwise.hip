@@ -48,6 +48,39 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T
   }
 }
 
+// z = relu?(y*scale + shift): the activated tensor the LDS-DMA convolutions (conv_dma.hip, wgrad) read directly
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(int M, int C, const T* __restrict__ y,
+                                                           const float* __restrict__ coef, int relu,
+                                                           T* __restrict__ z) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cpr = C / EPC;
+  const int cpb = cpr < 256 ? cpr : 256;
+  const int rpb = 256 / cpb;
+  const int ccol = threadIdx.x % cpb, rlane = threadIdx.x / cpb;
+  for (int c0 = 0; c0 < cpr; c0 += cpb) {
+    const int cc = c0 + ccol;
+    if (cc >= cpr || rlane >= rpb) continue;
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      sc[e] = coef[2 * C + cc * EPC + e];
+      sh[e] = coef[3 * C + cc * EPC + e];
+    }
+    for (int m = blockIdx.x * rpb + rlane; m < M; m += gridDim.x * rpb) {
+      const size_t o = (size_t)m * C + cc * EPC;
+      float f[EPC];
+      Chunk<T>::unpack(*reinterpret_cast<const uint4*>(y + o), f);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float v = f[e] * sc[e] + sh[e];
+        f[e] = relu ? fmaxf(v, 0.f) : v;
+      }
+      *reinterpret_cast<uint4*>(z + o) = Chunk<T>::pack(f);
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void relu_mask_kernel(long nchunks, const T* __restrict__ dout,
                                                         const T* __restrict__ out, T* __restrict__ g,
@@ -215,6 +248,23 @@ extern "C" int pxl_residual_fwd(int dtype, long M, int C, const void* y, const f
   else
     hipLaunchKernelGGL(residual_fwd_kernel<bf16_t>, dim3(row_grid(M, C, epc)), dim3(256), 0, s, (int)M, C,
                        cp<bf16_t>(y), ycoef, cp<bf16_t>(res), rcoef, mp<bf16_t>(out));
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_bn_apply_fwd(int dtype, long M, int C, const void* y, const float* coef, int relu, void* z,
+                                void* stream) {
+  PXL_REQUIRE(y && coef && z, "bn_apply_fwd: null argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "bn_apply_fwd: bad dtype");
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  PXL_REQUIRE(C % epc == 0, "bn_apply_fwd: C=%d must be a multiple of %d", C, epc);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<float>, dim3(row_grid(M, C, epc)), dim3(256), 0, s, (int)M, C, cp<float>(y),
+                       coef, relu, mp<float>(z));
+  else
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<bf16_t>, dim3(row_grid(M, C, epc)), dim3(256), 0, s, (int)M, C,
+                       cp<bf16_t>(y), coef, relu, mp<bf16_t>(z));
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

@@ -24,6 +24,7 @@
 
 extern "C" {
 int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream);
+int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_scale, const void* workspace);
 }
 
 namespace {
@@ -51,6 +52,10 @@ struct BnInfo {
   size_t bsum_off = 0;     // scratch: [2C]
   size_t bcoef_off = 0;    // scratch: [2C]
   int y_tensor = -1;
+  // bf16 engine: relu(bn(y)) materialised once (z) when a convolution consumes it, so that the LDS-DMA
+  // kernels read plain operands (the fp32 parity engine keeps the fused prologue)
+  bool has_z = false;
+  size_t z_off = 0;
 };
 
 struct OpInfo {
@@ -147,6 +152,19 @@ struct Timed {
     n->stamps.push_back({a, b, kind, flops});
   }
 };
+
+// operand a convolution (forward and weight gradient) reads: the raw tensor, the materialised relu(bn(y)),
+// or the raw tensor + the fused (scale, shift) prologue
+struct ConvIn { const void* ptr; const float* sc; const float* sh; };
+inline ConvIn conv_input(const pxl_net* n, const pxl_op& d, const void* arena) {
+  const TensorInfo& tin = n->tensors[d.in0];
+  const unsigned char* base = reinterpret_cast<const unsigned char*>(arena);
+  if (d.bn_in0 < 0) return {base + tin.off, nullptr, nullptr};
+  const BnInfo& b = n->bns[d.bn_in0];
+  if (b.has_z) return {base + b.z_off, nullptr, nullptr};
+  const float* coef = reinterpret_cast<const float*>(base + b.coef_off);
+  return {base + tin.off, coef + 2 * b.d.C, coef + 3 * b.d.C};
+}
 
 inline double conv_flops(const pxl_net* n, const pxl_op& d, const TensorInfo& tout) {
   return 2.0 * n->B * tout.H * tout.W * (double)d.cout * d.kh * d.kw * d.ngroups * d.cin;
@@ -330,6 +348,19 @@ extern "C" int pxl_net_plan(pxl_net* n, int B, int H, int W) {
         return pxl_set_error(PXL_ERR_ARG, "net_plan: unknown op kind %d", d.kind);
     }
   }
+  for (auto& b : n->bns) b.has_z = false;
+  if (n->dtype == PXL_BF16) {
+    for (auto& op : n->ops) {
+      const pxl_op& d = op.d;
+      if (d.kind != PXL_OP_CONV || d.bn_in0 < 0) continue;
+      BnInfo& b = n->bns[d.bn_in0];
+      const TensorInfo& tin = n->tensors[d.in0];
+      if (b.y_tensor != d.in0 || tin.Cp % 64 != 0 || tin.Cp != b.d.C || b.has_z) continue;
+      b.has_z = true;
+      b.z_off = arena;
+      arena += tin.bytes;
+    }
+  }
   n->arena_bytes = arena;
   n->scratch_bytes = scratch;
   n->packed_bytes = packed;
@@ -407,21 +438,19 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
     if (d.kind != PXL_OP_CONV) continue;
     const TensorInfo& tin = n->tensors[d.in0];
     const TensorInfo& tout = n->tensors[d.out];
-    const float* sc = nullptr; const float* sh = nullptr;
-    if (d.bn_in0 >= 0) {
-      const BnInfo& bi = n->bns[d.bn_in0];
-      sc = fat(arena, bi.coef_off) + 2 * bi.d.C;
-      sh = fat(arena, bi.coef_off) + 3 * bi.d.C;
-    }
+    const ConvIn cin = conv_input(n, d, arena);
+    const float* sc = cin.sc; const float* sh = cin.sh;
     float* stats = d.bn_out >= 0 ? fat(arena, n->bns[d.bn_out].stats_off) : nullptr;
     const float* bias = d.b_off[0] >= 0 ? fat(packed, op.bias_off) : nullptr;
     // forward
     {
       int best_cfg = -1; float best = 1e30f;
-      for (int cfg = 0; cfg < 8; ++cfg) {
-        if ((cfg & 3) == 3 && tout.Cp > 64) continue;
+      const bool dma = pxl_conv_dma_eligible(&op.fwd, sc, nullptr) != 0;
+      for (int cfg = dma ? 8 : 0; cfg < (dma ? 20 : 8); ++cfg) {
+        if (!dma && (cfg & 3) == 3 && tout.Cp > 64) continue;
+        if (dma && cfg >= 12 && cfg < 16) continue;          // 4-stage rings never won on the ResNet shapes
         pxl_conv_desc q = op.fwd; q.tile_cfg = cfg;
-        float t = time_launch([&]() { return pxl_conv_igemm(&q, at(arena, tin.off), at(packed, op.wf_off), at(arena, tout.off),
+        float t = time_launch([&]() { return pxl_conv_igemm(&q, cin.ptr, at(packed, op.wf_off), at(arena, tout.off),
                                                             sc, sh, bias, nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr,
                                                             op.ws_bytes, stream); }, s, a, b, reps);
         if (t < 0) { rc_all = PXL_ERR_HIP; continue; }
@@ -432,8 +461,10 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
     // data gradient
     if (d.need_dgrad) {
       int best_cfg = -1; float best = 1e30f;
-      for (int cfg = 0; cfg < 8; ++cfg) {
-        if ((cfg & 3) == 3 && tin.Cp > 64) continue;
+      const bool dma = pxl_conv_dma_eligible(&op.bwd, nullptr, nullptr) != 0;
+      for (int cfg = dma ? 8 : 0; cfg < (dma ? 20 : 8); ++cfg) {
+        if (!dma && (cfg & 3) == 3 && tin.Cp > 64) continue;
+        if (dma && cfg >= 12 && cfg < 16) continue;
         pxl_conv_desc q = op.bwd; q.tile_cfg = cfg;
         float t = time_launch([&]() { return pxl_conv_igemm(&q, at(scratch, tout.goff), at(packed, op.wt_off), at(scratch, tin.goff),
                                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream); },
@@ -449,7 +480,7 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
       for (int cfg = 0; cfg < 3; ++cfg) {
         if (cfg == 2 && d.cout > 64) continue;
         pxl_conv_desc q = op.grp[g]; q.tile_cfg = cfg;
-        float t = time_launch([&]() { return pxl_conv_wgrad(&q, at(arena, tin.off), sc, sh, at(scratch, tout.goff),
+        float t = time_launch([&]() { return pxl_conv_wgrad(&q, cin.ptr, sc, sh, at(scratch, tout.goff),
                                                             grads + d.w_off[g], d.cin, d.cin, stream); }, s, a, b, reps);
         if (t < 0) { rc_all = PXL_ERR_HIP; continue; }
         if (t < best) { best = t; best_cfg = cfg; }
@@ -485,17 +516,13 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
       case PXL_OP_CONV: {
         const TensorInfo& tin = n->tensors[d.in0];
         const TensorInfo& tout = n->tensors[d.out];
-        const float* sc = nullptr; const float* sh = nullptr;
-        if (d.bn_in0 >= 0) {
-          const BnInfo& b = n->bns[d.bn_in0];
-          sc = fat(arena, b.coef_off) + 2 * b.d.C;
-          sh = fat(arena, b.coef_off) + 3 * b.d.C;
-        }
+        const ConvIn cin = conv_input(n, d, arena);
+        const float* sc = cin.sc; const float* sh = cin.sh;
         float* stats = (d.bn_out >= 0 && training) ? fat(arena, n->bns[d.bn_out].stats_off) : nullptr;
         const float* bias = d.b_off[0] >= 0 ? fat(packed, op.bias_off) : nullptr;
         {
           Timed t(n, s, 0, conv_flops(n, d, tout));
-          rc = pxl_conv_igemm(&op.fwd, at(arena, tin.off), at(packed, op.wf_off), at(arena, tout.off), sc, sh, bias,
+          rc = pxl_conv_igemm(&op.fwd, cin.ptr, at(packed, op.wf_off), at(arena, tout.off), sc, sh, bias,
                               nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr, op.ws_bytes, stream);
         }
         if (rc != PXL_OK) return rc;
@@ -513,6 +540,10 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
                                params + b.d.beta_off, running ? running + b.d.rmean_off : nullptr,
                                running ? running + b.d.rvar_off : nullptr, b.d.momentum, b.d.eps, training,
                                n->world > 1 ? 1 : 0, fat(arena, b.coef_off), stream);
+          if (rc != PXL_OK) return rc;
+          if (b.has_z)
+            rc = pxl_bn_apply_fwd(dt, (long)n->B * tout.H * tout.W, tout.Cp, at(arena, tout.off), fat(arena, b.coef_off),
+                                  b.relu, at(arena, b.z_off), stream);
         }
         break;
       }
@@ -644,16 +675,12 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
           rc = pxl_bn_bwd_apply(dt, M, tout.Cp, dy, at(arena, tout.off), coef, fat(scratch, b.bcoef_off), b.relu, dy, stream);
           if (rc != PXL_OK) return rc;
         }
-        const float* sc = nullptr; const float* sh = nullptr;
-        if (d.bn_in0 >= 0) {
-          const BnInfo& bi = n->bns[d.bn_in0];
-          sc = fat(arena, bi.coef_off) + 2 * bi.d.C;
-          sh = fat(arena, bi.coef_off) + 3 * bi.d.C;
-        }
+        const ConvIn cin = conv_input(n, d, arena);
+        const float* sc = cin.sc; const float* sh = cin.sh;
         for (int g = 0; g < d.ngroups; ++g) {
           {
             Timed t(n, s, 1, conv_flops(n, d, tout) / d.ngroups);
-            rc = pxl_conv_wgrad(&op.grp[g], at(arena, tin.off), sc, sh, dy, grads + d.w_off[g], d.cin, d.cin, stream);
+            rc = pxl_conv_wgrad(&op.grp[g], cin.ptr, sc, sh, dy, grads + d.w_off[g], d.cin, d.cin, stream);
           }
           if (rc != PXL_OK) return rc;
           if (d.b_off[g] >= 0) {
