@@ -209,6 +209,9 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) issue(s);
 
+  // retire every scalar (kernel-argument) load the compiler still counts as outstanding: its own
+  // `s_waitcnt lgkmcnt(0)` at the first use would otherwise land inside the loop and drain the LDS reads
+  __builtin_amdgcn_s_waitcnt(0xc07f);
   int st_c = 0;               // stage being multiplied
   int st_l = NST - 1;         // stage being filled
   for (int ks = 0; ks < p.nk; ++ks) {

@@ -364,6 +364,10 @@ int launch_wgrad(const WgradArgs& a, int force_cfg, hipStream_t stream) {
 
 }  // namespace
 
+extern "C" int pxl_conv_wgrad_dma_eligible(const pxl_conv_desc* d, const float* in_scale);
+extern "C" int pxl_conv_wgrad_dma(const pxl_conv_desc* d, const void* in, const void* dy, float* dw, int creal,
+                                  int dw_cpitch, void* stream);
+
 extern "C" int pxl_conv_wgrad(const pxl_conv_desc* d, const void* in, const float* in_scale,
                               const float* in_shift, const void* dy, float* dw, int creal,
                               int dw_cpitch, void* stream) {
@@ -376,6 +380,11 @@ extern "C" int pxl_conv_wgrad(const pxl_conv_desc* d, const void* in, const floa
   PXL_REQUIRE(d->ntaps >= 1 && d->ntaps <= 64, "conv_wgrad: ntaps %d out of range", d->ntaps);
   PXL_REQUIRE(creal >= 1 && creal <= d->Cin && dw_cpitch >= creal, "conv_wgrad: bad creal/dw_cpitch");
   PXL_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv_wgrad: scale/shift must come together");
+  // plain bf16 operands with Cin % 64 == 0 take the LDS-DMA kernel (conv_wgrad_dma.hip); tile_cfg 0..2 forces this one
+  if (d->tile_cfg < 0 || d->tile_cfg >= 8) {
+    if (pxl_conv_wgrad_dma_eligible(d, in_scale)) return pxl_conv_wgrad_dma(d, in, dy, dw, creal, dw_cpitch, stream);
+    PXL_REQUIRE(d->tile_cfg < 8, "conv_wgrad: tile config %d needs plain bf16 operands with Cin %% 64 == 0", d->tile_cfg);
+  }
   WgradArgs a;
   a.in = in; a.dy = dy; a.dw = dw; a.in_scale = in_scale; a.in_shift = in_shift;
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin;

@@ -25,6 +25,7 @@
 extern "C" {
 int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream);
 int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_scale, const void* workspace);
+int pxl_conv_wgrad_dma_eligible(const pxl_conv_desc* d, const float* in_scale);
 }
 
 namespace {
@@ -477,8 +478,10 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
     // weight gradient (per tap group)
     for (int g = 0; g < d.ngroups; ++g) {
       int best_cfg = -1; float best = 1e30f;
-      for (int cfg = 0; cfg < 3; ++cfg) {
+      const bool wdma = pxl_conv_wgrad_dma_eligible(&op.grp[g], sc) != 0;
+      for (int cfg = 0; cfg < (wdma ? 14 : 3); ++cfg) {
         if (cfg == 2 && d.cout > 64) continue;
+        if (cfg >= 3 && cfg < 8) continue;
         pxl_conv_desc q = op.grp[g]; q.tile_cfg = cfg;
         float t = time_launch([&]() { return pxl_conv_wgrad(&q, cin.ptr, sc, sh, at(scratch, tout.goff),
                                                             grads + d.w_off[g], d.cin, d.cin, stream); }, s, a, b, reps);

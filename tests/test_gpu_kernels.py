@@ -160,6 +160,43 @@ def test_conv_dma_forward_and_dgrad(case, cfg):
     assert rel_err(from_nhwc(dx, Cin), x.grad) < TOL[dtype], "dgrad %s cfg %d" % (name, cfg)
 
 
+WDMA_CASES = [
+    # name, B, Cin, Cout, H, W, k, stride, dil, pad   (Cin % 128 == 0: conv_wgrad_dma.hip)
+    ("wdma_1x1", 3, 256, 72, 9, 13, 1, 1, 1, 0),
+    ("wdma_1x1_s2", 2, 128, 160, 17, 17, 1, 2, 1, 0),
+    ("wdma_3x3", 2, 128, 128, 33, 33, 3, 1, 1, 1),
+    ("wdma_3x3_s2", 2, 128, 96, 17, 19, 3, 2, 1, 1),
+    ("wdma_3x3_d2", 2, 128, 128, 9, 9, 3, 1, 2, 2),
+    ("wdma_3x3_tiny", 5, 256, 64, 3, 5, 3, 1, 1, 1),      # Ho*Wo < 64: a reduction step spans several images
+    ("wdma_4x4_s2", 1, 128, 256, 33, 33, 4, 2, 1, 1),
+    ("wdma_3x3_c64", 2, 64, 96, 17, 17, 3, 1, 1, 1),        # Cin = 64: 64-channel column tiles only
+    ("wdma_1x1_c192", 2, 192, 40, 9, 9, 1, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", WDMA_CASES, ids=[c[0] for c in WDMA_CASES])
+@pytest.mark.parametrize("cfg", [-1, 8, 9, 10, 11, 12, 13])
+def test_conv_wgrad_dma(case, cfg):
+    """LDS-DMA weight gradient (ds_read_b64_tr_b16 fragments): accumulates on top of a non-zero buffer."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    name, B, Cin, Cout, H, W, k, s, d, p = case
+    g = torch.Generator().manual_seed(_seed(name) + 3)
+    x = qround(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = qround(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p, d)
+    Ho, Wo = y.shape[2:]
+    dy = qround(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    cip, cop = _pitch(Cin), _pitch(Cout)
+    fdesc = ops.conv_desc(dtype, B, H, W, cip, Ho, Wo, cop, Cout, ops.fwd_taps(k, k, d, p), out_stride=s, tile_cfg=cfg)
+    dw = torch.ones(Cout, k * k, Cin, device=DEV)
+    ops.conv_wgrad(fdesc, to_nhwc(x, cip, dtype), to_nhwc(dy, cop, dtype), dw, Cin, Cin)
+    torch.cuda.synchronize()
+    got = (dw.cpu() - 1.0).view(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    assert rel_err(got, w.grad) < 2 * TOL[dtype], "wgrad %s cfg %d" % (name, cfg)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_prologue_epilogue(dtype):
     """relu(bn(x)) fused into the load (zero padding stays zero), bias, addend, BN statistics."""

@@ -101,7 +101,7 @@ def main():
                                          out_stride=1, div=s, tile_cfg=cfg)
                     fn = lambda: ops.conv_igemm(desc, y, wt, x)
                 else:
-                    if cfg > 2:
+                    if 2 < cfg < 8 or cfg > 13:
                         continue
                     desc = ops.conv_desc(dtype, B, H, H, cip, Ho, Ho, cop, cout, taps, out_stride=s, tile_cfg=cfg)
                     fn = lambda: ops.conv_wgrad(desc, x, y, dw, cin, cin)
