@@ -139,6 +139,11 @@ int pxl_bn_bwd_reduce(int dtype, int M, int C, const void* dz, const void* y, co
  * dgamma += sum dz'*xhat ; dbeta += sum dz' */
 int pxl_bn_bwd_finalize(int C, const float* sums, int nrep, float count, float* dgamma, float* dbeta,
                         float* bcoef, int training, void* stream);
+/* finalize + apply in one launch: sums is ONE [2C] vector (replicas folded / all-reduced by the caller),
+ * count = elements per channel over all devices; also accumulates dgamma += sum dz'*xhat, dbeta += sum dz'. */
+int pxl_bn_bwd_apply_fused(int dtype, int M, int C, const void* dz, const void* y, const float* coef,
+                           const float* sums, float count, int training, int relu, float* dgamma, float* dbeta,
+                           void* dy, void* stream);
 /* dy = scale * (dz' - bcoef0 - xhat*bcoef1)  -- gradient w.r.t. the raw conv output (in place allowed) */
 int pxl_bn_bwd_apply(int dtype, int M, int C, const void* dz, const void* y, const float* coef,
                      const float* bcoef, int relu, void* dy, void* stream);

@@ -58,64 +58,66 @@ __global__ void fold_replicas_kernel(int n, int nrep, float* __restrict__ buf) {
 }
 
 // sums[rep][0..C) += sum_m dzh ; sums[rep][C..2C) += sum_m dzh * xhat     dzh = dz * (relu ? z>0 : 1)
+// One LDS reduction over the row lanes and ONE atomic per (channel, sum) per block: 2*8*CG atomics per block
+// instead of 2*C (the previous row-major blocks issued 2 M atomics for an 8712 x 1024 tensor).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int M, int C, const T* __restrict__ dz,
                                                             const T* __restrict__ y,
                                                             const float* __restrict__ coef, int relu,
-                                                            float* __restrict__ sums, int nrep) {
+                                                            float* __restrict__ sums, int nrep, int rows_per_group) {
   constexpr int EPC = Elem<T>::EPC;
-  const int cpr = C / EPC;
-  const int cpb = cpr < 256 ? cpr : 256;
-  const int rpb = 256 / cpb;
-  const int ccol = threadIdx.x % cpb, rlane = threadIdx.x / cpb;
-  extern __shared__ float red[];                  // [rpb][cpb][2*EPC]
-  float* rep = sums + (size_t)(blockIdx.x % nrep) * 2 * C;
-  for (int c0 = 0; c0 < cpr; c0 += cpb) {
-    const int cc = c0 + ccol;
-    const bool active = cc < cpr && rlane < rpb;
-    float a1[EPC], a2[EPC];
+  const ColGeom g = col_geom(C, EPC);
+  const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
+  const int cc = blockIdx.x * g.cg + ccol;
+  __shared__ float red[256 * 2 * EPC];            // [rl][cg][2*EPC]
+  float mean[EPC], rstd[EPC], sc[EPC], sh[EPC], a1[EPC], a2[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
-    if (active) {
-      float mean[EPC], rstd[EPC], sc[EPC], sh[EPC];
+  for (int e = 0; e < EPC; ++e) {
+    const int c = cc * EPC + e;
+    mean[e] = coef[c]; rstd[e] = coef[C + c]; sc[e] = coef[2 * C + c]; sh[e] = coef[3 * C + c];
+    a1[e] = 0.f; a2[e] = 0.f;
+  }
+  const int m_begin = blockIdx.y * rows_per_group;
+  const int m_end = min(M, m_begin + rows_per_group);
+  auto accum = [&](const uint4& vd, const uint4& vy) {
+    float fd[EPC], fy[EPC];
+    Chunk<T>::unpack(vd, fd);
+    Chunk<T>::unpack(vy, fy);
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        const int c = cc * EPC + e;
-        mean[e] = coef[c]; rstd[e] = coef[C + c]; sc[e] = coef[2 * C + c]; sh[e] = coef[3 * C + c];
-      }
-      for (int m = blockIdx.x * rpb + rlane; m < M; m += gridDim.x * rpb) {
-        const size_t o = (size_t)m * C + cc * EPC;
-        float fd[EPC], fy[EPC];
-        Chunk<T>::unpack(*reinterpret_cast<const uint4*>(dz + o), fd);
-        Chunk<T>::unpack(*reinterpret_cast<const uint4*>(y + o), fy);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-          float g = fd[e];
-          if (relu && !(fy[e] * sc[e] + sh[e] > 0.f)) g = 0.f;
-          a1[e] += g;
-          a2[e] += g * (fy[e] - mean[e]) * rstd[e];
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        red[(rlane * cpb + ccol) * 2 * EPC + e] = a1[e];
-        red[(rlane * cpb + ccol) * 2 * EPC + EPC + e] = a2[e];
-      }
+    for (int e = 0; e < EPC; ++e) {
+      float gd = fd[e];
+      if (relu && !(fy[e] * sc[e] + sh[e] > 0.f)) gd = 0.f;
+      a1[e] += gd;
+      a2[e] += gd * (fy[e] - mean[e]) * rstd[e];
     }
-    __syncthreads();
-    if (active && rlane == 0) {
+  };
+  int m = m_begin + rlane;
+  for (; m + g.rl < m_end; m += 2 * g.rl) {        // two rows in flight per thread
+    const size_t o0 = (size_t)m * C + cc * EPC, o1 = (size_t)(m + g.rl) * C + cc * EPC;
+    const uint4 d0 = *reinterpret_cast<const uint4*>(dz + o0), y0 = *reinterpret_cast<const uint4*>(y + o0);
+    const uint4 d1 = *reinterpret_cast<const uint4*>(dz + o1), y1 = *reinterpret_cast<const uint4*>(y + o1);
+    accum(d0, y0);
+    accum(d1, y1);
+  }
+  if (m < m_end) {
+    const size_t o0 = (size_t)m * C + cc * EPC;
+    accum(*reinterpret_cast<const uint4*>(dz + o0), *reinterpret_cast<const uint4*>(y + o0));
+  }
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int r = 0; r < rpb; ++r) {
-          s1 += red[(r * cpb + ccol) * 2 * EPC + e];
-          s2 += red[(r * cpb + ccol) * 2 * EPC + EPC + e];
-        }
-        atomicAdd(rep + cc * EPC + e, s1);
-        atomicAdd(rep + C + cc * EPC + e, s2);
-      }
-    }
-    __syncthreads();
+  for (int e = 0; e < EPC; ++e) {
+    red[(rlane * g.cg + ccol) * 2 * EPC + e] = a1[e];
+    red[(rlane * g.cg + ccol) * 2 * EPC + EPC + e] = a2[e];
+  }
+  __syncthreads();
+  // thread t < cg * 2 * EPC sums one (column, which, element) over the row lanes
+  const int nout = g.cg * 2 * EPC;
+  if ((int)threadIdx.x < nout) {
+    const int col = threadIdx.x / (2 * EPC), w = threadIdx.x % (2 * EPC);
+    float v = 0.f;
+    for (int r = 0; r < g.rl; ++r) v += red[(r * g.cg + col) * 2 * EPC + w];
+    float* rep = sums + (size_t)((blockIdx.y + blockIdx.x) % nrep) * 2 * C;
+    const int c = (blockIdx.x * g.cg + col) * EPC + (w % EPC);
+    atomicAdd(rep + (w / EPC) * C + c, v);
   }
 }
 
@@ -172,6 +174,62 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int C, const T
   }
 }
 
+// dy = scale * (dzh - c1 - xhat*c2) with (c1, c2) = sums / count computed in the kernel's prologue (sums must be
+// a single [2C] vector: fold + all-reduce happen before): removes the bn_bwd_finalize launch per layer.  The
+// blocks of row group 0 also accumulate dgamma / dbeta.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(int M, int C, const T* __restrict__ dz,
+                                                                 const T* __restrict__ y,
+                                                                 const float* __restrict__ coef,
+                                                                 const float* __restrict__ sums, float inv_count,
+                                                                 int training, int relu, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, T* __restrict__ dy,
+                                                                 int rows_per_group) {
+  constexpr int EPC = Elem<T>::EPC;
+  const ColGeom g = col_geom(C, EPC);
+  const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
+  const int cc = blockIdx.x * g.cg + ccol;
+  float mean[EPC], rstd[EPC], sc[EPC], sh[EPC], b1[EPC], b2[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    const int c = cc * EPC + e;
+    mean[e] = coef[c]; rstd[e] = coef[C + c]; sc[e] = coef[2 * C + c]; sh[e] = coef[3 * C + c];
+    const float s1 = sums[c], s2 = sums[C + c];
+    b1[e] = training ? s1 * inv_count : 0.f;      // eval-mode BN is a fixed affine: no batch-mean terms
+    b2[e] = training ? s2 * inv_count : 0.f;
+    if (blockIdx.y == 0 && rlane == 0) {
+      if (dgamma) dgamma[c] += s2;
+      if (dbeta) dbeta[c] += s1;
+    }
+  }
+  const int m_begin = blockIdx.y * rows_per_group;
+  const int m_end = min(M, m_begin + rows_per_group);
+  auto one = [&](const uint4& vd, const uint4& vy) -> uint4 {
+    float fd[EPC], fy[EPC], v[EPC];
+    Chunk<T>::unpack(vd, fd);
+    Chunk<T>::unpack(vy, fy);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float gd = fd[e];
+      if (relu && !(fy[e] * sc[e] + sh[e] > 0.f)) gd = 0.f;
+      v[e] = sc[e] * (gd - b1[e] - (fy[e] - mean[e]) * rstd[e] * b2[e]);
+    }
+    return Chunk<T>::pack(v);
+  };
+  int m = m_begin + rlane;
+  for (; m + g.rl < m_end; m += 2 * g.rl) {
+    const size_t o0 = (size_t)m * C + cc * EPC, o1 = (size_t)(m + g.rl) * C + cc * EPC;
+    const uint4 d0 = *reinterpret_cast<const uint4*>(dz + o0), y0 = *reinterpret_cast<const uint4*>(y + o0);
+    const uint4 d1 = *reinterpret_cast<const uint4*>(dz + o1), y1 = *reinterpret_cast<const uint4*>(y + o1);
+    *reinterpret_cast<uint4*>(dy + o0) = one(d0, y0);
+    *reinterpret_cast<uint4*>(dy + o1) = one(d1, y1);
+  }
+  if (m < m_end) {
+    const size_t o0 = (size_t)m * C + cc * EPC;
+    *reinterpret_cast<uint4*>(dy + o0) = one(*reinterpret_cast<const uint4*>(dz + o0), *reinterpret_cast<const uint4*>(y + o0));
+  }
+}
+
 inline int row_grid(long M, int C, int epc, int cap) {
   const int cpr = C / epc;
   const int rpb = 256 / (cpr < 256 ? cpr : 256);
@@ -211,15 +269,37 @@ extern "C" int pxl_bn_bwd_reduce(int dtype, int M, int C, const void* dz, const 
   PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "bn_bwd_reduce: bad dtype %d", dtype);
   const int epc = dtype == PXL_F32 ? 4 : 8;
   PXL_REQUIRE(C % epc == 0, "bn_bwd_reduce: C=%d must be a multiple of %d", C, epc);
-  const int blocks = row_grid(M, C, epc, 1024);
-  const size_t smem = (size_t)256 * 2 * epc * sizeof(float);
+  const ColGeom g = col_geom(C, epc);
+  const int rpg = rows_per_group(M, g, 1024);
+  const dim3 grid(g.ncg, cdiv(M, rpg));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), smem, s, M, C, (const float*)dz,
-                       (const float*)y, coef, relu, sums, nrep);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, M, C, (const float*)dz,
+                       (const float*)y, coef, relu, sums, nrep, rpg);
   else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), smem, s, M, C, (const bf16_t*)dz,
-                       (const bf16_t*)y, coef, relu, sums, nrep);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, M, C, (const bf16_t*)dz,
+                       (const bf16_t*)y, coef, relu, sums, nrep, rpg);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_bn_bwd_apply_fused(int dtype, int M, int C, const void* dz, const void* y, const float* coef,
+                                      const float* sums, float count, int training, int relu, float* dgamma,
+                                      float* dbeta, void* dy, void* stream) {
+  PXL_REQUIRE(dz && y && coef && sums && dy && M > 0 && count > 0.f, "bn_bwd_apply_fused: bad argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "bn_bwd_apply_fused: bad dtype %d", dtype);
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  PXL_REQUIRE(C % epc == 0, "bn_bwd_apply_fused: C=%d must be a multiple of %d", C, epc);
+  const ColGeom g = col_geom(C, epc);
+  const int rpg = rows_per_group(M, g, 2048);
+  const dim3 grid(g.ncg, cdiv(M, rpg));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<float>, grid, dim3(256), 0, s, M, C, (const float*)dz, (const float*)y,
+                       coef, sums, 1.f / count, training, relu, dgamma, dbeta, (float*)dy, rpg);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<bf16_t>, grid, dim3(256), 0, s, M, C, (const bf16_t*)dz,
+                       (const bf16_t*)y, coef, sums, 1.f / count, training, relu, dgamma, dbeta, (bf16_t*)dy, rpg);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

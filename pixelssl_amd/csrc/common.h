@@ -107,6 +107,31 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, i
   if (r < 0) { --q; r += d; }
 }
 
+// Column-group geometry shared by the row-streaming kernels below: a block is CG 16-byte chunk columns
+// (<= 16 chunks = 256 contiguous bytes of a row) x RL row lanes; blockIdx.x = column group, blockIdx.y = row
+// group.  Each thread keeps its channel chunk (and the per-channel coefficients) in registers and walks rows.
+struct ColGeom { int cg, rl, ncg; };
+__host__ __device__ inline ColGeom col_geom(int C, int epc) {
+  const int cpr = C / epc;
+  ColGeom g;
+  g.cg = cpr < 16 ? cpr : 16;
+  while (256 % g.cg != 0 || cpr % g.cg != 0) --g.cg;   // channel pitches are multiples of 32 -> cg in {4, 8, 16}
+  g.rl = 256 / g.cg;
+  g.ncg = cpr / g.cg;
+  return g;
+}
+
+
+// rows per row group so that the launch has about `target` blocks (each block streams >= 4 row-lane passes)
+static inline int rows_per_group(int M, const ColGeom& g, int target) {
+  int groups = target / g.ncg;
+  if (groups < 1) groups = 1;
+  int rpg = (M + groups - 1) / groups;
+  const int min_rows = 4 * g.rl;
+  if (rpg < min_rows) rpg = min_rows;
+  return (rpg + g.rl - 1) / g.rl * g.rl;
+}
+
 // XCD-aware bijective remap of a linear block id (guide T1): consecutive logical
 // tiles land on the same XCD (= same L2).  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

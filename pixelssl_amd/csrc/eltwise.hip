@@ -13,38 +13,46 @@ inline int grid_for(long n, int block = 256) {
   return (int)g;
 }
 
-// Per-channel-affine element-wise kernels keep their channel chunk FIXED per thread and walk rows, so the
-// per-channel coefficients are loaded once into registers (not once per element).
+// Per-channel-affine element-wise kernels: column-group blocks (common.h: col_geom), the channel chunk is FIXED
+// per thread so the coefficients are loaded once into registers, two rows in flight per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T* __restrict__ y,
                                                            const float* __restrict__ ycoef,
                                                            const T* __restrict__ res,
                                                            const float* __restrict__ rcoef,
-                                                           T* __restrict__ out) {
+                                                           T* __restrict__ out, int rows_per_group) {
   constexpr int EPC = Elem<T>::EPC;
-  const int cpr = C / EPC;
-  const int cpb = cpr < 256 ? cpr : 256;     // chunk columns per block pass
-  const int rpb = 256 / cpb;                 // rows in flight per block
-  const int ccol = threadIdx.x % cpb, rlane = threadIdx.x / cpb;
-  for (int c0 = 0; c0 < cpr; c0 += cpb) {
-    const int cc = c0 + ccol;
-    if (cc >= cpr || rlane >= rpb) continue;
-    float ys[EPC], yb[EPC], rs[EPC], rb[EPC];
+  const ColGeom g = col_geom(C, EPC);
+  const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
+  const int cc = blockIdx.x * g.cg + ccol;
+  float ys[EPC], yb[EPC], rs[EPC], rb[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      const int c = cc * EPC + e;
-      ys[e] = ycoef[2 * C + c]; yb[e] = ycoef[3 * C + c];
-      rs[e] = rcoef ? rcoef[2 * C + c] : 1.f; rb[e] = rcoef ? rcoef[3 * C + c] : 0.f;
-    }
-    for (int m = blockIdx.x * rpb + rlane; m < M; m += gridDim.x * rpb) {
-      const size_t o = (size_t)m * C + cc * EPC;
-      float fy[EPC], fr[EPC], v[EPC];
-      Chunk<T>::unpack(*reinterpret_cast<const uint4*>(y + o), fy);
-      Chunk<T>::unpack(*reinterpret_cast<const uint4*>(res + o), fr);
+  for (int e = 0; e < EPC; ++e) {
+    const int c = cc * EPC + e;
+    ys[e] = ycoef[2 * C + c]; yb[e] = ycoef[3 * C + c];
+    rs[e] = rcoef ? rcoef[2 * C + c] : 1.f; rb[e] = rcoef ? rcoef[3 * C + c] : 0.f;
+  }
+  auto one = [&](const uint4& vy, const uint4& vr) -> uint4 {
+    float fy[EPC], fr[EPC], v[EPC];
+    Chunk<T>::unpack(vy, fy);
+    Chunk<T>::unpack(vr, fr);
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) v[e] = fmaxf(fy[e] * ys[e] + yb[e] + (fr[e] * rs[e] + rb[e]), 0.f);
-      *reinterpret_cast<uint4*>(out + o) = Chunk<T>::pack(v);
-    }
+    for (int e = 0; e < EPC; ++e) v[e] = fmaxf(fy[e] * ys[e] + yb[e] + (fr[e] * rs[e] + rb[e]), 0.f);
+    return Chunk<T>::pack(v);
+  };
+  const int m_begin = blockIdx.y * rows_per_group;
+  const int m_end = min(M, m_begin + rows_per_group);
+  int m = m_begin + rlane;
+  for (; m + g.rl < m_end; m += 2 * g.rl) {
+    const size_t o0 = (size_t)m * C + cc * EPC, o1 = (size_t)(m + g.rl) * C + cc * EPC;
+    const uint4 a0 = *reinterpret_cast<const uint4*>(y + o0), b0 = *reinterpret_cast<const uint4*>(res + o0);
+    const uint4 a1 = *reinterpret_cast<const uint4*>(y + o1), b1 = *reinterpret_cast<const uint4*>(res + o1);
+    *reinterpret_cast<uint4*>(out + o0) = one(a0, b0);
+    *reinterpret_cast<uint4*>(out + o1) = one(a1, b1);
+  }
+  if (m < m_end) {
+    const size_t o0 = (size_t)m * C + cc * EPC;
+    *reinterpret_cast<uint4*>(out + o0) = one(*reinterpret_cast<const uint4*>(y + o0), *reinterpret_cast<const uint4*>(res + o0));
   }
 }
 
@@ -52,32 +60,40 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(int M, int C, const T* __restrict__ y,
                                                            const float* __restrict__ coef, int relu,
-                                                           T* __restrict__ z) {
+                                                           T* __restrict__ z, int rows_per_group) {
   constexpr int EPC = Elem<T>::EPC;
-  const int cpr = C / EPC;
-  const int cpb = cpr < 256 ? cpr : 256;
-  const int rpb = 256 / cpb;
-  const int ccol = threadIdx.x % cpb, rlane = threadIdx.x / cpb;
-  for (int c0 = 0; c0 < cpr; c0 += cpb) {
-    const int cc = c0 + ccol;
-    if (cc >= cpr || rlane >= rpb) continue;
-    float sc[EPC], sh[EPC];
+  const ColGeom g = col_geom(C, EPC);
+  const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
+  const int cc = blockIdx.x * g.cg + ccol;
+  float sc[EPC], sh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    sc[e] = coef[2 * C + cc * EPC + e];
+    sh[e] = coef[3 * C + cc * EPC + e];
+  }
+  auto one = [&](const uint4& vy) -> uint4 {
+    float f[EPC];
+    Chunk<T>::unpack(vy, f);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      sc[e] = coef[2 * C + cc * EPC + e];
-      sh[e] = coef[3 * C + cc * EPC + e];
+      const float v = f[e] * sc[e] + sh[e];
+      f[e] = relu ? fmaxf(v, 0.f) : v;
     }
-    for (int m = blockIdx.x * rpb + rlane; m < M; m += gridDim.x * rpb) {
-      const size_t o = (size_t)m * C + cc * EPC;
-      float f[EPC];
-      Chunk<T>::unpack(*reinterpret_cast<const uint4*>(y + o), f);
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        const float v = f[e] * sc[e] + sh[e];
-        f[e] = relu ? fmaxf(v, 0.f) : v;
-      }
-      *reinterpret_cast<uint4*>(z + o) = Chunk<T>::pack(f);
-    }
+    return Chunk<T>::pack(f);
+  };
+  const int m_begin = blockIdx.y * rows_per_group;
+  const int m_end = min(M, m_begin + rows_per_group);
+  int m = m_begin + rlane;
+  for (; m + g.rl < m_end; m += 2 * g.rl) {
+    const size_t o0 = (size_t)m * C + cc * EPC, o1 = (size_t)(m + g.rl) * C + cc * EPC;
+    const uint4 a0 = *reinterpret_cast<const uint4*>(y + o0);
+    const uint4 a1 = *reinterpret_cast<const uint4*>(y + o1);
+    *reinterpret_cast<uint4*>(z + o0) = one(a0);
+    *reinterpret_cast<uint4*>(z + o1) = one(a1);
+  }
+  if (m < m_end) {
+    const size_t o0 = (size_t)m * C + cc * EPC;
+    *reinterpret_cast<uint4*>(z + o0) = one(*reinterpret_cast<const uint4*>(y + o0));
   }
 }
 
@@ -242,12 +258,15 @@ extern "C" int pxl_residual_fwd(int dtype, long M, int C, const void* y, const f
   const int epc = dtype == PXL_F32 ? 4 : 8;
   PXL_REQUIRE(C % epc == 0, "residual_fwd: C=%d must be a multiple of %d", C, epc);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const ColGeom g = col_geom(C, epc);
+  const int rpg = rows_per_group((int)M, g, 2048);
+  const dim3 grid(g.ncg, cdiv((int)M, rpg));
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(residual_fwd_kernel<float>, dim3(row_grid(M, C, epc)), dim3(256), 0, s, (int)M, C,
-                       cp<float>(y), ycoef, cp<float>(res), rcoef, mp<float>(out));
+    hipLaunchKernelGGL(residual_fwd_kernel<float>, grid, dim3(256), 0, s, (int)M, C,
+                       cp<float>(y), ycoef, cp<float>(res), rcoef, mp<float>(out), rpg);
   else
-    hipLaunchKernelGGL(residual_fwd_kernel<bf16_t>, dim3(row_grid(M, C, epc)), dim3(256), 0, s, (int)M, C,
-                       cp<bf16_t>(y), ycoef, cp<bf16_t>(res), rcoef, mp<bf16_t>(out));
+    hipLaunchKernelGGL(residual_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (int)M, C,
+                       cp<bf16_t>(y), ycoef, cp<bf16_t>(res), rcoef, mp<bf16_t>(out), rpg);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -259,12 +278,15 @@ extern "C" int pxl_bn_apply_fwd(int dtype, long M, int C, const void* y, const f
   const int epc = dtype == PXL_F32 ? 4 : 8;
   PXL_REQUIRE(C % epc == 0, "bn_apply_fwd: C=%d must be a multiple of %d", C, epc);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const ColGeom g = col_geom(C, epc);
+  const int rpg = rows_per_group((int)M, g, 2048);
+  const dim3 grid(g.ncg, cdiv((int)M, rpg));
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(bn_apply_fwd_kernel<float>, dim3(row_grid(M, C, epc)), dim3(256), 0, s, (int)M, C, cp<float>(y),
-                       coef, relu, mp<float>(z));
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<float>, grid, dim3(256), 0, s, (int)M, C, cp<float>(y),
+                       coef, relu, mp<float>(z), rpg);
   else
-    hipLaunchKernelGGL(bn_apply_fwd_kernel<bf16_t>, dim3(row_grid(M, C, epc)), dim3(256), 0, s, (int)M, C,
-                       cp<bf16_t>(y), coef, relu, mp<bf16_t>(z));
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (int)M, C,
+                       cp<bf16_t>(y), coef, relu, mp<bf16_t>(z), rpg);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

@@ -269,7 +269,7 @@ extern "C" int pxl_net_plan(pxl_net* n, int B, int H, int W) {
   n->stats_region_bytes = arena - n->stats_region_off;
   for (auto& b : n->bns) { b.coef_off = arena; arena += align_up(4 * (size_t)b.d.C * 4); }
   n->bsum_region_off = scratch;
-  for (auto& b : n->bns) { b.bsum_off = scratch; scratch += align_up(STATS_REP * 2 * (size_t)b.d.C * 4); }
+  for (auto& b : n->bns) { b.bsum_off = scratch; scratch += align_up(2 * (size_t)b.d.C * 4); }
   n->bsum_region_bytes = scratch - n->bsum_region_off;
   for (auto& b : n->bns) { b.bcoef_off = scratch; scratch += align_up(2 * (size_t)b.d.C * 4); }
 
@@ -661,21 +661,16 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         if (d.bn_out >= 0) {
           BnInfo& b = n->bns[d.bn_out];
           const float* coef = fat(arena, b.coef_off);
-          rc = pxl_bn_bwd_reduce(dt, M, tout.Cp, dy, at(arena, tout.off), coef, b.relu, fat(scratch, b.bsum_off),
-                                 STATS_REP, stream);
+          // one [2C] vector per BN (the reduce kernel issues one atomic per channel per block, no replicas needed)
+          rc = pxl_bn_bwd_reduce(dt, M, tout.Cp, dy, at(arena, tout.off), coef, b.relu, fat(scratch, b.bsum_off), 1, stream);
           if (rc != PXL_OK) return rc;
-          int nrep = STATS_REP;
           if (training && n->sync && n->world > 1) {
-            rc = pxl_bn_fold_replicas(2 * b.d.C, STATS_REP, fat(scratch, b.bsum_off), stream);
-            if (rc != PXL_OK) return rc;
             rc = n->sync(n->sync_user, fat(scratch, b.bsum_off), 2 * b.d.C, stream);
             if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_backward: SyncBN all-reduce hook failed (%d)", rc);
-            nrep = 1;
           }
-          rc = pxl_bn_bwd_finalize(b.d.C, fat(scratch, b.bsum_off), nrep, (float)b.M * n->world, grads + b.d.gamma_off,
-                                   grads + b.d.beta_off, fat(scratch, b.bcoef_off), training, stream);
-          if (rc != PXL_OK) return rc;
-          rc = pxl_bn_bwd_apply(dt, M, tout.Cp, dy, at(arena, tout.off), coef, fat(scratch, b.bcoef_off), b.relu, dy, stream);
+          rc = pxl_bn_bwd_apply_fused(dt, M, tout.Cp, dy, at(arena, tout.off), coef, fat(scratch, b.bsum_off),
+                                      (float)b.M * n->world, training, b.relu, grads + b.d.gamma_off, grads + b.d.beta_off,
+                                      dy, stream);
           if (rc != PXL_OK) return rc;
         }
         const ConvIn cin = conv_input(n, d, arena);

@@ -95,6 +95,25 @@ def bn_backward(dz, y, coef, count, relu, dgamma, dbeta, nrep=4):
     return dy
 
 
+def bn_backward_fused(dz, y, coef, count, relu, dgamma, dbeta, training=True):
+    """Reduce + (finalize fused into) apply: the two-launch backward the executor uses."""
+    M, Cc = dz.shape[0], dz.shape[1]
+    code = dtype_code(dz.dtype)
+    sums = torch.zeros(2 * Cc, device=dz.device, dtype=torch.float32)
+    dy = torch.empty_like(dz)
+    check(lib().pxl_bn_bwd_reduce(code, M, Cc, ptr(dz), ptr(y), ptr(coef), int(relu), ptr(sums), 1, stream_ptr()))
+    check(lib().pxl_bn_bwd_apply_fused(code, M, Cc, ptr(dz), ptr(y), ptr(coef), ptr(sums), float(count), int(training),
+                                       int(relu), ptr(dgamma), ptr(dbeta), ptr(dy), stream_ptr()))
+    return dy
+
+
+def bn_apply_fwd(y, coef, relu=True):
+    z = torch.empty_like(y)
+    M = y.numel() // y.shape[-1]
+    check(lib().pxl_bn_apply_fwd(dtype_code(y.dtype), M, y.shape[-1], ptr(y), ptr(coef), int(relu), ptr(z), stream_ptr()))
+    return z
+
+
 def residual_fwd(y, ycoef, res, rcoef=None):
     out = torch.empty_like(y)
     M = y.numel() // y.shape[-1]

@@ -322,11 +322,10 @@ def test_aspp_multirate_as_one_launch():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("C", [64, 256, 2048])
-def test_batchnorm_finalize_and_backward(dtype, C):
+@pytest.mark.parametrize("C,B,H,W", [(64, 2, 9, 7), (256, 2, 9, 7), (2048, 2, 9, 7), (96, 3, 33, 17), (1024, 2, 33, 33)])
+def test_batchnorm_finalize_and_backward(dtype, C, B, H, W):
     ops = _ops()
     g = torch.Generator().manual_seed(C)
-    B, H, W = 2, 9, 7
     y = qround(torch.randn(B, C, H, W, generator=g) * 2 + 0.5, dtype).requires_grad_(True)
     gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
     beta = (torch.randn(C, generator=g) * 0.2).requires_grad_(True)
@@ -352,6 +351,16 @@ def test_batchnorm_finalize_and_backward(dtype, C):
     assert rel_err(from_nhwc(dy.view(B, H, W, C), C), y.grad) < tol
     assert rel_err(dgamma.cpu(), gamma.grad) < tol
     assert rel_err(dbeta.cpu(), beta.grad) < tol
+    # the executor's two-launch form (finalize fused into apply), accumulating on top of existing gradients
+    dgamma2, dbeta2 = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+    dy2 = ops.bn_backward_fused(to_nhwc(dz, C, dtype).view(M, C), yd.view(M, C), coef, M, True, dgamma2, dbeta2)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(dy2.view(B, H, W, C), C), y.grad) < tol
+    assert rel_err(dgamma2.cpu() - 1, gamma.grad) < tol and rel_err(dbeta2.cpu() - 1, beta.grad) < tol
+    # materialised activation relu(bn(y))
+    zz = ops.bn_apply_fwd(yd, coef, relu=True)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(zz, C), z.detach()) < (1e-5 if dtype == torch.float32 else 8e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
