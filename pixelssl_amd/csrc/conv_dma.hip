@@ -89,7 +89,9 @@ template <int I, int N, int STRIDE, int BASE> struct FragLoad {
 };
 
 // BM x BN output tile (pixels x channels), 4 waves as WM x WN, NST LDS stages, GATHER = taps / padding logic
-template <int BM, int BN, int WM, int WN, int NST, bool GATHER>
+// ABL: timing ablations for tools/conv_bench.py (results are garbage): 1 = no DMA in the loop, 2 = no MFMA,
+// 4 = no fragment reads, 8 = no barrier.  0 in every product instantiation.
+template <int BM, int BN, int WM, int WN, int NST, bool GATHER, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   constexpr int TMI = BM / WM / 32;          // 32-pixel tiles per wave
   constexpr int TNI = BN / WN / 32;          // 32-channel tiles per wave
@@ -216,16 +218,23 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   int st_l = NST - 1;         // stage being filled
   for (int ks = 0; ks < p.nk; ++ks) {
     wait_vmcnt<(NST - 2) * (LA + LB)>();      // this wave's share of tile ks has landed
-    __builtin_amdgcn_s_barrier();             // ... everyone's has; stage st_l is no longer being read
-    issue(st_l);
+    if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();   // ... everyone's has; stage st_l is no longer being read
+    if constexpr (!(ABL & 1)) issue(st_l);
     // all 4*(TMI+TNI) fragment reads of the step are issued up front (LDS returns in order), the MFMAs of
     // k-chunk kk start as soon as its own reads are back: lgkmcnt counts the reads still outstanding
     const unsigned sbase = lds0 + st_c * SB;
     u32x4 fa[4][TMI], fw[4][TNI];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      FragLoad<0, TMI, 4096, 0>::run(fa[kk], sbase + aoff[kk]);
-      FragLoad<0, TNI, 4096, BM * 128>::run(fw[kk], sbase + boff[kk]);
+      if constexpr (ABL & 4) {
+#pragma unroll
+        for (int i = 0; i < TMI; ++i) fa[kk][i] = u32x4{sbase, sbase, sbase, sbase};
+#pragma unroll
+        for (int j = 0; j < TNI; ++j) fw[kk][j] = u32x4{sbase, sbase, sbase, sbase};
+      } else {
+        FragLoad<0, TMI, 4096, 0>::run(fa[kk], sbase + aoff[kk]);
+        FragLoad<0, TNI, 4096, BM * 128>::run(fw[kk], sbase + boff[kk]);
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -233,12 +242,14 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
       if (kk == 1) wait_chunk<2 * (TMI + TNI)>(fa[1], fw[1], acc);
       if (kk == 2) wait_chunk<1 * (TMI + TNI)>(fa[2], fw[2], acc);
       if (kk == 3) wait_chunk<0>(fa[3], fw[3], acc);
+      if constexpr (!(ABL & 2)) {
 #pragma unroll
-      for (int j = 0; j < TNI; ++j)
+        for (int j = 0; j < TNI; ++j)
 #pragma unroll
-        for (int i = 0; i < TMI; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[kk][j]),
-                                                              __builtin_bit_cast(bf16x8, fa[kk][i]), acc[j][i], 0, 0, 0);
+          for (int i = 0; i < TMI; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[kk][j]),
+                                                                __builtin_bit_cast(bf16x8, fa[kk][i]), acc[j][i], 0, 0, 0);
+      }
     }
     st_c = st_c + 1 == NST ? 0 : st_c + 1;
     st_l = st_l + 1 == NST ? 0 : st_l + 1;
@@ -246,6 +257,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   wait_vmcnt<0>();                 // the tail DMAs (tiles past nk) must not land in the staging area
   __builtin_amdgcn_s_barrier();
 
+  if constexpr (ABL & 16) return;
   // ---- epilogue 1: accumulators -> bf16 tile T[m][n] in LDS.  C/D layout of the 32x32 MFMA with swapped
   // roles: column (lane & 31) = pixel, rows (r&3) + 8*(r>>2) + 4*(lane>>5) = channel
   unsigned char* T = smem;
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   const bf16_t* __restrict__ gadd = reinterpret_cast<const bf16_t*>(p.addend);
   const bool has_bias = p.bias != nullptr;
   const bool has_add = gadd != nullptr;
-  const bool has_stats = p.stats != nullptr;
+  const bool has_stats = p.stats != nullptr && !(ABL & 32);
   float bv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bv[e] = (has_bias && n + e < p.Kreal) ? p.bias[n + e] : 0.f;
@@ -341,6 +353,19 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
       }
     }
   }
+}
+
+template <int BM, int BN, int NST, int ABL>
+int launch_abl(const DmaArgs& a, hipStream_t stream) {
+  DmaArgs p = a;
+  p.tiles_m = cdiv(p.M, BM);
+  p.tiles_n = cdiv(p.Cout, BN);
+  constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
+  PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, 2, 2, NST, true, ABL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL((conv_dma_kernel<BM, BN, 2, 2, NST, true, ABL>), dim3(p.tiles_m * p.tiles_n), dim3(256), smem, stream, p);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
 }
 
 template <int BM, int BN, int WM, int WN, int NST>
@@ -422,6 +447,19 @@ extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* 
     case 17: return launch_dma<128, 64, 2, 2, 2>(a, gather, s);
     case 18: return launch_dma<64, 128, 2, 2, 2>(a, gather, s);
     case 19: return launch_dma<64, 64, 2, 2, 2>(a, gather, s);
+    // timing ablations (garbage results): 64x128 3-stage gather kernel, 100 + ABL bits
+    case 100: return launch_abl<64, 128, 3, 0>(a, s);
+    case 101: return launch_abl<64, 128, 3, 1>(a, s);
+    case 102: return launch_abl<64, 128, 3, 2>(a, s);
+    case 103: return launch_abl<64, 128, 3, 3>(a, s);
+    case 104: return launch_abl<64, 128, 3, 4>(a, s);
+    case 106: return launch_abl<64, 128, 3, 6>(a, s);
+    case 107: return launch_abl<64, 128, 3, 7>(a, s);
+    case 115: return launch_abl<64, 128, 3, 15>(a, s);
+    case 116: return launch_abl<64, 128, 3, 16>(a, s);
+    case 131: return launch_abl<64, 128, 3, 31>(a, s);
+    case 132: return launch_abl<64, 128, 3, 32>(a, s);
+    case 147: return launch_abl<64, 128, 3, 47>(a, s);
     default: return pxl_set_error(PXL_ERR_ARG, "conv_dma: unknown tile config %d", cfg);
   }
 }

@@ -18,6 +18,7 @@
 // aliasing games: every tensor gets its own slot.
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 
 #include "common.h"
@@ -94,6 +95,13 @@ struct pxl_net {
   struct Stamp { hipEvent_t a, b; int kind; double flops; };
   std::vector<Stamp> stamps;
   std::vector<hipEvent_t> pool;
+  // backward runs the weight gradients on a second stream, concurrently with the data gradients (both only read
+  // dy): the contraction kernels of this network are ~1 workgroup per CU and latency-bound, two in flight fill
+  // each other's bubbles.  Created lazily; PXL_SIDE_STREAM=0 disables it.
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> fork_ev;
+  hipEvent_t join_ev = nullptr;
+  int use_side = -1;
 };
 
 namespace {
@@ -221,6 +229,9 @@ extern "C" void pxl_net_destroy(pxl_net* net) {
   if (!net) return;
   for (auto& st : net->stamps) { (void)hipEventDestroy(st.a); (void)hipEventDestroy(st.b); }
   for (auto e : net->pool) (void)hipEventDestroy(e);
+  for (auto e : net->fork_ev) if (e) (void)hipEventDestroy(e);
+  if (net->join_ev) (void)hipEventDestroy(net->join_ev);
+  if (net->side) (void)hipStreamDestroy(net->side);
   delete net;
 }
 
@@ -611,6 +622,16 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
   if (n->bsum_region_bytes)
     PXL_CHECK_HIP(hipMemsetAsync(at(scratch, n->bsum_region_off), 0, n->bsum_region_bytes, s));
   std::vector<char> written(n->tensors.size(), 0);
+  if (n->use_side < 0) {
+    const char* e = getenv("PXL_SIDE_STREAM");
+    n->use_side = (e && e[0] == '0') ? 0 : 1;
+    if (n->use_side) {
+      PXL_CHECK_HIP(hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
+      PXL_CHECK_HIP(hipEventCreateWithFlags(&n->join_ev, hipEventDisableTiming));
+      n->fork_ev.assign(n->ops.size(), nullptr);
+    }
+  }
+  bool forked = false;
 
   for (int i = (int)n->ops.size() - 1; i >= 0; --i) {
     OpInfo& op = n->ops[i];
@@ -675,14 +696,22 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         }
         const ConvIn cin = conv_input(n, d, arena);
         const float* sc = cin.sc; const float* sh = cin.sh;
+        hipStream_t ws = s;
+        if (n->use_side && d.need_dgrad) {       // fork: dy is final on the main stream from here on
+          if (!n->fork_ev[i]) PXL_CHECK_HIP(hipEventCreateWithFlags(&n->fork_ev[i], hipEventDisableTiming));
+          PXL_CHECK_HIP(hipEventRecord(n->fork_ev[i], s));
+          PXL_CHECK_HIP(hipStreamWaitEvent(n->side, n->fork_ev[i], 0));
+          ws = n->side;
+          forked = true;
+        }
         for (int g = 0; g < d.ngroups; ++g) {
           {
-            Timed t(n, s, 1, conv_flops(n, d, tout) / d.ngroups);
-            rc = pxl_conv_wgrad(&op.grp[g], cin.ptr, sc, sh, dy, grads + d.w_off[g], d.cin, d.cin, stream);
+            Timed t(n, ws, 1, conv_flops(n, d, tout) / d.ngroups);
+            rc = pxl_conv_wgrad(&op.grp[g], cin.ptr, sc, sh, dy, grads + d.w_off[g], d.cin, d.cin, ws);
           }
           if (rc != PXL_OK) return rc;
           if (d.b_off[g] >= 0) {
-            rc = pxl_colsum(dt, M, tout.Cp, d.cout, dy, grads + d.b_off[g], stream);
+            rc = pxl_colsum(dt, M, tout.Cp, d.cout, dy, grads + d.b_off[g], ws);
             if (rc != PXL_OK) return rc;
           }
         }
@@ -699,6 +728,10 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         break;
     }
     if (rc != PXL_OK) return rc;
+  }
+  if (forked) {                                  // join: every weight gradient is complete before the caller goes on
+    PXL_CHECK_HIP(hipEventRecord(n->join_ev, n->side));
+    PXL_CHECK_HIP(hipStreamWaitEvent(s, n->join_ev, 0));
   }
   return PXL_OK;
 }

@@ -65,6 +65,13 @@ class SSLMT(ssl_base._SSLBase):
         self.criterions = {'s_criterion': self.s_criterion, 'cons_criterion': self.cons_criterion}
         self.gaussian_noiser = GaussianNoiseLayer(self.args.gaussian_noise_std)
 
+    def _teacher_stream(self):
+        if not hasattr(self, '_t_stream'):
+            import os
+            on = os.environ.get('PXL_TEACHER_STREAM', '1') != '0' and torch.cuda.is_available()
+            self._t_stream = torch.cuda.Stream() if on else None
+        return self._t_stream
+
     def train_step(self, inp, gt, cur_step, total_rampup_steps):
         """One iteration of ssl_mt.py:131-220 on device-resident tuples.
         Returns dict(s_task_loss, t_task_loss, cons_loss) of detached device scalars."""
@@ -74,19 +81,41 @@ class SSLMT(ssl_base._SSLBase):
         ramp = func.sigmoid_rampup(cur_step, total_rampup_steps)
 
         self.s_optimizer.zero_grad()
+        l_gt = func.split_tensor_tuple(gt, 0, lbs)
+
+        def teacher_pass():
+            with torch.no_grad():
+                t_res, _ = self.t_model.forward(t_inp)
+                if 'pred' not in t_res.keys():
+                    self._need_pred(t_res, 'SSL_MT')
+                t_prd = tool.dict_value(t_res, 'pred')
+                t_loss = torch.mean(self.s_criterion.forward(func.split_tensor_tuple(t_prd, 0, lbs), l_gt,
+                                                             func.split_tensor_tuple(t_inp, 0, lbs)))
+            return t_res, t_prd, t_loss
+
+        # The teacher's no-grad forward does not depend on the student's: it is enqueued FIRST, on a second HIP
+        # stream, and runs concurrently with the student forward (each network's kernels are ~1 workgroup per CU
+        # and latency-bound, two in flight fill each other's bubbles).  PXL_TEACHER_STREAM=0 keeps one stream.
+        side = self._teacher_stream()
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)          # inputs and the EMA-updated teacher weights are ready
+            with torch.cuda.stream(side):
+                t_resulter, t_pred, t_task_loss = teacher_pass()
         s_resulter, _ = self.s_model.forward(s_inp)
         self._need_pred(s_resulter, 'SSL_MT')
         s_pred = tool.dict_value(s_resulter, 'pred')
-        l_gt = func.split_tensor_tuple(gt, 0, lbs)
         s_task_loss = torch.mean(self.s_criterion.forward(func.split_tensor_tuple(s_pred, 0, lbs), l_gt,
                                                           func.split_tensor_tuple(s_inp, 0, lbs)))
-        with torch.no_grad():
-            t_resulter, _ = self.t_model.forward(t_inp)
-            if 'pred' not in t_resulter.keys():
-                self._need_pred(t_resulter, 'SSL_MT')
-            t_pred = tool.dict_value(t_resulter, 'pred')
-            t_task_loss = torch.mean(self.s_criterion.forward(func.split_tensor_tuple(t_pred, 0, lbs), l_gt,
-                                                              func.split_tensor_tuple(t_inp, 0, lbs)))
+        if side is not None:
+            main.wait_stream(side)
+            outs = [t_task_loss]
+            for v in t_resulter.values():
+                outs += [t for t in (v if isinstance(v, (tuple, list)) else (v,)) if torch.is_tensor(t)]
+            for t in outs:
+                t.record_stream(main)       # allocated on the side stream, consumed on the main one
+        else:
+            t_resulter, t_pred, t_task_loss = teacher_pass()
         t_pseudo_gt = t_pred[0].detach()
         if self.args.cons_for_labeled:
             cons_loss = self.cons_criterion(s_pred[0], t_pseudo_gt)
