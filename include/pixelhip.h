@@ -139,6 +139,9 @@ int pxl_bn_bwd_reduce(int dtype, int M, int C, const void* dz, const void* y, co
  * dgamma += sum dz'*xhat ; dbeta += sum dz' */
 int pxl_bn_bwd_finalize(int C, const float* sums, int nrep, float count, float* dgamma, float* dbeta,
                         float* bcoef, int training, void* stream);
+/* dgamma += sums[C..2C), dbeta += sums[0..C).  Multi-rank training takes the affine gradients from the LOCAL
+ * sums (before the Sync-BN all-reduce): the rank-average of local gradients is the global-batch gradient. */
+int pxl_bn_param_grad(int C, const float* sums, float* dgamma, float* dbeta, void* stream);
 /* finalize + apply in one launch: sums is ONE [2C] vector (replicas folded / all-reduced by the caller),
  * count = elements per channel over all devices; also accumulates dgamma += sum dz'*xhat, dbeta += sum dz'. */
 int pxl_bn_bwd_apply_fused(int dtype, int M, int C, const void* dz, const void* y, const float* coef,

@@ -73,6 +73,7 @@ SIGNATURES = {
     "pxl_bn_bwd_reduce": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
     "pxl_bn_bwd_finalize": (_I, [_I, _P, _I, _F, _P, _P, _P, _I, _P]),
     "pxl_bn_bwd_apply": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "pxl_bn_param_grad": (_I, [_I, _P, _P, _P, _P]),
     "pxl_bn_bwd_apply_fused": (_I, [_I, _I, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P]),
     "pxl_residual_fwd": (_I, [_I, _L, _I, _P, _P, _P, _P, _P, _P]),
     "pxl_relu_mask": (_I, [_I, _L, _P, _P, _P, _P, _P]),

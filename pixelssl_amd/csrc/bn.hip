@@ -48,6 +48,16 @@ __global__ void bn_finalize_kernel(int C, const float* __restrict__ stats, int n
   coef[3 * C + c] = b - mean * scale;
 }
 
+// dgamma += sums[C..2C), dbeta += sums[0..C): the LOCAL backward sums (multi-rank: taken before the all-reduce, so
+// that the rank-average of the parameter gradients is the global-batch gradient)
+__global__ void bn_param_grad_kernel(int C, const float* __restrict__ sums, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dgamma) dgamma[c] += sums[C + c];
+  if (dbeta) dbeta[c] += sums[c];
+}
+
 // buf[0][i] = sum_r buf[r][i]  (i < n)
 __global__ void fold_replicas_kernel(int n, int nrep, float* __restrict__ buf) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,6 +260,14 @@ extern "C" int pxl_bn_finalize(int C, const float* stats, int nrep, float count,
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      C, stats, nrep, count, gamma, beta, running_mean, running_var, momentum, eps, training,
                      clamp_var, coef);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_bn_param_grad(int C, const float* sums, float* dgamma, float* dbeta, void* stream) {
+  PXL_REQUIRE(C > 0 && sums, "bn_param_grad: bad argument");
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), C,
+                     sums, dgamma, dbeta);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

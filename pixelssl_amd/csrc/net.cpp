@@ -102,6 +102,8 @@ struct pxl_net {
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
   int use_side = -1;
+  // tests: use the reference's multi-device variance formula clamp(var, eps) on a single rank too
+  bool force_clamp = getenv("PXL_FORCE_CLAMP_VAR") != nullptr;
 };
 
 namespace {
@@ -553,7 +555,7 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
           rc = pxl_bn_finalize(b.d.C, fat(arena, b.stats_off), nrep, (float)b.M * n->world, params + b.d.gamma_off,
                                params + b.d.beta_off, running ? running + b.d.rmean_off : nullptr,
                                running ? running + b.d.rvar_off : nullptr, b.d.momentum, b.d.eps, training,
-                               n->world > 1 ? 1 : 0, fat(arena, b.coef_off), stream);
+                               (n->world > 1 || n->force_clamp) ? 1 : 0, fat(arena, b.coef_off), stream);
           if (rc != PXL_OK) return rc;
           if (b.has_z)
             rc = pxl_bn_apply_fwd(dt, (long)n->B * tout.H * tout.W, tout.Cp, at(arena, tout.off), fat(arena, b.coef_off),
@@ -685,13 +687,19 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
           // one [2C] vector per BN (the reduce kernel issues one atomic per channel per block, no replicas needed)
           rc = pxl_bn_bwd_reduce(dt, M, tout.Cp, dy, at(arena, tout.off), coef, b.relu, fat(scratch, b.bsum_off), 1, stream);
           if (rc != PXL_OK) return rc;
+          float* dgam = grads + b.d.gamma_off;
+          float* dbet = grads + b.d.beta_off;
           if (training && n->sync && n->world > 1) {
+            // affine gradients from the LOCAL sums (the gradient all-reduce averages them over the ranks), then
+            // the batch-mean terms of dy from the all-reduced sums
+            rc = pxl_bn_param_grad(b.d.C, fat(scratch, b.bsum_off), dgam, dbet, stream);
+            if (rc != PXL_OK) return rc;
+            dgam = dbet = nullptr;
             rc = n->sync(n->sync_user, fat(scratch, b.bsum_off), 2 * b.d.C, stream);
             if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_backward: SyncBN all-reduce hook failed (%d)", rc);
           }
           rc = pxl_bn_bwd_apply_fused(dt, M, tout.Cp, dy, at(arena, tout.off), coef, fat(scratch, b.bsum_off),
-                                      (float)b.M * n->world, training, b.relu, grads + b.d.gamma_off, grads + b.d.beta_off,
-                                      dy, stream);
+                                      (float)b.M * n->world, training, b.relu, dgam, dbet, dy, stream);
           if (rc != PXL_OK) return rc;
         }
         const ConvIn cin = conv_input(n, d, arena);

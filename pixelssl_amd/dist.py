@@ -29,7 +29,9 @@ def world_size():
 
 
 def local_device():
-    return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    """This rank's GPU: LOCAL_RANK, or PXL_FORCE_DEVICE (tests run two gloo ranks on one GPU)."""
+    forced = os.environ.get('PXL_FORCE_DEVICE')
+    return torch.device('cuda', int(forced if forced is not None else os.environ.get('LOCAL_RANK', '0')))
 
 
 def init_from_env(backend=None):
@@ -37,6 +39,7 @@ def init_from_env(backend=None):
     ws = int(os.environ.get('WORLD_SIZE', '1'))
     if ws <= 1 or (dist.is_available() and dist.is_initialized()):
         return
+    backend = os.environ.get('PXL_DIST_BACKEND', backend)      # tests: two gloo ranks on one GPU
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     if backend == 'nccl':
