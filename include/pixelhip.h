@@ -196,6 +196,36 @@ int pxl_mse_fwd(long n, const float* a, const float* b, float* out, void* stream
 int pxl_mse_bwd(long n, const float* a, const float* b, const float* gout, float* da, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* GCT flaw-map pipeline (fp32 NCHW, single-channel maps [B][1][H][W])                           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* out = mu * sum_c |onehot(gt)[c] - pred[c]| with the one-hot taken from float class ids (ignore_index and ids
+ * outside [0,C) give an all-zero one-hot): sslgct_prepare_task_gt_for_fdgt (task/sseg/func.py:179-192) fused
+ * with FDGTGenerator.forward's abs/sum (ssl_algorithm/ssl_gct.py:715-716). */
+int pxl_absdiff_chansum(int B, int C, long HW, const float* pred, const float* gt, int ignore_index, float mu,
+                        float* out, void* stream);
+/* explicit one-hot [B][C][HW] with ignored pixels all-zero (task/sseg/func.py:159-168, 179-192) */
+int pxl_onehot_ignore(int B, int C, long HW, const float* gt, int ignore_index, float* out, void* stream);
+/* GaussianBlurLayer (nn/module/gaussian_blur.py:31-61) of single-channel maps: separable evaluation of the rank-1
+ * k x k kernel, `taps` = the k 1-D weights (device), reflect padding k/2; tmp = scratch of the same size. */
+int pxl_gauss_sep_reflect(int B, int H, int W, const float* x, const float* taps, int k, float* tmp, float* out,
+                          void* stream);
+/* x *= (x >= 0) in place: FlawmapHandler mutates its argument (ssl_gct.py:643-645) */
+int pxl_clamp_min0_inplace(long n, float* x, void* stream);
+/* nn.ReflectionPad2d(1) + nn.MaxPool2d(3, 1) (ssl_gct.py:707-710) */
+int pxl_dilate3_reflect(int B, int H, int W, const float* x, float* out, void* stream);
+/* out = ((max > clip ? x : 0) - min) / (max - min + 1e-9) per sample; mm = [B][2] scratch (min, max).
+ * clip = -INFINITY: FDGT normalisation (ssl_gct.py:722-725); clip = 0.1: FlawmapHandler (:648-655). */
+int pxl_minmax_norm_persample(int B, long HW, const float* x, float clip_threshold, float* mm, float* out,
+                              void* stream);
+/* DCGTGenerator.forward (ssl_gct.py:668-689): l_fm / r_fm are updated IN PLACE (fm <= thr ? fm : 1) */
+int pxl_dcgt(int B, int C, long HW, const float* l_pred, const float* r_pred, float* l_fm, float* r_fm,
+             float threshold, float* l_gt, float* r_gt, float* both_bad, void* stream);
+/* FlawDetectorCriterion (ssl_gct.py:617-621): loss[b] = mean over (C,H,W) of (a-g)^2; da = 2(a-g)/n * gout[b] */
+int pxl_mse_persample_fwd(int B, long n, const float* a, const float* g, float* loss, void* stream);
+int pxl_mse_persample_bwd(int B, long n, const float* a, const float* g, const float* gout, float* da, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Optimizer / EMA over flat fp32 buffers                                                       */
 /* ------------------------------------------------------------------------------------------ */
 

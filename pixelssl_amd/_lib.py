@@ -89,6 +89,15 @@ SIGNATURES = {
     "pxl_ce_bwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "pxl_mse_fwd": (_I, [_L, _P, _P, _P, _P]),
     "pxl_mse_bwd": (_I, [_L, _P, _P, _P, _P, _P]),
+    "pxl_absdiff_chansum": (_I, [_I, _I, _L, _P, _P, _I, _F, _P, _P]),
+    "pxl_onehot_ignore": (_I, [_I, _I, _L, _P, _I, _P, _P]),
+    "pxl_gauss_sep_reflect": (_I, [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "pxl_clamp_min0_inplace": (_I, [_L, _P, _P]),
+    "pxl_dilate3_reflect": (_I, [_I, _I, _I, _P, _P, _P]),
+    "pxl_minmax_norm_persample": (_I, [_I, _L, _P, _F, _P, _P, _P]),
+    "pxl_dcgt": (_I, [_I, _I, _L, _P, _P, _P, _P, _F, _P, _P, _P, _P]),
+    "pxl_mse_persample_fwd": (_I, [_I, _L, _P, _P, _P, _P]),
+    "pxl_mse_persample_bwd": (_I, [_I, _L, _P, _P, _P, _P, _P]),
     "pxl_sgd_step": (_I, [_L, _P, _P, _P, _F, _F, _F, _I, _P]),
     "pxl_ema_update": (_I, [_L, _P, _P, _F, _P]),
     "pxl_scale_inplace": (_I, [_L, _P, _F, _P]),

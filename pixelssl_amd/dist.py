@@ -80,8 +80,20 @@ class _DevView:
                                          'version': 2, 'strides': None}
 
 
+_views = {}
+
+
 def _sync_stats_callback(buf_ptr, n, stream):
-    t = torch.as_tensor(_DevView(buf_ptr, n), device=torch.device('cuda', torch.cuda.current_device()))
+    """all-reduce(sum) of `n` floats at device pointer `buf_ptr` (the executor's Sync-BN hook).  Called ~200 times
+    per network pass, so the zero-copy tensor views are cached per (pointer, length): the caching allocator hands
+    the executor the same arena addresses every iteration."""
+    key = (int(buf_ptr), int(n))
+    t = _views.get(key)
+    if t is None:
+        if len(_views) > 8192:
+            _views.clear()
+        t = torch.as_tensor(_DevView(buf_ptr, n), device=torch.device('cuda', torch.cuda.current_device()))
+        _views[key] = t
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return 0
 
