@@ -158,6 +158,10 @@ int pxl_bn_bwd_apply(int dtype, int M, int C, const void* dz, const void* y, con
 /* out = relu( y*ycoef.scale+ycoef.shift + (rcoef ? res*rcoef.scale+rcoef.shift : res) )  resnet.py:44-48 */
 int pxl_residual_fwd(int dtype, long M, int C, const void* y, const float* ycoef, const void* res,
                      const float* rcoef, void* out, void* stream);
+/* nn.LeakyReLU(slope) forward / backward of the FCDiscriminator and FlawDetector stacks (ssl_adv.py:474,480-485;
+ * ssl_gct.py:567-585): y = x > 0 ? x : slope*x ; dx = x > 0 ? dy : slope*dy */
+int pxl_leaky_fwd(int dtype, long n, const void* x, float slope, void* y, void* stream);
+int pxl_leaky_bwd(int dtype, long n, const void* dy, const void* x, float slope, void* dx, void* stream);
 /* g = dout * (out > 0), optionally duplicated into g2 (the residual branch's gradient) */
 int pxl_relu_mask(int dtype, long n, const void* dout, const void* out, void* g, void* g2, void* stream);
 /* out[c] += sum_m x[m][c] for c < Creal (bias gradient; x NHWC with channel pitch Cp <= 256) */
@@ -191,6 +195,14 @@ int pxl_ce_fwd(int N, int C, int HW, const float* logits, const float* gt, int i
                void* stream);
 int pxl_ce_bwd(int N, int C, int HW, const float* logits, const float* gt, int ignore_index, const float* gout,
                float* dlogits, void* stream);
+/* FCDiscriminatorCriterion (ssl_adv.py:496-503) fused with ssladv_preprocess_fcd_criterion (task/sseg/func.py:
+ * 137-157): x = discriminator logits [B][1][HW], task_gt = float labels [B][1][HW] or NULL (unlabeled: nothing
+ * masked), target = 1 (real) / 0 (fake).  Pixels whose label is ignore_index get x := 0, t := 0 and still count in
+ * the mean (they add log 2 each), exactly like the reference's mask-then-BCE; loss[b] = mean over HW. */
+int pxl_bce_logits_masked_fwd(int B, long HW, const float* x, const float* task_gt, int ignore_index, float target,
+                              float* loss, void* stream);
+int pxl_bce_logits_masked_bwd(int B, long HW, const float* x, const float* task_gt, int ignore_index, float target,
+                              const float* gout, float* dx, void* stream);
 /* nn.MSELoss() (ssl_mt.py:115,182-184): out[0] = mean((a-b)^2); da = 2(a-b)/n * gout[0] */
 int pxl_mse_fwd(long n, const float* a, const float* b, float* out, void* stream);
 int pxl_mse_bwd(long n, const float* a, const float* b, const float* gout, float* da, void* stream);
@@ -232,6 +244,10 @@ int pxl_mse_persample_bwd(int B, long n, const float* a, const float* g, const f
 /* torch.optim.SGD(momentum, weight_decay) semantics, pixelssl/nn/optimizer.py:57-75 */
 int pxl_sgd_step(long n, float* p, const float* g, float* buf, float lr, float momentum, float weight_decay,
                  int first_step, void* stream);
+/* torch.optim.Adam(lr, betas, eps) without weight decay over a flat buffer (ssl_adv.py:101-102, discriminator);
+ * `step` counts from 1 (bias correction) */
+int pxl_adam_step(long n, float* p, const float* g, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                  float beta2, float eps, int step, void* stream);
 /* SSLMT._update_ema_variables, pixelssl/ssl_algorithm/ssl_mt.py:359-363 */
 int pxl_ema_update(long n, float* teacher, const float* student, float alpha, void* stream);
 int pxl_scale_inplace(long n, float* x, float a, void* stream);
@@ -249,6 +265,7 @@ int pxl_scale_inplace(long n, float* x, float a, void* stream);
 #define PXL_OP_MAXPOOL 2    /* 3x3/s2/p1 max-pool of relu(bn(in))                    */
 #define PXL_OP_RESIDUAL 3   /* out = relu(bn(in0) + (bn(in1) | in1))                 */
 #define PXL_OP_HEAD 4       /* upsample + softmax of the low-res logits -> outputs   */
+#define PXL_OP_ACT 5        /* out = LeakyReLU(in0, slope) (conv stacks without BN)  */
 
 typedef struct pxl_op {
   int32_t kind;
@@ -263,6 +280,7 @@ typedef struct pxl_op {
   int32_t cin, cout;           /* real channels                                                      */
   int32_t kh, kw, stride;
   int32_t need_dgrad;          /* 0 for the stem (the image needs no gradient)                       */
+  float slope;                 /* PXL_OP_ACT: negative slope of the LeakyReLU                        */
 } pxl_op;
 
 typedef struct pxl_bn_desc {
@@ -305,6 +323,12 @@ int pxl_net_latent_shape(const pxl_net* net, int* C, int* h, int* w);
 int pxl_net_backward(pxl_net* net, const float* params, const void* packed, const float* dlogits,
                      const float* dprob, const float* prob, float* grads, void* arena, size_t arena_bytes,
                      void* scratch, size_t scratch_bytes, int training, void* stream);
+
+/* gradient w.r.t. the network input of the last backward (NCHW fp32 [B,Cin,H,W]); the first convolution of the
+ * program must have need_dgrad = 1 (discriminator / flaw detector: the input is the task model's softmax) */
+int pxl_net_input_grad(pxl_net* net, const void* scratch, float* dx, void* stream);
+/* enable = 0: backward skips every parameter gradient (a frozen discriminator only relays dL/dinput) */
+int pxl_net_set_wgrad(pxl_net* net, int enable);
 
 /* Measurement aid (bench.py roofline leg): bracket every contraction launch of this net with HIP
  * events on the launch stream.  kind 0 = implicit-GEMM conv (forward + data gradient), 1 = weight

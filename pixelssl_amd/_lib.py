@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpixelhip.so")
 
 PXL_F32, PXL_BF16 = 0, 1
-OP_INPUT, OP_CONV, OP_MAXPOOL, OP_RESIDUAL, OP_HEAD = 0, 1, 2, 3, 4
+OP_INPUT, OP_CONV, OP_MAXPOOL, OP_RESIDUAL, OP_HEAD, OP_ACT = 0, 1, 2, 3, 4, 5
 
 
 class PixelHipError(RuntimeError):
@@ -34,7 +34,7 @@ class Op(C.Structure):
                 ("ngroups", C.c_int32), ("w_off", C.c_int32 * 4), ("b_off", C.c_int32 * 4),
                 ("dil", C.c_int32 * 4), ("pads", C.c_int32 * 4), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
-                ("need_dgrad", C.c_int32)]
+                ("need_dgrad", C.c_int32), ("slope", C.c_float)]
 
 
 class PackItem(C.Structure):
@@ -76,6 +76,8 @@ SIGNATURES = {
     "pxl_bn_param_grad": (_I, [_I, _P, _P, _P, _P]),
     "pxl_bn_bwd_apply_fused": (_I, [_I, _I, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P]),
     "pxl_residual_fwd": (_I, [_I, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "pxl_leaky_fwd": (_I, [_I, _L, _P, _F, _P, _P]),
+    "pxl_leaky_bwd": (_I, [_I, _L, _P, _P, _F, _P, _P]),
     "pxl_relu_mask": (_I, [_I, _L, _P, _P, _P, _P, _P]),
     "pxl_colsum": (_I, [_I, _I, _I, _I, _P, _P, _P]),
     "pxl_vec_sum4": (_I, [_I, _P, _P, _P, _P, _P, _P]),
@@ -87,6 +89,8 @@ SIGNATURES = {
     "pxl_upsample_softmax_bwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "pxl_ce_fwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P]),
     "pxl_ce_bwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "pxl_bce_logits_masked_fwd": (_I, [_I, _L, _P, _P, _I, _F, _P, _P]),
+    "pxl_bce_logits_masked_bwd": (_I, [_I, _L, _P, _P, _I, _F, _P, _P, _P]),
     "pxl_mse_fwd": (_I, [_L, _P, _P, _P, _P]),
     "pxl_mse_bwd": (_I, [_L, _P, _P, _P, _P, _P]),
     "pxl_absdiff_chansum": (_I, [_I, _I, _L, _P, _P, _I, _F, _P, _P]),
@@ -99,6 +103,7 @@ SIGNATURES = {
     "pxl_mse_persample_fwd": (_I, [_I, _L, _P, _P, _P, _P]),
     "pxl_mse_persample_bwd": (_I, [_I, _L, _P, _P, _P, _P, _P]),
     "pxl_sgd_step": (_I, [_L, _P, _P, _P, _F, _F, _F, _I, _P]),
+    "pxl_adam_step": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _I, _P]),
     "pxl_ema_update": (_I, [_L, _P, _P, _F, _P]),
     "pxl_scale_inplace": (_I, [_L, _P, _F, _P]),
     "pxl_net_create": (_I, [_I, _I, C.POINTER(Op), _I, C.POINTER(BnDesc), _I, _I, C.POINTER(_P)]),
@@ -113,6 +118,8 @@ SIGNATURES = {
     "pxl_net_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
     "pxl_net_latent": (_I, [_P, _P, _P, _P]),
     "pxl_net_latent_shape": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "pxl_net_input_grad": (_I, [_P, _P, _P, _P]),
+    "pxl_net_set_wgrad": (_I, [_P, _I]),
     "pxl_net_profile": (_I, [_P, _I]),
     "pxl_net_profile_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
     "pxl_net_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),

@@ -97,6 +97,33 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(int M, int C, const T
   }
 }
 
+// LeakyReLU of the discriminator / flaw-detector conv stacks (ssl_adv.py:474-487, ssl_gct.py:567-585)
+template <typename T>
+__global__ __launch_bounds__(256) void leaky_fwd_kernel(long nchunks, const T* __restrict__ x, float slope,
+                                                        T* __restrict__ y) {
+  constexpr int EPC = Elem<T>::EPC;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    float f[EPC];
+    Chunk<T>::unpack(reinterpret_cast<const uint4*>(x)[i], f);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) f[e] = f[e] > 0.f ? f[e] : f[e] * slope;
+    reinterpret_cast<uint4*>(y)[i] = Chunk<T>::pack(f);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void leaky_bwd_kernel(long nchunks, const T* __restrict__ dy,
+                                                        const T* __restrict__ x, float slope, T* __restrict__ dx) {
+  constexpr int EPC = Elem<T>::EPC;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    float fd[EPC], fx[EPC];
+    Chunk<T>::unpack(reinterpret_cast<const uint4*>(dy)[i], fd);
+    Chunk<T>::unpack(reinterpret_cast<const uint4*>(x)[i], fx);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) fd[e] = fx[e] > 0.f ? fd[e] : fd[e] * slope;
+    reinterpret_cast<uint4*>(dx)[i] = Chunk<T>::pack(fd);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void relu_mask_kernel(long nchunks, const T* __restrict__ dout,
                                                         const T* __restrict__ out, T* __restrict__ g,
@@ -114,13 +141,16 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(long nchunks, const T* _
   }
 }
 
-// out[c] += sum_m x[m][c]  for c < Creal (bias gradient of the ASPP head)
+// out[c] += sum_m x[m][c]  for c < Creal (bias gradients: ASPP head, discriminator / flaw-detector convolutions).
+// blockIdx.y selects a 256-column slab (pitches > 256); inside a slab `cw` columns x 256/cw row lanes.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(int M, int Cp, int Creal, const T* __restrict__ x,
                                                      float* __restrict__ out, int rows_per_block) {
-  const int c = threadIdx.x % Cp;
-  const int rr = threadIdx.x / Cp;
-  const int rstep = 256 / Cp;
+  const int c0 = blockIdx.y * 256;
+  const int cw = min(256, Cp - c0);
+  const int c = c0 + threadIdx.x % cw;
+  const int rr = threadIdx.x / cw;
+  const int rstep = 256 / cw;
   const int m_end = min(M, (int)(blockIdx.x + 1) * rows_per_block);
   float acc = 0.f;
   if (rr < rstep && c < Creal)
@@ -291,6 +321,36 @@ extern "C" int pxl_bn_apply_fwd(int dtype, long M, int C, const void* y, const f
   return PXL_OK;
 }
 
+extern "C" int pxl_leaky_fwd(int dtype, long n, const void* x, float slope, void* y, void* stream) {
+  PXL_REQUIRE(x && y && n > 0, "leaky_fwd: bad argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "leaky_fwd: bad dtype");
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  PXL_REQUIRE(n % epc == 0, "leaky_fwd: n must be a multiple of %d", epc);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long nchunks = n / epc;
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(leaky_fwd_kernel<float>, dim3(grid_for(nchunks)), dim3(256), 0, s, nchunks, cp<float>(x), slope, mp<float>(y));
+  else
+    hipLaunchKernelGGL(leaky_fwd_kernel<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, s, nchunks, cp<bf16_t>(x), slope, mp<bf16_t>(y));
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_leaky_bwd(int dtype, long n, const void* dy, const void* x, float slope, void* dx, void* stream) {
+  PXL_REQUIRE(dy && x && dx && n > 0, "leaky_bwd: bad argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "leaky_bwd: bad dtype");
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  PXL_REQUIRE(n % epc == 0, "leaky_bwd: n must be a multiple of %d", epc);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long nchunks = n / epc;
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(leaky_bwd_kernel<float>, dim3(grid_for(nchunks)), dim3(256), 0, s, nchunks, cp<float>(dy), cp<float>(x), slope, mp<float>(dx));
+  else
+    hipLaunchKernelGGL(leaky_bwd_kernel<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, s, nchunks, cp<bf16_t>(dy), cp<bf16_t>(x), slope, mp<bf16_t>(dx));
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
 extern "C" int pxl_relu_mask(int dtype, long n, const void* dout, const void* out, void* g, void* g2,
                              void* stream) {
   PXL_REQUIRE(dout && out && g, "relu_mask: null argument");
@@ -312,16 +372,16 @@ extern "C" int pxl_relu_mask(int dtype, long n, const void* dout, const void* ou
 extern "C" int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream) {
   PXL_REQUIRE(x && out && M > 0, "colsum: bad argument");
   PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "colsum: bad dtype");
-  PXL_REQUIRE(Cp >= 1 && Cp <= 256 && Creal <= Cp, "colsum: channel pitch %d unsupported (max 256)", Cp);
+  PXL_REQUIRE(Cp >= 1 && Creal <= Cp, "colsum: bad channel pitch %d", Cp);
   int blocks = cdiv(M, 256);
   if (blocks > 512) blocks = 512;
   const int rpb = cdiv(M, blocks);
   blocks = cdiv(M, rpb);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(256), 0, s, M, Cp, Creal, cp<float>(x), out, rpb);
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks, cdiv(Cp, 256)), dim3(256), 0, s, M, Cp, Creal, cp<float>(x), out, rpb);
   else
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, M, Cp, Creal, cp<bf16_t>(x), out, rpb);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks, cdiv(Cp, 256)), dim3(256), 0, s, M, Cp, Creal, cp<bf16_t>(x), out, rpb);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

@@ -137,6 +137,57 @@ extern "C" int pxl_ce_bwd(int N, int C, int HW, const float* logits, const float
   return PXL_OK;
 }
 
+namespace {
+// FCDiscriminatorCriterion (ssl_adv.py:496-503) fused with ssladv_preprocess_fcd_criterion (task/sseg/func.py:137-157):
+// per pixel m = (task_gt == NULL || task_gt != ignore), x' = x*m, t' = target*m (target = 1 real / 0 fake);
+// loss[b] = mean over ALL pixels of BCEWithLogits(x', t')  (masked pixels contribute log 2 like in the reference);
+// dx = m * (sigmoid(x') - t') / HW * gout[b]
+__global__ void bce_masked_fwd_kernel(long HW, const float* __restrict__ x, const float* __restrict__ task_gt,
+                                      int ignore, float target, float* __restrict__ loss) {
+  const int b = blockIdx.y;
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+    const float m = (task_gt == nullptr || (int)task_gt[b * HW + i] != ignore) ? 1.f : 0.f;
+    const float xv = x[b * HW + i] * m, t = target * m;
+    s += fmaxf(xv, 0.f) - xv * t + log1pf(expf(-fabsf(xv)));
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(loss + b, s / (float)HW);
+}
+__global__ void bce_masked_bwd_kernel(long HW, const float* __restrict__ x, const float* __restrict__ task_gt,
+                                      int ignore, float target, const float* __restrict__ gout,
+                                      float* __restrict__ dx) {
+  const int b = blockIdx.y;
+  const float k = gout[b] / (float)HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+    const float m = (task_gt == nullptr || (int)task_gt[b * HW + i] != ignore) ? 1.f : 0.f;
+    const float xv = x[b * HW + i] * m, t = target * m;
+    dx[b * HW + i] = m * (1.f / (1.f + expf(-xv)) - t) * k;
+  }
+}
+}  // namespace
+
+extern "C" int pxl_bce_logits_masked_fwd(int B, long HW, const float* x, const float* task_gt, int ignore_index,
+                                         float target, float* loss, void* stream) {
+  PXL_REQUIRE(x && loss && B > 0 && HW > 0, "bce_logits_masked_fwd: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PXL_CHECK_HIP(hipMemsetAsync(loss, 0, (size_t)B * sizeof(float), s));
+  const int gx = (int)((HW + 256 * 8 - 1) / (256 * 8));
+  hipLaunchKernelGGL(bce_masked_fwd_kernel, dim3(gx, B), dim3(256), 0, s, HW, x, task_gt, ignore_index, target, loss);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_bce_logits_masked_bwd(int B, long HW, const float* x, const float* task_gt, int ignore_index,
+                                         float target, const float* gout, float* dx, void* stream) {
+  PXL_REQUIRE(x && gout && dx && B > 0 && HW > 0, "bce_logits_masked_bwd: bad argument");
+  const int gx = (int)((HW + 256 * 8 - 1) / (256 * 8));
+  hipLaunchKernelGGL(bce_masked_bwd_kernel, dim3(gx, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), HW, x,
+                     task_gt, ignore_index, target, gout, dx);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
 extern "C" int pxl_mse_fwd(long n, const float* a, const float* b, float* out, void* stream) {
   PXL_REQUIRE(a && b && out && n > 0, "mse_fwd: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -102,6 +102,8 @@ struct pxl_net {
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
   int use_side = -1;
+  bool wgrad_on = true;
+  int input_tensor = -1;
   // tests: use the reference's multi-device variance formula clamp(var, eps) on a single rank too
   bool force_clamp = getenv("PXL_FORCE_CLAMP_VAR") != nullptr;
 };
@@ -218,6 +220,7 @@ extern "C" int pxl_net_create(int dtype, int num_classes, const pxl_op* ops, int
     if ((d.kind == PXL_OP_CONV || d.kind == PXL_OP_MAXPOOL) && d.bn_in0 >= 0) n->bns[d.bn_in0].relu = 1;
     if (d.kind == PXL_OP_CONV && d.bn_out >= 0) n->bns[d.bn_out].y_tensor = d.out;
     if (d.kind == PXL_OP_HEAD) n->head_op = i;
+    if (d.kind == PXL_OP_INPUT) n->input_tensor = d.out;
   }
   if (n->head_op < 0) {
     delete n;
@@ -347,6 +350,12 @@ extern "C" int pxl_net_plan(pxl_net* n, int B, int H, int W) {
         PXL_REQUIRE(a.H == r.H && a.W == r.W && a.C == r.C, "net_plan: residual op %zu shape mismatch", i);
         PXL_REQUIRE(d.bn_in0 >= 0, "net_plan: residual op %zu needs a BN on its main branch", i);
         plan_tensor(d.out, a.H, a.W, a.C);
+        break;
+      }
+      case PXL_OP_ACT: {
+        PXL_REQUIRE(d.in0 >= 0 && n->tensors[d.in0].planned, "net_plan: op %zu consumes an unplanned tensor", i);
+        const TensorInfo& tin = n->tensors[d.in0];
+        plan_tensor(d.out, tin.H, tin.W, tin.C);
         break;
       }
       case PXL_OP_HEAD: {
@@ -581,6 +590,12 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
                               at(arena, o.off), stream);
         break;
       }
+      case PXL_OP_ACT: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        rc = pxl_leaky_fwd(dt, (long)n->B * tin.H * tin.W * tin.Cp, at(arena, tin.off), d.slope, at(arena, tout.off), stream);
+        break;
+      }
       case PXL_OP_HEAD: {
         const TensorInfo& low = n->tensors[d.in0];
         rc = pxl_upsample_softmax_fwd(dt, n->B, low.H, low.W, low.Cp, n->classes, n->H, n->W, at(arena, low.off),
@@ -591,6 +606,18 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
     if (rc != PXL_OK) return rc;
   }
   return PXL_OK;
+}
+
+extern "C" int pxl_net_set_wgrad(pxl_net* net, int enable) {
+  PXL_REQUIRE(net, "net_set_wgrad: null net");
+  net->wgrad_on = enable != 0;
+  return PXL_OK;
+}
+
+extern "C" int pxl_net_input_grad(pxl_net* n, const void* scratch, float* dx, void* stream) {
+  PXL_REQUIRE(n && n->planned && scratch && dx && n->input_tensor >= 0, "net_input_grad: bad argument");
+  const TensorInfo& t = n->tensors[n->input_tensor];
+  return pxl_nhwc_to_nchw(n->dtype, at(scratch, t.goff), dx, n->B, t.C, t.H, t.W, t.Cp, stream);
 }
 
 extern "C" int pxl_net_latent_shape(const pxl_net* n, int* C, int* h, int* w) {
@@ -644,6 +671,16 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         const TensorInfo& low = n->tensors[d.in0];
         rc = pxl_upsample_softmax_bwd(dt, n->B, low.H, low.W, low.Cp, n->classes, n->H, n->W, dlogits, dprob, prob,
                                       at(scratch, low.goff), at(scratch, n->up_ws_off), n->up_ws_bytes, stream);
+        written[d.in0] = 1;
+        break;
+      }
+      case PXL_OP_ACT: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        if (!written[d.out]) return pxl_set_error(PXL_ERR_ARG, "net_backward: activation op %d output has no gradient", i);
+        if (written[d.in0]) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net_backward: activation input consumed twice");
+        rc = pxl_leaky_bwd(dt, (long)n->B * tin.H * tin.W * tin.Cp, at(scratch, tout.goff), at(arena, tin.off), d.slope,
+                           at(scratch, tin.goff), stream);
         written[d.in0] = 1;
         break;
       }
@@ -705,14 +742,14 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         const ConvIn cin = conv_input(n, d, arena);
         const float* sc = cin.sc; const float* sh = cin.sh;
         hipStream_t ws = s;
-        if (n->use_side && d.need_dgrad) {       // fork: dy is final on the main stream from here on
+        if (n->use_side && d.need_dgrad && n->wgrad_on) {       // fork: dy is final on the main stream from here on
           if (!n->fork_ev[i]) PXL_CHECK_HIP(hipEventCreateWithFlags(&n->fork_ev[i], hipEventDisableTiming));
           PXL_CHECK_HIP(hipEventRecord(n->fork_ev[i], s));
           PXL_CHECK_HIP(hipStreamWaitEvent(n->side, n->fork_ev[i], 0));
           ws = n->side;
           forked = true;
         }
-        for (int g = 0; g < d.ngroups; ++g) {
+        for (int g = 0; g < d.ngroups && n->wgrad_on; ++g) {
           {
             Timed t(n, ws, 1, conv_flops(n, d, tout) / d.ngroups);
             rc = pxl_conv_wgrad(&op.grp[g], cin.ptr, sc, sh, dy, grads + d.w_off[g], d.cin, d.cin, ws);

@@ -2,6 +2,8 @@
 // learning-rate group instead of 320 per-tensor launches).  HBM-bound, float4 per lane.
 //   * SGD with momentum + weight decay: torch.optim.SGD semantics (pixelssl/nn/optimizer.py:57-75)
 //   * EMA teacher update (ssl_mt.py:359-363)
+#include <cmath>
+
 #include "common.h"
 
 namespace {
@@ -22,6 +24,20 @@ __global__ __launch_bounds__(256) void ema_kernel(long n, float* __restrict__ t,
                                                   float alpha) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     t[i] = t[i] * alpha + (1.f - alpha) * s[i];
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad): the FC discriminator / flaw detector optimizer (ssl_adv.py:101-102)
+__global__ __launch_bounds__(256) void adam_kernel(long n, float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, float step_size,
+                                                   float beta1, float beta2, float eps, float inv_sqrt_bc2) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+  }
 }
 
 __global__ __launch_bounds__(256) void scale_kernel(long n, float* __restrict__ x, float a) {
@@ -50,6 +66,17 @@ extern "C" int pxl_ema_update(long n, float* teacher, const float* student, floa
   PXL_REQUIRE(teacher && student && n > 0, "ema_update: bad argument");
   hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n,
                      teacher, student, alpha);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_adam_step(long n, float* p, const float* g, float* exp_avg, float* exp_avg_sq, float lr,
+                             float beta1, float beta2, float eps, int step, void* stream) {
+  PXL_REQUIRE(p && g && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_step: bad argument (step counts from 1)");
+  // torch: denom = sqrt(v) / sqrt(1 - beta2^t) + eps ; p -= lr / (1 - beta1^t) * m / denom
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, p, g,
+                     exp_avg, exp_avg_sq, (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)));
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

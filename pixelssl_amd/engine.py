@@ -160,6 +160,11 @@ class ProgramBuilder:
             self.modules[nm] = "conv_bias" if bias else "conv"
         return t
 
+    def act(self, t_in, slope):
+        t = self.tensor()
+        self._op(_lib.OP_ACT, in0=t_in, out=t, slope=float(slope))
+        return t
+
     def maxpool(self, t_in, bn_in):
         t = self.tensor()
         self._op(_lib.OP_MAXPOOL, in0=t_in, out=t, bn_in0=bn_in)
@@ -220,16 +225,17 @@ class SegNetCore(nn.Module):
         self.num_classes = num_classes
         self._store = FlatStore(self._device)
         self._pb = ProgramBuilder(self._store)
-        self._net = ctypes.c_void_p()
-        self._shape = None
-        self._packed = None
-        self._packed_version = None
-        self._scratch = None
-        self._eval_arena = None
+        self._plans = {}                # (B, H, W) -> _Plan: one executor instance + buffers per input shape
+        self._cur = None
         self._sync_cb = None
+        self._sync_world = 1
+        self._profile_on = False
         self._anchor = None
         self.freeze_bn = False
         self.autotune = os.environ.get("PXL_AUTOTUNE", "1") != "0"
+        self.want_prob = True           # HEAD also returns softmax(logits) (segmentation nets; not the discriminators)
+        self.has_latent = True
+        self._wgrad_on = True
 
     # -- construction -----------------------------------------------------------------------
     def _finalize(self):
@@ -258,10 +264,8 @@ class SegNetCore(nn.Module):
                 leaf.register_buffer("num_batches_tracked", self._nbt[bn_index])
                 bn_index += 1
             self._attach(dotted, leaf)
-        ops = (Op * len(pb.ops))(*pb.ops)
-        bns = (BnDesc * len(pb.bns))(*pb.bns)
-        check(lib().pxl_net_create(self._code, self.num_classes, ops, len(pb.ops), bns, len(pb.bns), pb.ntensors,
-                                   ctypes.byref(self._net)))
+        self._ops_arr = (Op * len(pb.ops))(*pb.ops)
+        self._bns_arr = (BnDesc * max(len(pb.bns), 1))(*pb.bns)
         self._anchor = torch.zeros((), device=self._device, requires_grad=True)
 
     def _attach(self, dotted, leaf):
@@ -275,10 +279,18 @@ class SegNetCore(nn.Module):
 
     def __del__(self):
         try:
-            if self._net:
-                lib().pxl_net_destroy(self._net)
+            for pl in self._plans.values():
+                if pl.net:
+                    lib().pxl_net_destroy(pl.net)
         except Exception:
             pass
+
+    # the state of the plan in use (kept as attributes for the call sites / tests that read them)
+    _net = property(lambda self: self._cur.net)
+    _packed = property(lambda self: self._cur.packed)
+    _scratch = property(lambda self: self._cur.scratch)
+    _arena_bytes = property(lambda self: self._cur.arena_bytes)
+    _shape = property(lambda self: self._cur.shape if self._cur is not None else None)
 
     # -- parameter plumbing -----------------------------------------------------------------
     @property
@@ -310,34 +322,48 @@ class SegNetCore(nn.Module):
 
     # -- planning ---------------------------------------------------------------------------
     def _plan(self, B, H, W):
-        if self._shape == (B, H, W):
-            return
-        check(lib().pxl_net_plan(self._net, B, H, W))
-        self._shape = (B, H, W)
-        dev = self._device
-        self._packed = torch.empty(lib().pxl_net_packed_bytes(self._net), device=dev, dtype=torch.uint8)
-        self._packed_version = None
-        self._scratch = torch.empty(lib().pxl_net_scratch_bytes(self._net), device=dev, dtype=torch.uint8)
-        self._arena_bytes = lib().pxl_net_arena_bytes(self._net)
-        self._eval_arena = None
-        self._tuned = False
+        """Select (or create) the executor instance planned for this input shape.  Networks that see several
+        batch sizes per iteration (the AdvSSL discriminator: B fake + lbs real maps) keep one plan each, so a
+        backward always runs on the plan its forward used."""
+        key = (B, H, W)
+        pl = self._plans.get(key)
+        if pl is None:
+            pl = _Plan(key)
+            pb = self._pb
+            check(lib().pxl_net_create(self._code, self.num_classes, self._ops_arr, len(pb.ops), self._bns_arr,
+                                       len(pb.bns), pb.ntensors, ctypes.byref(pl.net)))
+            check(lib().pxl_net_plan(pl.net, B, H, W))
+            dev = self._device
+            pl.packed = torch.empty(lib().pxl_net_packed_bytes(pl.net), device=dev, dtype=torch.uint8)
+            pl.scratch = torch.empty(lib().pxl_net_scratch_bytes(pl.net), device=dev, dtype=torch.uint8)
+            pl.arena_bytes = lib().pxl_net_arena_bytes(pl.net)
+            if self._sync_cb is not None:
+                check(lib().pxl_net_set_sync(pl.net, self._sync_cb, None, self._sync_world))
+            if not self._wgrad_on:
+                check(lib().pxl_net_set_wgrad(pl.net, 0))
+            if self._profile_on:
+                check(lib().pxl_net_profile(pl.net, 1))
+            self._plans[key] = pl
+        self._cur = pl
+        return pl
 
     def _ensure_packed(self):
+        pl = self._cur
         v = self._store.version()
-        if self._packed_version != v:
-            check(lib().pxl_net_pack(self._net, ptr(self._store.params), ptr(self._packed), stream_ptr()))
-            self._packed_version = v
-        if not self._tuned and self.autotune:
+        if pl.packed_version != v:
+            check(lib().pxl_net_pack(pl.net, ptr(self._store.params), ptr(pl.packed), stream_ptr()))
+            pl.packed_version = v
+        if not pl.tuned and self.autotune:
             # per-shape tile selection, measured on this GPU (csrc/net.cpp: pxl_net_tune)
-            arena = torch.zeros(self._arena_bytes, device=self._device, dtype=torch.uint8)
-            self._scratch.zero_()
+            arena = torch.zeros(pl.arena_bytes, device=self._device, dtype=torch.uint8)
+            pl.scratch.zero_()
             keep = self._store.grads.clone()
-            check(lib().pxl_net_tune(self._net, ptr(self._store.params), ptr(self._packed), ptr(self._store.grads),
-                                     ptr(arena), arena.numel(), ptr(self._scratch), self._scratch.numel(),
+            check(lib().pxl_net_tune(pl.net, ptr(self._store.params), ptr(pl.packed), ptr(self._store.grads),
+                                     ptr(arena), arena.numel(), ptr(pl.scratch), pl.scratch.numel(),
                                      stream_ptr()))
             self._store.grads.copy_(keep)
             del arena
-        self._tuned = True
+        pl.tuned = True
 
     def set_sync(self, callback, world_size):
         """callback(buf_ptr:int, n:int, stream:int) -> int ; installs the SyncBN statistics hook."""
@@ -349,11 +375,21 @@ class SegNetCore(nn.Module):
                 traceback.print_exc()
                 return 1
         self._sync_cb = _lib.ALLREDUCE_FN(_cb)
-        check(lib().pxl_net_set_sync(self._net, self._sync_cb, None, world_size))
+        self._sync_world = world_size
+        for pl in self._plans.values():
+            check(lib().pxl_net_set_sync(pl.net, self._sync_cb, None, world_size))
 
     # -- execution --------------------------------------------------------------------------
-    def _forward_raw(self, x, arena, want_prob=True):
+    def set_wgrad(self, enable):
+        """enable=False: backward only relays dL/dinput (a frozen discriminator inside the task model's step)."""
+        if bool(enable) != self._wgrad_on:
+            for pl in self._plans.values():
+                check(lib().pxl_net_set_wgrad(pl.net, int(bool(enable))))
+            self._wgrad_on = bool(enable)
+
+    def _forward_raw(self, x, arena, want_prob=None):
         B, _, H, W = x.shape
+        want_prob = self.want_prob if want_prob is None else want_prob
         logits = torch.empty(B, self.num_classes, H, W, device=x.device, dtype=torch.float32)
         prob = torch.empty_like(logits) if want_prob else None
         training = self.training and not self.freeze_bn
@@ -377,51 +413,72 @@ class SegNetCore(nn.Module):
         B, _, H, W = x.shape
         self._plan(B, H, W)
         self._ensure_packed()
-        need_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list[:1])
+        need_graph = torch.is_grad_enabled() and (any(p.requires_grad for p in self._param_list[:1]) or x.requires_grad)
         if need_graph:
             arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
             logits, prob = _SegNetFn.apply(x, self._anchor, self, arena)
         else:
-            if self._eval_arena is None:
-                self._eval_arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
-            arena = self._eval_arena
+            if self._cur.eval_arena is None:
+                self._cur.eval_arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
+            arena = self._cur.eval_arena
             logits, prob = self._forward_raw(x, arena)
-        return logits, prob, _LatentHandle(self, arena)
+        return logits, prob, (_LatentHandle(self, arena, self._cur) if self.has_latent else None)
 
     def profile(self, enable=True):
         """Bracket every contraction launch with HIP events (bench.py roofline leg)."""
-        check(lib().pxl_net_profile(self._net, int(enable)))
+        self._profile_on = bool(enable)
+        for pl in self._plans.values():
+            check(lib().pxl_net_profile(pl.net, int(enable)))
 
     def profile_read(self, kind):
         """-> (kernel ms, launches, algorithmic flops) of kind 0 = conv igemm (fwd+dgrad), 1 = wgrad."""
-        ms, n, fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
-        check(lib().pxl_net_profile_read(self._net, kind, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
-        return ms.value, n.value, fl.value
+        tot = [0.0, 0, 0.0]
+        for pl in self._plans.values():
+            ms, n, fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+            check(lib().pxl_net_profile_read(pl.net, kind, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
+            tot = [tot[0] + ms.value, tot[1] + n.value, tot[2] + fl.value]
+        return tuple(tot)
 
-    def latent_from(self, arena):
+    def latent_from(self, arena, plan=None):
+        pl = plan if plan is not None else self._cur
         c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        check(lib().pxl_net_latent_shape(self._net, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)))
-        out = torch.empty(self._shape[0], c.value, h.value, w.value, device=self._device, dtype=torch.float32)
-        check(lib().pxl_net_latent(self._net, ptr(arena), ptr(out), stream_ptr()))
+        check(lib().pxl_net_latent_shape(pl.net, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)))
+        out = torch.empty(pl.shape[0], c.value, h.value, w.value, device=self._device, dtype=torch.float32)
+        check(lib().pxl_net_latent(pl.net, ptr(arena), ptr(out), stream_ptr()))
         return out
 
 
+class _Plan:
+    """One executor instance (csrc/net.cpp pxl_net) planned for a fixed input shape, with its buffers."""
+
+    def __init__(self, shape):
+        self.shape = shape
+        self.net = ctypes.c_void_p()
+        self.packed = self.scratch = self.eval_arena = None
+        self.packed_version = None
+        self.arena_bytes = 0
+        self.tuned = False
+
+
 class _LatentHandle:
-    def __init__(self, core, arena):
-        self.core, self.arena = core, arena
+    def __init__(self, core, arena, plan=None):
+        self.core, self.arena, self.plan = core, arena, plan
 
     def __call__(self):
-        return self.core.latent_from(self.arena)
+        return self.core.latent_from(self.arena, self.plan)
 
 
 class _SegNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, core, arena):
         logits, prob = core._forward_raw(x, arena)
-        ctx.core, ctx.arena = core, arena
+        ctx.core, ctx.arena, ctx.plan = core, arena, core._cur
         ctx.bn_training = bool(core.training and not core.freeze_bn)
+        ctx.x_shape = tuple(x.shape)
         ctx.save_for_backward(prob)
         ctx.set_materialize_grads(False)
+        if prob is None:
+            ctx.mark_non_differentiable()
         return logits, prob
 
     @staticmethod
@@ -436,14 +493,19 @@ class _SegNetFn(torch.autograd.Function):
             dprob = dprob.contiguous()
         core.ensure_grad_views()
         s = core._store
-        check(lib().pxl_net_backward(core._net, ptr(s.params), ptr(core._packed), ptr(dlogits), ptr(dprob), ptr(prob),
-                                     ptr(s.grads), ptr(ctx.arena), ctx.arena.numel(), ptr(core._scratch),
-                                     core._scratch.numel(), int(ctx.bn_training), stream_ptr()))
+        pl = ctx.plan
+        check(lib().pxl_net_backward(pl.net, ptr(s.params), ptr(pl.packed), ptr(dlogits), ptr(dprob), ptr(prob),
+                                     ptr(s.grads), ptr(ctx.arena), ctx.arena.numel(), ptr(pl.scratch),
+                                     pl.scratch.numel(), int(ctx.bn_training), stream_ptr()))
+        dx = None
+        if ctx.needs_input_grad[0]:        # discriminator / flaw detector: gradient w.r.t. the task model's softmax
+            dx = torch.empty(ctx.x_shape, device=core._device, dtype=torch.float32)
+            check(lib().pxl_net_input_grad(pl.net, ptr(pl.scratch), ptr(dx), stream_ptr()))
         hook = getattr(core, "_post_backward_hook", None)
-        if hook is not None:
+        if hook is not None and core._wgrad_on:
             hook(core)
         ctx.arena = None
-        return None, None, None, None
+        return dx, None, None, None
 
 
 class DeepLabV2Core(SegNetCore):
@@ -503,3 +565,42 @@ class DeepLabV2Core(SegNetCore):
         for name, prm in self.named_parameters():
             if name.startswith("classifier") and prm.requires_grad:
                 yield prm
+
+
+class FCDiscriminatorCore(SegNetCore):
+    """FC discriminator of AdvSSL (pixelssl/ssl_algorithm/ssl_adv.py:463-493): 4 x (conv 4x4 / stride 2 / pad 1 + bias
+    + LeakyReLU 0.2), a 1-channel classifier conv and bilinear up-sampling (align_corners=True) to the input size --
+    the same layer program / executor as the segmentation networks, no BatchNorm.  Parameter names follow the
+    reference module: conv1..conv4, classifier.  The input is the task model's softmax (NCHW fp32) and its gradient
+    is returned to autograd (the adversarial loss trains the task model through the discriminator)."""
+    ndf = 64
+
+    def __init__(self, in_channels, device="cuda", engine_dtype=torch.float32):
+        super().__init__(device, engine_dtype, 1)
+        self.want_prob = False
+        self.has_latent = False
+        pb = self._pb
+        t = pb.input(in_channels)
+        cin = in_channels
+        for i, mult in enumerate((1, 2, 4, 8)):
+            t = pb.conv("conv%d" % (i + 1), t, -1, cin, self.ndf * mult, 4, 2, 1, 1, bias=True, need_dgrad=True)
+            t = pb.act(t, 0.2)
+            cin = self.ndf * mult
+        low = pb.conv("classifier", t, -1, cin, 1, 4, 2, 1, 1, bias=True)
+        pb.head(low, -1)
+        self._finalize()
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self, generator=None):
+        """torch's default nn.Conv2d initialisation (kaiming_uniform(a=sqrt(5)) weights, uniform bias)."""
+        import math
+        for name, prm in self.named_parameters():
+            if name.endswith("weight"):
+                fan_in = prm.shape[1] * prm.shape[2] * prm.shape[3]
+                bound = math.sqrt(6.0 / ((1 + 5.0) * fan_in))
+                prm.copy_((torch.rand(prm.shape, generator=generator) * 2 - 1) * bound)
+                self._last_fan_in = fan_in
+            else:
+                bound = 1.0 / math.sqrt(self._last_fan_in)
+                prm.copy_((torch.rand(prm.shape, generator=generator) * 2 - 1) * bound)

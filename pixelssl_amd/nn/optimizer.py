@@ -83,6 +83,46 @@ class FusedSGD(Optimizer):
             store.grads.zero_()
 
 
+class FusedAdam(Optimizer):
+    """torch.optim.Adam semantics (no weight decay / amsgrad) as one fused launch per contiguous run of the flat
+    parameter buffer: the discriminator optimizer of AdvSSL (ssl_adv.py:101-102, betas (0.9, 0.99))."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        self._runs = []
+        for group in self.param_groups:
+            group['params'] = list(group['params'])
+            self._runs.append(_segments(group['params']))
+        self._stores = {}
+        for runs in self._runs:
+            for store, _, _ in runs:
+                self._stores[id(store)] = store
+        for store in self._stores.values():
+            if not hasattr(store, 'exp_avg'):
+                store.exp_avg = torch.zeros_like(store.params)
+                store.exp_avg_sq = torch.zeros_like(store.params)
+        self._step = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self._step += 1
+        for group, runs in zip(self.param_groups, self._runs):
+            b1, b2 = group['betas']
+            for store, off, n in runs:
+                _lib.check(_lib.lib().pxl_adam_step(n, _lib.ptr(store.params[off:off + n]), _lib.ptr(store.grads[off:off + n]),
+                                                    _lib.ptr(store.exp_avg[off:off + n]), _lib.ptr(store.exp_avg_sq[off:off + n]),
+                                                    float(group['lr']), float(b1), float(b2), float(group['eps']),
+                                                    self._step, _lib.stream_ptr()))
+        for store in self._stores.values():
+            store.touch()
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        for store in self._stores.values():
+            store.grads.zero_()
+
+
 def sgd(args):
     args.lr = 0.01 if args.lr == -1 else args.lr
     args.weight_decay = 0 if args.weight_decay == -1 else args.weight_decay

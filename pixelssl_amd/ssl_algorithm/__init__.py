@@ -1,8 +1,9 @@
 """Registry of the SSL algorithms (pixelssl/ssl_algorithm/__init__.py:10-27): module name == NAME ==
 export-function name; looked up as `ssl_algorithm.__dict__[name].__dict__[name]`."""
-from . import ssl_base, ssl_null, ssl_mt
+from . import ssl_base, ssl_null, ssl_mt, ssl_adv, ssl_gct
 
 SSL_NULL = ssl_null.SSLNULL.NAME
 SSL_MT = ssl_mt.SSLMT.NAME
+SSL_ADV = ssl_adv.SSLADV.NAME
 
-SSL_ALGORITHMS = [SSL_NULL, SSL_MT]
+SSL_ALGORITHMS = [SSL_NULL, SSL_MT, SSL_ADV]     # ssl_gct: building blocks only so far (ssl_gct.py)

@@ -63,12 +63,15 @@ def test_plan_sizes_and_workspace_guards():
     from pixelssl_amd._lib import lib, check
     core = DeepLabV2Core(device="cpu", engine_dtype=torch.float32)
     h = lib()
-    assert h.pxl_net_arena_bytes(core._net) == 0          # not planned yet
-    check(h.pxl_net_plan(core._net, 2, 65, 65))
+    assert core._shape is None                            # not planned yet: one executor instance per input shape
+    core._plan(2, 65, 65)
     a65 = h.pxl_net_arena_bytes(core._net)
-    check(h.pxl_net_plan(core._net, 8, 513, 513))
+    p65 = core._cur
+    core._plan(8, 513, 513)
     a513 = h.pxl_net_arena_bytes(core._net)
     assert 0 < a65 < a513 < 16 * 2 ** 30
+    assert core._plan(2, 65, 65) is p65 and core._shape == (2, 65, 65)      # plans are cached per shape
+    core._plan(8, 513, 513)
     c, hh, ww = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     check(h.pxl_net_latent_shape(core._net, ctypes.byref(c), ctypes.byref(hh), ctypes.byref(ww)))
     assert (c.value, hh.value, ww.value) == (2048, 33, 33)
@@ -114,7 +117,7 @@ def test_polynomial_lr_matches_oracle_schedule():
 def test_helpers_and_registry():
     import pixelssl_amd as P
     from pixelssl_amd.nn import func
-    assert P.SSL_ALGORITHMS == ["ssl_null", "ssl_mt"]
+    assert P.SSL_ALGORITHMS == ["ssl_null", "ssl_mt", "ssl_adv"]
     for name in P.SSL_ALGORITHMS:      # lookup convention of task_template/proxy.py:433
         assert callable(P.ssl_algorithm.__dict__[name].__dict__[name])
         assert callable(P.ssl_algorithm.__dict__[name].add_parser_arguments)
