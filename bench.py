@@ -32,7 +32,7 @@ def parse():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    p.add_argument("--algo", default="mt", choices=["mt", "suponly"])
+    p.add_argument("--algo", default="mt", choices=["mt", "suponly", "adv"])
     p.add_argument("--size", type=int, default=513)
     p.add_argument("--lbs", type=int, default=4, help="labeled samples per GPU")
     p.add_argument("--ubs", type=int, default=4, help="unlabeled samples per GPU")
@@ -48,7 +48,11 @@ def make_args(a, world):
         # proxy.py:258-261: lr and batch sizes are multiplied by #GPUs; per rank we keep the per-GPU batch
         lr=2.5e-4 * world, momentum=0.9, weight_decay=5e-4, dampening=-1, nesterov=False, power=-1,
         last_epoch=-1, epochs=20, iters_per_epoch=1000, ignore_index=255, labeled_batch_size=a.lbs,
-        unlabeled_batch_size=a.ubs if a.algo == "mt" else 0, ignore_unlabeled=a.algo != "mt",
+        unlabeled_batch_size=a.ubs if a.algo != "suponly" else 0, ignore_unlabeled=a.algo == "suponly",
+        batch_size=a.lbs + (a.ubs if a.algo != "suponly" else 0), gpus=1,
+        # AdvSSL hyper-parameters of the shipped script (task/sseg/script/deeplabv2_pascalvoc_1-8_ssladv.py:23-28)
+        adv_for_labeled=True, labeled_adv_scale=0.01, unlabeled_adv_scale=0.001, discriminator_lr=1e-4 * world,
+        discriminator_power=0.9, unlabeled_for_discriminator=True, discriminator_scale=1.0,
         is_epoch_lrer=False, log_freq=10 ** 9, task="sseg", cons_for_labeled=False, cons_scale=1.0,
         cons_rampup_epochs=3, ema_decay=0.99, gaussian_noise_std=None)
     return ns
@@ -105,6 +109,11 @@ def main():
         cores = [algo.s_model.module.model, algo.t_model.module.model]
         algo.s_model.train()
         algo.t_model.train()
+    elif a.algo == "adv":
+        algo = P.ssl_algorithm.ssl_adv.ssl_adv(args, *factories, P.sseg.func.task_func()(args))
+        cores = [algo.model.module.model, algo.d_model.module.core]
+        algo.model.train()
+        algo.d_model.train()
     else:
         algo = P.ssl_algorithm.ssl_null.ssl_null(args, *factories, None)
         cores = [algo.model.module.model]
@@ -112,7 +121,7 @@ def main():
 
     # synthetic data, resident in HBM before timing; 4 distinct batches cycled
     import torch_oracle as TO
-    per_gpu = a.lbs + (a.ubs if a.algo == "mt" else 0)
+    per_gpu = a.lbs + (a.ubs if a.algo != "suponly" else 0)
     batches = []
     for i in range(4):
         x, gt = TO.synthetic_batch(per_gpu, a.size, a.lbs, seed=1234 + rank * 1000 + i)
@@ -169,9 +178,10 @@ def main():
                "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "%s sseg, DeepLab-v2/ResNet-101, %dx%dx%d (%d labeled + %d unlabeled) per GPU, "
-                                      "21 classes" % ("MT (mean-teacher)" if a.algo == "mt" else "SupOnly", per_gpu,
+                                      "21 classes" % ({"mt": "MT (mean-teacher)", "adv": "AdvSSL (+ FC discriminator)",
+                                                       "suponly": "SupOnly"}[a.algo], per_gpu,
                                                       a.size, a.size, a.lbs, per_gpu - a.lbs),
-                          "algorithm": "ssl_" + ("mt" if a.algo == "mt" else "null"), "global_batch": gb,
+                          "algorithm": "ssl_" + {"mt": "mt", "adv": "adv", "suponly": "null"}[a.algo], "global_batch": gb,
                           "im_size": a.size, "parallelism": "dp%d" % world, "sync_bn": world > 1},
                "final_losses": loss_vals}
         if kern:
@@ -183,7 +193,7 @@ def main():
                                "algorithmic_gflop_per_launch": kern[dom]["algorithmic_gflop_per_launch"]}
             out["kernels"] = kern
             # whole-step view: algorithmic conv FLOPs per image over wall time
-            flop_img = 449.9e9 if a.algo == "mt" else 337.1e9
+            flop_img = {"mt": 449.9e9, "adv": 435.0e9, "suponly": 337.1e9}[a.algo]
             out["step_mfma_frac"] = round(out["value"] * flop_img / world / (peak * 1e12), 4) if a.size == 513 else None
         if world == 1 and not a.no_cpu_baseline:
             del algo
