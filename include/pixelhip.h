@@ -203,6 +203,11 @@ int pxl_bce_logits_masked_fwd(int B, long HW, const float* x, const float* task_
                               float* loss, void* stream);
 int pxl_bce_logits_masked_bwd(int B, long HW, const float* x, const float* task_gt, int ignore_index, float target,
                               const float* gout, float* dx, void* stream);
+/* CutMix mask-and-mix (ssl_cutmix.py:193-201 teacher softmax halves, :424-430 input images):
+ * out[b][c] = mask[b]*a[b][c] + (1-mask[b])*b[b][c], mask [B][1][HW]; if count != NULL it receives the number of
+ * pixels whose mixed max over channels exceeds `threshold` (confidence = count / (B*HW), ssl_cutmix.py:200). */
+int pxl_cutmix_mix(int B, int C, long HW, const float* mask, const float* a, const float* b, float* out,
+                   float threshold, float* count, void* stream);
 /* nn.MSELoss() (ssl_mt.py:115,182-184): out[0] = mean((a-b)^2); da = 2(a-b)/n * gout[0] */
 int pxl_mse_fwd(long n, const float* a, const float* b, float* out, void* stream);
 int pxl_mse_bwd(long n, const float* a, const float* b, const float* gout, float* da, void* stream);

@@ -91,6 +91,7 @@ SIGNATURES = {
     "pxl_ce_bwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "pxl_bce_logits_masked_fwd": (_I, [_I, _L, _P, _P, _I, _F, _P, _P]),
     "pxl_bce_logits_masked_bwd": (_I, [_I, _L, _P, _P, _I, _F, _P, _P, _P]),
+    "pxl_cutmix_mix": (_I, [_I, _I, _L, _P, _P, _P, _P, _F, _P, _P]),
     "pxl_mse_fwd": (_I, [_L, _P, _P, _P, _P]),
     "pxl_mse_bwd": (_I, [_L, _P, _P, _P, _P, _P]),
     "pxl_absdiff_chansum": (_I, [_I, _I, _L, _P, _P, _I, _F, _P, _P]),

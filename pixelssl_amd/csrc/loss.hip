@@ -167,6 +167,45 @@ __global__ void bce_masked_bwd_kernel(long HW, const float* __restrict__ x, cons
 }
 }  // namespace
 
+namespace {
+// CutMix (ssl_cutmix.py:193-201, 424-430): out = mask*a + (1-mask)*b with a box mask [B][1][HW] broadcast over C;
+// optionally counts the pixels whose mixed maximum over channels exceeds `thr` (the confidence numerator).
+__global__ void cutmix_mix_kernel(int B, int C, long HW, const float* __restrict__ mask, const float* __restrict__ a,
+                                  const float* __restrict__ b, float* __restrict__ out, float thr,
+                                  float* __restrict__ count) {
+  const long total = (long)B * HW;
+  float cnt = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long bb = i / HW, p = i - bb * HW;
+    const float m = mask[i];
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+      const long o = (bb * C + c) * HW + p;
+      const float v = m * a[o] + (1.f - m) * b[o];
+      out[o] = v;
+      mx = fmaxf(mx, v);
+    }
+    cnt += mx > thr ? 1.f : 0.f;
+  }
+  if (count != nullptr) {
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt != 0.f) atomicAdd(count, cnt);
+  }
+}
+}  // namespace
+
+extern "C" int pxl_cutmix_mix(int B, int C, long HW, const float* mask, const float* a, const float* b, float* out,
+                              float threshold, float* count, void* stream) {
+  PXL_REQUIRE(mask && a && b && out && B > 0 && C > 0 && HW > 0, "cutmix_mix: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (count) PXL_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(float), s));
+  long g = ((long)B * HW + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(cutmix_mix_kernel, dim3((int)g), dim3(256), 0, s, B, C, HW, mask, a, b, out, threshold, count);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
 extern "C" int pxl_bce_logits_masked_fwd(int B, long HW, const float* x, const float* task_gt, int ignore_index,
                                          float target, float* loss, void* stream) {
   PXL_REQUIRE(x && loss && B > 0 && HW > 0, "bce_logits_masked_fwd: bad argument");
