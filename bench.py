@@ -158,14 +158,15 @@ def main():
 
     kern = {}
     if not a.no_kernel_events:
-        for kind, name in ((0, "conv_igemm(fwd+dgrad)"), (1, "conv_wgrad")):
-            ms = n = fl = 0.0
+        for kind, name in ((0, "conv_dma/conv_igemm (fwd+dgrad)"), (1, "conv_wgrad_dma/conv_wgrad")):
+            ms = n = fl = by = 0.0
             for c in cores:
                 m_, n_, f_ = c.profile_read(kind)
-                ms, n, fl = ms + m_, n + n_, fl + f_
+                ms, n, fl, by = ms + m_, n + n_, fl + f_, by + c.profile_bytes(kind)
             if n:
                 kern[name] = {"launches": int(n), "avg_us": round(1e3 * ms / n, 3), "total_ms": round(ms, 3),
                               "algorithmic_gflop_per_launch": round(fl / n / 1e9, 4),
+                              "algorithmic_mbytes_per_launch": round(by / n / 1e6, 3),
                               "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
         for c in cores:
             c.profile(False)
@@ -187,10 +188,23 @@ def main():
         if kern:
             dom = max(kern, key=lambda k: kern[k]["total_ms"])
             peak = MFMA_PEAK_TFLOPS[a.dtype]
+            # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+            # separate rocprofv3 runs of this same command, tools/pmc_traffic.py -> profiles/traffic.json)
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                key = "conv_dma_kernel" if dom.startswith("conv_dma") else "conv_wgrad_dma_kernel"
+                traffic = tj["kernels"][key]["traffic_bytes_per_launch"] if a.algo == "mt" and a.dtype == "bf16" else None
+            except Exception:
+                traffic = None
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["achieved_tflops"],
                                "peak": peak, "unit": "TFLOP/s", "frac": round(kern[dom]["achieved_tflops"] / peak, 4),
-                               "traffic": None, "avg_launch_us": kern[dom]["avg_us"],
-                               "algorithmic_gflop_per_launch": kern[dom]["algorithmic_gflop_per_launch"]}
+                               "traffic": traffic, "avg_launch_us": kern[dom]["avg_us"],
+                               "algorithmic_gflop_per_launch": kern[dom]["algorithmic_gflop_per_launch"],
+                               "algorithmic_bytes_per_launch": int(kern[dom]["algorithmic_mbytes_per_launch"] * 1e6),
+                               "note": "kernels of two HIP streams overlap (teacher || student forward, wgrad || dgrad): "
+                                       "per-launch event durations include the co-running kernel; step_mfma_frac is the "
+                                       "whole-step figure"}
             out["kernels"] = kern
             # whole-step view: algorithmic conv FLOPs per image over wall time
             flop_img = {"mt": 449.9e9, "adv": 435.0e9, "suponly": 337.1e9}[a.algo]

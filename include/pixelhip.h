@@ -341,6 +341,9 @@ int pxl_net_set_wgrad(pxl_net* net, int enable);
  * of launches and their ALGORITHMIC flops (2*MAC of the real, unpadded problem), and resets. */
 int pxl_net_profile(pxl_net* net, int enable);
 int pxl_net_profile_read(pxl_net* net, int kind, double* ms, long* launches, double* flops);
+/* algorithmic operand bytes (activations in + weights + output, each once) of the launches stamped since the last
+ * call, per kind; resets the counter */
+int pxl_net_profile_bytes(pxl_net* net, int kind, double* bytes);
 
 #ifdef __cplusplus
 }

@@ -123,6 +123,7 @@ SIGNATURES = {
     "pxl_net_set_wgrad": (_I, [_P, _I]),
     "pxl_net_profile": (_I, [_P, _I]),
     "pxl_net_profile_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
+    "pxl_net_profile_bytes": (_I, [_P, _I, C.POINTER(C.c_double)]),
     "pxl_net_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
 }
 

@@ -95,6 +95,7 @@ struct pxl_net {
   struct Stamp { hipEvent_t a, b; int kind; double flops; };
   std::vector<Stamp> stamps;
   std::vector<hipEvent_t> pool;
+  double prof_bytes[2] = {0.0, 0.0};     // algorithmic operand bytes of the stamped launches, per kind
   // backward runs the weight gradients on a second stream, concurrently with the data gradients (both only read
   // dy): the contraction kernels of this network are ~1 workgroup per CU and latency-bound, two in flight fill
   // each other's bubbles.  Created lazily; PXL_SIDE_STREAM=0 disables it.
@@ -177,6 +178,14 @@ inline ConvIn conv_input(const pxl_net* n, const pxl_op& d, const void* arena) {
   if (b.has_z) return {base + b.z_off, nullptr, nullptr};
   const float* coef = reinterpret_cast<const float*>(base + b.coef_off);
   return {base + tin.off, coef + 2 * b.d.C, coef + 3 * b.d.C};
+}
+
+// algorithmic HBM bytes of one contraction launch: every operand once (activations in, weights, output)
+inline double conv_bytes(const pxl_net* n, const pxl_op& d, const TensorInfo& tin, const TensorInfo& tout, bool wgrad) {
+  const double e = n->esize;
+  const double act_in = (double)n->B * tin.H * tin.W * tin.C * e, act_out = (double)n->B * tout.H * tout.W * tout.C * e;
+  const double w = (double)d.cout * d.kh * d.kw * d.ngroups * d.cin;
+  return wgrad ? act_in + act_out + w * 4.0 : act_in + act_out + w * e;
 }
 
 inline double conv_flops(const pxl_net* n, const pxl_op& d, const TensorInfo& tout) {
@@ -270,6 +279,13 @@ extern "C" int pxl_net_profile_read(pxl_net* net, int kind, double* ms, long* la
   }
   net->stamps.swap(keep);
   *ms = t; *launches = c; *flops = f;
+  return PXL_OK;
+}
+
+extern "C" int pxl_net_profile_bytes(pxl_net* net, int kind, double* bytes) {
+  PXL_REQUIRE(net && bytes && (kind == 0 || kind == 1), "net_profile_bytes: bad argument");
+  *bytes = net->prof_bytes[kind];
+  net->prof_bytes[kind] = 0.0;
   return PXL_OK;
 }
 
@@ -547,6 +563,7 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
         const float* bias = d.b_off[0] >= 0 ? fat(packed, op.bias_off) : nullptr;
         {
           Timed t(n, s, 0, conv_flops(n, d, tout));
+          if (n->profile) n->prof_bytes[0] += conv_bytes(n, d, tin, tout, false);
           rc = pxl_conv_igemm(&op.fwd, cin.ptr, at(packed, op.wf_off), at(arena, tout.off), sc, sh, bias,
                               nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr, op.ws_bytes, stream);
         }
@@ -752,6 +769,7 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         for (int g = 0; g < d.ngroups && n->wgrad_on; ++g) {
           {
             Timed t(n, ws, 1, conv_flops(n, d, tout) / d.ngroups);
+            if (n->profile) n->prof_bytes[1] += conv_bytes(n, d, tin, tout, true) / d.ngroups;
             rc = pxl_conv_wgrad(&op.grp[g], cin.ptr, sc, sh, dy, grads + d.w_off[g], d.cin, d.cin, ws);
           }
           if (rc != PXL_OK) return rc;
@@ -763,6 +781,7 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         if (d.need_dgrad) {
           void* din = at(scratch, tin.goff);
           Timed t(n, s, 0, conv_flops(n, d, tout));
+          if (n->profile) n->prof_bytes[0] += conv_bytes(n, d, tin, tout, false);
           rc = pxl_conv_igemm(&op.bwd, dy, at(packed, op.wt_off), din, nullptr, nullptr, nullptr,
                               written[d.in0] ? din : nullptr, nullptr, nullptr, 0, stream);
           written[d.in0] = 1;

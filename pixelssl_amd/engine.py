@@ -439,6 +439,15 @@ class SegNetCore(nn.Module):
             tot = [tot[0] + ms.value, tot[1] + n.value, tot[2] + fl.value]
         return tuple(tot)
 
+    def profile_bytes(self, kind):
+        """algorithmic operand bytes of the stamped launches of `kind` since the last call"""
+        tot = 0.0
+        for pl in self._plans.values():
+            b = ctypes.c_double()
+            check(lib().pxl_net_profile_bytes(pl.net, kind, ctypes.byref(b)))
+            tot += b.value
+        return tot
+
     def latent_from(self, arena, plan=None):
         pl = plan if plan is not None else self._cur
         c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
