@@ -151,6 +151,23 @@ int pxl_bn_bwd_apply_fused(int dtype, int M, int C, const void* dz, const void* 
 int pxl_bn_bwd_apply(int dtype, int M, int C, const void* dz, const void* y, const float* coef,
                      const float* bcoef, int relu, void* dy, void* stream);
 
+/* IBNorm + LeakyReLU of the GCT flaw detector (ssl_gct.py:588-607, 567-585), y NHWC [B][HW][C]: channels [0,nb) are
+ * batch-normalised (affine, Sync-BN), channels [nb,C) instance-normalised (no affine).  Forward: stats -> fold ->
+ * [all-reduce bn (2*nb floats) for Sync-BN] -> coef -> apply.  Backward: bwd_reduce -> fold (+ dgamma/dbeta from the
+ * LOCAL sums) -> [all-reduce] -> bwd_apply.  sums / bsums: [B][2][C] fp32, bn: [2*nb], coef: [B][4][C]. */
+int pxl_ibn_stats(int dtype, int B, int HW, int C, const void* y, float* sums, void* stream);
+int pxl_ibn_fold(int B, int C, int nb, const float* sums, float* bn, float* dgamma, float* dbeta, void* stream);
+int pxl_ibn_coef(int B, int C, int nb, int HW, float count_bn, const float* sums, const float* bn, const float* gamma,
+                 const float* beta, float* running_mean, float* running_var, float momentum, float eps, int training,
+                 int clamp_var, float* coef, void* stream);
+int pxl_ibn_apply_fwd(int dtype, int B, int HW, int C, const void* y, const float* coef, float slope, void* out,
+                      void* stream);
+int pxl_ibn_bwd_reduce(int dtype, int B, int HW, int C, const void* dout, const void* y, const float* coef, float slope,
+                       float* bsums, void* stream);
+int pxl_ibn_bwd_apply(int dtype, int B, int HW, int C, int nb, const void* dout, const void* y, const float* coef,
+                      const float* bsums, const float* bn, float count_bn, int training, float slope, void* dy,
+                      void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* ResNet trunk element-wise / pooling                                                          */
 /* ------------------------------------------------------------------------------------------ */
@@ -238,6 +255,10 @@ int pxl_minmax_norm_persample(int B, long HW, const float* x, float clip_thresho
 /* DCGTGenerator.forward (ssl_gct.py:668-689): l_fm / r_fm are updated IN PLACE (fm <= thr ? fm : 1) */
 int pxl_dcgt(int B, int C, long HW, const float* l_pred, const float* r_pred, float* l_fm, float* r_fm,
              float threshold, float* l_gt, float* r_gt, float* both_bad, void* stream);
+/* flaw-correction constraint (ssl_gct.py:429-439): out[0] = mean(mask * x^2) over all n elements (x = flaw map,
+ * ground truth zero, mask = both_bad); dx = 2 * mask * x / n * gout[0] */
+int pxl_masked_sq_mean_fwd(long n, const float* x, const float* mask, float* out, void* stream);
+int pxl_masked_sq_mean_bwd(long n, const float* x, const float* mask, const float* gout, float* dx, void* stream);
 /* FlawDetectorCriterion (ssl_gct.py:617-621): loss[b] = mean over (C,H,W) of (a-g)^2; da = 2(a-g)/n * gout[b] */
 int pxl_mse_persample_fwd(int B, long n, const float* a, const float* g, float* loss, void* stream);
 int pxl_mse_persample_bwd(int B, long n, const float* a, const float* g, const float* gout, float* da, void* stream);
@@ -271,6 +292,7 @@ int pxl_scale_inplace(long n, float* x, float a, void* stream);
 #define PXL_OP_RESIDUAL 3   /* out = relu(bn(in0) + (bn(in1) | in1))                 */
 #define PXL_OP_HEAD 4       /* upsample + softmax of the low-res logits -> outputs   */
 #define PXL_OP_ACT 5        /* out = LeakyReLU(in0, slope) (conv stacks without BN)  */
+#define PXL_OP_IBN 6        /* out = LeakyReLU(IBNorm(in0), slope); bn_out = BN half  */
 
 typedef struct pxl_op {
   int32_t kind;

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpixelhip.so")
 
 PXL_F32, PXL_BF16 = 0, 1
-OP_INPUT, OP_CONV, OP_MAXPOOL, OP_RESIDUAL, OP_HEAD, OP_ACT = 0, 1, 2, 3, 4, 5
+OP_INPUT, OP_CONV, OP_MAXPOOL, OP_RESIDUAL, OP_HEAD, OP_ACT, OP_IBN = 0, 1, 2, 3, 4, 5, 6
 
 
 class PixelHipError(RuntimeError):
@@ -75,6 +75,12 @@ SIGNATURES = {
     "pxl_bn_bwd_apply": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "pxl_bn_param_grad": (_I, [_I, _P, _P, _P, _P]),
     "pxl_bn_bwd_apply_fused": (_I, [_I, _I, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P]),
+    "pxl_ibn_stats": (_I, [_I, _I, _I, _I, _P, _P, _P]),
+    "pxl_ibn_fold": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
+    "pxl_ibn_coef": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P]),
+    "pxl_ibn_apply_fwd": (_I, [_I, _I, _I, _I, _P, _P, _F, _P, _P]),
+    "pxl_ibn_bwd_reduce": (_I, [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P]),
+    "pxl_ibn_bwd_apply": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _I, _F, _P, _P]),
     "pxl_residual_fwd": (_I, [_I, _L, _I, _P, _P, _P, _P, _P, _P]),
     "pxl_leaky_fwd": (_I, [_I, _L, _P, _F, _P, _P]),
     "pxl_leaky_bwd": (_I, [_I, _L, _P, _P, _F, _P, _P]),
@@ -101,6 +107,8 @@ SIGNATURES = {
     "pxl_dilate3_reflect": (_I, [_I, _I, _I, _P, _P, _P]),
     "pxl_minmax_norm_persample": (_I, [_I, _L, _P, _F, _P, _P, _P]),
     "pxl_dcgt": (_I, [_I, _I, _L, _P, _P, _P, _P, _F, _P, _P, _P, _P]),
+    "pxl_masked_sq_mean_fwd": (_I, [_L, _P, _P, _P, _P]),
+    "pxl_masked_sq_mean_bwd": (_I, [_L, _P, _P, _P, _P, _P]),
     "pxl_mse_persample_fwd": (_I, [_I, _L, _P, _P, _P, _P]),
     "pxl_mse_persample_bwd": (_I, [_I, _L, _P, _P, _P, _P, _P]),
     "pxl_sgd_step": (_I, [_L, _P, _P, _P, _F, _F, _F, _I, _P]),

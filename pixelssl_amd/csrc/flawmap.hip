@@ -180,6 +180,21 @@ __global__ void mse_ps_bwd_kernel(long n, const float* __restrict__ a, const flo
     da[b * n + i] = k * (a[b * n + i] - g[b * n + i]);
 }
 
+__global__ void masked_sq_fwd_kernel(long n, const float* __restrict__ x, const float* __restrict__ mask,
+                                     float* __restrict__ out) {
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    s += mask[i] * x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s / (float)n);
+}
+__global__ void masked_sq_bwd_kernel(long n, const float* __restrict__ x, const float* __restrict__ mask,
+                                     const float* __restrict__ gout, float* __restrict__ dx) {
+  const float k = 2.f * gout[0] / (float)n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = k * mask[i] * x[i];
+}
+
 inline int g1(long n) {
   long g = (n + 255) / 256;
   return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -269,6 +284,23 @@ extern "C" int pxl_mse_persample_bwd(int B, long n, const float* a, const float*
   PXL_REQUIRE(a && g && gout && da && B > 0 && n > 0, "mse_persample_bwd: bad argument");
   const int gx = (int)((n + 256 * 8 - 1) / (256 * 8));
   hipLaunchKernelGGL(mse_ps_bwd_kernel, dim3(gx, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, a, g, gout, da);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_masked_sq_mean_fwd(long n, const float* x, const float* mask, float* out, void* stream) {
+  PXL_REQUIRE(x && mask && out && n > 0, "masked_sq_mean_fwd: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PXL_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), s));
+  long g = (n + 256 * 8 - 1) / (256 * 8);
+  hipLaunchKernelGGL(masked_sq_fwd_kernel, dim3((int)(g > 2048 ? 2048 : g)), dim3(256), 0, s, n, x, mask, out);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_masked_sq_mean_bwd(long n, const float* x, const float* mask, const float* gout, float* dx, void* stream) {
+  PXL_REQUIRE(x && mask && gout && dx && n > 0, "masked_sq_mean_bwd: bad argument");
+  hipLaunchKernelGGL(masked_sq_bwd_kernel, dim3(g1(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, x, mask, gout, dx);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

@@ -68,6 +68,8 @@ struct OpInfo {
   pxl_conv_desc grp[4];    // per-group forward geometry (wgrad)
   size_t wf_off = 0, wt_off = 0, bias_off = 0;   // packed buffer offsets
   size_t idx_off = 0;      // arena: maxpool argmax
+  // IBNorm op: arena [B][2][C] sums + [2*nb] folded BN part + [B][4][C] coefficients; scratch: the backward twins
+  size_t ibn_sums = 0, ibn_bn = 0, ibn_coef = 0, ibn_bsums = 0, ibn_bbn = 0;
   size_t ws_off = 0, ws_bytes = 0;               // arena: split-K fp32 workspace (small-N, long-K convs)
 };
 
@@ -374,6 +376,22 @@ extern "C" int pxl_net_plan(pxl_net* n, int B, int H, int W) {
         plan_tensor(d.out, tin.H, tin.W, tin.C);
         break;
       }
+      case PXL_OP_IBN: {
+        PXL_REQUIRE(d.in0 >= 0 && n->tensors[d.in0].planned, "net_plan: op %zu consumes an unplanned tensor", i);
+        PXL_REQUIRE(d.bn_out >= 0, "net_plan: IBNorm op %zu names no BN half", i);
+        const TensorInfo& tin = n->tensors[d.in0];
+        PXL_REQUIRE(tin.Cp == tin.C, "net_plan: IBNorm op %zu needs an unpadded channel count (%d)", i, tin.C);
+        const int nb = n->bns[d.bn_out].d.C;
+        PXL_REQUIRE(nb >= 1 && nb <= tin.C, "net_plan: IBNorm op %zu: BN half %d of %d channels", i, nb, tin.C);
+        plan_tensor(d.out, tin.H, tin.W, tin.C);
+        const size_t per = align_up((size_t)B * 2 * tin.Cp * 4);
+        op.ibn_sums = arena; arena += per;
+        op.ibn_bn = arena; arena += align_up(2 * (size_t)nb * 4);
+        op.ibn_coef = arena; arena += align_up((size_t)B * 4 * tin.Cp * 4);
+        op.ibn_bsums = scratch; scratch += per;
+        op.ibn_bbn = scratch; scratch += align_up(2 * (size_t)nb * 4);
+        break;
+      }
       case PXL_OP_HEAD: {
         PXL_REQUIRE(d.in0 >= 0 && n->tensors[d.in0].planned, "net_plan: head consumes an unplanned tensor");
         PXL_REQUIRE(n->tensors[d.in0].C == n->classes, "net_plan: head input has %d channels, expected %d",
@@ -613,6 +631,29 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
         rc = pxl_leaky_fwd(dt, (long)n->B * tin.H * tin.W * tin.Cp, at(arena, tin.off), d.slope, at(arena, tout.off), stream);
         break;
       }
+      case PXL_OP_IBN: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        const BnInfo& b = n->bns[d.bn_out];
+        const int nb = b.d.C, HW = tin.H * tin.W;
+        const int train = training ? 1 : 0;
+        rc = pxl_ibn_stats(dt, n->B, HW, tin.Cp, at(arena, tin.off), fat(arena, op.ibn_sums), stream);
+        if (rc != PXL_OK) return rc;
+        rc = pxl_ibn_fold(n->B, tin.Cp, nb, fat(arena, op.ibn_sums), fat(arena, op.ibn_bn), nullptr, nullptr, stream);
+        if (rc != PXL_OK) return rc;
+        if (train && n->sync && n->world > 1) {
+          rc = n->sync(n->sync_user, fat(arena, op.ibn_bn), 2 * nb, stream);
+          if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_forward: SyncBN all-reduce hook failed (%d)", rc);
+        }
+        rc = pxl_ibn_coef(n->B, tin.Cp, nb, HW, (float)n->B * HW * n->world, fat(arena, op.ibn_sums), fat(arena, op.ibn_bn),
+                          params + b.d.gamma_off, params + b.d.beta_off, running ? running + b.d.rmean_off : nullptr,
+                          running ? running + b.d.rvar_off : nullptr, b.d.momentum, b.d.eps, train,
+                          (n->world > 1 || n->force_clamp) ? 1 : 0, fat(arena, op.ibn_coef), stream);
+        if (rc != PXL_OK) return rc;
+        rc = pxl_ibn_apply_fwd(dt, n->B, HW, tin.Cp, at(arena, tin.off), fat(arena, op.ibn_coef), d.slope,
+                               at(arena, tout.off), stream);
+        break;
+      }
       case PXL_OP_HEAD: {
         const TensorInfo& low = n->tensors[d.in0];
         rc = pxl_upsample_softmax_fwd(dt, n->B, low.H, low.W, low.Cp, n->classes, n->H, n->W, at(arena, low.off),
@@ -698,6 +739,30 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         if (written[d.in0]) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net_backward: activation input consumed twice");
         rc = pxl_leaky_bwd(dt, (long)n->B * tin.H * tin.W * tin.Cp, at(scratch, tout.goff), at(arena, tin.off), d.slope,
                            at(scratch, tin.goff), stream);
+        written[d.in0] = 1;
+        break;
+      }
+      case PXL_OP_IBN: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        if (!written[d.out]) return pxl_set_error(PXL_ERR_ARG, "net_backward: IBNorm op %d output has no gradient", i);
+        if (written[d.in0]) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net_backward: IBNorm input consumed twice");
+        const BnInfo& b = n->bns[d.bn_out];
+        const int nb = b.d.C, HW = tin.H * tin.W;
+        rc = pxl_ibn_bwd_reduce(dt, n->B, HW, tin.Cp, at(scratch, tout.goff), at(arena, tin.off), fat(arena, op.ibn_coef),
+                                d.slope, fat(scratch, op.ibn_bsums), stream);
+        if (rc != PXL_OK) return rc;
+        // BN half: fold over the samples; affine gradients from the LOCAL sums, batch-mean terms from the all-reduced
+        rc = pxl_ibn_fold(n->B, tin.Cp, nb, fat(scratch, op.ibn_bsums), fat(scratch, op.ibn_bbn),
+                          n->wgrad_on ? grads + b.d.gamma_off : nullptr, n->wgrad_on ? grads + b.d.beta_off : nullptr, stream);
+        if (rc != PXL_OK) return rc;
+        if (training && n->sync && n->world > 1) {
+          rc = n->sync(n->sync_user, fat(scratch, op.ibn_bbn), 2 * nb, stream);
+          if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_backward: SyncBN all-reduce hook failed (%d)", rc);
+        }
+        rc = pxl_ibn_bwd_apply(dt, n->B, HW, tin.Cp, nb, at(scratch, tout.goff), at(arena, tin.off), fat(arena, op.ibn_coef),
+                               fat(scratch, op.ibn_bsums), fat(scratch, op.ibn_bbn), (float)n->B * HW * n->world, training,
+                               d.slope, at(scratch, tin.goff), stream);
         written[d.in0] = 1;
         break;
       }

@@ -165,6 +165,15 @@ class ProgramBuilder:
         self._op(_lib.OP_ACT, in0=t_in, out=t, slope=float(slope))
         return t
 
+    def ibn(self, name, t_in, C, slope, split=0.5):
+        """IBNorm (+ LeakyReLU): BN half `name.bnorm` with affine parameters and running statistics, IN half
+        parameter-free (ssl_gct.py:588-607)."""
+        nb = int(C * split + 0.5)
+        b = self.bn(name + ".bnorm", nb)
+        t = self.tensor()
+        self._op(_lib.OP_IBN, in0=t_in, out=t, bn_out=b, cout=C, slope=float(slope))
+        return t
+
     def maxpool(self, t_in, bn_in):
         t = self.tensor()
         self._op(_lib.OP_MAXPOOL, in0=t_in, out=t, bn_in0=bn_in)
@@ -613,3 +622,47 @@ class FCDiscriminatorCore(SegNetCore):
             else:
                 bound = 1.0 / math.sqrt(self._last_fan_in)
                 prm.copy_((torch.rand(prm.shape, generator=generator) * 2 - 1) * bound)
+
+
+class FlawDetectorCore(SegNetCore):
+    """Flaw detector of GCT (pixelssl/ssl_algorithm/ssl_gct.py:539-585): 7 x (conv 4x4 + bias, IBNorm, LeakyReLU 0.2)
+    with strides 2,2,1,2,1,2,1, a 1-channel classifier conv (stride 2) and bilinear up-sampling (align_corners=True)
+    to the input size.  Input: cat(image, softmax) NCHW fp32; its gradient is returned to autograd.  Parameter names
+    follow the reference: conv1, ibn1.bnorm, conv2, ..., conv4_1, ibn4_1.bnorm, classifier."""
+    ndf = 64
+    LAYERS = (("conv1", 64, 2, "ibn1"), ("conv2", 128, 2, "ibn2"), ("conv2_1", 128, 1, "ibn2_1"), ("conv3", 256, 2, "ibn3"),
+              ("conv3_1", 256, 1, "ibn3_1"), ("conv4", 512, 2, "ibn4"), ("conv4_1", 512, 1, "ibn4_1"))
+
+    def __init__(self, in_channels, device="cuda", engine_dtype=torch.float32):
+        super().__init__(device, engine_dtype, 1)
+        self.want_prob = False
+        self.has_latent = False
+        pb = self._pb
+        t = pb.input(in_channels)
+        cin = in_channels
+        for name, cout, stride, ibn in self.LAYERS:
+            t = pb.conv(name, t, -1, cin, cout, 4, stride, 1, 1, bias=True, need_dgrad=True)
+            t = pb.ibn(ibn, t, cout, 0.2)
+            cin = cout
+        low = pb.conv("classifier", t, -1, cin, 1, 4, 2, 1, 1, bias=True)
+        pb.head(low, -1)
+        self._finalize()
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self, generator=None):
+        import math
+        for name, prm in self.named_parameters():
+            if ".bnorm." in name:
+                prm.fill_(1.0) if name.endswith("weight") else prm.zero_()
+            elif name.endswith("weight"):
+                fan_in = prm.shape[1] * prm.shape[2] * prm.shape[3]
+                prm.copy_((torch.rand(prm.shape, generator=generator) * 2 - 1) * math.sqrt(1.0 / fan_in))
+                self._last_fan_in = fan_in
+            else:
+                prm.copy_((torch.rand(prm.shape, generator=generator) * 2 - 1) / math.sqrt(self._last_fan_in))
+        for name, buf in self.named_buffers():
+            if name.endswith("running_var"):
+                buf.fill_(1.0)
+            elif name.endswith("running_mean") or name.endswith("num_batches_tracked"):
+                buf.zero_()

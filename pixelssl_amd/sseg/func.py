@@ -48,5 +48,8 @@ class SSEGFunc(func_template.TaskFunc):
         return gct_modules.onehot_ignore(task_gt, self.args.num_classes, ignore_index=self.args.ignore_index)
 
     # ---- SSL_GCT (task/sseg/func.py:175-192)
+    def sslgct_fd_in_channels(self):
+        return self.args.num_classes + 3
+
     def sslgct_prepare_task_gt_for_fdgt(self, task_gt):
         return gct_modules.onehot_ignore(task_gt, self.args.num_classes, ignore_index=self.args.ignore_index)

@@ -6,5 +6,6 @@ SSL_NULL = ssl_null.SSLNULL.NAME
 SSL_MT = ssl_mt.SSLMT.NAME
 SSL_ADV = ssl_adv.SSLADV.NAME
 SSL_CUTMIX = ssl_cutmix.SSLCUTMIX.NAME
+SSL_GCT = ssl_gct.SSLGCT.NAME
 
-SSL_ALGORITHMS = [SSL_NULL, SSL_MT, SSL_ADV, SSL_CUTMIX]     # ssl_gct: building blocks only so far (ssl_gct.py)
+SSL_ALGORITHMS = [SSL_NULL, SSL_MT, SSL_ADV, SSL_CUTMIX, SSL_GCT]

@@ -1,12 +1,17 @@
-"""GCT building blocks on the device (reference: pixelssl/ssl_algorithm/ssl_gct.py).
+"""Guided Collaborative Training (reference: pixelssl/ssl_algorithm/ssl_gct.py) on the device.
 
-This module currently holds the flaw-map pipeline of GCT with the reference's class names and call signatures --
-FlawDetectorCriterion (:610-621), FlawmapHandler (:624-657), DCGTGenerator (:660-689), FDGTGenerator (:692-728) --
-implemented on libpixelhip kernels (csrc/flawmap.hip).  Tensors are fp32 NCHW on the GPU, exactly what the task
-model returns.  The SSLGCT trainer itself (three optimizers, FlawDetector with IBNorm) is the next step
-(DESIGN.md section 7); `ssl_gct` is therefore not exported yet.
+Two independently initialised task models see the same batch; a flaw detector (conv 4x4 + IBNorm + LeakyReLU stack,
+engine.FlawDetectorCore) predicts where each is wrong.  Per iteration (ssl_gct.py:186-269): step 0 no-grad task
+forwards + detector forwards whose graphs are kept, flaw-map post-processing and the dynamic-consistency pseudo
+ground truth; step 1 trains both task models (CE + flaw-correction + dynamic-consistency, the detector frozen: only
+dL/dsoftmax is relayed); step 2 trains the detector against the FDGT maps through the step-0 graphs.  The flaw-map
+pipeline -- FlawDetectorCriterion (:610-621), FlawmapHandler (:624-657), DCGTGenerator (:660-689), FDGTGenerator
+(:692-728) -- keeps the reference's class names and call signatures on libpixelhip kernels (csrc/flawmap.hip);
+tensors are fp32 NCHW on the GPU, exactly what the task model returns.
 """
 import math
+import os
+import time
 
 import numpy as np
 import scipy.ndimage
@@ -16,7 +21,7 @@ import torch.nn as nn
 from .. import _lib
 from .._lib import check, lib, ptr, stream_ptr
 
-NAME = 'ssl_gct'
+MODE_GCT, MODE_DC, MODE_FC = 'gct', 'dc', 'fc'
 
 
 def _gpu(*ts):
@@ -171,3 +176,287 @@ def onehot_ignore(gt, num_classes, ignore_index=255):
     out = torch.empty(B, num_classes, H, W, device=gt.device, dtype=torch.float32)
     check(lib().pxl_onehot_ignore(B, num_classes, H * W, ptr(gt), ignore_index, ptr(out), stream_ptr()))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# flaw detector + trainer
+# ---------------------------------------------------------------------------------------------------------------------
+
+def add_parser_arguments(parser):
+    from . import ssl_base
+    from ..utils import cmd   # noqa: F401
+    ssl_base.add_parser_arguments(parser)
+    parser.add_argument('--ssl-mode', type=str, default=MODE_GCT, choices=[MODE_GCT, MODE_DC, MODE_FC],
+                        help='sslgct - select semi-supervised constraints for training (gct = dc + fc)')
+    parser.add_argument('--fc-ssl-scale', type=float, default=-1.0, help='sslgct - flaw correction constraint coefficient')
+    parser.add_argument('--dc-ssl-scale', type=float, default=-1.0, help='sslgct - dynamic consistency constraint coefficient')
+    parser.add_argument('--dc-threshold', type=float, default=-1.0, help='sslgct - threshold of dynamic consistency constraint')
+    parser.add_argument('--dc-rampup-epochs', type=int, default=-1, help='sslgct - ramp-up epochs of dynamic consistency constraint')
+    parser.add_argument('--fd-lr', type=float, default=1e-4, help='sslgct - the initial learning rate of the flaw detector')
+    parser.add_argument('--fd-scale', type=float, default=1.0, help='sslgct - coefficient of the flaw detector constraint')
+    parser.add_argument('--mu', type=float, default=-1.0, help="sslgct - channel average coefficient of the FDGT generator")
+    parser.add_argument('--nu', type=int, default=-1, help="sslgct - operations repeat coefficient of the FDGT generator")
+
+
+def ssl_gct(args, model_dict, optimizer_dict, lrer_dict, criterion_dict, task_func):
+    """Export function (ssl_gct.py:53-86): one 'model' entry is instantiated twice, or 'lmodel' / 'rmodel'."""
+    from ..utils import logger
+    if not len(model_dict) == len(optimizer_dict) == len(lrer_dict) == len(criterion_dict):
+        logger.log_err('The len(element_dict) of SSL_GCT should be the same\n')
+    if len(model_dict) == 1:
+        if list(model_dict.keys())[0] != 'model':
+            logger.log_err("In SSL_GCT, the key of 1-value element_dict should be 'model',\nbut '{0}' is given\n"
+                           .format(model_dict.keys()))
+        pick = lambda d: [d['model'], d['model']]
+    elif len(model_dict) == 2:
+        if 'lmodel' not in model_dict or 'rmodel' not in model_dict:
+            logger.log_err("In SSL_GCT, the key of 2-value element_dict should be '(lmodel, rmodel)', "
+                           "but '{0}' is given\n".format(model_dict.keys()))
+        pick = lambda d: [d['lmodel'], d['rmodel']]
+    else:
+        logger.log_err('The SSL_GCT algorithm supports element_dict with 1 or 2 elements, '
+                       'but given {0} elements\n'.format(len(model_dict)))
+    algorithm = SSLGCT(args)
+    algorithm.build(pick(model_dict), pick(optimizer_dict), pick(lrer_dict), pick(criterion_dict), task_func)
+    return algorithm
+
+
+class FlawDetector(nn.Module):
+    """ssl_gct.py:539-585 on the layer-program executor; forward(task_inp: tuple, task_pred) -> {'flawmap': logits}."""
+    ndf = 64
+
+    def __init__(self, in_channels, engine_dtype=torch.float32):
+        super().__init__()
+        from ..engine import FlawDetectorCore
+        from .. import dist as pdist
+        self.core = FlawDetectorCore(in_channels, device=pdist.local_device(), engine_dtype=engine_dtype)
+
+    def state_dict(self, *a, **k):
+        return self.core.state_dict(*a, **k)
+
+    def load_state_dict(self, sd, strict=True):
+        return self.core.load_state_dict(sd, strict=strict)
+
+    def parameters(self, recurse=True):
+        return self.core.parameters(recurse)
+
+    def named_parameters(self, *a, **k):
+        return self.core.named_parameters(*a, **k)
+
+    def forward(self, task_inp, task_pred):
+        x = torch.cat(tuple(task_inp) + (task_pred,), dim=1)
+        flawmap, _, _ = self.core(x)
+        assert flawmap.shape[2:] == task_pred.shape[2:]
+        return {'flawmap': flawmap}, {}
+
+
+class _MaskedSqMean(torch.autograd.Function):
+    """mean(mask * x^2): the flaw-correction constraint (MSE of the flaw map against zeros, masked by both_bad)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        _gpu(x, mask)
+        x, mask = x.contiguous(), mask.contiguous()
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+        check(lib().pxl_masked_sq_mean_fwd(x.numel(), ptr(x), ptr(mask), ptr(out), stream_ptr()))
+        ctx.save_for_backward(x, mask)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, mask = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        check(lib().pxl_masked_sq_mean_bwd(x.numel(), ptr(x), ptr(mask), ptr(gout.contiguous().float().view(1)), ptr(dx),
+                                           stream_ptr()))
+        return dx, None
+
+
+class SSLGCT:
+    pass
+
+
+def _define_sslgct():
+    from . import ssl_base
+    from ..utils import REGRESSION, CLASSIFICATION, logger, tool
+    from ..nn import func
+    from ..nn.lrer import PolynomialLR
+    from ..nn.optimizer import FusedAdam
+    from ..nn.module import patch_replication_callback
+    from ..functional import MSELoss
+
+    class _SSLGCT(ssl_base._SSLBase):
+        NAME = 'ssl_gct'
+        SUPPORTED_TASK_TYPES = [REGRESSION, CLASSIFICATION]
+
+        def __init__(self, args):
+            super().__init__(args)
+            self.l_model = self.r_model = self.fd_model = None
+            self.l_optimizer = self.r_optimizer = self.fd_optimizer = None
+            self.l_lrer = self.r_lrer = self.fd_lrer = None
+            self.l_criterion = self.r_criterion = self.fd_criterion = self.dc_criterion = None
+            self.flawmap_handler = self.dcgt_generator = self.fdgt_generator = None
+            self.args.fd_lr *= getattr(self.args, 'gpus', 1)        # ssl_gct.py:107
+            a = self.args
+            if a.unlabeled_batch_size > 0:
+                if a.ssl_mode in (MODE_GCT, MODE_FC) and a.fc_ssl_scale < 0:
+                    logger.log_err('The argument - fc_ssl_scale - is not set (or invalid)\n')
+                if a.ssl_mode in (MODE_GCT, MODE_DC):
+                    if a.dc_rampup_epochs < 0 or a.dc_ssl_scale < 0 or a.dc_threshold < 0 or a.mu < 0 or a.nu < 0:
+                        logger.log_err('The dynamic consistency constraint needs dc_rampup_epochs, dc_ssl_scale, '
+                                       'dc_threshold, mu and nu to be set\n')
+            if a.ssl_mode != MODE_GCT:
+                raise NotImplementedError("SSL_GCT on the MI355X engine implements ssl_mode 'gct' (what every script uses)")
+
+        def _build(self, model_funcs, optimizer_funcs, lrer_funcs, criterion_funcs, task_func):
+            a = self.args
+            self.task_func = task_func
+            self.l_model = patch_replication_callback(func.create_model(model_funcs[0], 'l_model', args=a))
+            self.r_model = patch_replication_callback(func.create_model(model_funcs[1], 'r_model', args=a))
+            fd_dtype = torch.float32 if getattr(a, 'engine_dtype', 'bf16') in ('fp32', 'f32') else torch.bfloat16
+            self.fd_model = patch_replication_callback(func.create_model(
+                FlawDetector, 'fd_model', in_channels=self.task_func.sslgct_fd_in_channels(), engine_dtype=fd_dtype))
+            self.models = {'l_model': self.l_model, 'r_model': self.r_model, 'fd_model': self.fd_model}
+            self.l_optimizer = optimizer_funcs[0](self.l_model.module.param_groups)
+            self.r_optimizer = optimizer_funcs[1](self.r_model.module.param_groups)
+            self.fd_optimizer = FusedAdam(filter(lambda p: p.requires_grad, self.fd_model.parameters()), lr=a.fd_lr,
+                                          betas=(0.9, 0.99))
+            self.optimizers = {'l_optimizer': self.l_optimizer, 'r_optimizer': self.r_optimizer,
+                               'fd_optimizer': self.fd_optimizer}
+            self.l_lrer = lrer_funcs[0](self.l_optimizer)
+            self.r_lrer = lrer_funcs[1](self.r_optimizer)
+            self.fd_lrer = PolynomialLR(self.fd_optimizer, a.epochs, a.iters_per_epoch, power=0.9, last_epoch=-1)
+            self.lrers = {'l_lrer': self.l_lrer, 'r_lrer': self.r_lrer, 'fd_lrer': self.fd_lrer}
+            self.l_criterion = criterion_funcs[0](a)
+            self.r_criterion = criterion_funcs[1](a)
+            self.fd_criterion = FlawDetectorCriterion()
+            self.dc_criterion = MSELoss()
+            self.criterions = {'l_criterion': self.l_criterion, 'r_criterion': self.r_criterion,
+                               'fd_criterion': self.fd_criterion, 'dc_criterion': self.dc_criterion}
+            self.flawmap_handler = FlawmapHandler(a)
+            self.dcgt_generator = DCGTGenerator(a)
+            self.fdgt_generator = FDGTGenerator(a, ignore_index=a.ignore_index)
+
+        # ---- one task-model pass of step 1 (_task_model_iter, ssl_gct.py:401-480)
+        def _task_model_iter(self, mid, lbs, inp, gt, dc_gt, fc_mask, dc_rampup_scale):
+            a = self.args
+            model, criterion = (self.l_model, self.l_criterion) if mid == 'l' else (self.r_model, self.r_criterion)
+            resulter, _ = model.forward(inp)
+            self._need_pred(resulter, 'SSL_GCT')
+            pred = tool.dict_value(resulter, 'pred')
+            activated_pred = tool.dict_value(resulter, 'activated_pred')
+            flawmap = tool.dict_value(self.fd_model.forward(inp, activated_pred[0])[0], 'flawmap')
+            task_loss = torch.mean(criterion.forward(func.split_tensor_tuple(pred, 0, lbs), func.split_tensor_tuple(gt, 0, lbs),
+                                                     func.split_tensor_tuple(inp, 0, lbs)))
+            # flaw correction: MSE of the flaw map against zeros, masked by both_bad (ssl_gct.py:429-439)
+            fc_ssl_loss = a.fc_ssl_scale * _MaskedSqMean.apply(flawmap, fc_mask)
+            dc_ssl_loss = dc_rampup_scale * a.dc_ssl_scale * torch.mean(self.dc_criterion.forward(activated_pred[0], dc_gt))
+            # (the reference also builds an FDGT map of the full batch here, used only for visualisation: skipped)
+            return task_loss + fc_ssl_loss + dc_ssl_loss, dict(task=task_loss.detach(), fc=fc_ssl_loss.detach(),
+                                                               dc=dc_ssl_loss.detach())
+
+        def train_step(self, inp, gt, cur_step, total_rampup_steps):
+            """One iteration of ssl_gct.py:186-269 on device-resident tuples (both task models see the same batch)."""
+            a = self.args
+            lbs = a.labeled_batch_size
+            fd_core = self.fd_model.module.core
+            dc_rampup_scale = func.sigmoid_rampup(cur_step, total_rampup_steps)
+            # ---- step 0: no-grad task forwards, flaw-detector forwards whose graphs are kept for step 2
+            with torch.no_grad():
+                l_prob = tool.dict_value(self.l_model.forward(inp)[0], 'activated_pred')
+                r_prob = tool.dict_value(self.r_model.forward(inp)[0], 'activated_pred')
+            fd_core.set_wgrad(True)
+            l_flawmap = tool.dict_value(self.fd_model.forward(inp, l_prob[0])[0], 'flawmap')
+            r_flawmap = tool.dict_value(self.fd_model.forward(inp, r_prob[0])[0], 'flawmap')
+            with torch.no_grad():
+                l_handled = self.flawmap_handler.forward(l_flawmap)         # clamps l_flawmap / r_flawmap IN PLACE
+                r_handled = self.flawmap_handler.forward(r_flawmap)
+                l_dc_gt, r_dc_gt, l_fc_mask, r_fc_mask = self.dcgt_generator.forward(l_prob[0].detach(), r_prob[0].detach(),
+                                                                                    l_handled, r_handled)
+            # ---- step 1: task models; the flaw detector is frozen (requires_grad False in the reference)
+            fd_core.set_wgrad(False)
+            out = {}
+            for mid, optimizer, dc_gt, fc_mask in (('l', self.l_optimizer, l_dc_gt, l_fc_mask),
+                                                   ('r', self.r_optimizer, r_dc_gt, r_fc_mask)):
+                loss, parts = self._task_model_iter(mid, lbs, inp, gt, dc_gt, fc_mask, dc_rampup_scale)
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+                for k, v in parts.items():
+                    out['{0}_{1}_loss'.format(mid, k)] = v
+            # ---- step 2: flaw detector, ground truth from the STEP-0 predictions of the labeled samples
+            fd_core.set_wgrad(True)
+            with torch.no_grad():
+                l_fm_gt = self.fdgt_generator.forward(l_prob[0][:lbs, ...].detach(), gt[0][:lbs, ...])
+                r_fm_gt = self.fdgt_generator.forward(r_prob[0][:lbs, ...].detach(), gt[0][:lbs, ...])
+            l_fd_loss = a.fd_scale * torch.mean(self.fd_criterion.forward(l_flawmap[:lbs, ...], l_fm_gt))
+            r_fd_loss = a.fd_scale * torch.mean(self.fd_criterion.forward(r_flawmap[:lbs, ...], r_fm_gt))
+            fd_loss = (l_fd_loss + r_fd_loss) / 2
+            self.fd_optimizer.zero_grad()
+            fd_loss.backward()
+            self.fd_optimizer.step()
+            self.fd_lrer.step()
+            if not a.is_epoch_lrer:
+                self.l_lrer.step()
+                self.r_lrer.step()
+            out['l_fd_loss'], out['r_fd_loss'] = l_fd_loss.detach(), r_fd_loss.detach()
+            return out
+
+        def _train(self, data_loader, epoch):
+            self.meters.reset()
+            for m in (self.l_model, self.r_model, self.fd_model):
+                m.train()
+            for idx, (inp, gt) in enumerate(data_loader):
+                timer = time.time()
+                inp, gt = self._to_device(inp), self._to_device(gt)
+                cur = len(data_loader) * epoch + idx
+                losses = self.train_step(inp, gt, cur, len(data_loader) * self.args.dc_rampup_epochs)
+                for k, v in losses.items():
+                    self.meters.update(k, v)
+                self.meters.update('batch_time', time.time() - timer)
+                if idx % self.args.log_freq == 0:
+                    m = self.meters
+                    logger.log_info('step: [{0}][{1}/{2}]\tbatch-time: {3:.3f}\n'
+                                    '  l\t=>\ttask {4:.6f}\tdc {5:.6f}\tfc {6:.6f}\n  r\t=>\ttask {7:.6f}\tdc {8:.6f}\tfc {9:.6f}\n'
+                                    '  fd\t=>\tl {10:.6f}\tr {11:.6f}\n'
+                                    .format(epoch + 1, idx, len(data_loader), m['batch_time'].avg,
+                                            float(m['l_task_loss'].avg), float(m['l_dc_loss'].avg), float(m['l_fc_loss'].avg),
+                                            float(m['r_task_loss'].avg), float(m['r_dc_loss'].avg), float(m['r_fc_loss'].avg),
+                                            float(m['l_fd_loss'].avg), float(m['r_fd_loss'].avg)))
+            if self.args.is_epoch_lrer:
+                self.l_lrer.step()
+                self.r_lrer.step()
+
+        def _validate(self, data_loader, epoch):
+            self.meters.reset()
+            for m in (self.l_model, self.r_model, self.fd_model):
+                m.eval()
+            for idx, (inp, gt) in enumerate(data_loader):
+                inp, gt = self._to_device(inp), self._to_device(gt)
+                for mid, model, criterion in (('l', self.l_model, self.l_criterion), ('r', self.r_model, self.r_criterion)):
+                    resulter, _ = model.forward(inp)
+                    self._need_pred(resulter, 'SSL_GCT')
+                    self.meters.update(mid + '_task_loss',
+                                       torch.mean(criterion.forward(tool.dict_value(resulter, 'pred'), gt, inp)).detach())
+                    self.task_func.metrics(tool.dict_value(resulter, 'activated_pred'), gt, inp, self.meters, id_str=mid)
+
+        def _save_checkpoint(self, epoch):
+            state = {'algorithm': self.NAME, 'epoch': epoch}
+            for k, v in list(self.models.items()) + list(self.optimizers.items()) + list(self.lrers.items()):
+                state[k] = v.state_dict()
+            torch.save(state, os.path.join(self.args.checkpoint_path, 'checkpoint_{0}.ckpt'.format(epoch)))
+
+        def _load_checkpoint(self):
+            checkpoint = torch.load(self.args.resume, map_location='cpu')
+            found = tool.dict_value(checkpoint, 'algorithm', default='unknown')
+            if found != self.NAME:
+                logger.log_err('Unmatched SSL algorithm format in checkpoint => required: {0} - given: {1}\n'
+                               .format(self.NAME, found))
+            for k, v in self.models.items():
+                v.load_state_dict(checkpoint[k])
+            return checkpoint['epoch']
+
+    return _SSLGCT
+
+
+SSLGCT = _define_sslgct()
+NAME = SSLGCT.NAME
