@@ -32,7 +32,7 @@ def parse():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    p.add_argument("--algo", default="mt", choices=["mt", "suponly", "adv"])
+    p.add_argument("--algo", default="mt", choices=["mt", "suponly", "adv", "gct"])
     p.add_argument("--size", type=int, default=513)
     p.add_argument("--lbs", type=int, default=4, help="labeled samples per GPU")
     p.add_argument("--ubs", type=int, default=4, help="unlabeled samples per GPU")
@@ -53,6 +53,9 @@ def make_args(a, world):
         # AdvSSL hyper-parameters of the shipped script (task/sseg/script/deeplabv2_pascalvoc_1-8_ssladv.py:23-28)
         adv_for_labeled=True, labeled_adv_scale=0.01, unlabeled_adv_scale=0.001, discriminator_lr=1e-4 * world,
         discriminator_power=0.9, unlabeled_for_discriminator=True, discriminator_scale=1.0,
+        # GCT hyper-parameters of the shipped script (task/sseg/script/deeplabv2_pascalvoc_1-8_sslgct.py:21-33)
+        im_size=a.size, ssl_mode="gct", fc_ssl_scale=1.0, dc_ssl_scale=100.0, dc_threshold=0.6, dc_rampup_epochs=3,
+        fd_lr=1e-4 * world, fd_scale=10.0, mu=0.5, nu=1,
         is_epoch_lrer=False, log_freq=10 ** 9, task="sseg", cons_for_labeled=False, cons_scale=1.0,
         cons_rampup_epochs=3, ema_decay=0.99, gaussian_noise_std=None)
     return ns
@@ -109,6 +112,11 @@ def main():
         cores = [algo.s_model.module.model, algo.t_model.module.model]
         algo.s_model.train()
         algo.t_model.train()
+    elif a.algo == "gct":
+        algo = P.ssl_algorithm.ssl_gct.ssl_gct(args, *factories, P.sseg.func.task_func()(args))
+        cores = [algo.l_model.module.model, algo.r_model.module.model, algo.fd_model.module.core]
+        for m in (algo.l_model, algo.r_model, algo.fd_model):
+            m.train()
     elif a.algo == "adv":
         algo = P.ssl_algorithm.ssl_adv.ssl_adv(args, *factories, P.sseg.func.task_func()(args))
         cores = [algo.model.module.model, algo.d_model.module.core]
@@ -131,6 +139,8 @@ def main():
         inp, gt = batches[it % len(batches)]
         if a.algo == "mt":
             return algo.train_step(inp, gt, it, 3 * args.iters_per_epoch)[0]
+        if a.algo == "gct":
+            return algo.train_step(inp, gt, it, 3 * args.iters_per_epoch)
         return algo.train_step(inp, gt)[0]
 
     def fence():
@@ -180,9 +190,10 @@ def main():
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "%s sseg, DeepLab-v2/ResNet-101, %dx%dx%d (%d labeled + %d unlabeled) per GPU, "
                                       "21 classes" % ({"mt": "MT (mean-teacher)", "adv": "AdvSSL (+ FC discriminator)",
+                                                       "gct": "GCT (dual task model + flaw detector)",
                                                        "suponly": "SupOnly"}[a.algo], per_gpu,
                                                       a.size, a.size, a.lbs, per_gpu - a.lbs),
-                          "algorithm": "ssl_" + {"mt": "mt", "adv": "adv", "suponly": "null"}[a.algo], "global_batch": gb,
+                          "algorithm": "ssl_" + {"mt": "mt", "adv": "adv", "gct": "gct", "suponly": "null"}[a.algo], "global_batch": gb,
                           "im_size": a.size, "parallelism": "dp%d" % world, "sync_bn": world > 1},
                "final_losses": loss_vals}
         if kern:
@@ -207,7 +218,7 @@ def main():
                                        "whole-step figure"}
             out["kernels"] = kern
             # whole-step view: algorithmic conv FLOPs per image over wall time
-            flop_img = {"mt": 449.9e9, "adv": 435.0e9, "suponly": 337.1e9}[a.algo]
+            flop_img = {"mt": 449.9e9, "adv": 435.0e9, "gct": 1291.2e9, "suponly": 337.1e9}[a.algo]
             out["step_mfma_frac"] = round(out["value"] * flop_img / world / (peak * 1e12), 4) if a.size == 513 else None
         if world == 1 and not a.no_cpu_baseline:
             del algo
