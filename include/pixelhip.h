@@ -193,6 +193,30 @@ int pxl_maxpool3x3s2_bwd(int dtype, int B, int Hi, int Wi, int C, const void* dp
                          void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* PSPNet head data movement (task/sseg/module/_pspnet.py:41-55, 88-102), NHWC                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* nn.AdaptiveAvgPool2d(bin): in [B][H][W][Cp] -> out [B][bin][bin][Cp] (torch windows floor/ceil).  bwd: din (+)= ... */
+int pxl_adaptive_avgpool_fwd(int dtype, int B, int H, int W, int Cp, int bin, const void* in, void* out, void* stream);
+int pxl_adaptive_avgpool_bwd(int dtype, int B, int H, int W, int Cp, int bin, const void* dout, void* din,
+                             int accumulate, void* stream);
+/* F.interpolate(bilinear, align_corners=False) of relu?(in*scale+shift) ([B][h][w][Cp_in], C channels; coef = the BN's
+ * [4*Cp_in] coefficients or NULL) written into channels [c_off, c_off+C) of out [B][H][W][Cp_out] (the torch.cat slot);
+ * bwd: din = gradient wrt the activated low-resolution input from the same slice of dout */
+int pxl_upsample_slice_fwd(int dtype, int B, int h, int w, int Cp_in, int C, const void* in, const float* coef,
+                           int relu, int H, int W, void* out, int Cp_out, int c_off, void* stream);
+int pxl_upsample_slice_bwd(int dtype, int B, int h, int w, int Cp_in, int C, const void* dout, int H, int W,
+                           int Cp_out, int c_off, void* din, void* stream);
+/* dst[m][d_off + c] (+)= src[m][s_off + c], c < C (channel-slice copy between NHWC tensors of different pitch) */
+int pxl_slice_copy(int dtype, long M, int C, const void* src, int Cp_src, int s_off, void* dst, int Cp_dst, int d_off,
+                   int accumulate, void* stream);
+/* nn.PixelShuffle(2) of relu(in): in [B][h][w][Cp_in] holding 4*C channels -> out [B][2h][2w][Cp_out] holding C */
+int pxl_pixshuf_relu_fwd(int dtype, int B, int h, int w, int Cp_in, int C, const void* in, void* out, int Cp_out,
+                         void* stream);
+int pxl_pixshuf_relu_bwd(int dtype, int B, int h, int w, int Cp_in, int C, const void* dout, int Cp_out,
+                         const void* in, void* din, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Head tail + losses                                                                           */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -293,11 +317,16 @@ int pxl_scale_inplace(long n, float* x, float a, void* stream);
 #define PXL_OP_HEAD 4       /* upsample + softmax of the low-res logits -> outputs   */
 #define PXL_OP_ACT 5        /* out = LeakyReLU(in0, slope) (conv stacks without BN)  */
 #define PXL_OP_IBN 6        /* out = LeakyReLU(IBNorm(in0), slope); bn_out = BN half  */
+#define PXL_OP_AVGPOOL 7    /* out = AdaptiveAvgPool2d(kh)(in0)                      */
+#define PXL_OP_CONCAT 8     /* out = new tensor of cout channels; in0 -> channels [0, cin)           */
+#define PXL_OP_UPCAT 9      /* bilinear(relu(bn(in0))) -> channels [c_off, c_off+cin) of `out` (made by CONCAT) */
+#define PXL_OP_PIXSHUF 10   /* out = PixelShuffle(2)(relu(in0)); cout = cin / 4      */
 
 typedef struct pxl_op {
   int32_t kind;
   int32_t in0, in1, out;       /* tensor ids (-1 = none); HEAD: in0 = low-res logits, in1 = latent   */
-  int32_t bn_in0, bn_in1;      /* BN ids applied to in0/in1 on load (conv/maxpool add the ReLU)      */
+  int32_t bn_in0, bn_in1;      /* BN ids applied to in0/in1 on load (conv/maxpool add the ReLU); HEAD: bn_in1 >= 0
+                                  makes the latent relu(bn(in1)) (PSPNet) instead of the raw tensor  */
   int32_t bn_out;              /* BN id whose statistics this conv produces (-1 = none)              */
   int32_t ngroups;             /* tap groups: 1 for plain convs, 4 for the ASPP sum                  */
   int32_t w_off[4];            /* weight offset (floats) of each tap group in the parameter buffer   */
@@ -308,6 +337,7 @@ typedef struct pxl_op {
   int32_t kh, kw, stride;
   int32_t need_dgrad;          /* 0 for the stem (the image needs no gradient)                       */
   float slope;                 /* PXL_OP_ACT: negative slope of the LeakyReLU                        */
+  int32_t c_off;               /* PXL_OP_UPCAT: first channel of the slice written in `out`          */
 } pxl_op;
 
 typedef struct pxl_bn_desc {
@@ -350,6 +380,10 @@ int pxl_net_latent_shape(const pxl_net* net, int* C, int* h, int* w);
 int pxl_net_backward(pxl_net* net, const float* params, const void* packed, const float* dlogits,
                      const float* dprob, const float* prob, float* grads, void* arena, size_t arena_bytes,
                      void* scratch, size_t scratch_bytes, int training, void* stream);
+
+/* Seed the gradient of the latent tensor before pxl_net_backward (auxiliary decoders that consume the latent outside
+ * this program, SSLCCT): dlatent NCHW fp32 [B,C,h,w]; consumed (and cleared) by the next backward */
+int pxl_net_seed_latent_grad(pxl_net* net, void* scratch, size_t scratch_bytes, const float* dlatent, void* stream);
 
 /* gradient w.r.t. the network input of the last backward (NCHW fp32 [B,Cin,H,W]); the first convolution of the
  * program must have need_dgrad = 1 (discriminator / flaw detector: the input is the task model's softmax) */

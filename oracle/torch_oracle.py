@@ -204,6 +204,110 @@ def deeplabv2_forward(sd, x, train=True, layers=RESNET101):
 
 
 # -----------------------------------------------------------------------------
+# PSPNet (row M4): pyramid pooling head + sub-pixel decoder on the same backbone
+# -----------------------------------------------------------------------------
+
+PSP_BINS = (1, 2, 3, 6)     # task/sseg/module/_pspnet.py:117
+PSP_UPSCALE_STEPS = 3       # upsample(512, num_classes, upscale=8) -> log2(8) PixelShuffle blocks (:118, :21)
+
+
+def pspnet_param_shapes(num_classes=21, layers=RESNET101):
+    """name -> shape in the reference's state_dict naming for `_PSPNet` (task/sseg/module/_pspnet.py:106-118):
+    backbone.* as DeepLab, psp.stages.{i}.{1,2} (conv, BN), psp.bottleneck.{0,1}, decoder.0 (1x1 conv) and
+    decoder.{1..3}.conv (PixelShuffle blocks)."""
+    sd = OrderedDict((k, v) for k, v in deeplabv2_param_shapes(num_classes, layers).items()
+                     if k.startswith("backbone"))
+
+    def bn(prefix, c):
+        sd[prefix + ".weight"] = (c,)
+        sd[prefix + ".bias"] = (c,)
+        sd[prefix + ".running_mean"] = (c,)
+        sd[prefix + ".running_var"] = (c,)
+        sd[prefix + ".num_batches_tracked"] = ()
+
+    for i in range(len(PSP_BINS)):
+        sd["psp.stages.%d.1.weight" % i] = (512, 2048, 1, 1)
+        bn("psp.stages.%d.2" % i, 512)
+    sd["psp.bottleneck.0.weight"] = (512, 2048 + 512 * len(PSP_BINS), 3, 3)
+    bn("psp.bottleneck.1", 512)
+    sd["decoder.0.weight"] = (num_classes, 512, 1, 1)
+    for i in range(1, PSP_UPSCALE_STEPS + 1):
+        sd["decoder.%d.conv.weight" % i] = (num_classes * 4, num_classes, 1, 1)
+        sd["decoder.%d.conv.bias" % i] = (num_classes * 4,)
+    return sd
+
+
+def init_pspnet_state(num_classes=21, seed=0, layers=RESNET101):
+    """Random init with the reference's distributions (not its RNG stream): backbone as DeepLab; psp convs
+    kaiming_uniform(fan_in, relu) (_pspnet.py:76-80); decoder.0 kaiming_normal(relu) (:18-19); PixelShuffle convs
+    ICNR -- the 4 sub-pixel rows of a class share one kaiming_normal row (:26-38) -- with torch's default bias."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for name, shape in pspnet_param_shapes(num_classes, layers).items():
+        if name.endswith("num_batches_tracked"):
+            sd[name] = torch.zeros((), dtype=torch.long)
+        elif name.endswith("running_mean"):
+            sd[name] = torch.zeros(shape)
+        elif name.endswith("running_var"):
+            sd[name] = torch.ones(shape)
+        elif name.startswith("psp") and len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            bound = math.sqrt(2.0) * math.sqrt(3.0 / fan_in)
+            sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif name == "decoder.0.weight":
+            sd[name] = torch.randn(shape, generator=g) * math.sqrt(2.0 / shape[1])
+        elif name.startswith("decoder") and name.endswith("conv.weight"):
+            base = torch.randn(shape[0] // 4, shape[1], 1, 1, generator=g) * math.sqrt(2.0 / shape[1])
+            sd[name] = base.repeat_interleave(4, dim=0).contiguous()
+        elif name.startswith("decoder") and name.endswith("conv.bias"):
+            bound = 1.0 / math.sqrt(num_classes)
+            sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        elif len(shape) == 4:
+            n = shape[2] * shape[3] * shape[0]
+            sd[name] = torch.randn(shape, generator=g) * math.sqrt(2.0 / n)
+        elif name.endswith(".weight"):
+            sd[name] = torch.ones(shape)
+        else:
+            sd[name] = torch.zeros(shape)
+    return sd
+
+
+def psp_forward(sd, feat, train=True, prefix="psp"):
+    """_PSPModule.forward (task/sseg/module/_pspnet.py:96-102): per bin adaptive average pool -> 1x1 conv -> BN ->
+    ReLU -> bilinear (align_corners=False) back to the feature size; concat [features, 4 pyramids]; 3x3 conv + BN +
+    ReLU."""
+    h, w = feat.shape[2:]
+    pyramids = [feat]
+    for i, b in enumerate(PSP_BINS):
+        s = F.adaptive_avg_pool2d(feat, b)
+        s = F.conv2d(s, sd["%s.stages.%d.1.weight" % (prefix, i)])
+        s = F.relu(_bn(sd, "%s.stages.%d.2" % (prefix, i), s, train))
+        pyramids.append(F.interpolate(s, size=(h, w), mode="bilinear", align_corners=False))
+    o = F.conv2d(torch.cat(pyramids, dim=1), sd[prefix + ".bottleneck.0.weight"], None, padding=1)
+    return F.relu(_bn(sd, prefix + ".bottleneck.1", o, train))
+
+
+def subpixel_decoder_forward(sd, px, prefix="decoder", steps=PSP_UPSCALE_STEPS):
+    """`upsample(...)` Sequential (task/sseg/module/_pspnet.py:15-24): 1x1 conv without bias, then `steps` x
+    [1x1 conv n->4n with bias, ReLU, PixelShuffle(2)] (:41-55)."""
+    x = F.conv2d(px, sd[prefix + ".0.weight"])
+    for i in range(1, steps + 1):
+        x = F.conv2d(x, sd["%s.%d.conv.weight" % (prefix, i)], sd["%s.%d.conv.bias" % (prefix, i)])
+        x = F.pixel_shuffle(F.relu(x), 2)
+    return x
+
+
+def pspnet_forward(sd, x, train=True, layers=RESNET101):
+    """_PSPNet.forward (task/sseg/module/_pspnet.py:123-129) + PSPNet.forward's softmax (task/sseg/model.py:
+    118-123).  Returns (logits, softmax, latent = psp output, decoder output before the final upsample)."""
+    feat = resnet_forward(sd, x, train, layers=layers)
+    px = psp_forward(sd, feat, train)
+    low = subpixel_decoder_forward(sd, px)
+    logits = F.interpolate(low, size=x.shape[2:], mode="bilinear", align_corners=True)
+    return logits, F.softmax(logits, dim=1), px, low
+
+
+# -----------------------------------------------------------------------------
 # Losses and schedules
 # -----------------------------------------------------------------------------
 
@@ -292,7 +396,8 @@ class OracleTrainer:
              cons_scale, cons_rampup_iters, cons_for_labeled, ema_decay)
     """
 
-    def __init__(self, state, hp, teacher_state=None):
+    def __init__(self, state, hp, teacher_state=None, forward=None):
+        self.forward = forward or deeplabv2_forward      # or pspnet_forward: same (logits, prob, latent, low) tuple
         self.sd = state
         self.t_sd = teacher_state
         self.hp = dict(lr=2.5e-4, momentum=0.9, weight_decay=5e-4, power=0.9,
@@ -316,7 +421,7 @@ class OracleTrainer:
         """SSLNULL._train body (pixelssl/ssl_algorithm/ssl_null.py:97-143)."""
         leaves = _param_leaves(self.sd)
         run = _with_leaves(self.sd, leaves)
-        logits, prob, _, low = deeplabv2_forward(run, x, train=True)
+        logits, prob, _, low = self.forward(run, x, train=True)
         for k in self.sd:                      # running stats were updated in `run`
             if is_buffer(k):
                 self.sd[k] = run[k]
@@ -339,13 +444,13 @@ class OracleTrainer:
         ramp = sigmoid_rampup(self.it, hp["cons_rampup_iters"])
         leaves = _param_leaves(self.sd)
         run = _with_leaves(self.sd, leaves)
-        s_logits, _, _, s_low = deeplabv2_forward(run, x, train=True)
+        s_logits, _, _, s_low = self.forward(run, x, train=True)
         for k in self.sd:
             if is_buffer(k):
                 self.sd[k] = run[k]
         s_task = sseg_criterion(s_logits[:lbs], gt[:lbs], hp["ignore_index"]).mean()
         with torch.no_grad():
-            t_logits, _, _, _ = deeplabv2_forward(self.t_sd, x, train=True)
+            t_logits, _, _, _ = self.forward(self.t_sd, x, train=True)
             t_task = sseg_criterion(t_logits[:lbs], gt[:lbs], hp["ignore_index"]).mean()
         if hp["cons_for_labeled"]:
             cons = mse_loss(s_logits, t_logits)

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpixelhip.so")
 
 PXL_F32, PXL_BF16 = 0, 1
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_RESIDUAL, OP_HEAD, OP_ACT, OP_IBN = 0, 1, 2, 3, 4, 5, 6
+OP_AVGPOOL, OP_CONCAT, OP_UPCAT, OP_PIXSHUF = 7, 8, 9, 10
 
 
 class PixelHipError(RuntimeError):
@@ -34,7 +35,7 @@ class Op(C.Structure):
                 ("ngroups", C.c_int32), ("w_off", C.c_int32 * 4), ("b_off", C.c_int32 * 4),
                 ("dil", C.c_int32 * 4), ("pads", C.c_int32 * 4), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
-                ("need_dgrad", C.c_int32), ("slope", C.c_float)]
+                ("need_dgrad", C.c_int32), ("slope", C.c_float), ("c_off", C.c_int32)]
 
 
 class PackItem(C.Structure):
@@ -90,6 +91,13 @@ SIGNATURES = {
     "pxl_add_inplace": (_I, [_I, _L, _P, _P, _P]),
     "pxl_maxpool3x3s2_fwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "pxl_maxpool3x3s2_bwd": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "pxl_adaptive_avgpool_fwd": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "pxl_adaptive_avgpool_bwd": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "pxl_upsample_slice_fwd": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _I, _P]),
+    "pxl_upsample_slice_bwd": (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P]),
+    "pxl_slice_copy": (_I, [_I, _L, _I, _P, _I, _I, _P, _I, _I, _I, _P]),
+    "pxl_pixshuf_relu_fwd": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "pxl_pixshuf_relu_bwd": (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
     "pxl_upsample_softmax_fwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "pxl_upsample_bwd_workspace": (_Z, [_I, _I, _I, _I]),
     "pxl_upsample_softmax_bwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
@@ -128,6 +136,7 @@ SIGNATURES = {
     "pxl_net_latent": (_I, [_P, _P, _P, _P]),
     "pxl_net_latent_shape": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "pxl_net_input_grad": (_I, [_P, _P, _P, _P]),
+    "pxl_net_seed_latent_grad": (_I, [_P, _P, _Z, _P, _P]),
     "pxl_net_set_wgrad": (_I, [_P, _I]),
     "pxl_net_profile": (_I, [_P, _I]),
     "pxl_net_profile_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),

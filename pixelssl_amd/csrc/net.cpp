@@ -107,6 +107,7 @@ struct pxl_net {
   int use_side = -1;
   bool wgrad_on = true;
   int input_tensor = -1;
+  bool latent_seeded = false;      // pxl_net_seed_latent_grad ran: the next backward starts from that gradient
   // tests: use the reference's multi-device variance formula clamp(var, eps) on a single rank too
   bool force_clamp = getenv("PXL_FORCE_CLAMP_VAR") != nullptr;
 };
@@ -228,7 +229,8 @@ extern "C" int pxl_net_create(int dtype, int num_classes, const pxl_op* ops, int
       return pxl_set_error(PXL_ERR_ARG, "net_create: op %d has %d tap groups", i, d.ngroups);
     }
     // the ReLU after a BN is decided by its consumer kind
-    if ((d.kind == PXL_OP_CONV || d.kind == PXL_OP_MAXPOOL) && d.bn_in0 >= 0) n->bns[d.bn_in0].relu = 1;
+    if ((d.kind == PXL_OP_CONV || d.kind == PXL_OP_MAXPOOL || d.kind == PXL_OP_UPCAT) && d.bn_in0 >= 0) n->bns[d.bn_in0].relu = 1;
+    if (d.kind == PXL_OP_HEAD && d.bn_in1 >= 0) n->bns[d.bn_in1].relu = 1;
     if (d.kind == PXL_OP_CONV && d.bn_out >= 0) n->bns[d.bn_out].y_tensor = d.out;
     if (d.kind == PXL_OP_HEAD) n->head_op = i;
     if (d.kind == PXL_OP_INPUT) n->input_tensor = d.out;
@@ -392,6 +394,34 @@ extern "C" int pxl_net_plan(pxl_net* n, int B, int H, int W) {
         op.ibn_bbn = scratch; scratch += align_up(2 * (size_t)nb * 4);
         break;
       }
+      case PXL_OP_AVGPOOL: {
+        PXL_REQUIRE(d.in0 >= 0 && n->tensors[d.in0].planned && d.kh >= 1, "net_plan: op %zu consumes an unplanned tensor", i);
+        plan_tensor(d.out, d.kh, d.kh, n->tensors[d.in0].C);
+        break;
+      }
+      case PXL_OP_CONCAT: {
+        PXL_REQUIRE(d.in0 >= 0 && n->tensors[d.in0].planned, "net_plan: op %zu consumes an unplanned tensor", i);
+        const TensorInfo& tin = n->tensors[d.in0];
+        PXL_REQUIRE(d.cout >= tin.C && tin.C == tin.Cp && tin.C % 8 == 0, "net_plan: concat op %zu: %d channels into %d", i, tin.C, d.cout);
+        plan_tensor(d.out, tin.H, tin.W, d.cout);
+        break;
+      }
+      case PXL_OP_UPCAT: {
+        PXL_REQUIRE(d.in0 >= 0 && d.out >= 0 && n->tensors[d.in0].planned && n->tensors[d.out].planned,
+                    "net_plan: op %zu needs its input and the concat tensor planned before it", i);
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        PXL_REQUIRE(d.c_off >= 0 && d.c_off % 8 == 0 && tin.C % 8 == 0 && d.c_off + tin.C <= tout.C,
+                    "net_plan: op %zu writes channels [%d, %d) of a %d-channel tensor", i, d.c_off, d.c_off + tin.C, tout.C);
+        break;
+      }
+      case PXL_OP_PIXSHUF: {
+        PXL_REQUIRE(d.in0 >= 0 && n->tensors[d.in0].planned, "net_plan: op %zu consumes an unplanned tensor", i);
+        const TensorInfo& tin = n->tensors[d.in0];
+        PXL_REQUIRE(tin.C % 4 == 0, "net_plan: PixelShuffle op %zu on %d channels", i, tin.C);
+        plan_tensor(d.out, 2 * tin.H, 2 * tin.W, tin.C / 4);
+        break;
+      }
       case PXL_OP_HEAD: {
         PXL_REQUIRE(d.in0 >= 0 && n->tensors[d.in0].planned, "net_plan: head consumes an unplanned tensor");
         PXL_REQUIRE(n->tensors[d.in0].C == n->classes, "net_plan: head input has %d channels, expected %d",
@@ -406,17 +436,19 @@ extern "C" int pxl_net_plan(pxl_net* n, int B, int H, int W) {
     }
   }
   for (auto& b : n->bns) b.has_z = false;
-  if (n->dtype == PXL_BF16) {
-    for (auto& op : n->ops) {
-      const pxl_op& d = op.d;
-      if (d.kind != PXL_OP_CONV || d.bn_in0 < 0) continue;
-      BnInfo& b = n->bns[d.bn_in0];
-      const TensorInfo& tin = n->tensors[d.in0];
-      if (b.y_tensor != d.in0 || tin.Cp % 64 != 0 || tin.Cp != b.d.C || b.has_z) continue;
-      b.has_z = true;
-      b.z_off = arena;
-      arena += tin.bytes;
-    }
+  for (auto& op : n->ops) {
+    const pxl_op& d = op.d;
+    int bn = -1, t = -1;
+    if (d.kind == PXL_OP_CONV && d.bn_in0 >= 0 && n->dtype == PXL_BF16) { bn = d.bn_in0; t = d.in0; }
+    if (d.kind == PXL_OP_HEAD && d.bn_in1 >= 0) { bn = d.bn_in1; t = d.in1; }     // activated latent: any dtype
+    if (bn < 0) continue;
+    BnInfo& b = n->bns[bn];
+    const TensorInfo& tin = n->tensors[t];
+    if (d.kind == PXL_OP_HEAD) PXL_REQUIRE(b.y_tensor == t && tin.Cp == b.d.C, "net_plan: latent BN %d does not belong to tensor %d", bn, t);
+    if (b.y_tensor != t || tin.Cp % 64 != 0 || tin.Cp != b.d.C || b.has_z) continue;
+    b.has_z = true;
+    b.z_off = arena;
+    arena += tin.bytes;
   }
   n->arena_bytes = arena;
   n->scratch_bytes = scratch;
@@ -654,6 +686,33 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
                                at(arena, tout.off), stream);
         break;
       }
+      case PXL_OP_AVGPOOL: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        rc = pxl_adaptive_avgpool_fwd(dt, n->B, tin.H, tin.W, tin.Cp, d.kh, at(arena, tin.off), at(arena, tout.off), stream);
+        break;
+      }
+      case PXL_OP_CONCAT: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        rc = pxl_slice_copy(dt, (long)n->B * tin.H * tin.W, tin.C, at(arena, tin.off), tin.Cp, 0, at(arena, tout.off), tout.Cp, 0,
+                            0, stream);
+        break;
+      }
+      case PXL_OP_UPCAT: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        const float* coef = d.bn_in0 >= 0 ? fat(arena, n->bns[d.bn_in0].coef_off) : nullptr;
+        rc = pxl_upsample_slice_fwd(dt, n->B, tin.H, tin.W, tin.Cp, tin.C, at(arena, tin.off), coef, coef ? 1 : 0, tout.H, tout.W,
+                                    at(arena, tout.off), tout.Cp, d.c_off, stream);
+        break;
+      }
+      case PXL_OP_PIXSHUF: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        rc = pxl_pixshuf_relu_fwd(dt, n->B, tin.H, tin.W, tin.Cp, tout.C, at(arena, tin.off), at(arena, tout.off), tout.Cp, stream);
+        break;
+      }
       case PXL_OP_HEAD: {
         const TensorInfo& low = n->tensors[d.in0];
         rc = pxl_upsample_softmax_fwd(dt, n->B, low.H, low.W, low.Cp, n->classes, n->H, n->W, at(arena, low.off),
@@ -693,7 +752,20 @@ extern "C" int pxl_net_latent(pxl_net* n, const void* arena, float* latent, void
   const int t = n->ops[n->head_op].d.in1;
   PXL_REQUIRE(t >= 0, "net_latent: program names no latent tensor");
   const TensorInfo& ti = n->tensors[t];
-  return pxl_nhwc_to_nchw(n->dtype, at(arena, ti.off), latent, n->B, ti.C, ti.H, ti.W, ti.Cp, stream);
+  const int bn = n->ops[n->head_op].d.bn_in1;
+  const size_t off = bn >= 0 ? n->bns[bn].z_off : ti.off;       // PSPNet: the latent is relu(bn(bottleneck))
+  return pxl_nhwc_to_nchw(n->dtype, at(arena, off), latent, n->B, ti.C, ti.H, ti.W, ti.Cp, stream);
+}
+
+extern "C" int pxl_net_seed_latent_grad(pxl_net* n, void* scratch, size_t scratch_bytes, const float* dlatent, void* stream) {
+  PXL_REQUIRE(n && n->planned && scratch && dlatent && n->head_op >= 0, "net_seed_latent_grad: bad argument");
+  if (scratch_bytes < n->scratch_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_seed_latent_grad: scratch too small");
+  const int t = n->ops[n->head_op].d.in1;
+  PXL_REQUIRE(t >= 0, "net_seed_latent_grad: program names no latent tensor");
+  const TensorInfo& ti = n->tensors[t];
+  int rc = pxl_nchw_to_nhwc(n->dtype, dlatent, at(scratch, ti.goff), n->B, ti.C, ti.H, ti.W, ti.Cp, stream);
+  if (rc == PXL_OK) n->latent_seeded = true;
+  return rc;
 }
 
 extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* packed, const float* dlogits,
@@ -709,6 +781,10 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
   if (n->bsum_region_bytes)
     PXL_CHECK_HIP(hipMemsetAsync(at(scratch, n->bsum_region_off), 0, n->bsum_region_bytes, s));
   std::vector<char> written(n->tensors.size(), 0);
+  if (n->latent_seeded) {
+    written[n->ops[n->head_op].d.in1] = 1;
+    n->latent_seeded = false;
+  }
   if (n->use_side < 0) {
     const char* e = getenv("PXL_SIDE_STREAM");
     n->use_side = (e && e[0] == '0') ? 0 : 1;
@@ -729,6 +805,44 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         const TensorInfo& low = n->tensors[d.in0];
         rc = pxl_upsample_softmax_bwd(dt, n->B, low.H, low.W, low.Cp, n->classes, n->H, n->W, dlogits, dprob, prob,
                                       at(scratch, low.goff), at(scratch, n->up_ws_off), n->up_ws_bytes, stream);
+        written[d.in0] = 1;
+        break;
+      }
+      case PXL_OP_PIXSHUF: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        if (!written[d.out]) return pxl_set_error(PXL_ERR_ARG, "net_backward: PixelShuffle op %d output has no gradient", i);
+        if (written[d.in0]) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net_backward: PixelShuffle input consumed twice");
+        rc = pxl_pixshuf_relu_bwd(dt, n->B, tin.H, tin.W, tin.Cp, tout.C, at(scratch, tout.goff), tout.Cp, at(arena, tin.off),
+                                  at(scratch, tin.goff), stream);
+        written[d.in0] = 1;
+        break;
+      }
+      case PXL_OP_UPCAT: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        if (!written[d.out]) return pxl_set_error(PXL_ERR_ARG, "net_backward: concat tensor of op %d has no gradient", i);
+        if (written[d.in0]) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net_backward: pyramid stage output consumed twice");
+        rc = pxl_upsample_slice_bwd(dt, n->B, tin.H, tin.W, tin.Cp, tin.C, at(scratch, tout.goff), tout.H, tout.W, tout.Cp, d.c_off,
+                                    at(scratch, tin.goff), stream);
+        written[d.in0] = 1;
+        break;
+      }
+      case PXL_OP_CONCAT: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        if (!written[d.out]) return pxl_set_error(PXL_ERR_ARG, "net_backward: concat op %d output has no gradient", i);
+        rc = pxl_slice_copy(dt, (long)n->B * tin.H * tin.W, tin.C, at(scratch, tout.goff), tout.Cp, 0, at(scratch, tin.goff), tin.Cp,
+                            0, written[d.in0] ? 1 : 0, stream);
+        written[d.in0] = 1;
+        break;
+      }
+      case PXL_OP_AVGPOOL: {
+        const TensorInfo& tin = n->tensors[d.in0];
+        const TensorInfo& tout = n->tensors[d.out];
+        if (!written[d.out]) return pxl_set_error(PXL_ERR_ARG, "net_backward: pooling op %d output has no gradient", i);
+        rc = pxl_adaptive_avgpool_bwd(dt, n->B, tin.H, tin.W, tin.Cp, d.kh, at(scratch, tout.goff), at(scratch, tin.goff),
+                                      written[d.in0] ? 1 : 0, stream);
         written[d.in0] = 1;
         break;
       }

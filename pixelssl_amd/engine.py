@@ -10,6 +10,7 @@ Design (MI355X-first):
   * the network itself is a layer program interpreted by libpixelhip (csrc/net.cpp).
 """
 import ctypes
+import math
 import os
 from collections import OrderedDict
 
@@ -184,8 +185,28 @@ class ProgramBuilder:
         self._op(_lib.OP_RESIDUAL, in0=t_main, in1=t_res, out=t, bn_in0=bn_main, bn_in1=bn_res)
         return t
 
-    def head(self, t_low, t_latent):
-        self._op(_lib.OP_HEAD, in0=t_low, in1=t_latent)
+    def avgpool(self, t_in, bins):
+        t = self.tensor()
+        self._op(_lib.OP_AVGPOOL, in0=t_in, out=t, kh=bins, kw=bins)
+        return t
+
+    def concat(self, t_in, cin, ctotal):
+        """New tensor of `ctotal` channels whose first `cin` are a copy of t_in (torch.cat slot 0); `upcat` fills the
+        remaining slices."""
+        t = self.tensor()
+        self._op(_lib.OP_CONCAT, in0=t_in, out=t, cin=cin, cout=ctotal)
+        return t
+
+    def upcat(self, t_in, bn_in, t_cat, c_off, cin):
+        self._op(_lib.OP_UPCAT, in0=t_in, bn_in0=bn_in, out=t_cat, c_off=c_off, cin=cin)
+
+    def pixshuf(self, t_in, cin):
+        t = self.tensor()
+        self._op(_lib.OP_PIXSHUF, in0=t_in, out=t, cin=cin, cout=cin // 4)
+        return t
+
+    def head(self, t_low, t_latent, bn_latent=-1):
+        self._op(_lib.OP_HEAD, in0=t_low, in1=t_latent, bn_in1=bn_latent)
 
 
 def build_resnet_trunk(pb, prefix, layers, output_stride=16):
@@ -425,13 +446,29 @@ class SegNetCore(nn.Module):
         need_graph = torch.is_grad_enabled() and (any(p.requires_grad for p in self._param_list[:1]) or x.requires_grad)
         if need_graph:
             arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
-            logits, prob = _SegNetFn.apply(x, self._anchor, self, arena)
+            logits, prob, _ = _SegNetFn.apply(x, self._anchor, self, arena, False)
         else:
             if self._cur.eval_arena is None:
                 self._cur.eval_arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
             arena = self._cur.eval_arena
             logits, prob = self._forward_raw(x, arena)
         return logits, prob, (_LatentHandle(self, arena, self._cur) if self.has_latent else None)
+
+    def forward_with_latent(self, x):
+        """-> (logits, softmax, latent) where the latent (NCHW fp32) is part of the autograd graph: a gradient that
+        reaches it (SSLCCT's auxiliary decoders, which consume 'sslcct_ad_inp' outside this program) is seeded into the
+        executor's backward next to dlogits / dprob."""
+        if not x.is_cuda:
+            raise _lib.PixelHipError("SegNetCore runs on the GPU only (input is on %s); there is no CPU path" % x.device)
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        self._plan(B, H, W)
+        self._ensure_packed()
+        arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
+        if torch.is_grad_enabled():
+            return _SegNetFn.apply(x, self._anchor, self, arena, True)
+        logits, prob = self._forward_raw(x, arena)
+        return logits, prob, self.latent_from(arena)
 
     def profile(self, enable=True):
         """Bracket every contraction launch with HIP events (bench.py roofline leg)."""
@@ -488,23 +525,24 @@ class _LatentHandle:
 
 class _SegNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, anchor, core, arena):
+    def forward(ctx, x, anchor, core, arena, with_latent):
         logits, prob = core._forward_raw(x, arena)
         ctx.core, ctx.arena, ctx.plan = core, arena, core._cur
         ctx.bn_training = bool(core.training and not core.freeze_bn)
         ctx.x_shape = tuple(x.shape)
         ctx.save_for_backward(prob)
         ctx.set_materialize_grads(False)
-        if prob is None:
-            ctx.mark_non_differentiable()
-        return logits, prob
+        latent = core.latent_from(arena) if with_latent else None
+        return logits, prob, latent
 
     @staticmethod
-    def backward(ctx, dlogits, dprob):
+    def backward(ctx, dlogits, dprob, dlatent):
         core = ctx.core
         (prob,) = ctx.saved_tensors
-        if dlogits is None and dprob is None:
-            return None, None, None, None
+        if dlogits is None and dprob is None and dlatent is None:
+            return None, None, None, None, None
+        if dlogits is None and dprob is None:           # only the latent carries a gradient
+            dlogits = torch.zeros((ctx.x_shape[0], core.num_classes) + ctx.x_shape[2:], device=core._device)
         if dlogits is not None:
             dlogits = dlogits.contiguous()
         if dprob is not None:
@@ -512,6 +550,9 @@ class _SegNetFn(torch.autograd.Function):
         core.ensure_grad_views()
         s = core._store
         pl = ctx.plan
+        if dlatent is not None:
+            dlatent = dlatent.contiguous().float()
+            check(lib().pxl_net_seed_latent_grad(pl.net, ptr(pl.scratch), pl.scratch.numel(), ptr(dlatent), stream_ptr()))
         check(lib().pxl_net_backward(pl.net, ptr(s.params), ptr(pl.packed), ptr(dlogits), ptr(dprob), ptr(prob),
                                      ptr(s.grads), ptr(ctx.arena), ctx.arena.numel(), ptr(pl.scratch),
                                      pl.scratch.numel(), int(ctx.bn_training), stream_ptr()))
@@ -523,7 +564,7 @@ class _SegNetFn(torch.autograd.Function):
         if hook is not None and core._wgrad_on:
             hook(core)
         ctx.arena = None
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 class DeepLabV2Core(SegNetCore):
@@ -583,6 +624,106 @@ class DeepLabV2Core(SegNetCore):
         for name, prm in self.named_parameters():
             if name.startswith("classifier") and prm.requires_grad:
                 yield prm
+
+
+PSP_BINS = (1, 2, 3, 6)               # task/sseg/module/_pspnet.py:117
+
+
+def build_subpixel_decoder(pb, prefix, t_in, bn_in, cin, num_classes, upscale=8):
+    """`upsample(cin, num_classes, upscale)` of task/sseg/module/_pspnet.py:15-24: 1x1 conv without bias, then
+    log2(upscale) x [1x1 conv n -> 4n with bias, ReLU, PixelShuffle(2)].  Returns the tensor id of the result."""
+    t = pb.conv(prefix + ".0", t_in, bn_in, cin, num_classes, 1, 1, 1, 0)
+    steps = int(round(math.log(upscale, 2)))
+    for i in range(1, steps + 1):
+        y = pb.conv("%s.%d.conv" % (prefix, i), t, -1, num_classes, num_classes * 4, 1, 1, 1, 0, bias=True)
+        t = pb.pixshuf(y, num_classes * 4)
+    return t
+
+
+@torch.no_grad()
+def init_subpixel_decoder(named_params, prefix, generator=None):
+    """kaiming_normal(relu) for the 1x1 conv, ICNR for the PixelShuffle convs (the 4 sub-pixel rows of one output
+    channel share a kaiming_normal row), torch's default bias (task/sseg/module/_pspnet.py:18-19, 26-38, 47-48)."""
+    for name, prm in named_params:
+        if not name.startswith(prefix + "."):
+            continue
+        if name == prefix + ".0.weight":
+            prm.copy_(torch.randn(prm.shape, generator=generator) * math.sqrt(2.0 / prm.shape[1]))
+        elif name.endswith("conv.weight"):
+            base = torch.randn(prm.shape[0] // 4, prm.shape[1], 1, 1, generator=generator) * math.sqrt(2.0 / prm.shape[1])
+            prm.copy_(base.repeat_interleave(4, dim=0))
+        elif name.endswith("conv.bias"):
+            bound = 1.0 / math.sqrt(prm.shape[0] // 4)
+            prm.copy_((torch.rand(prm.shape, generator=generator) * 2 - 1) * bound)
+
+
+class PSPNetCore(SegNetCore):
+    """PSPNet = ResNet trunk + pyramid pooling module + sub-pixel decoder + bilinear up-sampling to the input size
+    (task/sseg/module/_pspnet.py:58-129).  The pyramid stages are [adaptive avg-pool to 1/2/3/6 bins -> 1x1 conv ->
+    BN -> ReLU -> bilinear (align_corners=False)] written straight into their channel slice of the 4096-channel
+    concat tensor; the 3x3 4096->512 bottleneck (+BN+ReLU) output is the latent the CCT auxiliary decoders consume.
+    Parameter names follow the reference module tree: backbone.*, psp.stages.{i}.{1,2}, psp.bottleneck.{0,1},
+    decoder.0, decoder.{1..3}.conv."""
+
+    def __init__(self, backbone="resnet101", output_stride=16, num_classes=21, device="cuda",
+                 engine_dtype=torch.float32, freeze_bn=False):
+        super().__init__(device, engine_dtype, num_classes)
+        if isinstance(backbone, (tuple, list)):
+            layers = tuple(backbone)
+        elif backbone in RESNET_LAYERS:
+            layers = RESNET_LAYERS[backbone]
+        else:
+            raise NotImplementedError("backbone %r" % backbone)
+        pb = self._pb
+        feat, c = build_resnet_trunk(pb, "backbone", layers, output_stride)
+        oc = c // len(PSP_BINS)
+        cat = pb.concat(feat, c, c + oc * len(PSP_BINS))
+        for i, bins in enumerate(PSP_BINS):
+            pooled = pb.avgpool(feat, bins)
+            b = pb.bn("psp.stages.%d.2" % i, oc)
+            y = pb.conv("psp.stages.%d.1" % i, pooled, -1, c, oc, 1, 1, 1, 0, bn_out=b)
+            pb.upcat(y, b, cat, c + i * oc, oc)
+        bb = pb.bn("psp.bottleneck.1", oc)
+        px = pb.conv("psp.bottleneck.0", cat, -1, c + oc * len(PSP_BINS), oc, 3, 1, 1, 1, bn_out=bb)
+        low = build_subpixel_decoder(pb, "decoder", px, bb, oc, num_classes, upscale=8)
+        pb.head(low, px, bn_latent=bb)
+        self._finalize()
+        self.freeze_bn = freeze_bn
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self, generator=None):
+        """Backbone: conv ~ N(0, sqrt(2/(k*k*cout))), BN gamma=1/beta=0 (resnet.py:133-143); psp convs
+        kaiming_uniform(fan_in, relu) (_pspnet.py:76-80); decoder: see init_subpixel_decoder."""
+        for name, prm in self.named_parameters():
+            if name.startswith("decoder"):
+                continue
+            if prm.dim() == 4 and name.startswith("psp"):
+                fan_in = prm.shape[1] * prm.shape[2] * prm.shape[3]
+                bound = math.sqrt(2.0) * math.sqrt(3.0 / fan_in)
+                prm.copy_((torch.rand(prm.shape, generator=generator) * 2 - 1) * bound)
+            elif prm.dim() == 4:
+                n = prm.shape[2] * prm.shape[3] * prm.shape[0]
+                prm.copy_(torch.randn(prm.shape, generator=generator) * math.sqrt(2.0 / n))
+            elif name.endswith("weight"):
+                prm.fill_(1.0)
+            else:
+                prm.zero_()
+        init_subpixel_decoder(self.named_parameters(), "decoder", generator)
+        for name, buf in self.named_buffers():
+            if name.endswith("running_var"):
+                buf.fill_(1.0)
+            elif name.endswith("running_mean") or name.endswith("num_batches_tracked"):
+                buf.zero_()
+
+    def get_backbone_params(self):
+        return (p for n, p in self.named_parameters() if n.startswith("backbone") and p.requires_grad)
+
+    def get_psp_params(self):
+        return (p for n, p in self.named_parameters() if n.startswith("psp") and p.requires_grad)
+
+    def get_decoder_params(self):
+        return (p for n, p in self.named_parameters() if n.startswith("decoder") and p.requires_grad)
 
 
 class FCDiscriminatorCore(SegNetCore):

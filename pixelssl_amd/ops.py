@@ -146,6 +146,72 @@ def maxpool_bwd(dp, idx, Hi, Wi):
     return dz
 
 
+def adaptive_avgpool_fwd(x, bins):
+    """x NHWC [B,H,W,Cp] -> [B,bins,bins,Cp] (nn.AdaptiveAvgPool2d windows)"""
+    _require_cuda(x)
+    B, H, W, Cp = x.shape
+    out = torch.empty(B, bins, bins, Cp, device=x.device, dtype=x.dtype)
+    check(lib().pxl_adaptive_avgpool_fwd(dtype_code(x.dtype), B, H, W, Cp, bins, ptr(x), ptr(out), stream_ptr()))
+    return out
+
+
+def adaptive_avgpool_bwd(dout, H, W, din=None):
+    """gradient of adaptive_avgpool_fwd; `din` given = accumulate into it"""
+    _require_cuda(dout, din)
+    B, bins, _, Cp = dout.shape
+    acc = din is not None
+    if din is None:
+        din = torch.empty(B, H, W, Cp, device=dout.device, dtype=dout.dtype)
+    check(lib().pxl_adaptive_avgpool_bwd(dtype_code(dout.dtype), B, H, W, Cp, bins, ptr(dout), ptr(din), int(acc),
+                                         stream_ptr()))
+    return din
+
+
+def upsample_slice_fwd(x, C, out, c_off, coef=None, relu=False):
+    """bilinear (align_corners=False) of relu?(x*scale+shift) [B,h,w,Cp] into channels [c_off, c_off+C) of `out`"""
+    _require_cuda(x, out, coef)
+    B, h, w, Cpi = x.shape
+    _, H, W, Cpo = out.shape
+    check(lib().pxl_upsample_slice_fwd(dtype_code(x.dtype), B, h, w, Cpi, C, ptr(x), ptr(coef), int(relu), H, W, ptr(out),
+                                       Cpo, c_off, stream_ptr()))
+    return out
+
+
+def upsample_slice_bwd(dout, c_off, C, h, w, Cp_in):
+    _require_cuda(dout)
+    B, H, W, Cpo = dout.shape
+    din = torch.empty(B, h, w, Cp_in, device=dout.device, dtype=dout.dtype)
+    check(lib().pxl_upsample_slice_bwd(dtype_code(dout.dtype), B, h, w, Cp_in, C, ptr(dout), H, W, Cpo, c_off, ptr(din),
+                                       stream_ptr()))
+    return din
+
+
+def slice_copy(src, s_off, C, dst, d_off, accumulate=False):
+    _require_cuda(src, dst)
+    M = src.numel() // src.shape[-1]
+    check(lib().pxl_slice_copy(dtype_code(src.dtype), M, C, ptr(src), src.shape[-1], s_off, ptr(dst), dst.shape[-1], d_off,
+                               int(accumulate), stream_ptr()))
+    return dst
+
+
+def pixshuf_relu_fwd(x, C, Cp_out):
+    """x NHWC [B,h,w,Cp_in] holding 4*C channels -> PixelShuffle(2)(relu(x)) [B,2h,2w,Cp_out]"""
+    _require_cuda(x)
+    B, h, w, Cpi = x.shape
+    out = torch.empty(B, 2 * h, 2 * w, Cp_out, device=x.device, dtype=x.dtype)
+    check(lib().pxl_pixshuf_relu_fwd(dtype_code(x.dtype), B, h, w, Cpi, C, ptr(x), ptr(out), Cp_out, stream_ptr()))
+    return out
+
+
+def pixshuf_relu_bwd(dout, x, C):
+    _require_cuda(dout, x)
+    B, h, w, Cpi = x.shape
+    din = torch.empty_like(x)
+    check(lib().pxl_pixshuf_relu_bwd(dtype_code(x.dtype), B, h, w, Cpi, C, ptr(dout), dout.shape[-1], ptr(x), ptr(din),
+                                     stream_ptr()))
+    return din
+
+
 def upsample_softmax_fwd(low, C, H, W, want_prob=True):
     B, h, w, Cp = low.shape
     logits = torch.empty(B, C, H, W, device=low.device, dtype=torch.float32)

@@ -4,7 +4,7 @@ import torch
 
 from ..task_template import model as model_template
 from ..utils import logger, cmd
-from ..engine import DeepLabV2Core
+from ..engine import DeepLabV2Core, PSPNetCore
 from .. import dist as pdist
 
 
@@ -20,6 +20,10 @@ def add_parser_arguments(parser):
 
 def deeplabv2():
     return DeepLabV2
+
+
+def pspnet():
+    return PSPNet
 
 
 class _Resulter(dict):
@@ -58,6 +62,35 @@ class DeepLabV2(model_template.TaskModel):
     def forward(self, inp):
         if not len(inp) == 1:
             logger.log_err('Semantic segmentation model DeepLab requires only one input\n'
+                           'However, {0} inputs are given\n'.format(len(inp)))
+        pred, prob, latent_fn = self.model(inp[0])
+        resulter = _Resulter(latent_fn)
+        resulter['pred'] = (pred,)
+        resulter['activated_pred'] = (prob,)
+        resulter['ssls4l_rc_inp'] = pred
+        return resulter, {}
+
+
+class PSPNet(model_template.TaskModel):
+    """task/sseg/model.py:83-125: PSPNet TaskModel with three parameter groups (backbone lr, psp / decoder lr x10);
+    'sslcct_ad_inp' is the pyramid module's 512-channel output."""
+
+    def __init__(self, args):
+        super().__init__(args)
+        if args.backbone not in ('resnet50', 'resnet101', 'resnet101-coco'):
+            logger.log_err('PSPNet does not support the backbone: {0}\n'.format(args.backbone))
+        dtype = getattr(args, 'engine_dtype', 'bf16')
+        self.model = PSPNetCore(backbone=args.backbone, output_stride=args.output_stride,
+                                num_classes=args.num_classes, device=pdist.local_device(),
+                                engine_dtype=torch.float32 if dtype in ('fp32', 'f32') else torch.bfloat16,
+                                freeze_bn=args.freeze_bn)
+        self.param_groups = [{'params': self.model.get_backbone_params(), 'lr': self.args.lr},
+                             {'params': self.model.get_psp_params(), 'lr': self.args.lr * 10},
+                             {'params': self.model.get_decoder_params(), 'lr': self.args.lr * 10}]
+
+    def forward(self, inp):
+        if not len(inp) == 1:
+            logger.log_err('Semantic segmentation model PSPNet requires only one input\n'
                            'However, {0} inputs are given\n'.format(len(inp)))
         pred, prob, latent_fn = self.model(inp[0])
         resulter = _Resulter(latent_fn)

@@ -1,0 +1,372 @@
+"""PSPNet rows (M4).
+
+CPU: the oracle's PSPNet restatement (oracle/torch_oracle.py: pspnet_forward) against the golden fixtures that
+oracle/make_golden_psp.py produced from the REAL reference (`PSPNet` TaskModel, `SSLNULL._train`).
+GPU: the pyramid / sub-pixel kernels against plain torch fp32 ops, then the executor's PSPNet program (through the
+C-ABI) against the fixtures and the oracle -- fp32 engine = parity gate, bf16 engine = throughput mode.
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import torch_oracle as TO
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda"
+
+
+def _load(name):
+    return torch.load(os.path.join(GOLD, name), weights_only=False)
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+def _close(a, b, rtol=1e-5, atol=1e-6):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    assert (a - b).abs().max().item() <= atol + rtol * b.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU: oracle vs reference fixtures
+# ------------------------------------------------------------------------------------------------
+
+def test_oracle_pspnet_forward_matches_reference():
+    fx = _load("pspnet_forward_65.pt")
+    sd = TO.init_pspnet_state(seed=fx["weight_seed"])
+    x, gt = TO.synthetic_batch(fx["batch"], fx["size"], fx["batch"], seed=fx["data_seed"], block=fx["block"])
+    leaves = TO._param_leaves(sd)
+    run = TO._with_leaves(sd, leaves)
+    logits, prob, latent, low = TO.pspnet_forward(run, x, train=True)
+    _close(logits, fx["logits"])
+    _close(low, fx["low"])
+    _close(latent.detach().reshape(-1)[:256], fx["latent_head"])
+    assert abs(float(latent.detach().double().sum()) - fx["latent_sum"]) <= 1e-5 * fx["latent_abssum"]
+    ps = TO.sseg_criterion(logits, gt)
+    _close(ps, fx["per_sample"])
+    ps.mean().backward()
+    for k, ref in fx["grads"].items():
+        _close(leaves[k].grad.reshape(-1)[:512], ref["head"], rtol=1e-4)
+        assert abs(float(leaves[k].grad.double().abs().sum()) - ref["abssum"]) <= 1e-4 * ref["abssum"]
+    for k, ref in fx["probes"].items():
+        _close(run[k].detach().float().reshape(-1)[:64], ref["head"])
+
+
+def test_oracle_pspnet_param_table():
+    """65,590,248 parameters as the reference logs for PSPNet/ResNet-101 (make_golden_psp.py output), 3 lr groups."""
+    shapes = TO.pspnet_param_shapes()
+    n = sum(int(torch.tensor(s).prod()) if len(s) else 1 for k, s in shapes.items() if not TO.is_buffer(k))
+    assert n == 65590248
+    assert TO.lr_group_of("psp.bottleneck.0.weight") == 1 and TO.lr_group_of("decoder.2.conv.bias") == 1
+    assert TO.lr_group_of("backbone.layer1.0.conv1.weight") == 0
+    sd = TO.init_pspnet_state(seed=3)
+    w = sd["decoder.2.conv.weight"]            # ICNR: the four sub-pixel rows of a class are identical
+    assert torch.equal(w[0::4], w[1::4]) and torch.equal(w[0::4], w[3::4])
+
+
+def test_oracle_pspnet_suponly_matches_reference():
+    fx = _load("pspnet_suponly_65.pt")
+    tr = TO.OracleTrainer(TO.init_pspnet_state(seed=fx["weight_seed"]), dict(max_iters=fx["max_iters"]),
+                          forward=TO.pspnet_forward)
+    losses = []
+    for s in fx["data_seeds"]:
+        x, gt = TO.synthetic_batch(fx["batch"], fx["size"], fx["batch"], seed=s, block=fx["block"])
+        losses.append(tr.suponly_step(x, gt)["task_loss"])
+    _close(sum(losses) / len(losses), fx["mean_task_loss"])
+    for k, ref in fx["probes"].items():
+        _close(tr.sd[k].detach().float().reshape(-1)[:64], ref["head"], rtol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU: kernels vs torch
+# ------------------------------------------------------------------------------------------------
+
+def _nhwc(x, Cp, dtype):
+    B, C, H, W = x.shape
+    out = torch.zeros(B, H, W, Cp, dtype=dtype, device=DEV)
+    out[..., :C] = x.permute(0, 2, 3, 1).to(device=DEV, dtype=dtype)
+    return out
+
+
+def _nchw(x, C):
+    return x[..., :C].permute(0, 3, 1, 2).float().cpu()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("H,W,bins", [(33, 33, 1), (33, 33, 2), (33, 33, 3), (33, 33, 6), (5, 5, 6), (9, 7, 3)])
+def test_adaptive_avgpool_kernels(dtype, tol, H, W, bins):
+    from pixelssl_amd import ops
+    g = torch.Generator().manual_seed(H * 100 + bins)
+    x = torch.randn(2, 64, H, W, generator=g)
+    xq = _nchw(_nhwc(x, 64, dtype), 64).requires_grad_(True)
+    ref = F.adaptive_avg_pool2d(xq, bins)
+    got = ops.adaptive_avgpool_fwd(_nhwc(x, 64, dtype), bins)
+    assert rel(_nchw(got, 64), ref.detach()) < tol
+    dout = torch.randn(ref.shape, generator=g)
+    dq = _nchw(_nhwc(dout, 64, dtype), 64)
+    ref.backward(dq)
+    din = ops.adaptive_avgpool_bwd(_nhwc(dout, 64, dtype), H, W)
+    assert rel(_nchw(din, 64), xq.grad) < tol
+    base = torch.randn(2, 64, H, W, generator=g)
+    acc = ops.adaptive_avgpool_bwd(_nhwc(dout, 64, dtype), H, W, din=_nhwc(base, 64, dtype))
+    assert rel(_nchw(acc, 64), _nchw(_nhwc(base, 64, dtype), 64) + xq.grad) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("h,H,W", [(1, 33, 33), (2, 33, 33), (3, 33, 33), (6, 33, 33), (6, 5, 5), (3, 9, 7)])
+def test_upsample_slice_kernels(dtype, tol, h, H, W):
+    """F.interpolate(bilinear, align_corners=False) of relu(bn(y)) into a channel slice of the concat tensor."""
+    from pixelssl_amd import ops
+    g = torch.Generator().manual_seed(h * 10 + H)
+    C, Cpo, c_off = 64, 192, 96
+    y = torch.randn(2, C, h, h, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    coef = torch.zeros(4 * C)
+    coef[2 * C:3 * C], coef[3 * C:] = sc, sh
+    yq = _nchw(_nhwc(y, C, dtype), C)
+    z = F.relu(yq * sc[None, :, None, None] + sh[None, :, None, None]).requires_grad_(True)
+    ref = F.interpolate(z, size=(H, W), mode="bilinear", align_corners=False)
+    out = torch.full((2, H, W, Cpo), 7.0, device=DEV, dtype=dtype)
+    ops.upsample_slice_fwd(_nhwc(y, C, dtype), C, out, c_off, coef=coef.to(DEV), relu=True)
+    assert rel(_nchw(out[..., c_off:], C), ref.detach()) < tol
+    assert torch.all(out[..., :c_off] == 7.0) and torch.all(out[..., c_off + C:] == 7.0)    # neighbours untouched
+    dout = torch.randn(2, Cpo, H, W, generator=g)
+    dq = _nchw(_nhwc(dout, Cpo, dtype), Cpo)
+    ref.backward(dq[:, c_off:c_off + C])
+    din = ops.upsample_slice_bwd(_nhwc(dout, Cpo, dtype), c_off, C, h, h, C)
+    assert rel(_nchw(din, C), z.grad) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_slice_copy_and_pixshuf_kernels(dtype):
+    from pixelssl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(3, 7, 5, 64, generator=g).to(DEV, dtype)
+    dst = torch.zeros(3, 7, 5, 160, device=DEV, dtype=dtype)
+    ops.slice_copy(src, 0, 64, dst, 32)
+    assert torch.equal(dst[..., 32:96], src) and dst[..., :32].abs().sum() == 0 and dst[..., 96:].abs().sum() == 0
+    back = torch.ones(3, 7, 5, 64, device=DEV, dtype=dtype)
+    ops.slice_copy(dst, 32, 64, back, 0, accumulate=True)
+    assert rel(back.float().cpu(), (src.float() + 1).to(dtype).float().cpu()) < 1e-6
+    # ReLU + PixelShuffle(2): 84 channels (pitch 96) -> 21 (pitch 32)
+    x = torch.randn(2, 84, 6, 5, generator=g)
+    xq = _nchw(_nhwc(x, 96, dtype), 84).requires_grad_(True)
+    ref = F.pixel_shuffle(F.relu(xq), 2)
+    xin = _nhwc(x, 96, dtype)
+    out = ops.pixshuf_relu_fwd(xin, 21, 32)
+    assert torch.equal(_nchw(out, 21), ref.detach())
+    assert out[..., 21:].abs().sum() == 0
+    dout = torch.randn(2, 21, 12, 10, generator=g)
+    ref.backward(_nchw(_nhwc(dout, 32, dtype), 21))
+    din = ops.pixshuf_relu_bwd(_nhwc(dout, 32, dtype), xin, 21)
+    assert torch.equal(_nchw(din, 84), xq.grad)
+    assert din[..., 84:].abs().sum() == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU: the PSPNet program
+# ------------------------------------------------------------------------------------------------
+
+def _core(dtype, state, backbone="resnet101"):
+    from pixelssl_amd.engine import PSPNetCore
+    core = PSPNetCore(backbone=backbone, device=DEV, engine_dtype=dtype)
+    core.load_state_dict(state)
+    core.train()
+    return core
+
+
+@pytest.mark.gpu
+def test_pspnet_fp32_vs_reference_fixture():
+    """fp32 engine on the reference's own fixture: logits, argmax, CE, latent (= psp output), gradients."""
+    from pixelssl_amd import functional as PF
+    fx = _load("pspnet_forward_65.pt")
+    state = TO.init_pspnet_state(seed=fx["weight_seed"])
+    core = _core(torch.float32, state)
+    assert sum(p.numel() for p in core.parameters()) == 65590248
+    x, gt = TO.synthetic_batch(fx["batch"], fx["size"], fx["batch"], seed=fx["data_seed"], block=fx["block"])
+    logits, prob, latent_fn = core(x.to(DEV))
+    lg = logits.detach().cpu()
+    print("fp32 PSPNet logits rel err %.3e" % rel(lg, fx["logits"]))
+    assert rel(lg, fx["logits"]) < 1e-3
+    top2 = fx["logits"].topk(2, dim=1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 1e-3 * fx["logits"].abs().max()
+    assert torch.equal(lg.argmax(1)[decided], fx["logits"].argmax(1)[decided])
+    assert rel(prob.detach().cpu(), torch.softmax(fx["logits"], 1)) < 1e-3
+    lat = latent_fn().cpu()
+    assert tuple(lat.shape) == (fx["batch"], 512, 5, 5)
+    assert rel(lat.reshape(-1)[:256], fx["latent_head"]) < 1e-3
+    assert abs(lat.double().abs().sum().item() - fx["latent_abssum"]) < 1e-3 * fx["latent_abssum"]
+    ps = PF.cross_entropy_per_sample(logits, gt.to(DEV), 255)
+    assert rel(ps.detach().cpu(), fx["per_sample"]) < 1e-3
+    ps.mean().backward()
+    torch.cuda.synchronize()
+    grads = dict((n, p.grad.cpu()) for n, p in core.named_parameters())
+    errs = {k: rel(grads[k].reshape(-1)[:512], ref["head"]) for k, ref in fx["grads"].items()}
+    for k, e in errs.items():
+        print("grad %-34s rel err %.3e" % (k, e))
+    # This fixture is ill-conditioned by construction (train-mode BN over B*bin^2 = 2 / 8 / 18 values in the pyramid
+    # stages, 104 BN layers on 2x5x5-pixel maps): the REFERENCE arithmetic itself moves these gradients by 1e-2..6e-2
+    # between fp32 and fp64 or under a 1e-7 relative weight perturbation (measured with the oracle: decoder 4e-3..3e-2,
+    # psp 1e-2..6e-2, layer4 4e-2, stem 6e-2).  Head-side gradients are held to that noise level; the stem gradient
+    # decorrelates and is not asserted here -- the full-depth backward plan is pinned in eval-BN mode against fp64
+    # ground truth by test_pspnet_full_depth_eval_bn_gradients, every op kind by test_pspnet_shallow_every_gradient.
+    for k, e in errs.items():
+        if k.startswith("backbone"):
+            continue
+        assert e < 6e-2, k
+    assert errs["backbone.layer4.2.conv3.weight"] < 0.3
+    sd = core.state_dict()
+    for k in ("psp.stages.2.2.running_mean", "psp.bottleneck.1.running_var"):
+        assert rel(sd[k].cpu().reshape(-1)[:64], fx["probes"][k]["head"]) < 1e-3
+
+
+SHALLOW = (1, 1, 1, 3)
+FULL = (3, 4, 23, 3)
+
+
+def _oracle_run(state, x, gt, w, wl, dtype, train, layers=SHALLOW):
+    st = TO.clone_state(state)
+    for k in st:
+        if st[k].is_floating_point():
+            st[k] = st[k].to(dtype)
+    leaves = TO._param_leaves(st)
+    run = TO._with_leaves(st, leaves)
+    logits, prob, lat, _ = TO.pspnet_forward(run, x.to(dtype), train=train, layers=layers)
+    loss = TO.sseg_criterion(logits, gt).mean() + (prob * w.to(dtype)).sum() + (lat * wl.to(dtype)).sum()
+    loss.backward()
+    return dict(logits=logits.detach(), latent=lat.detach(), loss=loss.item(),
+                grads={k: v.grad for k, v in leaves.items()})
+
+
+def _engine_run(state, x, gt, w, wl, dtype, train, layers=SHALLOW):
+    from pixelssl_amd import functional as PF
+    core = _core(dtype, state, backbone=layers)
+    core.train(train)
+    logits, prob, latent = core.forward_with_latent(x.to(DEV))
+    loss = PF.cross_entropy_per_sample(logits, gt.to(DEV), 255).mean() + (prob * w.to(DEV)).sum() + (latent * wl.to(DEV)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    return dict(logits=logits.detach().cpu(), latent=latent.detach().cpu(), loss=loss.item(),
+                grads={k: p.grad.cpu() for k, p in core.named_parameters()})
+
+
+def _setup(train, size=97, batch=3, seed=17, layers=SHALLOW):
+    state = TO.init_pspnet_state(seed=seed, layers=layers)
+    if not train:
+        g = torch.Generator().manual_seed(4)
+        for k in state:
+            if k.endswith("running_mean"):
+                state[k] = torch.randn(state[k].shape, generator=g) * 0.05
+            elif k.endswith("running_var"):
+                state[k] = torch.rand(state[k].shape, generator=g) + 0.5
+    x, gt = TO.synthetic_batch(batch, size, batch, seed=seed + 1, block=16)
+    w = torch.randn(batch, 21, size, size, generator=torch.Generator().manual_seed(1)) * 1e-3
+    hw = (size + 15) // 16
+    wl = torch.randn(batch, 512, hw, hw, generator=torch.Generator().manual_seed(2)) * 1e-3
+    return state, x, gt, w, wl
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("train", [False, True])
+def test_pspnet_shallow_every_gradient(train):
+    """Every parameter gradient of the PSPNet program -- including the path that enters through the latent (the CCT
+    auxiliary decoders' gradient, seeded into the executor) -- against the oracle, judged against fp64 ground truth."""
+    state, x, gt, w, wl = _setup(train)
+    o = _oracle_run(state, x, gt, w, wl, torch.float32, train)
+    t = _oracle_run(state, x, gt, w, wl, torch.float64, train)
+    e = _engine_run(state, x, gt, w, wl, torch.float32, train)
+    assert rel(e["logits"], o["logits"]) < (1e-3 if train else 1e-4)
+    assert rel(e["latent"], o["latent"]) < (1e-3 if train else 1e-4)
+    assert abs(e["loss"] - o["loss"]) < 1e-4 * abs(o["loss"])
+    rows = []
+    for k in t["grads"]:
+        eo, ee = rel(o["grads"][k], t["grads"][k]), rel(e["grads"][k], t["grads"][k])
+        rows.append((ee - 3.0 * eo, k, ee, eo))
+    rows.sort(reverse=True)
+    print("worst gradient %s: engine %.2e vs fp64, reference fp32 %.2e vs fp64" % rows[0][1:])
+    # train mode: the bin-1 pyramid stage normalises over B = 3 values per channel, which amplifies ReLU-mask-flip
+    # noise; the eval-mode case pins the backward plan at 1e-2 (measured 1e-3)
+    assert rows[0][0] < (3e-2 if train else 1e-2), rows[:5]
+
+
+@pytest.mark.gpu
+def test_pspnet_full_depth_eval_bn_gradients():
+    """ResNet-101 depth, eval-mode BN (the freeze_bn path; well conditioned): every one of the 340 parameter gradients
+    of the full PSPNet program against fp64 ground truth."""
+    state, x, gt, w, wl = _setup(False, size=65, batch=2, seed=23, layers=FULL)
+    o = _oracle_run(state, x, gt, w, wl, torch.float32, False, layers=FULL)
+    t = _oracle_run(state, x, gt, w, wl, torch.float64, False, layers=FULL)
+    e = _engine_run(state, x, gt, w, wl, torch.float32, False, layers=FULL)
+    print("full depth eval: logits %.2e latent %.2e" % (rel(e["logits"], t["logits"]), rel(e["latent"], t["latent"])))
+    assert rel(e["logits"], t["logits"]) < 1e-4
+    assert rel(e["latent"], t["latent"]) < 1e-4
+    rows = sorted(((rel(e["grads"][k], t["grads"][k]), rel(o["grads"][k], t["grads"][k]), k) for k in t["grads"]), reverse=True)
+    print("worst gradient %s: engine %.2e vs fp64 (reference fp32 %.2e)" % (rows[0][2], rows[0][0], rows[0][1]))
+    assert rows[0][0] < 1e-4, rows[:5]            # measured 2.4e-6
+
+
+@pytest.mark.gpu
+def test_pspnet_bf16_close_to_fp32():
+    """bf16 throughput mode: same program, bf16 operands / fp32 accumulation.  Stated tolerances: logits 5e-2 rel,
+    >= 90% argmax agreement with the fp32 engine, head-side gradients within 10%."""
+    state, x, gt, w, wl = _setup(False)
+    a = _engine_run(state, x, gt, w, wl, torch.float32, False)
+    b = _engine_run(state, x, gt, w, wl, torch.bfloat16, False)
+    print("bf16 vs fp32: logits %.3e latent %.3e" % (rel(b["logits"], a["logits"]), rel(b["latent"], a["latent"])))
+    assert rel(b["logits"], a["logits"]) < 5e-2
+    assert rel(b["latent"], a["latent"]) < 5e-2
+    assert (b["logits"].argmax(1) == a["logits"].argmax(1)).float().mean().item() > 0.9
+    for k in ("decoder.0.weight", "decoder.3.conv.weight", "psp.bottleneck.0.weight", "psp.stages.0.1.weight",
+              "psp.stages.3.1.weight", "psp.stages.1.2.weight"):
+        e = rel(b["grads"][k], a["grads"][k])
+        print("bf16 grad %-28s %.3e" % (k, e))
+        assert e < 0.2, k
+
+
+def _args(**kw):
+    import argparse
+    a = argparse.Namespace(backbone="resnet101", output_stride=16, num_classes=21, freeze_bn=False,
+                           lr=2.5e-4, momentum=0.9, weight_decay=5e-4, dampening=-1, nesterov=False,
+                           power=-1, last_epoch=-1, epochs=1, iters_per_epoch=4, ignore_index=255,
+                           labeled_batch_size=2, unlabeled_batch_size=0, ignore_unlabeled=True,
+                           is_epoch_lrer=False, log_freq=1000, task="sseg", engine_dtype="fp32")
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+@pytest.mark.gpu
+def test_pspnet_suponly_steps_vs_reference_fixture():
+    """SSLNULL train steps on the PSPNet TaskModel (3 lr groups) reproduce the reference's logged loss; post-step
+    weights move like the reference's (tolerances relative to the size of the update, see tests/test_gpu_net.py)."""
+    import pixelssl_amd as P
+    from pixelssl_amd.nn import optimizer as popt, lrer as plr
+    fx = _load("pspnet_suponly_65.pt")
+    args = _args(labeled_batch_size=fx["batch"], iters_per_epoch=fx["max_iters"])
+    algo = P.ssl_algorithm.ssl_null.ssl_null(args, {"model": P.sseg.model.pspnet()}, {"model": popt.sgd(args)},
+                                            {"model": plr.polynomiallr(args)},
+                                            {"model": P.sseg.criterion.sseg_criterion()}, None)
+    init = TO.init_pspnet_state(seed=fx["weight_seed"])
+    algo.model.module.model.load_state_dict(init)
+    algo.model.train()
+    assert [len(list(g["params"])) > 0 for g in algo.optimizer.param_groups] == [True, True, True]
+    losses = []
+    for s in fx["data_seeds"]:
+        x, gt = TO.synthetic_batch(fx["batch"], fx["size"], fx["batch"], seed=s, block=fx["block"])
+        loss, _ = algo.train_step((x.to(DEV),), (gt.to(DEV),))
+        losses.append(loss.item())
+    print("pspnet suponly losses", losses, "reference (oracle)", fx["oracle_losses"])
+    assert abs(losses[0] - fx["oracle_losses"][0]) < 1e-3 * abs(fx["oracle_losses"][0])
+    assert abs(losses[1] - fx["oracle_losses"][1]) < 8e-2 * abs(fx["oracle_losses"][1])
+    sd = algo.model.module.model.state_dict()
+    for k, ref in fx["probes"].items():
+        got = sd[k].detach().cpu().reshape(-1)[:64]
+        upd = (ref["head"] - init[k].reshape(-1)[:64].float()).abs().max().item()
+        assert (got - ref["head"]).abs().max().item() <= 1.25 * upd + 1e-6 * ref["head"].abs().max().item() + 1e-9, k
