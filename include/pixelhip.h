@@ -217,17 +217,44 @@ int pxl_pixshuf_relu_bwd(int dtype, int B, int h, int w, int Cp_in, int C, const
                          const void* in, void* din, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* SSLCCT auxiliary-decoder perturbations (pixelssl/ssl_algorithm/ssl_cct.py:535-745), NCHW fp32   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* out = x * mask[b][p] * cscale[b][c] * (1 + noise[c][p]) + add_scale * add (NULL factors skipped): x [B][C][HW].
+ * Covers Dropout2d (cscale), G-Cutout / Con-Msk / Obj-Msk / F-Drop (mask), F-Noise (noise), I-VAT (add); the same call
+ * with x = dout and add = NULL is the backward. */
+int pxl_latent_perturb(int B, int C, long HW, const float* x, const float* mask, const float* cscale, const float* noise,
+                       const float* add, float add_scale, float* out, void* stream);
+/* mask[b][i][j] = (argmax_c pred[b][:][..] > 0) (invert: 1 - ...) sampled like F.interpolate(mode='nearest') from
+ * [H][W] to [h][w]: the context / object masks of ssl_cct.py:664-676 */
+int pxl_fg_mask_nearest(int B, int C, int H, int W, const float* pred, int h, int w, int invert, float* mask, void* stream);
+/* att[b][p] = mean_c x[b][c][p] ; mask[b][p] = att[b][p] < max_p(att[b]) * u   (feature_dropout, ssl_cct.py:718-724) */
+int pxl_chan_mean(int B, int C, long HW, const float* x, float* att, void* stream);
+int pxl_fdrop_mask(int B, long HW, const float* att, float u, float* mask, void* stream);
+/* out[b] = scale * x[b] / (||x[b]||_2 + 1e-8)   (_l2_normalize, ssl_cct.py:577-581; scale = eps gives r_adv) */
+int pxl_l2_normalize_persample(int B, long n, const float* x, float scale, float* out, void* stream);
+/* out = (a - b) * scale: d KL(softmax(pred_hat) || pred) / d pred_hat with scale = 1/B (batchmean) */
+int pxl_sub_scale(long n, const float* a, const float* b, float scale, float* out, void* stream);
+/* HOST routine (no GPU): what G-Cutout's cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) + the `> 50 points`
+ * filter yield (ssl_cct.py:627-636): bounding boxes {min_x, max_x, min_y, max_y} of the external contours of the
+ * binary image mask[H][W] (host memory) whose border polygon has more than min_vertices vertices; *nboxes = number
+ * found (only the first max_boxes are written). */
+int pxl_external_contour_boxes_host(const uint8_t* mask, int H, int W, int min_vertices, int* boxes, int max_boxes,
+                                    int* nboxes);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Head tail + losses                                                                           */
 /* ------------------------------------------------------------------------------------------ */
 
-/* F.interpolate(bilinear, align_corners=True) + F.softmax(dim=1): low NHWC [B][h][w][Cp] ->
- * logits / prob NCHW fp32 [B][C][H][W] (prob may be NULL).  deeplab_v2.py:32, task/sseg/model.py:62 */
-int pxl_upsample_softmax_fwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W, const void* low,
-                             float* logits, float* prob, void* stream);
+/* F.interpolate(bilinear, align_corners) + F.softmax(dim=1): low NHWC [B][h][w][Cp] ->
+ * logits / prob NCHW fp32 [B][C][H][W] (prob may be NULL).  deeplab_v2.py:32, task/sseg/model.py:62 (align_corners =
+ * 1); ssl_cct.py:483 interpolates the auxiliary predictions with the default align_corners = 0 */
+int pxl_upsample_softmax_fwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners,
+                             const void* low, float* logits, float* prob, void* stream);
 size_t pxl_upsample_bwd_workspace(int B, int w, int C, int H);
 /* adjoint: dlow = U^T (dlogits + softmax_bwd(dprob, prob)); dlogits or dprob may be NULL */
-int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W, const float* dlogits,
-                             const float* dprob, const float* prob, void* dlow, void* workspace,
+int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners,
+                             const float* dlogits, const float* dprob, const float* prob, void* dlow, void* workspace,
                              size_t ws_bytes, void* stream);
 
 /* CommonSSEGCriterion (task/sseg/criterion.py:24-38): loss[n] = mean over ALL HW pixels of CE with
@@ -314,7 +341,8 @@ int pxl_scale_inplace(long n, float* x, float a, void* stream);
 #define PXL_OP_CONV 1       /* conv (+ optional BN statistics of the output)         */
 #define PXL_OP_MAXPOOL 2    /* 3x3/s2/p1 max-pool of relu(bn(in))                    */
 #define PXL_OP_RESIDUAL 3   /* out = relu(bn(in0) + (bn(in1) | in1))                 */
-#define PXL_OP_HEAD 4       /* upsample + softmax of the low-res logits -> outputs   */
+#define PXL_OP_HEAD 4       /* upsample + softmax of the low-res logits -> outputs (stride = 1: align_corners=True,
+                               stride = 0: align_corners=False)                                    */
 #define PXL_OP_ACT 5        /* out = LeakyReLU(in0, slope) (conv stacks without BN)  */
 #define PXL_OP_IBN 6        /* out = LeakyReLU(IBNorm(in0), slope); bn_out = BN half  */
 #define PXL_OP_AVGPOOL 7    /* out = AdaptiveAvgPool2d(kh)(in0)                      */
@@ -358,6 +386,9 @@ int pxl_net_create(int dtype, int num_classes, const pxl_op* ops, int nops, cons
 void pxl_net_destroy(pxl_net* net);
 /* plan buffers for a batch of B images of H x W; must be called before the *_bytes queries */
 int pxl_net_plan(pxl_net* net, int B, int H, int W);
+/* same, with the HEAD's output size given separately (SSLCCT auxiliary decoders: input = the 33x33 latent, output =
+ * the 513x513 image size, or the decoder's own 264x264 inside I-VAT) */
+int pxl_net_plan_out(pxl_net* net, int B, int H, int W, int Hout, int Wout);
 size_t pxl_net_packed_bytes(const pxl_net* net);     /* persistent packed-weight buffer            */
 size_t pxl_net_arena_bytes(const pxl_net* net);      /* activations saved between fwd and bwd      */
 size_t pxl_net_scratch_bytes(const pxl_net* net);    /* backward gradient buffers                  */

@@ -1,0 +1,120 @@
+"""Golden fixture for SSLCCT (row C1) from the REAL reference imported from /root/reference.
+Container-only; TEST INFRASTRUCTURE.
+
+    python oracle/make_golden_cct.py        # writes tests/golden/cct_65.pt
+
+Runs the reference's own `SSLCCT._train` (WrappedCCTModel: PSPNet + I-VAT / DropOut / Con-Msk / Obj-Msk / F-Drop /
+F-Noise auxiliary decoders; G-Cutout needs OpenCV, which this image does not have) for two iterations on seeded
+inputs, asserts that oracle/cct_oracle.py reproduces the logged losses and the post-step weights, and stores them
+together with the random draws the decoders consumed.
+"""
+import os
+import random
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim            # noqa: E402
+import torch_oracle as TO  # noqa: E402
+import cct_oracle as CO    # noqa: E402
+from make_golden import check, _ListLoader  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+BASE_CFG = dict(models={'model': 'pspnet'}, optimizers={'model': 'sgd'}, lrers={'model': 'polynomiallr'},
+                criterions={'model': 'sseg_criterion'}, lr=0.00025, momentum=0.9, weight_decay=0.0005,
+                output_stride=16, backbone='resnet101', epochs=1, log_freq=1000)
+
+DECODERS = [("vat", dict(xi=1e-6, eps=2.0)), ("drop", dict(rate=0.5, spatial=True)), ("context", {}), ("object", {}),
+            ("fd", {}), ("fn", dict(uniform=0.3))]
+
+MAIN_PROBES = ["backbone.conv1.weight", "backbone.layer4.2.conv2.weight", "psp.stages.0.1.weight",
+               "psp.stages.3.2.weight", "psp.bottleneck.0.weight", "psp.bottleneck.1.bias",
+               "psp.bottleneck.1.running_mean", "decoder.0.weight", "decoder.2.conv.bias"]
+AD_PROBES = ["upsample.0.weight", "upsample.1.conv.weight", "upsample.3.conv.bias"]
+
+
+def head(v):
+    v = v.detach().float().reshape(-1)
+    return dict(head=v[:64].clone(), sum=float(v.double().sum()), abssum=float(v.double().abs().sum()))
+
+
+def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234):
+    ref = ref_shim.load_reference()
+    pixelssl = ref['pixelssl']
+    from pixelssl.nn import optimizer as ropt, lrer as rlr
+    batch = lbs + ubs
+    args = ref_shim.make_args('ssl_cct', dict(BASE_CFG, batch_size=batch, unlabeled_batch_size=ubs, im_size=size,
+                                              ignore_unlabeled=False, cons_scale=30.0, cons_rampup_epochs=5,
+                                              ad_lr_scale=10.0, vat_dec_num=1, drop_dec_num=1, cut_dec_num=0,
+                                              context_dec_num=1, object_dec_num=1, fd_dec_num=1, fn_dec_num=1))
+    args.iters_per_epoch = 4
+    task_func = ref['func'].task_func()(args)
+    export = pixelssl.ssl_algorithm.__dict__['ssl_cct'].__dict__['ssl_cct']
+    algo = export(args, {'model': ref['model'].PSPNet}, {'model': ropt.sgd(args)}, {'model': rlr.polynomiallr(args)},
+                  {'model': ref['criterion'].CommonSSEGCriterion}, task_func)
+    state = TO.init_pspnet_state(seed=seed)
+    ad_states = [CO.init_decoder_state(seed + 100 + i) for i in range(len(DECODERS))]
+    wrapped = algo.model.module
+    wrapped.main_model.load_state_dict(OrderedDict(("model." + k, v.clone()) for k, v in state.items()))
+    kinds = [type(m).__name__ for m in wrapped.auxiliary_decoders]
+    print("reference decoders:", kinds)
+    for m, sd in zip(wrapped.auxiliary_decoders, ad_states):
+        m.load_state_dict(OrderedDict((k, v.clone()) for k, v in sd.items()))
+    batches = [TO.synthetic_batch(batch, size, lbs, seed=seed + 10 + i, block=16) for i in range(iters)]
+    loader = _ListLoader([((x,), (gt,)) for x, gt in batches])
+
+    torch.manual_seed(rng_seed); np.random.seed(rng_seed); random.seed(rng_seed)
+    algo._train(loader, 0)
+    meters = {k: float(algo.meters[k].avg) for k in ('task_loss', 'cons_loss')}
+    ref_main = OrderedDict((k[len("model."):], v) for k, v in wrapped.main_model.state_dict().items())
+    ref_ads = [m.state_dict() for m in wrapped.auxiliary_decoders]
+
+    # ---- the restatement, same RNG streams
+    torch.manual_seed(rng_seed); np.random.seed(rng_seed); random.seed(rng_seed)
+    decs = [(k, c, OrderedDict((n, v.clone()) for n, v in sd.items())) for (k, c), sd in zip(DECODERS, ad_states)]
+    tr = CO.CCTOracleTrainer(TO.clone_state(state), decs,
+                             dict(max_iters=args.epochs * args.iters_per_epoch, cons_scale=30.0,
+                                  cons_rampup_iters=len(loader) * 5, ad_lr_scale=10.0))
+    outs = [tr.cct_step(x, gt, lbs) for x, gt in batches]
+    print("case cct:")
+    for k in meters:
+        check("mean " + k, sum(o[k] for o in outs) / len(outs), meters[k])
+    for k in MAIN_PROBES:
+        check("main " + k, tr.sd[k], ref_main[k], rtol=2e-5)
+    for i, (kind, _, sd) in enumerate(tr.decoders):
+        for k in AD_PROBES:
+            check("decoder %d (%s) %s" % (i, kind, k), sd[k], ref_ads[i][k], rtol=2e-5)
+
+    # draws are replayable: the oracle fed with its own recorded draws gives the same losses
+    tr2 = CO.CCTOracleTrainer(TO.clone_state(state),
+                              [(k, c, OrderedDict((n, v.clone()) for n, v in sd.items())) for (k, c), sd in zip(DECODERS, ad_states)],
+                              dict(max_iters=args.epochs * args.iters_per_epoch, cons_scale=30.0,
+                                   cons_rampup_iters=len(loader) * 5, ad_lr_scale=10.0))
+    o0 = tr2.cct_step(batches[0][0], batches[0][1], lbs, draws=outs[0]["draws"])
+    check("replayed draws: cons", o0["cons_loss"], outs[0]["cons_loss"])
+
+    g0 = outs[0]
+    fx = dict(kind="cct", size=size, lbs=lbs, ubs=ubs, weight_seed=seed, decoder_seeds=[seed + 100 + i for i in range(len(DECODERS))],
+              decoders=DECODERS, data_seeds=[seed + 10 + i for i in range(iters)], block=16,
+              max_iters=args.epochs * args.iters_per_epoch, rampup_iters=len(loader) * 5,
+              meters=meters, per_iter=[dict(task_loss=o["task_loss"], cons_loss=o["cons_loss"]) for o in outs],
+              draws=[o["draws"] for o in outs],
+              grads0={k: head(g0["grads"][k]) for k in MAIN_PROBES if k in g0["grads"]},
+              ad_grads0=[{k: head(g[k]) for k in AD_PROBES} for g in g0["ad_grads"]],
+              main_probes={k: head(ref_main[k]) for k in MAIN_PROBES},
+              ad_probes=[{k: head(sd[k]) for k in AD_PROBES} for sd in ref_ads])
+    torch.save(fx, os.path.join(OUT, "cct_%d.pt" % size))
+
+
+if __name__ == "__main__":
+    if not ref_shim.reference_available():
+        raise SystemExit("reference tree not available; fixtures can only be generated in the build container")
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    case_cct()
+    print("golden fixtures written to", OUT)

@@ -98,9 +98,16 @@ SIGNATURES = {
     "pxl_slice_copy": (_I, [_I, _L, _I, _P, _I, _I, _P, _I, _I, _I, _P]),
     "pxl_pixshuf_relu_fwd": (_I, [_I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "pxl_pixshuf_relu_bwd": (_I, [_I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P]),
-    "pxl_upsample_softmax_fwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "pxl_latent_perturb": (_I, [_I, _I, _L, _P, _P, _P, _P, _P, _F, _P, _P]),
+    "pxl_fg_mask_nearest": (_I, [_I, _I, _I, _I, _P, _I, _I, _I, _P, _P]),
+    "pxl_chan_mean": (_I, [_I, _I, _L, _P, _P, _P]),
+    "pxl_fdrop_mask": (_I, [_I, _L, _P, _F, _P, _P]),
+    "pxl_l2_normalize_persample": (_I, [_I, _L, _P, _F, _P, _P]),
+    "pxl_sub_scale": (_I, [_L, _P, _P, _F, _P, _P]),
+    "pxl_external_contour_boxes_host": (_I, [_P, _I, _I, _I, _P, _I, C.POINTER(_I)]),
+    "pxl_upsample_softmax_fwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "pxl_upsample_bwd_workspace": (_Z, [_I, _I, _I, _I]),
-    "pxl_upsample_softmax_bwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "pxl_upsample_softmax_bwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "pxl_ce_fwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P]),
     "pxl_ce_bwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "pxl_bce_logits_masked_fwd": (_I, [_I, _L, _P, _P, _I, _F, _P, _P]),
@@ -126,6 +133,7 @@ SIGNATURES = {
     "pxl_net_create": (_I, [_I, _I, C.POINTER(Op), _I, C.POINTER(BnDesc), _I, _I, C.POINTER(_P)]),
     "pxl_net_destroy": (None, [_P]),
     "pxl_net_plan": (_I, [_P, _I, _I, _I]),
+    "pxl_net_plan_out": (_I, [_P, _I, _I, _I, _I, _I]),
     "pxl_net_packed_bytes": (_Z, [_P]),
     "pxl_net_arena_bytes": (_Z, [_P]),
     "pxl_net_scratch_bytes": (_Z, [_P]),

@@ -1,4 +1,4 @@
-// Segmentation head tail: bilinear up-sampling (align_corners=True) of the low-resolution logits
+// Segmentation head tail: bilinear up-sampling (align_corners=True, or False for SSLCCT's auxiliary decoders) of the low-resolution logits
 // to the input size, fused with the channel soft-max (deeplab_v2.py:32, task/sseg/model.py:62),
 // and its backward (adjoint of the interpolation, with the soft-max Jacobian folded in).
 //
@@ -12,9 +12,11 @@ namespace {
 
 constexpr int MAXC = 32;
 
-__device__ __forceinline__ void src_coord(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
-  // PyTorch area_pixel_compute_source_index(align_corners=True): src = scale * dst
-  const float src = scale * (float)o;
+// PyTorch area_pixel_compute_source_index: align_corners=True: src = scale * dst with scale = (in-1)/(out-1);
+// align_corners=False (the F.interpolate default, used on SSLCCT's auxiliary predictions): src = max(0,
+// scale * (dst + 0.5) - 0.5) with scale = in/out.  `align` selects the formula.
+__device__ __forceinline__ void src_coord(int o, float scale, int align, int in_size, int& i0, int& i1, float& l1) {
+  const float src = align ? scale * (float)o : fmaxf(scale * ((float)o + 0.5f) - 0.5f, 0.f);
   i0 = (int)src;
   if (i0 > in_size - 1) i0 = in_size - 1;
   i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
@@ -23,7 +25,7 @@ __device__ __forceinline__ void src_coord(int o, float scale, int in_size, int& 
 
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_softmax_fwd_kernel(int B, int h, int w, int Cp, int C, int H,
-                                                                   int W, float sy, float sx,
+                                                                   int W, float sy, float sx, int align,
                                                                    const T* __restrict__ low,
                                                                    float* __restrict__ logits,
                                                                    float* __restrict__ prob) {
@@ -33,8 +35,8 @@ __global__ __launch_bounds__(256) void upsample_softmax_fwd_kernel(int B, int h,
   if (x >= W) return;
   int y0, y1, x0, x1;
   float ly, lx;
-  src_coord(y, sy, h, y0, y1, ly);
-  src_coord(x, sx, w, x0, x1, lx);
+  src_coord(y, sy, align, h, y0, y1, ly);
+  src_coord(x, sx, align, w, x0, x1, lx);
   const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
   const T* p00 = low + ((size_t)(b * h + y0) * w + x0) * Cp;
   const T* p01 = low + ((size_t)(b * h + y0) * w + x1) * Cp;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void upsample_softmax_fwd_kernel(int B, int h,
 
 // pass 1 (one block per full-res row): G = dlogits + softmax_bwd(dprob, prob) ; reduce along x onto
 // the w low-res columns:  tmp[b][y][x0][c] = sum_x wx(x,x0) * G[b][c][y][x]
-__global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(int C, int H, int W, int w, float sx,
+__global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(int C, int H, int W, int w, float sx, int align,
                                                                 const float* __restrict__ dlogits,
                                                                 const float* __restrict__ dprob,
                                                                 const float* __restrict__ prob,
@@ -96,15 +98,16 @@ __global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(int C, int H, in
   for (int o = threadIdx.x; o < w * C; o += blockDim.x) {
     const int c = o % C, x0 = o / C;
     // candidate range: x in ((x0-1)/sx, (x0+1)/sx)
-    int xlo = (int)floorf((float)(x0 - 1) / sx) - 1;
-    int xhi = (int)ceilf((float)(x0 + 1) / sx) + 1;
+    const float xoff = align ? 0.f : 0.5f;     // dst = (src + off) / scale - off
+    int xlo = (int)floorf(((float)(x0 - 1) + xoff) / sx - xoff) - 1;
+    int xhi = (int)ceilf(((float)(x0 + 1) + xoff) / sx - xoff) + 1;
     if (xlo < 0) xlo = 0;
     if (xhi > W - 1) xhi = W - 1;
     float acc = 0.f;
     for (int x = xlo; x <= xhi; ++x) {
       int i0, i1;
       float l1;
-      src_coord(x, sx, w, i0, i1, l1);
+      src_coord(x, sx, align, w, i0, i1, l1);
       float wgt = 0.f;
       if (i0 == x0) wgt += 1.f - l1;
       if (i1 == x0) wgt += l1;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(int C, int H, in
 // channels zeroed)
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(int B, int h, int w, int Cp, int C, int H,
-                                                                float sy, const float* __restrict__ tmp,
+                                                                float sy, int align, const float* __restrict__ tmp,
                                                                 T* __restrict__ dlow) {
   const long total = (long)B * h * w * Cp;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -129,14 +132,15 @@ __global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(int B, int h, in
     const int b = (int)(r / h);
     float acc = 0.f;
     if (c < C) {
-      int ylo = (int)floorf((float)(y0 - 1) / sy) - 1;
-      int yhi = (int)ceilf((float)(y0 + 1) / sy) + 1;
+      const float yoff = align ? 0.f : 0.5f;
+      int ylo = (int)floorf(((float)(y0 - 1) + yoff) / sy - yoff) - 1;
+      int yhi = (int)ceilf(((float)(y0 + 1) + yoff) / sy - yoff) + 1;
       if (ylo < 0) ylo = 0;
       if (yhi > H - 1) yhi = H - 1;
       for (int y = ylo; y <= yhi; ++y) {
         int i0, i1;
         float l1;
-        src_coord(y, sy, h, i0, i1, l1);
+        src_coord(y, sy, align, h, i0, i1, l1);
         float wgt = 0.f;
         if (i0 == y0) wgt += 1.f - l1;
         if (i1 == y0) wgt += l1;
@@ -149,20 +153,21 @@ __global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(int B, int h, in
 
 }  // namespace
 
-extern "C" int pxl_upsample_softmax_fwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W,
+extern "C" int pxl_upsample_softmax_fwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners,
                                         const void* low, float* logits, float* prob, void* stream) {
   PXL_REQUIRE(low && logits, "upsample_softmax_fwd: null argument");
   PXL_REQUIRE(C >= 1 && C <= MAXC && C <= Cp, "upsample_softmax_fwd: C=%d unsupported (max %d)", C, MAXC);
   PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "upsample_softmax_fwd: bad dtype");
-  const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
-  const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  const int align = align_corners ? 1 : 0;
+  const float sy = align ? (H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f) : (float)h / (float)H;
+  const float sx = align ? (W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f) : (float)w / (float)W;
   dim3 grid(cdiv(W, 256), H, B);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(upsample_softmax_fwd_kernel<float>, grid, dim3(256), 0, s, B, h, w, Cp, C, H, W, sy, sx,
+    hipLaunchKernelGGL(upsample_softmax_fwd_kernel<float>, grid, dim3(256), 0, s, B, h, w, Cp, C, H, W, sy, sx, align,
                        (const float*)low, logits, prob);
   else
-    hipLaunchKernelGGL(upsample_softmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, B, h, w, Cp, C, H, W, sy, sx,
+    hipLaunchKernelGGL(upsample_softmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, B, h, w, Cp, C, H, W, sy, sx, align,
                        (const bf16_t*)low, logits, prob);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
@@ -172,7 +177,7 @@ extern "C" size_t pxl_upsample_bwd_workspace(int B, int w, int C, int H) {
   return (size_t)B * H * w * C * sizeof(float);
 }
 
-extern "C" int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W,
+extern "C" int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners,
                                         const float* dlogits, const float* dprob, const float* prob,
                                         void* dlow, void* workspace, size_t ws_bytes, void* stream) {
   PXL_REQUIRE(dlow && workspace, "upsample_softmax_bwd: null argument");
@@ -183,22 +188,23 @@ extern "C" int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, 
   if (ws_bytes < pxl_upsample_bwd_workspace(B, w, C, H))
     return pxl_set_error(PXL_ERR_WORKSPACE, "upsample_softmax_bwd: workspace too small");
   PXL_REQUIRE(H > 1 && W > 1 && h > 1 && w > 1, "upsample_softmax_bwd: degenerate sizes");
-  const float sy = (float)(h - 1) / (float)(H - 1);
-  const float sx = (float)(w - 1) / (float)(W - 1);
+  const int align = align_corners ? 1 : 0;
+  const float sy = align ? (float)(h - 1) / (float)(H - 1) : (float)h / (float)H;
+  const float sx = align ? (float)(w - 1) / (float)(W - 1) : (float)w / (float)W;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t smem = (size_t)C * (W + 1) * sizeof(float);
   PXL_REQUIRE(smem <= 64 * 1024, "upsample_softmax_bwd: row too wide for LDS staging (W=%d)", W);
-  hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(H, B), dim3(256), smem, s, C, H, W, w, sx, dlogits, dprob,
+  hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(H, B), dim3(256), smem, s, C, H, W, w, sx, align, dlogits, dprob,
                      prob, (float*)workspace);
   PXL_LAUNCH_CHECK();
   const long total = (long)B * h * w * Cp;
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(upsample_bwd_cols_kernel<float>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy,
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<float>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
                        (const float*)workspace, (float*)dlow);
   else
-    hipLaunchKernelGGL(upsample_bwd_cols_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy,
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
                        (const float*)workspace, (bf16_t*)dlow);
   PXL_LAUNCH_CHECK();
   return PXL_OK;

@@ -83,6 +83,7 @@ struct pxl_net {
   std::vector<BnInfo> bns;
   std::vector<TensorInfo> tensors;
   int B = 0, H = 0, W = 0;
+  int Ho = 0, Wo = 0;              // HEAD output size (== H, W unless planned with pxl_net_plan_out)
   bool planned = false;
   size_t packed_bytes = 0, arena_bytes = 0, scratch_bytes = 0;
   size_t stats_region_off = 0, stats_region_bytes = 0;      // arena: all BN forward sums
@@ -293,9 +294,11 @@ extern "C" int pxl_net_profile_bytes(pxl_net* net, int kind, double* bytes) {
   return PXL_OK;
 }
 
-extern "C" int pxl_net_plan(pxl_net* n, int B, int H, int W) {
-  PXL_REQUIRE(n && B > 0 && H > 0 && W > 0, "net_plan: bad argument");
-  n->B = B; n->H = H; n->W = W;
+extern "C" int pxl_net_plan(pxl_net* n, int B, int H, int W) { return pxl_net_plan_out(n, B, H, W, H, W); }
+
+extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int Wout) {
+  PXL_REQUIRE(n && B > 0 && H > 0 && W > 0 && Hout > 0 && Wout > 0, "net_plan: bad argument");
+  n->B = B; n->H = H; n->W = W; n->Ho = Hout; n->Wo = Wout;
   n->planned = false;
   for (auto& t : n->tensors) t = TensorInfo();
   size_t arena = 0, scratch = 0, packed = 0;
@@ -427,7 +430,7 @@ extern "C" int pxl_net_plan(pxl_net* n, int B, int H, int W) {
         PXL_REQUIRE(n->tensors[d.in0].C == n->classes, "net_plan: head input has %d channels, expected %d",
                     n->tensors[d.in0].C, n->classes);
         n->up_ws_off = scratch;
-        n->up_ws_bytes = align_up((size_t)B * H * n->tensors[d.in0].W * n->classes * 4);
+        n->up_ws_bytes = align_up((size_t)B * n->Ho * n->tensors[d.in0].W * n->classes * 4);
         scratch += n->up_ws_bytes;
         break;
       }
@@ -715,7 +718,7 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
       }
       case PXL_OP_HEAD: {
         const TensorInfo& low = n->tensors[d.in0];
-        rc = pxl_upsample_softmax_fwd(dt, n->B, low.H, low.W, low.Cp, n->classes, n->H, n->W, at(arena, low.off),
+        rc = pxl_upsample_softmax_fwd(dt, n->B, low.H, low.W, low.Cp, n->classes, n->Ho, n->Wo, d.stride, at(arena, low.off),
                                       logits, prob, stream);
         break;
       }
@@ -803,7 +806,7 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
     switch (d.kind) {
       case PXL_OP_HEAD: {
         const TensorInfo& low = n->tensors[d.in0];
-        rc = pxl_upsample_softmax_bwd(dt, n->B, low.H, low.W, low.Cp, n->classes, n->H, n->W, dlogits, dprob, prob,
+        rc = pxl_upsample_softmax_bwd(dt, n->B, low.H, low.W, low.Cp, n->classes, n->Ho, n->Wo, d.stride, dlogits, dprob, prob,
                                       at(scratch, low.goff), at(scratch, n->up_ws_off), n->up_ws_bytes, stream);
         written[d.in0] = 1;
         break;

@@ -205,8 +205,8 @@ class ProgramBuilder:
         self._op(_lib.OP_PIXSHUF, in0=t_in, out=t, cin=cin, cout=cin // 4)
         return t
 
-    def head(self, t_low, t_latent, bn_latent=-1):
-        self._op(_lib.OP_HEAD, in0=t_low, in1=t_latent, bn_in1=bn_latent)
+    def head(self, t_low, t_latent, bn_latent=-1, align_corners=True):
+        self._op(_lib.OP_HEAD, in0=t_low, in1=t_latent, bn_in1=bn_latent, stride=int(bool(align_corners)))
 
 
 def build_resnet_trunk(pb, prefix, layers, output_stride=16):
@@ -265,6 +265,7 @@ class SegNetCore(nn.Module):
         self.autotune = os.environ.get("PXL_AUTOTUNE", "1") != "0"
         self.want_prob = True           # HEAD also returns softmax(logits) (segmentation nets; not the discriminators)
         self.has_latent = True
+        self.differentiable_latent = False   # SSLCCT: the latent handed out by forward() carries autograd history
         self._wgrad_on = True
 
     # -- construction -----------------------------------------------------------------------
@@ -351,18 +352,20 @@ class SegNetCore(nn.Module):
         return fresh
 
     # -- planning ---------------------------------------------------------------------------
-    def _plan(self, B, H, W):
+    def _plan(self, B, H, W, out_size=None):
         """Select (or create) the executor instance planned for this input shape.  Networks that see several
         batch sizes per iteration (the AdvSSL discriminator: B fake + lbs real maps) keep one plan each, so a
-        backward always runs on the plan its forward used."""
-        key = (B, H, W)
+        backward always runs on the plan its forward used.  `out_size` = (Hout, Wout) of the HEAD when it differs
+        from the input size (SSLCCT auxiliary decoders)."""
+        out_size = tuple(out_size) if out_size is not None else (H, W)
+        key = (B, H, W) + out_size
         pl = self._plans.get(key)
         if pl is None:
-            pl = _Plan(key)
+            pl = _Plan((B, H, W), out_size)
             pb = self._pb
             check(lib().pxl_net_create(self._code, self.num_classes, self._ops_arr, len(pb.ops), self._bns_arr,
                                        len(pb.bns), pb.ntensors, ctypes.byref(pl.net)))
-            check(lib().pxl_net_plan(pl.net, B, H, W))
+            check(lib().pxl_net_plan_out(pl.net, B, H, W, out_size[0], out_size[1]))
             dev = self._device
             pl.packed = torch.empty(lib().pxl_net_packed_bytes(pl.net), device=dev, dtype=torch.uint8)
             pl.scratch = torch.empty(lib().pxl_net_scratch_bytes(pl.net), device=dev, dtype=torch.uint8)
@@ -418,7 +421,8 @@ class SegNetCore(nn.Module):
             self._wgrad_on = bool(enable)
 
     def _forward_raw(self, x, arena, want_prob=None):
-        B, _, H, W = x.shape
+        B = x.shape[0]
+        H, W = self._cur.out_size
         want_prob = self.want_prob if want_prob is None else want_prob
         logits = torch.empty(B, self.num_classes, H, W, device=x.device, dtype=torch.float32)
         prob = torch.empty_like(logits) if want_prob else None
@@ -435,15 +439,19 @@ class SegNetCore(nn.Module):
             self._bn_cache = [m for m in self.modules() if isinstance(m, SynchronizedBatchNorm2d)]
         return self._bn_cache
 
-    def forward(self, x):
+    def forward(self, x, out_size=None):
         """x: NCHW fp32 on the GPU -> (logits, softmax, latent_fn) with autograd attached."""
         if not x.is_cuda:
             raise _lib.PixelHipError("SegNetCore runs on the GPU only (input is on %s); there is no CPU path" % x.device)
         x = x.contiguous().float()
         B, _, H, W = x.shape
-        self._plan(B, H, W)
+        self._plan(B, H, W, out_size)
         self._ensure_packed()
         need_graph = torch.is_grad_enabled() and (any(p.requires_grad for p in self._param_list[:1]) or x.requires_grad)
+        if need_graph and self.differentiable_latent and self.has_latent:
+            arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
+            logits, prob, latent = _SegNetFn.apply(x, self._anchor, self, arena, True)
+            return logits, prob, (lambda: latent)
         if need_graph:
             arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
             logits, prob, _ = _SegNetFn.apply(x, self._anchor, self, arena, False)
@@ -506,8 +514,9 @@ class SegNetCore(nn.Module):
 class _Plan:
     """One executor instance (csrc/net.cpp pxl_net) planned for a fixed input shape, with its buffers."""
 
-    def __init__(self, shape):
+    def __init__(self, shape, out_size=None):
         self.shape = shape
+        self.out_size = tuple(out_size) if out_size is not None else tuple(shape[1:])
         self.net = ctypes.c_void_p()
         self.packed = self.scratch = self.eval_arena = None
         self.packed_version = None
@@ -542,7 +551,7 @@ class _SegNetFn(torch.autograd.Function):
         if dlogits is None and dprob is None and dlatent is None:
             return None, None, None, None, None
         if dlogits is None and dprob is None:           # only the latent carries a gradient
-            dlogits = torch.zeros((ctx.x_shape[0], core.num_classes) + ctx.x_shape[2:], device=core._device)
+            dlogits = torch.zeros((ctx.x_shape[0], core.num_classes) + ctx.plan.out_size, device=core._device)
         if dlogits is not None:
             dlogits = dlogits.contiguous()
         if dprob is not None:
@@ -724,6 +733,45 @@ class PSPNetCore(SegNetCore):
 
     def get_decoder_params(self):
         return (p for n, p in self.named_parameters() if n.startswith("decoder") and p.requires_grad)
+
+
+class AuxDecoderCore(SegNetCore):
+    """One SSLCCT auxiliary decoder body: `upsample(in_channels, num_classes, upscale)` (ssl_cct.py:524-532) on the
+    encoder latent, followed by the bilinear (align_corners=False) resize + soft-max that WrappedCCTModel applies to
+    every auxiliary prediction (ssl_cct.py:483-484) -- the resize target is the `out_size` of the call.  The input is
+    the (perturbed) latent, NCHW fp32, and its gradient is returned to autograd.  Parameter names: 0, {1..}.conv (the
+    module is attached as `.upsample` of the decoder, so checkpoints read auxiliary_decoders.k.upsample.*)."""
+
+    def __init__(self, upscale, in_channels, num_classes, device="cuda", engine_dtype=torch.float32):
+        super().__init__(device, engine_dtype, num_classes)
+        self.has_latent = False
+        self.upscale = upscale
+        pb = self._pb
+        x = pb.input(in_channels)
+        low = self._build(pb, x, in_channels, num_classes, upscale)
+        pb.head(low, -1, align_corners=False)
+        self._finalize()
+        self.reset_parameters()
+
+    @staticmethod
+    def _build(pb, x, in_channels, num_classes, upscale):
+        t = pb.conv("0", x, -1, in_channels, num_classes, 1, 1, 1, 0)
+        for i in range(1, int(round(math.log(upscale, 2))) + 1):
+            y = pb.conv("%d.conv" % i, t, -1, num_classes, num_classes * 4, 1, 1, 1, 0, bias=True)
+            t = pb.pixshuf(y, num_classes * 4)
+        return t
+
+    @torch.no_grad()
+    def reset_parameters(self, generator=None):
+        for name, prm in self.named_parameters():
+            if name == "0.weight":
+                prm.copy_(torch.randn(prm.shape, generator=generator) * math.sqrt(2.0 / prm.shape[1]))
+            elif name.endswith("conv.weight"):
+                base = torch.randn(prm.shape[0] // 4, prm.shape[1], 1, 1, generator=generator) * math.sqrt(2.0 / prm.shape[1])
+                prm.copy_(base.repeat_interleave(4, dim=0))
+            elif name.endswith("conv.bias"):
+                bound = 1.0 / math.sqrt(prm.shape[0] // 4)
+                prm.copy_((torch.rand(prm.shape, generator=generator) * 2 - 1) * bound)
 
 
 class FCDiscriminatorCore(SegNetCore):

@@ -212,22 +212,22 @@ def pixshuf_relu_bwd(dout, x, C):
     return din
 
 
-def upsample_softmax_fwd(low, C, H, W, want_prob=True):
+def upsample_softmax_fwd(low, C, H, W, want_prob=True, align_corners=True):
     B, h, w, Cp = low.shape
     logits = torch.empty(B, C, H, W, device=low.device, dtype=torch.float32)
     prob = torch.empty_like(logits) if want_prob else None
-    check(lib().pxl_upsample_softmax_fwd(dtype_code(low.dtype), B, h, w, Cp, C, H, W, ptr(low), ptr(logits),
+    check(lib().pxl_upsample_softmax_fwd(dtype_code(low.dtype), B, h, w, Cp, C, H, W, int(align_corners), ptr(low), ptr(logits),
                                          ptr(prob), stream_ptr()))
     return logits, prob
 
 
-def upsample_softmax_bwd(dtype, dlogits, dprob, prob, h, w, Cp):
+def upsample_softmax_bwd(dtype, dlogits, dprob, prob, h, w, Cp, align_corners=True):
     ref = dlogits if dlogits is not None else dprob
     B, Cc, H, W = ref.shape
     dlow = torch.empty(B, h, w, Cp, device=ref.device, dtype=_lib.torch_dtype(dtype_code(dtype)))
     nbytes = lib().pxl_upsample_bwd_workspace(B, w, Cc, H)
     ws = torch.empty(nbytes, device=ref.device, dtype=torch.uint8)
-    check(lib().pxl_upsample_softmax_bwd(dtype_code(dtype), B, h, w, Cp, Cc, H, W, ptr(dlogits), ptr(dprob), ptr(prob),
+    check(lib().pxl_upsample_softmax_bwd(dtype_code(dtype), B, h, w, Cp, Cc, H, W, int(align_corners), ptr(dlogits), ptr(dprob), ptr(prob),
                                          ptr(dlow), ptr(ws), nbytes, stream_ptr()))
     return dlow
 

@@ -53,3 +53,21 @@ class SSEGFunc(func_template.TaskFunc):
 
     def sslgct_prepare_task_gt_for_fdgt(self, task_gt):
         return gct_modules.onehot_ignore(task_gt, self.args.num_classes, ignore_index=self.args.ignore_index)
+
+    # ---- SSL_CCT (task/sseg/func.py:216-253)
+    def sslcct_activate_ad_preds(self, ad_preds):
+        return [torch.softmax(p, dim=1) for p in ad_preds]
+
+    def sslcct_ad_in_channels(self):
+        arch = self.args.models['model'] if hasattr(self.args, 'models') else 'pspnet'
+        if arch == 'pspnet':
+            return 512
+        if arch == 'deeplabv2':
+            return 2048
+        raise NotImplementedError("sslcct_ad_in_channels: model '%s'" % arch)
+
+    def sslcct_ad_out_channels(self):
+        return self.args.num_classes
+
+    def sslcct_ad_upsample_scale(self):
+        return 8

@@ -1,0 +1,272 @@
+"""SSLCCT.
+
+not gpu: the oracle (oracle/cct_oracle.py) against the fixture generated from the reference's own SSLCCT._train, the
+host contour routine of G-Cutout (C-ABI, no GPU) against the oracle's restatement of the published algorithm.
+gpu: perturbation kernels vs torch, every auxiliary decoder (forward, latent gradient, parameter gradients) vs the
+oracle with the reference's random draws replayed, and the mirrored training step vs the reference's logged losses.
+"""
+import argparse
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+FX = os.path.join(ROOT, "tests", "golden", "cct_65.pt")
+DEV = "cuda"
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+def _trainer(fx):
+    import torch_oracle as TO
+    import cct_oracle as CO
+    decs = [(k, c, CO.init_decoder_state(s)) for (k, c), s in zip(fx["decoders"], fx["decoder_seeds"])]
+    return CO.CCTOracleTrainer(TO.init_pspnet_state(seed=fx["weight_seed"]), decs,
+                               dict(max_iters=fx["max_iters"], cons_scale=30.0, cons_rampup_iters=fx["rampup_iters"],
+                                    ad_lr_scale=10.0))
+
+
+def test_oracle_reproduces_reference_fixture():
+    """Two SSLCCT iterations with the reference's draws replayed: logged losses + post-step weights of the reference."""
+    import torch_oracle as TO
+    fx = torch.load(FX, weights_only=False)
+    tr = _trainer(fx)
+    B = fx["lbs"] + fx["ubs"]
+    for i, s in enumerate(fx["data_seeds"]):
+        x, gt = TO.synthetic_batch(B, fx["size"], fx["lbs"], seed=s, block=fx["block"])
+        out = tr.cct_step(x, gt, fx["lbs"], draws=fx["draws"][i])
+        for k in ("task_loss", "cons_loss"):
+            assert abs(out[k] - fx["per_iter"][i][k]) <= 1e-5 * abs(fx["per_iter"][i][k]) + 1e-9, (i, k)
+    for k, ref in fx["main_probes"].items():
+        v = tr.sd[k].detach().float().reshape(-1)
+        assert (v[:64] - ref["head"]).abs().max().item() <= 2e-5 * ref["head"].abs().max().item() + 1e-7, k
+    for i, probes in enumerate(fx["ad_probes"]):
+        for k, ref in probes.items():
+            v = tr.decoders[i][2][k].detach().float().reshape(-1)
+            assert (v[:64] - ref["head"]).abs().max().item() <= 2e-5 * ref["head"].abs().max().item() + 1e-7, (i, k)
+
+
+def _blob_mask(H, W, n, seed):
+    r = np.random.RandomState(seed)
+    m = np.zeros((H, W), np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for _ in range(n):
+        cy, cx, ry, rx = r.randint(0, H), r.randint(0, W), r.randint(3, H // 3), r.randint(3, W // 3)
+        m |= ((((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) < 1).astype(np.uint8)
+    for _ in range(n // 2):                      # holes with islands inside (islands are NOT external contours)
+        cy, cx, ry, rx = r.randint(0, H), r.randint(0, W), r.randint(2, H // 6), r.randint(2, W // 6)
+        m &= 1 - ((((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) < 1).astype(np.uint8)
+        m[max(cy - 1, 0):cy + 1, max(cx - 1, 0):cx + 1] = 1
+    return m | (r.rand(H, W) < 0.02).astype(np.uint8)
+
+
+def test_contour_boxes_host_routine_matches_restatement():
+    """C-ABI host routine (csrc/contour.cpp) == the oracle's pure-python border following, incl. empty / full / frame-
+    touching / nested masks.  (Parity with OpenCV itself is unpinned: cv2 is not installed, see cct_oracle.py.)"""
+    import cct_oracle as CO
+    from pixelssl_amd.ssl_algorithm import ssl_cct as C
+    cases = [_blob_mask(97, 113, 6, s) for s in range(5)]
+    cases += [np.zeros((33, 33), np.uint8), np.ones((33, 33), np.uint8)]
+    ring = np.zeros((80, 80), np.uint8)
+    yy, xx = np.mgrid[0:80, 0:80]
+    rr = (yy - 40) ** 2 + (xx - 40) ** 2
+    ring[(rr < 38 ** 2) & (rr > 25 ** 2)] = 1          # an annulus with a large island in its hole
+    ring[rr < 15 ** 2] = 1
+    cases.append(ring)
+    for m in cases:
+        for mv in (50, 4, 0):
+            assert C.external_contour_boxes(m, mv) == CO.external_contour_boxes(m, mv)
+    assert len(C.external_contour_boxes(ring, 4)) == 1     # the island inside the hole is not an external contour
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_perturbation_kernels_match_torch():
+    from pixelssl_amd.ssl_algorithm import ssl_cct as C
+    g = torch.Generator().manual_seed(3)
+    B, Cc, h, w = 3, 64, 9, 7
+    x = torch.randn(B, Cc, h, w, generator=g)
+    mask = (torch.rand(B, h, w, generator=g) > 0.4).float()
+    cs = (torch.rand(B, Cc, generator=g) > 0.5).float() * 2
+    noise = (torch.rand(Cc, h, w, generator=g) * 2 - 1) * 0.3
+    add = torch.randn(B, Cc, h, w, generator=g)
+    xd = x.to(DEV).requires_grad_(True)
+    out = C.perturb(xd, mask.to(DEV), cs.to(DEV), noise.to(DEV), add.to(DEV), 0.25)
+    xr = x.clone().requires_grad_(True)
+    ref = xr * mask[:, None] * cs[:, :, None, None] * (1 + noise[None]) + 0.25 * add
+    assert rel(out.detach().cpu(), ref.detach()) < 1e-6
+    dout = torch.randn(ref.shape, generator=g)
+    ref.backward(dout)
+    out.backward(dout.to(DEV))
+    assert rel(xd.grad.cpu(), xr.grad) < 1e-6
+    # foreground masks (argmax > 0, nearest resize; ties resolve to the first maximum = background)
+    pred = torch.randn(B, 21, 65, 65, generator=g)
+    pred[0, :, :5] = 1.0
+    for size in ((5, 5), (9, 7), (65, 65)):
+        refm = F.interpolate((pred.argmax(1) > 0).float().unsqueeze(1), size=size, mode="nearest")[:, 0]
+        assert torch.equal(C.fg_mask_nearest(pred.to(DEV), size).cpu(), refm)
+        assert torch.equal(C.fg_mask_nearest(pred.to(DEV), size, invert=True).cpu(), 1 - refm)
+    # feature-drop mask, per-sample l2 normalisation, KL gradient helper
+    att = x.mean(1, keepdim=True)
+    thr = att.reshape(B, -1).max(1, keepdim=True)[0].reshape(B, 1, 1, 1) * 0.8
+    assert torch.equal(C.feature_drop_mask(x.to(DEV), 0.8).cpu(), (att < thr).float()[:, 0])
+    n = x.reshape(B, -1).norm(dim=1).reshape(B, 1, 1, 1)
+    assert rel(C.l2_normalize(x.to(DEV), 2.0).cpu(), 2.0 * x / (n + 1e-8)) < 1e-6
+    assert rel(C.sub_scale(x.to(DEV), add.to(DEV), 0.5).cpu(), (x - add) * 0.5) < 1e-7
+
+
+def _decoder(kind, cfg, state, dtype):
+    from pixelssl_amd.ssl_algorithm import ssl_cct as C
+    kw = dict(engine_dtype=dtype)
+    if kind == "vat":
+        d = C.VATDecoder(8, 512, 21, xi=cfg["xi"], eps=cfg["eps"], **kw)
+    elif kind == "drop":
+        d = C.DropOutDecoder(8, 512, 21, drop_rate=cfg["rate"], spatial_dropout=cfg["spatial"], **kw)
+    elif kind == "cut":
+        d = C.CutOutDecoder(8, 512, 21, erase=cfg.get("erase", 0.4), **kw)
+    elif kind == "context":
+        d = C.ContextMaskingDecoder(8, 512, 21, **kw)
+    elif kind == "object":
+        d = C.ObjectMaskingDecoder(8, 512, 21, **kw)
+    elif kind == "fd":
+        d = C.FeatureDropDecoder(8, 512, 21, **kw)
+    else:
+        d = C.FeatureNoiseDecoder(8, 512, 21, uniform_range=cfg["uniform"], **kw)
+    d.load_state_dict(state)
+    d.upsample.autotune = False
+    return d.train()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-3), (torch.bfloat16, 6e-2)])
+def test_every_auxiliary_decoder_matches_oracle(dtype, tol):
+    """Forward (resized + activated prediction), the gradient sent into the latent, and the parameter gradients of
+    every decoder kind (incl. G-Cutout) with the same draws as the oracle.  I-VAT: with the reference's default
+    xi = 1e-6 the inner perturbation is below fp32 resolution, so r_adv is the normalised ROUNDING NOISE of the two
+    passes in the reference too (a direction this arithmetic cannot share); it is run with xi = 0.5 here."""
+    import cct_oracle as CO
+    g = torch.Generator().manual_seed(11)
+    B, h, size = 2, 5, 65
+    x = torch.randn(B, 512, h, h, generator=g).abs() * (0.2 + 1.5 * torch.rand(B, 1, h, h, generator=g))   # F-Drop needs spatial contrast
+    main_pred = torch.randn(B, 21, size, size, generator=g)
+    main_pred = F.interpolate(F.interpolate(main_pred, size=(6, 6)), size=(size, size), mode="bilinear")   # blobby argmax
+    tgt = torch.softmax(torch.randn(B, 21, size, size, generator=g), 1)
+    # bf16: the finite-difference step of I-VAT must also be resolvable in the bf16 latent the engine reads (8 bits)
+    cases = [("vat", dict(xi=0.5 if dtype == torch.float32 else 20.0, eps=2.0)), ("drop", dict(rate=0.5, spatial=True)), ("cut", dict(erase=0.4, min_vertices=4)),
+             ("context", {}), ("object", {}), ("fd", {}), ("fn", dict(uniform=0.3))]
+    for i, (kind, cfg) in enumerate(cases):
+        state = CO.init_decoder_state(40 + i)
+        leaves = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in state.items())
+        xo = x.clone().requires_grad_(True)
+        torch.manual_seed(5 + i)
+        np.random.seed(5 + i)
+        # G-Cutout on a 65x65 image: lower the contour-size filter on both sides so that boxes exist; fixed draws
+        draw_in = [0.3, 0.7, 0.9, 0.1] * 16 if kind == "cut" else None
+        p, draw = CO.aux_forward(kind, cfg, leaves, xo, main_pred, draw_in)
+        act = torch.softmax(F.interpolate(p, size=(size, size), mode="bilinear"), 1)
+        F.mse_loss(act, tgt).backward()
+
+        dec = _decoder(kind, cfg, state, dtype)
+        if kind == "cut":
+            dec.min_vertices = cfg["min_vertices"]
+            assert len(draw) >= 2                     # at least one box was cut
+            draw = draw_in
+        if draw is not None:
+            dec.inject_draw(draw.clone() if torch.is_tensor(draw) else draw)
+        xd = x.to(DEV).requires_grad_(True)
+        pred, a = dec(xd, pred_of_main_decoder=main_pred.to(DEV), out_size=(size, size))
+        from pixelssl_amd.functional import mse_loss
+        mse_loss(a, tgt.to(DEV)).backward()
+        torch.cuda.synchronize()
+        e_act, e_dx = rel(a.detach().cpu(), act.detach()), rel(xd.grad.cpu(), xo.grad)
+        e_w = max(rel(prm.grad.cpu(), leaves["upsample." + n].grad) for n, prm in dec.upsample.named_parameters())
+        print("%-8s %s: act %.2e  dlatent %.2e  worst dparam %.2e" % (kind, str(dtype)[6:], e_act, e_dx, e_w))
+        if kind == "vat" and dtype == torch.bfloat16:
+            # the adversarial direction is a normalised bf16 gradient: only the decoded prediction is held to a bound
+            assert e_act < 0.15, kind
+            continue
+        assert e_act < tol and e_dx < 10 * tol and e_w < 10 * tol, kind
+
+
+def _args(**kw):
+    a = argparse.Namespace(backbone="resnet101", output_stride=16, num_classes=21, freeze_bn=False,
+                           lr=2.5e-4, momentum=0.9, weight_decay=5e-4, dampening=-1, nesterov=False,
+                           power=-1, last_epoch=-1, epochs=1, iters_per_epoch=4, ignore_index=255,
+                           labeled_batch_size=2, unlabeled_batch_size=2, batch_size=4, ignore_unlabeled=False,
+                           is_epoch_lrer=False, log_freq=1000, task="sseg", engine_dtype="fp32",
+                           models={"model": "pspnet"}, cons_scale=30.0, cons_rampup_epochs=5, ad_lr_scale=10.0,
+                           vat_dec_num=1, vat_dec_xi=1e-6, vat_dec_eps=2.0, drop_dec_num=1, drop_dec_rate=0.5,
+                           drop_dec_spatial=True, cut_dec_num=0, cut_dec_erase=0.4, context_dec_num=1,
+                           object_dec_num=1, fd_dec_num=1, fn_dec_num=1, fn_dec_uniform=0.3)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+@pytest.mark.gpu
+def test_cct_train_steps_vs_reference_fixture():
+    """The mirrored SSLCCT iteration (fp32 engine) with the reference's draws replayed: iteration-0 losses at 1e-3
+    (task) / 2e-2 (consistency: I-VAT's direction is rounding noise in the reference, see above), iteration 1 inside
+    the sanity band of the ill-conditioned random-init net; weights move like the reference's."""
+    import torch_oracle as TO
+    import cct_oracle as CO
+    import pixelssl_amd as P
+    from pixelssl_amd.nn import optimizer as popt, lrer as plr
+    from pixelssl_amd.sseg.func import SSEGFunc
+    fx = torch.load(FX, weights_only=False)
+    args = _args(labeled_batch_size=fx["lbs"], unlabeled_batch_size=fx["ubs"], batch_size=fx["lbs"] + fx["ubs"],
+                 iters_per_epoch=fx["max_iters"])
+    algo = P.ssl_algorithm.ssl_cct.ssl_cct(args, {"model": P.sseg.model.pspnet()}, {"model": popt.sgd(args)},
+                                          {"model": plr.polynomiallr(args)},
+                                          {"model": P.sseg.criterion.sseg_criterion()}, SSEGFunc(args))
+    wrapped = algo.model.module
+    kinds = [type(m).__name__ for m in wrapped.auxiliary_decoders]
+    assert kinds == ["VATDecoder", "DropOutDecoder", "ContextMaskingDecoder", "ObjectMaskingDecoder",
+                     "FeatureDropDecoder", "FeatureNoiseDecoder"]
+    assert len(algo.optimizer.param_groups) == 4
+    lrs = [g["lr"] for g in algo.optimizer.param_groups]       # backbone, psp, decoder, auxiliary decoders (x ad_lr_scale)
+    assert abs(lrs[1] - 10 * lrs[0]) < 1e-12 and abs(lrs[2] - 10 * lrs[0]) < 1e-12 and abs(lrs[3] - 10.0 * lrs[0]) < 1e-12
+    init = TO.init_pspnet_state(seed=fx["weight_seed"])
+    wrapped.main_model.model.load_state_dict(init)
+    ad_init = [CO.init_decoder_state(s) for s in fx["decoder_seeds"]]
+    for m, sd in zip(wrapped.auxiliary_decoders, ad_init):
+        m.load_state_dict(sd)
+        m.upsample.autotune = False
+    # checkpoint layout of the reference: main_model.model.* and auxiliary_decoders.k.upsample.*
+    keys = set(algo.model.state_dict().keys())
+    assert "module.main_model.model.psp.bottleneck.0.weight" in keys
+    assert "module.auxiliary_decoders.3.upsample.2.conv.bias" in keys
+    algo.model.train()
+    B = fx["lbs"] + fx["ubs"]
+    for i, s in enumerate(fx["data_seeds"]):
+        x, gt = TO.synthetic_batch(B, fx["size"], fx["lbs"], seed=s, block=fx["block"])
+        for m, d in zip(wrapped.auxiliary_decoders, fx["draws"][i]):
+            if d is not None:
+                m.inject_draw(d)
+        out, _, ul = algo.train_step((x.to(DEV),), (gt.to(DEV),), i, fx["rampup_iters"])
+        got = {k: v.item() for k, v in out.items()}
+        ref = fx["per_iter"][i]
+        print("cct iter", i, got, ref)
+        assert len(ul["ul_ad_preds"]) == 6 and tuple(ul["ul_ad_preds"][0].shape) == (fx["ubs"], 21, fx["size"], fx["size"])
+        assert abs(got["task_loss"] - ref["task_loss"]) < (1e-3 if i == 0 else 8e-2) * abs(ref["task_loss"])
+        assert abs(got["cons_loss"] - ref["cons_loss"]) < (2e-2 if i == 0 else 0.25) * abs(ref["cons_loss"])
+    sd = wrapped.main_model.model.state_dict()
+    for k, ref in fx["main_probes"].items():
+        got = sd[k].detach().cpu().reshape(-1)[:64]
+        upd = (ref["head"] - init[k].reshape(-1)[:64].float()).abs().max().item()
+        assert (got - ref["head"]).abs().max().item() <= 1.25 * upd + 1e-6 * ref["head"].abs().max().item() + 1e-9, k
+    for i, probes in enumerate(fx["ad_probes"]):
+        asd = wrapped.auxiliary_decoders[i].state_dict()
+        for k, ref in probes.items():
+            got = asd[k].detach().cpu().reshape(-1)[:64]
+            upd = (ref["head"] - ad_init[i][k].reshape(-1)[:64]).abs().max().item()
+            assert (got - ref["head"]).abs().max().item() <= 1.25 * upd + 1e-6 * ref["head"].abs().max().item() + 1e-9, (i, k)

@@ -407,14 +407,17 @@ def test_maxpool_fused_bn_relu(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("size", [(5, 65), (3, 33)])
-def test_upsample_softmax_forward_backward(dtype, size):
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("size", [(5, 65), (3, 33), (40, 65), (24, 24)])
+def test_upsample_softmax_forward_backward(dtype, size, align):
+    """align=True: the segmentation heads; align=False: F.interpolate's default, used on SSLCCT's auxiliary
+    predictions (ssl_cct.py:483); (24, 24) = the identity resize of the I-VAT inner passes."""
     ops = _ops()
     h, H = size
     g = torch.Generator().manual_seed(h)
     B, C, Cp = 2, 21, 32
     low = qround(torch.randn(B, C, h, h, generator=g) * 2, dtype).requires_grad_(True)
-    logits = F.interpolate(low, size=(H, H), mode="bilinear", align_corners=True)
+    logits = F.interpolate(low, size=(H, H), mode="bilinear", align_corners=align)
     prob = F.softmax(logits, dim=1)
     gl, gp = torch.randn(logits.shape, generator=g), torch.randn(logits.shape, generator=g)
     (logits * gl).sum().backward(retain_graph=True)
@@ -422,13 +425,13 @@ def test_upsample_softmax_forward_backward(dtype, size):
     low.grad = None
     ((logits * gl).sum() + (prob * gp).sum()).backward()
     lowd = to_nhwc(low.detach(), Cp, dtype)
-    lg, pr = ops.upsample_softmax_fwd(lowd, C, H, H)
+    lg, pr = ops.upsample_softmax_fwd(lowd, C, H, H, align_corners=align)
     torch.cuda.synchronize()
     assert rel_err(lg.cpu(), logits.detach()) < 1e-5
     assert rel_err(pr.cpu(), prob.detach()) < 1e-5
     tol = 1e-4 if dtype == torch.float32 else 8e-3
-    d1 = ops.upsample_softmax_bwd(dtype, gl.to(DEV), None, None, h, h, Cp)
-    d2 = ops.upsample_softmax_bwd(dtype, gl.to(DEV), gp.to(DEV), pr, h, h, Cp)
+    d1 = ops.upsample_softmax_bwd(dtype, gl.to(DEV), None, None, h, h, Cp, align_corners=align)
+    d2 = ops.upsample_softmax_bwd(dtype, gl.to(DEV), gp.to(DEV), pr, h, h, Cp, align_corners=align)
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(d1, C), g_only_logits) < tol
     assert rel_err(from_nhwc(d2, C), low.grad) < tol
