@@ -32,7 +32,7 @@ def parse():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    p.add_argument("--algo", default="mt", choices=["mt", "suponly", "adv", "gct"])
+    p.add_argument("--algo", default="mt", choices=["mt", "suponly", "adv", "gct", "cct"])
     p.add_argument("--size", type=int, default=513)
     p.add_argument("--lbs", type=int, default=4, help="labeled samples per GPU")
     p.add_argument("--ubs", type=int, default=4, help="unlabeled samples per GPU")
@@ -58,6 +58,15 @@ def make_args(a, world):
         fd_lr=1e-4 * world, fd_scale=10.0, mu=0.5, nu=1,
         is_epoch_lrer=False, log_freq=10 ** 9, task="sseg", cons_for_labeled=False, cons_scale=1.0,
         cons_rampup_epochs=3, ema_decay=0.99, gaussian_noise_std=None)
+    if a.algo == "cct":
+        # CCT hyper-parameters of the shipped script (task/sseg/script/pspnet_pascalvoc_1-8_sslcct.py:23-33) with the
+        # K = 7 decoders BASELINE.json's config names (one of each kind)
+        ns.models = {"model": "pspnet"}
+        ns.cons_scale, ns.cons_rampup_epochs, ns.ad_lr_scale = 30.0, 5, 10.0
+        ns.vat_dec_num = ns.drop_dec_num = ns.cut_dec_num = ns.context_dec_num = ns.object_dec_num = 1
+        ns.fd_dec_num = ns.fn_dec_num = 1
+        ns.vat_dec_xi, ns.vat_dec_eps, ns.drop_dec_rate, ns.drop_dec_spatial = 1e-6, 2.0, 0.5, True
+        ns.cut_dec_erase, ns.fn_dec_uniform = 0.4, 0.3
     return ns
 
 
@@ -82,7 +91,7 @@ def cpu_baseline(a):
     return {"value": round((lbs + ubs) * a.cpu_sample_steps / dt, 4), "unit": "img/s", "cores": threads,
             "kind": "port",
             "sample": "%d timed %s steps (after 1 warm-up) of the CPU oracle at %dx%d, batch %d+%d, fp32, "
-                      "torch %s, %d threads" % (a.cpu_sample_steps, a.algo.upper(), a.size, a.size, lbs, ubs,
+                      "torch %s, %d threads" % (a.cpu_sample_steps, "MT" if a.algo == "mt" else "SupOnly (DeepLab-v2)", a.size, a.size, lbs, ubs,
                                                 torch.__version__, threads)}
 
 
@@ -122,6 +131,11 @@ def main():
         cores = [algo.model.module.model, algo.d_model.module.core]
         algo.model.train()
         algo.d_model.train()
+    elif a.algo == "cct":
+        factories = ({"model": P.sseg.model.pspnet()},) + factories[1:]
+        algo = P.ssl_algorithm.ssl_cct.ssl_cct(args, *factories, P.sseg.func.task_func()(args))
+        cores = [algo.main_model.model] + [d.upsample for d in algo.auxiliary_decoders]
+        algo.model.train()
     else:
         algo = P.ssl_algorithm.ssl_null.ssl_null(args, *factories, None)
         cores = [algo.model.module.model]
@@ -141,6 +155,8 @@ def main():
             return algo.train_step(inp, gt, it, 3 * args.iters_per_epoch)[0]
         if a.algo == "gct":
             return algo.train_step(inp, gt, it, 3 * args.iters_per_epoch)
+        if a.algo == "cct":
+            return algo.train_step(inp, gt, it, 5 * args.iters_per_epoch)[0]
         return algo.train_step(inp, gt)[0]
 
     def fence():
@@ -188,12 +204,14 @@ def main():
                "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": "%s sseg, DeepLab-v2/ResNet-101, %dx%dx%d (%d labeled + %d unlabeled) per GPU, "
+               "config": {"workload": "%s sseg, %s/ResNet-101, %dx%dx%d (%d labeled + %d unlabeled) per GPU, "
                                       "21 classes" % ({"mt": "MT (mean-teacher)", "adv": "AdvSSL (+ FC discriminator)",
                                                        "gct": "GCT (dual task model + flaw detector)",
-                                                       "suponly": "SupOnly"}[a.algo], per_gpu,
+                                                       "cct": "CCT (shared encoder + K=7 perturbed aux decoders)",
+                                                       "suponly": "SupOnly"}[a.algo],
+                                                      "PSPNet" if a.algo == "cct" else "DeepLab-v2", per_gpu,
                                                       a.size, a.size, a.lbs, per_gpu - a.lbs),
-                          "algorithm": "ssl_" + {"mt": "mt", "adv": "adv", "gct": "gct", "suponly": "null"}[a.algo], "global_batch": gb,
+                          "algorithm": "ssl_" + {"mt": "mt", "adv": "adv", "gct": "gct", "cct": "cct", "suponly": "null"}[a.algo], "global_batch": gb,
                           "im_size": a.size, "parallelism": "dp%d" % world, "sync_bn": world > 1},
                "final_losses": loss_vals}
         if kern:
@@ -218,7 +236,8 @@ def main():
                                        "whole-step figure"}
             out["kernels"] = kern
             # whole-step view: algorithmic conv FLOPs per image over wall time
-            flop_img = {"mt": 449.9e9, "adv": 435.0e9, "gct": 1291.2e9, "suponly": 337.1e9}[a.algo]
+            # CCT: 3 x F_P (150.74 GFLOP) per image through the PSPNet, decoders ~0.05 GFLOP each
+            flop_img = {"mt": 449.9e9, "adv": 435.0e9, "gct": 1291.2e9, "suponly": 337.1e9, "cct": 452.6e9}[a.algo]
             out["step_mfma_frac"] = round(out["value"] * flop_img / world / (peak * 1e12), 4) if a.size == 513 else None
         if world == 1 and not a.no_cpu_baseline:
             del algo
