@@ -422,6 +422,11 @@ int pxl_net_input_grad(pxl_net* net, const void* scratch, float* dx, void* strea
 /* enable = 0: backward skips every parameter gradient (a frozen discriminator only relays dL/dinput) */
 int pxl_net_set_wgrad(pxl_net* net, int enable);
 
+/* Tuning aid: target number of thread blocks of the row-streaming kernels (key: 0 = bn_bwd_reduce, 1 = bn_bwd_apply_fused,
+ * 2 = residual_fwd, 3 = bn_apply_fwd); tools/eltwise_bench.py sweeps it, the defaults are the measured optimum */
+#define PXL_TUNE_COUNT 5      /* key 4 = widest column group (16-byte chunks of one row per block) of those kernels */
+int pxl_tune_set(int key, int value);
+
 /* Measurement aid (bench.py roofline leg): bracket every contraction launch of this net with HIP
  * events on the launch stream.  kind 0 = implicit-GEMM conv (forward + data gradient), 1 = weight
  * gradient.  read() synchronises on the recorded events, returns the summed kernel time, the number

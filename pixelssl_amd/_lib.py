@@ -130,6 +130,7 @@ SIGNATURES = {
     "pxl_adam_step": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _I, _P]),
     "pxl_ema_update": (_I, [_L, _P, _P, _F, _P]),
     "pxl_scale_inplace": (_I, [_L, _P, _F, _P]),
+    "pxl_tune_set": (_I, [_I, _I]),
     "pxl_net_create": (_I, [_I, _I, C.POINTER(Op), _I, C.POINTER(BnDesc), _I, _I, C.POINTER(_P)]),
     "pxl_net_destroy": (None, [_P]),
     "pxl_net_plan": (_I, [_P, _I, _I, _I]),

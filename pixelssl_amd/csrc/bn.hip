@@ -74,19 +74,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int M, int C, const T* __restrict__ dz,
                                                             const T* __restrict__ y,
                                                             const float* __restrict__ coef, int relu,
-                                                            float* __restrict__ sums, int nrep, int rows_per_group) {
+                                                            float* __restrict__ sums, int nrep, int rows_per_group,
+                                                            int cgmax) {
   constexpr int EPC = Elem<T>::EPC;
-  const ColGeom g = col_geom(C, EPC);
+  const ColGeom g = col_geom(C, EPC, cgmax);
   const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
   const int cc = blockIdx.x * g.cg + ccol;
   __shared__ float red[256 * 2 * EPC];            // [rl][cg][2*EPC]
   float mean[EPC], rstd[EPC], sc[EPC], sh[EPC], a1[EPC], a2[EPC];
+  load_cvec<EPC>(coef + cc * EPC, mean);
+  load_cvec<EPC>(coef + C + cc * EPC, rstd);
+  load_cvec<EPC>(coef + 2 * C + cc * EPC, sc);
+  load_cvec<EPC>(coef + 3 * C + cc * EPC, sh);
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) {
-    const int c = cc * EPC + e;
-    mean[e] = coef[c]; rstd[e] = coef[C + c]; sc[e] = coef[2 * C + c]; sh[e] = coef[3 * C + c];
-    a1[e] = 0.f; a2[e] = 0.f;
-  }
+  for (int e = 0; e < EPC; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
   const int m_begin = blockIdx.y * rows_per_group;
   const int m_end = min(M, m_begin + rows_per_group);
   auto accum = [&](const uint4& vd, const uint4& vy) {
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int M, int C, const 
   __syncthreads();
   // thread t < cg * 2 * EPC sums one (column, which, element) over the row lanes
   const int nout = g.cg * 2 * EPC;
-  if ((int)threadIdx.x < nout) {
-    const int col = threadIdx.x / (2 * EPC), w = threadIdx.x % (2 * EPC);
+  for (int o = threadIdx.x; o < nout; o += 256) {
+    const int col = o / (2 * EPC), w = o % (2 * EPC);
     float v = 0.f;
     for (int r = 0; r < g.rl; ++r) v += red[(r * g.cg + col) * 2 * EPC + w];
     float* rep = sums + (size_t)((blockIdx.y + blockIdx.x) % nrep) * 2 * C;
@@ -188,28 +189,40 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int M, int C, const T
 // a single [2C] vector: fold + all-reduce happen before): removes the bn_bwd_finalize launch per layer.  The
 // blocks of row group 0 also accumulate dgamma / dbeta.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(int M, int C, const T* __restrict__ dz,
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(int M, int C, const T* dz,
                                                                  const T* __restrict__ y,
                                                                  const float* __restrict__ coef,
                                                                  const float* __restrict__ sums, float inv_count,
                                                                  int training, int relu, float* __restrict__ dgamma,
-                                                                 float* __restrict__ dbeta, T* __restrict__ dy,
-                                                                 int rows_per_group) {
+                                                                 float* __restrict__ dbeta, T* dy,
+                                                                 int rows_per_group, int cgmax) {
   constexpr int EPC = Elem<T>::EPC;
-  const ColGeom g = col_geom(C, EPC);
+  const ColGeom g = col_geom(C, EPC, cgmax);
   const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
   const int cc = blockIdx.x * g.cg + ccol;
-  float mean[EPC], rstd[EPC], sc[EPC], sh[EPC], b1[EPC], b2[EPC];
+  // dy = sc*(gd - b1 - (y - mean)*rstd*b2) = sc*gd - k0 - y*k1 with k1 = sc*rstd*b2, k0 = sc*b1 - mean*k1
+  float sc[EPC], sh[EPC], k0[EPC], k1[EPC];
+  {
+    float mean[EPC], rstd[EPC], s1[EPC], s2[EPC];
+    load_cvec<EPC>(coef + cc * EPC, mean);
+    load_cvec<EPC>(coef + C + cc * EPC, rstd);
+    load_cvec<EPC>(coef + 2 * C + cc * EPC, sc);
+    load_cvec<EPC>(coef + 3 * C + cc * EPC, sh);
+    load_cvec<EPC>(sums + cc * EPC, s1);
+    load_cvec<EPC>(sums + C + cc * EPC, s2);
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) {
-    const int c = cc * EPC + e;
-    mean[e] = coef[c]; rstd[e] = coef[C + c]; sc[e] = coef[2 * C + c]; sh[e] = coef[3 * C + c];
-    const float s1 = sums[c], s2 = sums[C + c];
-    b1[e] = training ? s1 * inv_count : 0.f;      // eval-mode BN is a fixed affine: no batch-mean terms
-    b2[e] = training ? s2 * inv_count : 0.f;
+    for (int e = 0; e < EPC; ++e) {
+      const float b1 = training ? s1[e] * inv_count : 0.f;      // eval-mode BN is a fixed affine: no batch-mean terms
+      const float b2 = training ? s2[e] * inv_count : 0.f;
+      k1[e] = sc[e] * rstd[e] * b2;
+      k0[e] = sc[e] * b1 - mean[e] * k1[e];
+    }
     if (blockIdx.y == 0 && rlane == 0) {
-      if (dgamma) dgamma[c] += s2;
-      if (dbeta) dbeta[c] += s1;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        if (dgamma) dgamma[cc * EPC + e] += s2[e];
+        if (dbeta) dbeta[cc * EPC + e] += s1[e];
+      }
     }
   }
   const int m_begin = blockIdx.y * rows_per_group;
@@ -222,20 +235,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(int M, int C, c
     for (int e = 0; e < EPC; ++e) {
       float gd = fd[e];
       if (relu && !(fy[e] * sc[e] + sh[e] > 0.f)) gd = 0.f;
-      v[e] = sc[e] * (gd - b1[e] - (fy[e] - mean[e]) * rstd[e] * b2[e]);
+      v[e] = sc[e] * gd - k0[e] - fy[e] * k1[e];
     }
     return Chunk<T>::pack(v);
   };
+  const size_t col = (size_t)cc * EPC, step = (size_t)g.rl * C;
   int m = m_begin + rlane;
-  for (; m + g.rl < m_end; m += 2 * g.rl) {
-    const size_t o0 = (size_t)m * C + cc * EPC, o1 = (size_t)(m + g.rl) * C + cc * EPC;
+  for (; m + 3 * g.rl < m_end; m += 4 * g.rl) {           // four rows (8 x 16-byte loads) in flight per thread
+    const size_t o0 = (size_t)m * C + col, o1 = o0 + step, o2 = o1 + step, o3 = o2 + step;
     const uint4 d0 = *reinterpret_cast<const uint4*>(dz + o0), y0 = *reinterpret_cast<const uint4*>(y + o0);
     const uint4 d1 = *reinterpret_cast<const uint4*>(dz + o1), y1 = *reinterpret_cast<const uint4*>(y + o1);
+    const uint4 d2 = *reinterpret_cast<const uint4*>(dz + o2), y2 = *reinterpret_cast<const uint4*>(y + o2);
+    const uint4 d3 = *reinterpret_cast<const uint4*>(dz + o3), y3 = *reinterpret_cast<const uint4*>(y + o3);
     *reinterpret_cast<uint4*>(dy + o0) = one(d0, y0);
     *reinterpret_cast<uint4*>(dy + o1) = one(d1, y1);
+    *reinterpret_cast<uint4*>(dy + o2) = one(d2, y2);
+    *reinterpret_cast<uint4*>(dy + o3) = one(d3, y3);
   }
-  if (m < m_end) {
-    const size_t o0 = (size_t)m * C + cc * EPC;
+  for (; m < m_end; m += g.rl) {
+    const size_t o0 = (size_t)m * C + col;
     *reinterpret_cast<uint4*>(dy + o0) = one(*reinterpret_cast<const uint4*>(dz + o0), *reinterpret_cast<const uint4*>(y + o0));
   }
 }
@@ -287,16 +305,18 @@ extern "C" int pxl_bn_bwd_reduce(int dtype, int M, int C, const void* dz, const 
   PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "bn_bwd_reduce: bad dtype %d", dtype);
   const int epc = dtype == PXL_F32 ? 4 : 8;
   PXL_REQUIRE(C % epc == 0, "bn_bwd_reduce: C=%d must be a multiple of %d", C, epc);
-  const ColGeom g = col_geom(C, epc);
-  const int rpg = rows_per_group(M, g, 1024);
+  const int cgmax = pxl_tune_get(4);
+  const ColGeom g = col_geom(C, epc, cgmax);
+  // every row group ends in one atomic per channel: cap the row groups at 256 (narrow tensors have 1-2 column groups)
+  const int rpg = rows_per_group(M, g, min(pxl_tune_get(0), 256 * g.ncg));
   const dim3 grid(g.ncg, cdiv(M, rpg));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PXL_F32)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, M, C, (const float*)dz,
-                       (const float*)y, coef, relu, sums, nrep, rpg);
+                       (const float*)y, coef, relu, sums, nrep, rpg, cgmax);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, M, C, (const bf16_t*)dz,
-                       (const bf16_t*)y, coef, relu, sums, nrep, rpg);
+                       (const bf16_t*)y, coef, relu, sums, nrep, rpg, cgmax);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -308,16 +328,17 @@ extern "C" int pxl_bn_bwd_apply_fused(int dtype, int M, int C, const void* dz, c
   PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "bn_bwd_apply_fused: bad dtype %d", dtype);
   const int epc = dtype == PXL_F32 ? 4 : 8;
   PXL_REQUIRE(C % epc == 0, "bn_bwd_apply_fused: C=%d must be a multiple of %d", C, epc);
-  const ColGeom g = col_geom(C, epc);
-  const int rpg = rows_per_group(M, g, 2048);
+  const int cgmax = pxl_tune_get(4);
+  const ColGeom g = col_geom(C, epc, cgmax);
+  const int rpg = rows_per_group(M, g, pxl_tune_get(1));
   const dim3 grid(g.ncg, cdiv(M, rpg));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == PXL_F32)
     hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<float>, grid, dim3(256), 0, s, M, C, (const float*)dz, (const float*)y,
-                       coef, sums, 1.f / count, training, relu, dgamma, dbeta, (float*)dy, rpg);
+                       coef, sums, 1.f / count, training, relu, dgamma, dbeta, (float*)dy, rpg, cgmax);
   else
     hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<bf16_t>, grid, dim3(256), 0, s, M, C, (const bf16_t*)dz,
-                       (const bf16_t*)y, coef, sums, 1.f / count, training, relu, dgamma, dbeta, (bf16_t*)dy, rpg);
+                       (const bf16_t*)y, coef, sums, 1.f / count, training, relu, dgamma, dbeta, (bf16_t*)dy, rpg, cgmax);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

@@ -18,6 +18,7 @@ typedef uint16_t bf16_t;   // storage type of bf16 activations / packed weights
 // error plumbing (thread-local last error, negative return codes)
 // ----------------------------------------------------------------------------
 int pxl_set_error(int code, const char* fmt, ...);
+int pxl_tune_get(int key);
 #define PXL_CHECK_HIP(expr)                                                        \
   do {                                                                             \
     hipError_t _e = (expr);                                                        \
@@ -86,6 +87,17 @@ template <> struct Chunk<bf16_t> {
   }
 };
 
+// EPC consecutive per-channel floats (coefficients, sums) as 16-byte loads: p must be 16-byte aligned (channel chunk
+// offsets are multiples of EPC >= 4 floats and every coefficient vector starts 16-byte aligned).  The scalar form
+// `for e: f[e] = p[e]` compiles to EPC dword loads whose lanes are 32 bytes apart -- 16 cache lines per wave-load.
+template <int EPC> __device__ __forceinline__ void load_cvec(const float* __restrict__ p, float* f) {
+#pragma unroll
+  for (int q = 0; q < EPC / 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+    f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -111,10 +123,10 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, i
 // (<= 16 chunks = 256 contiguous bytes of a row) x RL row lanes; blockIdx.x = column group, blockIdx.y = row
 // group.  Each thread keeps its channel chunk (and the per-channel coefficients) in registers and walks rows.
 struct ColGeom { int cg, rl, ncg; };
-__host__ __device__ inline ColGeom col_geom(int C, int epc) {
+__host__ __device__ inline ColGeom col_geom(int C, int epc, int cgmax = 16) {
   const int cpr = C / epc;
   ColGeom g;
-  g.cg = cpr < 16 ? cpr : 16;
+  g.cg = cpr < cgmax ? cpr : cgmax;
   while (256 % g.cg != 0 || cpr % g.cg != 0) --g.cg;   // channel pitches are multiples of 32 -> cg in {4, 8, 16}
   g.rl = 256 / g.cg;
   g.ncg = cpr / g.cg;

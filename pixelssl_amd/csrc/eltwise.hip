@@ -20,17 +20,20 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T
                                                            const float* __restrict__ ycoef,
                                                            const T* __restrict__ res,
                                                            const float* __restrict__ rcoef,
-                                                           T* __restrict__ out, int rows_per_group) {
+                                                           T* __restrict__ out, int rows_per_group, int cgmax) {
   constexpr int EPC = Elem<T>::EPC;
-  const ColGeom g = col_geom(C, EPC);
+  const ColGeom g = col_geom(C, EPC, cgmax);
   const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
   const int cc = blockIdx.x * g.cg + ccol;
   float ys[EPC], yb[EPC], rs[EPC], rb[EPC];
+  load_cvec<EPC>(ycoef + 2 * C + cc * EPC, ys);
+  load_cvec<EPC>(ycoef + 3 * C + cc * EPC, yb);
+  if (rcoef) {
+    load_cvec<EPC>(rcoef + 2 * C + cc * EPC, rs);
+    load_cvec<EPC>(rcoef + 3 * C + cc * EPC, rb);
+  } else {
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) {
-    const int c = cc * EPC + e;
-    ys[e] = ycoef[2 * C + c]; yb[e] = ycoef[3 * C + c];
-    rs[e] = rcoef ? rcoef[2 * C + c] : 1.f; rb[e] = rcoef ? rcoef[3 * C + c] : 0.f;
+    for (int e = 0; e < EPC; ++e) { rs[e] = 1.f; rb[e] = 0.f; }
   }
   auto one = [&](const uint4& vy, const uint4& vr) -> uint4 {
     float fy[EPC], fr[EPC], v[EPC];
@@ -60,17 +63,14 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(int M, int C, const T* __restrict__ y,
                                                            const float* __restrict__ coef, int relu,
-                                                           T* __restrict__ z, int rows_per_group) {
+                                                           T* __restrict__ z, int rows_per_group, int cgmax) {
   constexpr int EPC = Elem<T>::EPC;
-  const ColGeom g = col_geom(C, EPC);
+  const ColGeom g = col_geom(C, EPC, cgmax);
   const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
   const int cc = blockIdx.x * g.cg + ccol;
   float sc[EPC], sh[EPC];
-#pragma unroll
-  for (int e = 0; e < EPC; ++e) {
-    sc[e] = coef[2 * C + cc * EPC + e];
-    sh[e] = coef[3 * C + cc * EPC + e];
-  }
+  load_cvec<EPC>(coef + 2 * C + cc * EPC, sc);
+  load_cvec<EPC>(coef + 3 * C + cc * EPC, sh);
   auto one = [&](const uint4& vy) -> uint4 {
     float f[EPC];
     Chunk<T>::unpack(vy, f);
@@ -288,15 +288,16 @@ extern "C" int pxl_residual_fwd(int dtype, long M, int C, const void* y, const f
   const int epc = dtype == PXL_F32 ? 4 : 8;
   PXL_REQUIRE(C % epc == 0, "residual_fwd: C=%d must be a multiple of %d", C, epc);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const ColGeom g = col_geom(C, epc);
-  const int rpg = rows_per_group((int)M, g, 2048);
+  const int cgmax = pxl_tune_get(4);
+  const ColGeom g = col_geom(C, epc, cgmax);
+  const int rpg = rows_per_group((int)M, g, pxl_tune_get(2));
   const dim3 grid(g.ncg, cdiv((int)M, rpg));
   if (dtype == PXL_F32)
     hipLaunchKernelGGL(residual_fwd_kernel<float>, grid, dim3(256), 0, s, (int)M, C,
-                       cp<float>(y), ycoef, cp<float>(res), rcoef, mp<float>(out), rpg);
+                       cp<float>(y), ycoef, cp<float>(res), rcoef, mp<float>(out), rpg, cgmax);
   else
     hipLaunchKernelGGL(residual_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (int)M, C,
-                       cp<bf16_t>(y), ycoef, cp<bf16_t>(res), rcoef, mp<bf16_t>(out), rpg);
+                       cp<bf16_t>(y), ycoef, cp<bf16_t>(res), rcoef, mp<bf16_t>(out), rpg, cgmax);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -308,15 +309,16 @@ extern "C" int pxl_bn_apply_fwd(int dtype, long M, int C, const void* y, const f
   const int epc = dtype == PXL_F32 ? 4 : 8;
   PXL_REQUIRE(C % epc == 0, "bn_apply_fwd: C=%d must be a multiple of %d", C, epc);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const ColGeom g = col_geom(C, epc);
-  const int rpg = rows_per_group((int)M, g, 2048);
+  const int cgmax = pxl_tune_get(4);
+  const ColGeom g = col_geom(C, epc, cgmax);
+  const int rpg = rows_per_group((int)M, g, pxl_tune_get(3));
   const dim3 grid(g.ncg, cdiv((int)M, rpg));
   if (dtype == PXL_F32)
     hipLaunchKernelGGL(bn_apply_fwd_kernel<float>, grid, dim3(256), 0, s, (int)M, C, cp<float>(y),
-                       coef, relu, mp<float>(z), rpg);
+                       coef, relu, mp<float>(z), rpg, cgmax);
   else
     hipLaunchKernelGGL(bn_apply_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (int)M, C,
-                       cp<bf16_t>(y), coef, relu, mp<bf16_t>(z), rpg);
+                       cp<bf16_t>(y), coef, relu, mp<bf16_t>(z), rpg, cgmax);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
