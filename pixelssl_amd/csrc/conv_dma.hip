@@ -36,6 +36,8 @@ struct DmaArgs {
   int ntaps, so;
   int M, Ktot, nk;
   int tiles_m, tiles_n;
+  float* ws;         // split-K: pre-zeroed fp32 [M][Cout] accumulation buffer (blockIdx.y = K slice), else nullptr
+  int nk_per;        // K steps per slice
   unsigned in_bytes, w_bytes;
   int taps[64];      // (dy << 16) | (dx & 0xffff)
 };
@@ -154,9 +156,11 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   }
 
   // ---- load cursor: tap t, byte offset kcb inside the pixel's channel vector, kwb inside the weight row
-  int ld_t = 0;
-  unsigned kcb = 0, kwb = 0;
   const unsigned cin_bytes = (unsigned)p.Cin * 2;
+  const int ks_begin = blockIdx.y * p.nk_per;                   // split-K slice (whole range when gridDim.y == 1)
+  const int nk_here = min(p.nk, ks_begin + p.nk_per) - ks_begin;
+  int ld_t = (int)(((unsigned)ks_begin * 128u) / cin_bytes);
+  unsigned kcb = (unsigned)ks_begin * 128u - (unsigned)ld_t * cin_bytes, kwb = (unsigned)ks_begin * 128u;
   auto set_tap = [&](int t) {
     if constexpr (GATHER) {
       const int tp = p.taps[min(t, p.ntaps - 1)];
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
     boff[kk] = f + wn * TNI * 4096;
   }
 
-  set_tap(0);
+  set_tap(ld_t);
   // ---- prologue: NST-1 tiles in flight
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) issue(s);
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   __builtin_amdgcn_s_waitcnt(0xc07f);
   int st_c = 0;               // stage being multiplied
   int st_l = NST - 1;         // stage being filled
-  for (int ks = 0; ks < p.nk; ++ks) {
+  for (int ks = 0; ks < nk_here; ++ks) {
     wait_vmcnt<(NST - 2) * (LA + LB)>();      // this wave's share of tile ks has landed
     if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();   // ... everyone's has; stage st_l is no longer being read
     if constexpr (!(ABL & 1)) issue(st_l);
@@ -258,6 +262,21 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   __builtin_amdgcn_s_barrier();
 
   if constexpr (ABL & 16) return;
+  if (p.ws != nullptr) {
+    // split-K: fp32 partial sums of this K slice -> workspace; bias / rounding happen in the finish kernel
+#pragma unroll
+    for (int j = 0; j < TNI; ++j)
+#pragma unroll
+      for (int i = 0; i < TMI; ++i) {
+        const int m = m0 + (wm * TMI + i) * 32 + frow;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + (wn * TNI + j) * 32 + 8 * (r >> 2) + 4 * fhalf + (r & 3);
+          if (m < p.M && n < p.Kreal) atomicAdd(p.ws + (size_t)m * p.Cout + n, acc[j][i][r]);
+        }
+      }
+    return;
+  }
   // ---- epilogue 1: accumulators -> bf16 tile T[m][n] in LDS.  C/D layout of the 32x32 MFMA with swapped
   // roles: column (lane & 31) = pixel, rows (r&3) + 8*(r>>2) + 4*(lane>>5) = channel
   unsigned char* T = smem;
@@ -360,6 +379,8 @@ int launch_abl(const DmaArgs& a, hipStream_t stream) {
   DmaArgs p = a;
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.Cout, BN);
+  p.ws = nullptr;
+  p.nk_per = p.nk;
   constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
   PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, 2, 2, NST, true, ABL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -368,12 +389,29 @@ int launch_abl(const DmaArgs& a, hipStream_t stream) {
   return PXL_OK;
 }
 
+extern "C" int pxl_splitk_finish(int dtype, long total, int Cout, int Kreal, const float* ws, const float* bias, void* out,
+                                 void* stream);
+
 template <int BM, int BN, int WM, int WN, int NST>
-int launch_dma(const DmaArgs& a, bool gather, hipStream_t stream) {
+int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, hipStream_t stream) {
   DmaArgs p = a;
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.Cout, BN);
   const int grid = p.tiles_m * p.tiles_n;
+  // split-K: launches that cannot fill the chip and have a long reduction (ASPP: 137 tiles, K = 73728)
+  int splitk = 1;
+  const bool can_split = p.ws != nullptr && p.stats == nullptr && p.addend == nullptr &&
+                         ws_bytes >= (size_t)p.M * p.Cout * sizeof(float);
+  if (can_split) {
+    if (want_split > 1) splitk = want_split;
+    else if (want_split <= 0 && grid < 200 && p.nk >= 64) splitk = min(cdiv(768, grid), p.nk / 16);
+    if (splitk > p.nk) splitk = p.nk;
+    if (splitk < 1) splitk = 1;
+  }
+  p.nk_per = cdiv(p.nk, splitk);
+  splitk = cdiv(p.nk, p.nk_per);
+  if (splitk > 1) PXL_CHECK_HIP(hipMemsetAsync(p.ws, 0, (size_t)p.M * p.Cout * sizeof(float), stream));
+  else p.ws = nullptr;
   constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
   static bool raised[2] = {false, false};
   if (!raised[gather ? 1 : 0]) {
@@ -384,10 +422,12 @@ int launch_dma(const DmaArgs& a, bool gather, hipStream_t stream) {
     raised[gather ? 1 : 0] = true;
   }
   if (gather)
-    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, true>), dim3(grid), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, true>), dim3(grid, splitk), dim3(256), smem, stream, p);
   else
-    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, false>), dim3(grid), dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, false>), dim3(grid, splitk), dim3(256), smem, stream, p);
   PXL_LAUNCH_CHECK();
+  if (splitk > 1)
+    return pxl_splitk_finish(PXL_BF16, (long)p.M * p.Cout, p.Cout, p.Kreal, p.ws, p.bias, p.out, stream);
   return PXL_OK;
 }
 
@@ -398,7 +438,6 @@ extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_sca
   (void)workspace;
   if (d->dtype != PXL_BF16 || in_scale != nullptr) return 0;
   if (d->Cin % 64 != 0 || d->Cout % 8 != 0 || d->div != 1) return 0;
-  if (d->split_k > 1) return 0;
   if ((long)d->Kreal * d->ntaps * d->Cin * 2 >= (1L << 31)) return 0;
   return 1;
 }
@@ -406,8 +445,11 @@ extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_sca
 // tile configurations 8..: 8 = 128x128, 9 = 128(pixels)x64, 10 = 64x128, 11 = 64x64 with a 3-stage LDS ring;
 // 12..15 the same with 4 stages, 16..19 with 2 stages (more blocks per CU)
 extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
-                            const void* addend, float* stats, void* stream) {
+                            const void* addend, float* stats, void* workspace, size_t ws_bytes, void* stream) {
   DmaArgs a;
+  a.ws = reinterpret_cast<float*>(workspace);
+  a.nk_per = 0;
+  const int sk = d->split_k;
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = addend; a.stats = stats;
   a.stats_rep = d->stats_rep >= 1 ? d->stats_rep : 1;
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin;
@@ -435,18 +477,18 @@ extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* 
     else cfg = 9;
   }
   switch (cfg) {
-    case 8: return launch_dma<128, 128, 2, 2, 3>(a, gather, s);
-    case 9: return launch_dma<128, 64, 2, 2, 3>(a, gather, s);
-    case 10: return launch_dma<64, 128, 2, 2, 3>(a, gather, s);
-    case 11: return launch_dma<64, 64, 2, 2, 3>(a, gather, s);
-    case 12: return launch_dma<128, 128, 2, 2, 4>(a, gather, s);
-    case 13: return launch_dma<128, 64, 2, 2, 4>(a, gather, s);
-    case 14: return launch_dma<64, 128, 2, 2, 4>(a, gather, s);
-    case 15: return launch_dma<64, 64, 2, 2, 4>(a, gather, s);
-    case 16: return launch_dma<128, 128, 2, 2, 2>(a, gather, s);
-    case 17: return launch_dma<128, 64, 2, 2, 2>(a, gather, s);
-    case 18: return launch_dma<64, 128, 2, 2, 2>(a, gather, s);
-    case 19: return launch_dma<64, 64, 2, 2, 2>(a, gather, s);
+    case 8: return launch_dma<128, 128, 2, 2, 3>(a, gather, sk, ws_bytes, s);
+    case 9: return launch_dma<128, 64, 2, 2, 3>(a, gather, sk, ws_bytes, s);
+    case 10: return launch_dma<64, 128, 2, 2, 3>(a, gather, sk, ws_bytes, s);
+    case 11: return launch_dma<64, 64, 2, 2, 3>(a, gather, sk, ws_bytes, s);
+    case 12: return launch_dma<128, 128, 2, 2, 4>(a, gather, sk, ws_bytes, s);
+    case 13: return launch_dma<128, 64, 2, 2, 4>(a, gather, sk, ws_bytes, s);
+    case 14: return launch_dma<64, 128, 2, 2, 4>(a, gather, sk, ws_bytes, s);
+    case 15: return launch_dma<64, 64, 2, 2, 4>(a, gather, sk, ws_bytes, s);
+    case 16: return launch_dma<128, 128, 2, 2, 2>(a, gather, sk, ws_bytes, s);
+    case 17: return launch_dma<128, 64, 2, 2, 2>(a, gather, sk, ws_bytes, s);
+    case 18: return launch_dma<64, 128, 2, 2, 2>(a, gather, sk, ws_bytes, s);
+    case 19: return launch_dma<64, 64, 2, 2, 2>(a, gather, sk, ws_bytes, s);
     // timing ablations (garbage results): 64x128 3-stage gather kernel, 100 + ABL bits
     case 100: return launch_abl<64, 128, 3, 0>(a, s);
     case 101: return launch_abl<64, 128, 3, 1>(a, s);

@@ -436,7 +436,21 @@ int launch_conv(const ConvArgs& a, int force_cfg, int want_split, size_t ws_byte
 
 extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_scale, const void* workspace);
 extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
-                            const void* addend, float* stats, void* stream);
+                            const void* addend, float* stats, void* workspace, size_t ws_bytes, void* stream);
+
+// split-K epilogue shared with the LDS-DMA kernel: out = T(ws + bias)
+extern "C" int pxl_splitk_finish(int dtype, long total, int Cout, int Kreal, const float* ws, const float* bias, void* out,
+                                 void* stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  long g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(splitk_finish_kernel<float>, dim3((int)g), dim3(256), 0, s, total, Cout, Kreal, ws, bias, (float*)out);
+  else
+    hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, total, Cout, Kreal, ws, bias, (bf16_t*)out);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
 
 extern "C" int pxl_conv_igemm(const pxl_conv_desc* d, const void* in, const void* w, void* out,
                               const float* in_scale, const float* in_shift, const float* bias,
@@ -454,7 +468,7 @@ extern "C" int pxl_conv_igemm(const pxl_conv_desc* d, const void* in, const void
               "conv_igemm: tensor too large for 32-bit indexing");
   // plain bf16 operands take the LDS-DMA kernel (conv_dma.hip); tile_cfg 0..7 forces this generic kernel
   if (d->tile_cfg < 0 || d->tile_cfg >= 8) {
-    if (pxl_conv_dma_eligible(d, in_scale, workspace)) return pxl_conv_dma(d, in, w, out, bias, addend, stats, stream);
+    if (pxl_conv_dma_eligible(d, in_scale, workspace)) return pxl_conv_dma(d, in, w, out, bias, addend, stats, workspace, ws_bytes, stream);
     PXL_REQUIRE(d->tile_cfg < 8, "conv_igemm: tile config %d needs plain bf16 operands with Cin %% 64 == 0", d->tile_cfg);
   }
   ConvArgs a;

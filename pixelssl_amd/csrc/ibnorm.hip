@@ -24,12 +24,10 @@ __global__ __launch_bounds__(256) void ibn_reduce_kernel(int HW, int C, const T*
   __shared__ float red[256 * 2 * EPC];
   float a1[EPC], a2[EPC], mean[EPC], rstd[EPC], sc[EPC], sh[EPC];
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) {
-    a1[e] = a2[e] = 0.f;
-    if (MODE == 1) {
-      const float* cf = coef + (size_t)b * 4 * C + cc * EPC + e;
-      mean[e] = cf[0]; rstd[e] = cf[C]; sc[e] = cf[2 * C]; sh[e] = cf[3 * C];
-    }
+  for (int e = 0; e < EPC; ++e) a1[e] = a2[e] = 0.f;
+  if (MODE == 1) {
+    const float* cf = coef + (size_t)b * 4 * C + cc * EPC;
+    load_cvec<EPC>(cf, mean); load_cvec<EPC>(cf + C, rstd); load_cvec<EPC>(cf + 2 * C, sc); load_cvec<EPC>(cf + 3 * C, sh);
   }
   const int m_begin = blockIdx.y * rows_per_group;
   const int m_end = min(HW, m_begin + rows_per_group);
@@ -130,11 +128,8 @@ __global__ __launch_bounds__(256) void ibn_apply_fwd_kernel(int HW, int C, const
   const int cc = blockIdx.x * g.cg + ccol;
   const int b = blockIdx.z;
   float sc[EPC], sh[EPC];
-#pragma unroll
-  for (int e = 0; e < EPC; ++e) {
-    const float* cf = coef + (size_t)b * 4 * C + cc * EPC + e;
-    sc[e] = cf[2 * C]; sh[e] = cf[3 * C];
-  }
+  load_cvec<EPC>(coef + (size_t)b * 4 * C + 2 * C + cc * EPC, sc);
+  load_cvec<EPC>(coef + (size_t)b * 4 * C + 3 * C + cc * EPC, sh);
   const int m_begin = blockIdx.y * rows_per_group;
   const int m_end = min(HW, m_begin + rows_per_group);
   const size_t base = (size_t)b * HW * C;
@@ -165,11 +160,13 @@ __global__ __launch_bounds__(256) void ibn_bwd_apply_kernel(int HW, int C, int n
   const int cc = blockIdx.x * g.cg + ccol;
   const int b = blockIdx.z;
   float mean[EPC], rstd[EPC], sc[EPC], sh[EPC], m1[EPC], m2[EPC];
+  {
+    const float* cf = coef + (size_t)b * 4 * C + cc * EPC;
+    load_cvec<EPC>(cf, mean); load_cvec<EPC>(cf + C, rstd); load_cvec<EPC>(cf + 2 * C, sc); load_cvec<EPC>(cf + 3 * C, sh);
+  }
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
     const int c = cc * EPC + e;
-    const float* cf = coef + (size_t)b * 4 * C + c;
-    mean[e] = cf[0]; rstd[e] = cf[C]; sc[e] = cf[2 * C]; sh[e] = cf[3 * C];
     if (c < nb) {
       m1[e] = training ? bn[c] * inv_count_bn : 0.f;
       m2[e] = training ? bn[nb + c] * inv_count_bn : 0.f;
