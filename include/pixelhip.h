@@ -85,6 +85,14 @@ int pxl_conv_igemm(const pxl_conv_desc* desc, const void* in, const void* w, voi
                    const float* in_scale, const float* in_shift, const float* bias,
                    const void* addend, float* stats, void* workspace, size_t ws_bytes, void* stream);
 
+/* Data gradient with the BatchNorm-backward reduction of its OUTPUT fused into the epilogue (LDS-DMA kernel only):
+ * din = dgrad(dy) (+ addend) and bn_sums[0..C) += sum_m gd, bn_sums[C..2C) += sum_m gd * xhat over the tensor just
+ * written, gd = din * (bn_relu ? scale*bn_y + shift > 0 : 1), xhat = (bn_y - mean) * rstd from bn_coef [4C]; C =
+ * d->Kreal == d->Cout.  Stands in for pxl_conv_igemm + pxl_bn_bwd_reduce (one pass over (din, bn_y) less).  Returns
+ * PXL_ERR_UNSUPPORTED when the descriptor cannot run on the LDS-DMA kernel. */
+int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
+                            const void* bn_y, const float* bn_coef, int bn_relu, float* bn_sums, void* stream);
+
 /* dw[k][t][c] += sum_m dy[m][k] * act(in)[m,t,c]   (fp32, atomically accumulated: zero dw first
  * unless accumulating).  `desc` describes the FORWARD conv (in = its input, Ho/Wo/Cout = dy).
  * creal = real input channels (<= Cin pitch), dw_cpitch = channel pitch of dw.

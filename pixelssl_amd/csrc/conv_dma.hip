@@ -31,6 +31,12 @@ struct DmaArgs {
   const void* addend;
   float* stats;
   int stats_rep;
+  // data-gradient launches: fuse the BatchNorm-backward reduction of the tensor being written.  With bn_y set, `stats`
+  // ([2*Kreal], one replica) receives sum(gd) and sum(gd * xhat), gd = dz * (relu ? bn(y) > 0 : 1), instead of the
+  // forward statistics (sum, sum of squares)
+  const void* bn_y;
+  const float* bn_coef;
+  int bn_relu;
   int B, Hi, Wi, Cin;
   int Ho, Wo, Cout, Kreal;
   int ntaps, so;
@@ -306,6 +312,15 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   const bool has_bias = p.bias != nullptr;
   const bool has_add = gadd != nullptr;
   const bool has_stats = p.stats != nullptr && !(ABL & 32);
+  const bf16_t* __restrict__ gbny = reinterpret_cast<const bf16_t*>(p.bn_y);
+  const bool has_bnr = has_stats && gbny != nullptr;
+  float bn_mean[8], bn_rstd[8], bn_sc[8], bn_sh[8];
+  if (has_bnr && ncol) {
+    load_cvec<8>(p.bn_coef + n, bn_mean);
+    load_cvec<8>(p.bn_coef + p.Cout + n, bn_rstd);
+    load_cvec<8>(p.bn_coef + 2 * p.Cout + n, bn_sc);
+    load_cvec<8>(p.bn_coef + 3 * p.Cout + n, bn_sh);
+  }
   float bv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bv[e] = (has_bias && n + e < p.Kreal) ? p.bias[n + e] : 0.f;
@@ -334,10 +349,22 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
           v = Chunk<bf16_t>::pack(f);
           if (has_stats) Chunk<bf16_t>::unpack(v, f);     // statistics of the stored (rounded) values
         }
+        if (has_bnr) {
+          float fy[8];
+          Chunk<bf16_t>::unpack(*reinterpret_cast<const uint4*>(gbny + o), fy);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          s1[e] += f[e];
-          s2[e] += f[e] * f[e];
+          for (int e = 0; e < 8; ++e) {
+            float gd = f[e];
+            if (p.bn_relu && !(fy[e] * bn_sc[e] + bn_sh[e] > 0.f)) gd = 0.f;
+            s1[e] += gd;
+            s2[e] += gd * (fy[e] - bn_mean[e]) * bn_rstd[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s1[e] += f[e];
+            s2[e] += f[e] * f[e];
+          }
         }
       }
       *reinterpret_cast<uint4*>(gout + o) = v;
@@ -444,13 +471,40 @@ extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_sca
 
 // tile configurations 8..: 8 = 128x128, 9 = 128(pixels)x64, 10 = 64x128, 11 = 64x64 with a 3-stage LDS ring;
 // 12..15 the same with 4 stages, 16..19 with 2 stages (more blocks per CU)
+namespace { int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes, void* stream); }
+
 extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
                             const void* addend, float* stats, void* workspace, size_t ws_bytes, void* stream) {
   DmaArgs a;
+  a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = addend; a.stats = stats;
   a.ws = reinterpret_cast<float*>(workspace);
   a.nk_per = 0;
+  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0;
   const int sk = d->split_k;
-  a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = addend; a.stats = stats;
+  return conv_dma_launch(d, a, sk, ws_bytes, stream);
+}
+
+// Data gradient with the BatchNorm-backward reduction of its output fused into the epilogue: din = dgrad(dy) (+ addend)
+// and bn_sums[0..C) += sum_m gd, bn_sums[C..2C) += sum_m gd * xhat over the tensor just written (C = d->Kreal ==
+// d->Cout: an unpadded channel count), gd = din * (bn_relu ? bn_coef.scale * bn_y + bn_coef.shift > 0 : 1).  Replaces
+// a separate pxl_bn_bwd_reduce pass over (din, bn_y).  PXL_ERR_UNSUPPORTED when the LDS-DMA kernel cannot run the
+// descriptor (the caller then uses pxl_conv_igemm + pxl_bn_bwd_reduce).
+extern "C" int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
+                                       const void* bn_y, const float* bn_coef, int bn_relu, float* bn_sums, void* stream) {
+  PXL_REQUIRE(d && dy && wt && din && bn_y && bn_coef && bn_sums, "conv_dgrad_bnreduce: null argument");
+  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || d->Kreal != d->Cout || (d->tile_cfg >= 0 && d->tile_cfg < 8))
+    return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dgrad_bnreduce: descriptor is not eligible for the LDS-DMA kernel");
+  DmaArgs a;
+  a.in = dy; a.w = wt; a.out = din; a.bias = nullptr; a.addend = addend; a.stats = bn_sums;
+  a.ws = nullptr; a.nk_per = 0;
+  a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = bn_relu;
+  pxl_conv_desc q = *d;
+  q.stats_rep = 1;
+  return conv_dma_launch(&q, a, 1, 0, stream);
+}
+
+namespace {
+int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes, void* stream) {
   a.stats_rep = d->stats_rep >= 1 ? d->stats_rep : 1;
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.Kreal = d->Kreal;
@@ -505,3 +559,4 @@ extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* 
     default: return pxl_set_error(PXL_ERR_ARG, "conv_dma: unknown tile config %d", cfg);
   }
 }
+}  // namespace

@@ -24,6 +24,8 @@
 #include "common.h"
 
 extern "C" {
+int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
+                            const void* bn_y, const float* bn_coef, int bn_relu, float* bn_sums, void* stream);
 int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream);
 int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_scale, const void* workspace);
 int pxl_conv_wgrad_dma_eligible(const pxl_conv_desc* d, const float* in_scale);
@@ -58,6 +60,9 @@ struct BnInfo {
   // kernels read plain operands (the fp32 parity engine keeps the fused prologue)
   bool has_z = false;
   size_t z_off = 0;
+  // the only consumer of relu(bn(y)) is a convolution whose data gradient runs on the LDS-DMA kernel: that launch
+  // also produces this BN's backward sums (no separate reduce pass); -1 = no
+  int fused_reduce_op = -1;
 };
 
 struct OpInfo {
@@ -109,6 +114,7 @@ struct pxl_net {
   bool wgrad_on = true;
   int input_tensor = -1;
   bool latent_seeded = false;      // pxl_net_seed_latent_grad ran: the next backward starts from that gradient
+  bool fuse_bn_reduce = getenv("PXL_FUSE_BN_REDUCE") == nullptr || getenv("PXL_FUSE_BN_REDUCE")[0] != '0';
   // tests: use the reference's multi-device variance formula clamp(var, eps) on a single rank too
   bool force_clamp = getenv("PXL_FORCE_CLAMP_VAR") != nullptr;
 };
@@ -452,6 +458,28 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
     b.has_z = true;
     b.z_off = arena;
     arena += tin.bytes;
+  }
+  // BN-backward reduce fused into the data gradient that writes d(relu(bn(y))): y must have exactly one consumer
+  // (that convolution) and the launch must be eligible for the LDS-DMA kernel
+  for (auto& b : n->bns) b.fused_reduce_op = -1;
+  if (n->dtype == PXL_BF16 && n->fuse_bn_reduce) {
+    std::vector<int> uses(n->tensors.size(), 0);
+    for (auto& op : n->ops) {
+      const pxl_op& d = op.d;
+      if (d.kind == PXL_OP_HEAD) { if (d.in1 >= 0) uses[d.in1] += 2; continue; }     // the latent may receive a seeded gradient
+      if (d.in0 >= 0) ++uses[d.in0];
+      if (d.in1 >= 0) ++uses[d.in1];
+    }
+    for (size_t i = 0; i < n->ops.size(); ++i) {
+      OpInfo& op = n->ops[i];
+      const pxl_op& d = op.d;
+      if (d.kind != PXL_OP_CONV || d.bn_in0 < 0 || !d.need_dgrad || d.stride != 1) continue;
+      BnInfo& b = n->bns[d.bn_in0];
+      const TensorInfo& tin = n->tensors[d.in0];
+      if (b.y_tensor != d.in0 || uses[d.in0] != 1 || tin.Cp != tin.C || tin.C != b.d.C) continue;
+      if (!pxl_conv_dma_eligible(&op.bwd, nullptr, nullptr)) continue;
+      b.fused_reduce_op = (int)i;
+    }
   }
   n->arena_bytes = arena;
   n->scratch_bytes = scratch;
@@ -920,9 +948,12 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         if (d.bn_out >= 0) {
           BnInfo& b = n->bns[d.bn_out];
           const float* coef = fat(arena, b.coef_off);
-          // one [2C] vector per BN (the reduce kernel issues one atomic per channel per block, no replicas needed)
-          rc = pxl_bn_bwd_reduce(dt, M, tout.Cp, dy, at(arena, tout.off), coef, b.relu, fat(scratch, b.bsum_off), 1, stream);
-          if (rc != PXL_OK) return rc;
+          // one [2C] vector per BN (the reduce kernel issues one atomic per channel per block, no replicas needed);
+          // already filled when the consumer's data gradient ran with the fused reduction
+          if (b.fused_reduce_op < 0) {
+            rc = pxl_bn_bwd_reduce(dt, M, tout.Cp, dy, at(arena, tout.off), coef, b.relu, fat(scratch, b.bsum_off), 1, stream);
+            if (rc != PXL_OK) return rc;
+          }
           float* dgam = grads + b.d.gamma_off;
           float* dbet = grads + b.d.beta_off;
           if (training && n->sync && n->world > 1) {
@@ -964,8 +995,14 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
           void* din = at(scratch, tin.goff);
           Timed t(n, s, 0, conv_flops(n, d, tout));
           if (n->profile) n->prof_bytes[0] += conv_bytes(n, d, tin, tout, false);
-          rc = pxl_conv_igemm(&op.bwd, dy, at(packed, op.wt_off), din, nullptr, nullptr, nullptr,
-                              written[d.in0] ? din : nullptr, nullptr, nullptr, 0, stream);
+          if (d.bn_in0 >= 0 && n->bns[d.bn_in0].fused_reduce_op == i) {
+            const BnInfo& bi = n->bns[d.bn_in0];
+            rc = pxl_conv_dgrad_bnreduce(&op.bwd, dy, at(packed, op.wt_off), din, written[d.in0] ? din : nullptr,
+                                         at(arena, tin.off), fat(arena, bi.coef_off), bi.relu, fat(scratch, bi.bsum_off), stream);
+          } else {
+            rc = pxl_conv_igemm(&op.bwd, dy, at(packed, op.wt_off), din, nullptr, nullptr, nullptr,
+                                written[d.in0] ? din : nullptr, nullptr, nullptr, 0, stream);
+          }
           written[d.in0] = 1;
         }
         break;

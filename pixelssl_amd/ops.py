@@ -42,6 +42,14 @@ def conv_igemm(desc, x, w, out, in_scale=None, in_shift=None, bias=None, addend=
     return out
 
 
+def conv_dgrad_bnreduce(desc, dy, wt, din, bn_y, bn_coef, bn_relu, bn_sums, addend=None):
+    """data gradient + fused BN-backward reduction of its output (LDS-DMA kernel); raises when not eligible"""
+    _require_cuda(dy, wt, din, bn_y, bn_coef, bn_sums)
+    check(lib().pxl_conv_dgrad_bnreduce(desc, ptr(dy), ptr(wt), ptr(din), ptr(addend), ptr(bn_y), ptr(bn_coef), int(bn_relu),
+                                        ptr(bn_sums), stream_ptr()))
+    return din
+
+
 def conv_wgrad(desc, x, dy, dw, creal, dw_cpitch, in_scale=None, in_shift=None):
     _require_cuda(x, dy, dw)
     check(lib().pxl_conv_wgrad(desc, ptr(x), ptr(in_scale), ptr(in_shift), ptr(dy), ptr(dw), creal, dw_cpitch,

@@ -160,6 +160,42 @@ def test_conv_dma_forward_and_dgrad(case, cfg):
     assert rel_err(from_nhwc(dx, Cin), x.grad) < TOL[dtype], "dgrad %s cfg %d" % (name, cfg)
 
 
+@pytest.mark.parametrize("cfg", [-1, 8, 10, 11, 18])
+@pytest.mark.parametrize("shape", [(2, 128, 64, 17, 19, 3, 1, 1), (3, 64, 256, 9, 13, 1, 1, 0), (2, 192, 128, 12, 12, 3, 2, 2)])
+def test_conv_dgrad_with_fused_bn_backward_reduce(shape, cfg):
+    """pxl_conv_dgrad_bnreduce == pxl_conv_igemm (data gradient) followed by pxl_bn_bwd_reduce over the tensor just
+    written: identical din, and the [sum gd, sum gd*xhat] vectors of the stored (rounded) values, with and without an
+    addend and the ReLU mask."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    B, Cin, Cout, H, W, k, d, p = shape
+    g = torch.Generator().manual_seed(B * 100 + Cin + k)
+    w = qround(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype)
+    taps = ops.fwd_taps(k, k, d, p)
+    Ho, Wo = H + 2 * p - d * (k - 1), W + 2 * p - d * (k - 1)
+    dy = to_nhwc(qround(torch.randn(B, Cout, Ho, Wo, generator=g), dtype), Cout, dtype)
+    _, wt = pack_w(w, dtype, Cin, kp=Cout)
+    y = to_nhwc(qround(torch.randn(B, Cin, H, W, generator=g), dtype), Cin, dtype)           # BN input of the tensor
+    add = to_nhwc(qround(torch.randn(B, Cin, H, W, generator=g), dtype), Cin, dtype)
+    coef = torch.cat([torch.randn(Cin, generator=g) * 0.1, torch.rand(Cin, generator=g) + 0.5,
+                      torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3]).to(DEV)
+    bdesc = ops.conv_desc(dtype, B, Ho, Wo, Cout, H, W, Cin, Cin, [(-a, -b) for a, b in taps], out_stride=1, div=1, tile_cfg=cfg)
+    from pixelssl_amd._lib import lib, check, ptr, stream_ptr, dtype_code
+    for relu in (1, 0):
+        for addend in (None, add):
+            ref = torch.empty(B, H, W, Cin, device=DEV, dtype=dtype)
+            ops.conv_igemm(bdesc, dy, wt, ref, addend=addend)
+            rs = torch.zeros(2 * Cin, device=DEV)
+            check(lib().pxl_bn_bwd_reduce(dtype_code(dtype), B * H * W, Cin, ptr(ref), ptr(y), ptr(coef), relu, ptr(rs), 1,
+                                          stream_ptr()))
+            got = torch.empty_like(ref)
+            sums = torch.zeros(2 * Cin, device=DEV)
+            ops.conv_dgrad_bnreduce(bdesc, dy, wt, got, y, coef, relu, sums, addend=addend)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref)
+            assert rel_err(sums.cpu(), rs.cpu()) < 1e-4, (shape, cfg, relu, addend is not None)
+
+
 WDMA_CASES = [
     # name, B, Cin, Cout, H, W, k, stride, dil, pad   (Cin % 128 == 0: conv_wgrad_dma.hip)
     ("wdma_1x1", 3, 256, 72, 9, 13, 1, 1, 1, 0),
