@@ -145,6 +145,10 @@ int pxl_bn_bwd_reduce(int dtype, int M, int C, const void* dz, const void* y, co
                       float* sums, int nrep, void* stream);
 /* bcoef [2C] = fold(sums) / count (zeros when training == 0: eval-mode BN is a fixed affine);
  * dgamma += sum dz'*xhat ; dbeta += sum dz' */
+/* Backward of the bottleneck join out = relu(bn3(y) + res) (resnet.py:44-48) fused with bn3's reduction: g = dout *
+ * (out > 0) -> g (and g2 = the residual branch's copy, may be NULL); sums[0..C) += sum_m g, sums[C..2C) += sum_m g*xhat */
+int pxl_residual_bwd_reduce(int dtype, int M, int C, const void* dout, const void* out, const void* y, const float* coef,
+                            void* g, void* g2, float* sums, void* stream);
 int pxl_bn_bwd_finalize(int C, const float* sums, int nrep, float count, float* dgamma, float* dbeta,
                         float* bcoef, int training, void* stream);
 /* dgamma += sums[C..2C), dbeta += sums[0..C).  Multi-rank training takes the affine gradients from the LOCAL
@@ -427,6 +431,9 @@ int pxl_net_seed_latent_grad(pxl_net* net, void* scratch, size_t scratch_bytes, 
 /* gradient w.r.t. the network input of the last backward (NCHW fp32 [B,Cin,H,W]); the first convolution of the
  * program must have need_dgrad = 1 (discriminator / flaw detector: the input is the task model's softmax) */
 int pxl_net_input_grad(pxl_net* net, const void* scratch, float* dx, void* stream);
+/* enable = 0: pxl_net_pack skips the transposed (data-gradient) weight copies -- networks that only run forward (the
+ * Mean-Teacher teacher); pxl_net_backward then refuses to run */
+int pxl_net_set_pack_dgrad(pxl_net* net, int enable);
 /* enable = 0: backward skips every parameter gradient (a frozen discriminator only relays dL/dinput) */
 int pxl_net_set_wgrad(pxl_net* net, int enable);
 

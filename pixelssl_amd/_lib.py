@@ -73,6 +73,7 @@ SIGNATURES = {
     "pxl_bn_apply_fwd": (_I, [_I, _L, _I, _P, _P, _I, _P, _P]),
     "pxl_bn_fold_replicas": (_I, [_I, _I, _P, _P]),
     "pxl_bn_bwd_reduce": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
+    "pxl_residual_bwd_reduce": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pxl_bn_bwd_finalize": (_I, [_I, _P, _I, _F, _P, _P, _P, _I, _P]),
     "pxl_bn_bwd_apply": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "pxl_bn_param_grad": (_I, [_I, _P, _P, _P, _P]),
@@ -148,6 +149,7 @@ SIGNATURES = {
     "pxl_net_input_grad": (_I, [_P, _P, _P, _P]),
     "pxl_net_seed_latent_grad": (_I, [_P, _P, _Z, _P, _P]),
     "pxl_net_set_wgrad": (_I, [_P, _I]),
+    "pxl_net_set_pack_dgrad": (_I, [_P, _I]),
     "pxl_net_profile": (_I, [_P, _I]),
     "pxl_net_profile_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
     "pxl_net_profile_bytes": (_I, [_P, _I, C.POINTER(C.c_double)]),

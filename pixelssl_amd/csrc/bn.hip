@@ -70,16 +70,20 @@ __global__ void fold_replicas_kernel(int n, int nrep, float* __restrict__ buf) {
 // sums[rep][0..C) += sum_m dzh ; sums[rep][C..2C) += sum_m dzh * xhat     dzh = dz * (relu ? z>0 : 1)
 // One LDS reduction over the row lanes and ONE atomic per (channel, sum) per block: 2*8*CG atomics per block
 // instead of 2*C (the previous row-major blocks issued 2 M atomics for an 8712 x 1024 tensor).
-template <typename T>
+// MASK: the incoming gradient is first passed through the ReLU of a residual join, dz = dout * (mout > 0), and that
+// masked gradient is also WRITTEN (g, and g2 = the identity branch's copy): relu_mask + reduce in one pass.
+template <typename T, bool MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int M, int C, const T* __restrict__ dz,
                                                             const T* __restrict__ y,
                                                             const float* __restrict__ coef, int relu,
                                                             float* __restrict__ sums, int nrep, int rows_per_group,
-                                                            int cgmax) {
+                                                            int cgmax, const T* __restrict__ mout, T* __restrict__ g,
+                                                            T* __restrict__ g2) {
   constexpr int EPC = Elem<T>::EPC;
-  const ColGeom g = col_geom(C, EPC, cgmax);
-  const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
-  const int cc = blockIdx.x * g.cg + ccol;
+  const ColGeom geo = col_geom(C, EPC, cgmax);
+  const ColGeom& gq = geo;
+  const int ccol = threadIdx.x % gq.cg, rlane = threadIdx.x / gq.cg;
+  const int cc = blockIdx.x * gq.cg + ccol;
   __shared__ float red[256 * 2 * EPC];            // [rl][cg][2*EPC]
   float mean[EPC], rstd[EPC], sc[EPC], sh[EPC], a1[EPC], a2[EPC];
   load_cvec<EPC>(coef + cc * EPC, mean);
@@ -90,10 +94,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int M, int C, const 
   for (int e = 0; e < EPC; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
   const int m_begin = blockIdx.y * rows_per_group;
   const int m_end = min(M, m_begin + rows_per_group);
-  auto accum = [&](const uint4& vd, const uint4& vy) {
+  auto accum = [&](const uint4& vd, const uint4& vy, size_t o) {
     float fd[EPC], fy[EPC];
     Chunk<T>::unpack(vd, fd);
     Chunk<T>::unpack(vy, fy);
+    if constexpr (MASK) {
+      float fo[EPC];
+      Chunk<T>::unpack(*reinterpret_cast<const uint4*>(mout + o), fo);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) fd[e] = fo[e] > 0.f ? fd[e] : 0.f;
+      const uint4 v = Chunk<T>::pack(fd);
+      *reinterpret_cast<uint4*>(g + o) = v;
+      if (g2 != nullptr) *reinterpret_cast<uint4*>(g2 + o) = v;
+    }
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float gd = fd[e];
@@ -103,31 +116,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int M, int C, const 
     }
   };
   int m = m_begin + rlane;
-  for (; m + g.rl < m_end; m += 2 * g.rl) {        // two rows in flight per thread
-    const size_t o0 = (size_t)m * C + cc * EPC, o1 = (size_t)(m + g.rl) * C + cc * EPC;
+  for (; m + gq.rl < m_end; m += 2 * gq.rl) {        // two rows in flight per thread
+    const size_t o0 = (size_t)m * C + cc * EPC, o1 = (size_t)(m + gq.rl) * C + cc * EPC;
     const uint4 d0 = *reinterpret_cast<const uint4*>(dz + o0), y0 = *reinterpret_cast<const uint4*>(y + o0);
     const uint4 d1 = *reinterpret_cast<const uint4*>(dz + o1), y1 = *reinterpret_cast<const uint4*>(y + o1);
-    accum(d0, y0);
-    accum(d1, y1);
+    accum(d0, y0, o0);
+    accum(d1, y1, o1);
   }
   if (m < m_end) {
     const size_t o0 = (size_t)m * C + cc * EPC;
-    accum(*reinterpret_cast<const uint4*>(dz + o0), *reinterpret_cast<const uint4*>(y + o0));
+    accum(*reinterpret_cast<const uint4*>(dz + o0), *reinterpret_cast<const uint4*>(y + o0), o0);
   }
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
-    red[(rlane * g.cg + ccol) * 2 * EPC + e] = a1[e];
-    red[(rlane * g.cg + ccol) * 2 * EPC + EPC + e] = a2[e];
+    red[(rlane * gq.cg + ccol) * 2 * EPC + e] = a1[e];
+    red[(rlane * gq.cg + ccol) * 2 * EPC + EPC + e] = a2[e];
   }
   __syncthreads();
   // thread t < cg * 2 * EPC sums one (column, which, element) over the row lanes
-  const int nout = g.cg * 2 * EPC;
+  const int nout = gq.cg * 2 * EPC;
   for (int o = threadIdx.x; o < nout; o += 256) {
     const int col = o / (2 * EPC), w = o % (2 * EPC);
     float v = 0.f;
-    for (int r = 0; r < g.rl; ++r) v += red[(r * g.cg + col) * 2 * EPC + w];
+    for (int r = 0; r < gq.rl; ++r) v += red[(r * gq.cg + col) * 2 * EPC + w];
     float* rep = sums + (size_t)((blockIdx.y + blockIdx.x) % nrep) * 2 * C;
-    const int c = (blockIdx.x * g.cg + col) * EPC + (w % EPC);
+    const int c = (blockIdx.x * gq.cg + col) * EPC + (w % EPC);
     atomicAdd(rep + (w / EPC) * C + c, v);
   }
 }
@@ -299,26 +312,49 @@ extern "C" int pxl_bn_fold_replicas(int n, int nrep, float* buf, void* stream) {
   return PXL_OK;
 }
 
-extern "C" int pxl_bn_bwd_reduce(int dtype, int M, int C, const void* dz, const void* y, const float* coef,
-                                 int relu, float* sums, int nrep, void* stream) {
-  PXL_REQUIRE(dz && y && coef && sums && M > 0 && nrep >= 1, "bn_bwd_reduce: bad argument");
-  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "bn_bwd_reduce: bad dtype %d", dtype);
+namespace {
+int launch_bwd_reduce(int dtype, int M, int C, const void* dz, const void* y, const float* coef, int relu, float* sums,
+                      int nrep, const void* mout, void* g, void* g2, void* stream) {
   const int epc = dtype == PXL_F32 ? 4 : 8;
-  PXL_REQUIRE(C % epc == 0, "bn_bwd_reduce: C=%d must be a multiple of %d", C, epc);
   const int cgmax = pxl_tune_get(4);
-  const ColGeom g = col_geom(C, epc, cgmax);
+  const ColGeom geo = col_geom(C, epc, cgmax);
   // every row group ends in one atomic per channel: cap the row groups at 256 (narrow tensors have 1-2 column groups)
-  const int rpg = rows_per_group(M, g, min(pxl_tune_get(0), 256 * g.ncg));
-  const dim3 grid(g.ncg, cdiv(M, rpg));
+  const int rpg = rows_per_group(M, geo, min(pxl_tune_get(0), 256 * geo.ncg));
+  const dim3 grid(geo.ncg, cdiv(M, rpg));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == PXL_F32)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, M, C, (const float*)dz,
-                       (const float*)y, coef, relu, sums, nrep, rpg, cgmax);
-  else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, M, C, (const bf16_t*)dz,
-                       (const bf16_t*)y, coef, relu, sums, nrep, rpg, cgmax);
+  if (dtype == PXL_F32) {
+    if (mout) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), grid, dim3(256), 0, s, M, C, (const float*)dz, (const float*)y,
+                                 coef, relu, sums, nrep, rpg, cgmax, (const float*)mout, (float*)g, (float*)g2);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), grid, dim3(256), 0, s, M, C, (const float*)dz, (const float*)y,
+                            coef, relu, sums, nrep, rpg, cgmax, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+  } else {
+    if (mout) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), grid, dim3(256), 0, s, M, C, (const bf16_t*)dz,
+                                 (const bf16_t*)y, coef, relu, sums, nrep, rpg, cgmax, (const bf16_t*)mout, (bf16_t*)g, (bf16_t*)g2);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), grid, dim3(256), 0, s, M, C, (const bf16_t*)dz,
+                            (const bf16_t*)y, coef, relu, sums, nrep, rpg, cgmax, (const bf16_t*)nullptr, (bf16_t*)nullptr,
+                            (bf16_t*)nullptr);
+  }
   PXL_LAUNCH_CHECK();
   return PXL_OK;
+}
+}  // namespace
+
+extern "C" int pxl_bn_bwd_reduce(int dtype, int M, int C, const void* dz, const void* y, const float* coef, int relu,
+                                 float* sums, int nrep, void* stream) {
+  PXL_REQUIRE(dz && y && coef && sums && M > 0 && nrep >= 1, "bn_bwd_reduce: bad argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "bn_bwd_reduce: bad dtype %d", dtype);
+  PXL_REQUIRE(C % (dtype == PXL_F32 ? 4 : 8) == 0, "bn_bwd_reduce: C=%d is not 16-byte aligned", C);
+  return launch_bwd_reduce(dtype, M, C, dz, y, coef, relu, sums, nrep, nullptr, nullptr, nullptr, stream);
+}
+
+// Backward of the bottleneck join out = relu(bn3(y) + res) fused with bn3's reduction: g = dout * (out > 0) is written
+// to `g` (and `g2`, the residual branch's copy, may be NULL) and sums[0..C) += sum g, sums[C..2C) += sum g * xhat(y).
+extern "C" int pxl_residual_bwd_reduce(int dtype, int M, int C, const void* dout, const void* out, const void* y,
+                                       const float* coef, void* g, void* g2, float* sums, void* stream) {
+  PXL_REQUIRE(dout && out && y && coef && g && sums && M > 0, "residual_bwd_reduce: bad argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "residual_bwd_reduce: bad dtype %d", dtype);
+  PXL_REQUIRE(C % (dtype == PXL_F32 ? 4 : 8) == 0, "residual_bwd_reduce: C=%d is not 16-byte aligned", C);
+  return launch_bwd_reduce(dtype, M, C, dout, y, coef, 0, sums, 1, out, g, g2, stream);
 }
 
 extern "C" int pxl_bn_bwd_apply_fused(int dtype, int M, int C, const void* dz, const void* y, const float* coef,

@@ -27,6 +27,8 @@ extern "C" {
 int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
                             const void* bn_y, const float* bn_coef, int bn_relu, float* bn_sums, void* stream);
 int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream);
+int pxl_residual_bwd_reduce(int dtype, int M, int C, const void* dout, const void* out, const void* y, const float* coef,
+                            void* g, void* g2, float* sums, void* stream);
 int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_scale, const void* workspace);
 int pxl_conv_wgrad_dma_eligible(const pxl_conv_desc* d, const float* in_scale);
 }
@@ -112,6 +114,7 @@ struct pxl_net {
   hipEvent_t join_ev = nullptr;
   int use_side = -1;
   bool wgrad_on = true;
+  bool pack_dgrad = true;          // false: pxl_net_pack skips the transposed (data-gradient) weights (no-grad networks)
   int input_tensor = -1;
   bool latent_seeded = false;      // pxl_net_seed_latent_grad ran: the next backward starts from that gradient
   bool fuse_bn_reduce = getenv("PXL_FUSE_BN_REDUCE") == nullptr || getenv("PXL_FUSE_BN_REDUCE")[0] != '0';
@@ -505,7 +508,7 @@ extern "C" int pxl_net_pack(pxl_net* n, const float* params, void* packed, void*
       pxl_pack_item it;
       it.src_off = d.w_off[g];
       it.wf_off = (int64_t)op.wf_off;
-      it.wt_off = d.need_dgrad ? (int64_t)op.wt_off : -1;
+      it.wt_off = (d.need_dgrad && n->pack_dgrad) ? (int64_t)op.wt_off : -1;
       it.K = d.cout; it.T = tpg; it.C = d.cin;
       it.Cp = tin.Cp; it.T_total = op.ntaps; it.t_off = g * tpg; it.Kp = tout.Cp;
       items.push_back(it);
@@ -579,7 +582,7 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
       op.fwd.tile_cfg = best_cfg;
     }
     // data gradient
-    if (d.need_dgrad) {
+    if (d.need_dgrad && n->pack_dgrad) {
       int best_cfg = -1; float best = 1e30f;
       const bool dma = pxl_conv_dma_eligible(&op.bwd, nullptr, nullptr) != 0;
       for (int cfg = dma ? 8 : 0; cfg < (dma ? 20 : 8); ++cfg) {
@@ -595,7 +598,7 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
       op.bwd.tile_cfg = best_cfg;
     }
     // weight gradient (per tap group)
-    for (int g = 0; g < d.ngroups; ++g) {
+    for (int g = 0; g < d.ngroups && n->pack_dgrad; ++g) {
       int best_cfg = -1; float best = 1e30f;
       const bool wdma = pxl_conv_wgrad_dma_eligible(&op.grp[g], sc) != 0;
       for (int cfg = 0; cfg < (wdma ? 14 : 3); ++cfg) {
@@ -762,6 +765,12 @@ extern "C" int pxl_net_set_wgrad(pxl_net* net, int enable) {
   return PXL_OK;
 }
 
+extern "C" int pxl_net_set_pack_dgrad(pxl_net* net, int enable) {
+  PXL_REQUIRE(net, "net_set_pack_dgrad: null net");
+  net->pack_dgrad = enable != 0;
+  return PXL_OK;
+}
+
 extern "C" int pxl_net_input_grad(pxl_net* n, const void* scratch, float* dx, void* stream) {
   PXL_REQUIRE(n && n->planned && scratch && dx && n->input_tensor >= 0, "net_input_grad: bad argument");
   const TensorInfo& t = n->tensors[n->input_tensor];
@@ -805,6 +814,7 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
                                 void* stream) {
   PXL_REQUIRE(n && n->planned && params && packed && grads && arena && scratch, "net_backward: bad argument");
   PXL_REQUIRE(dlogits || dprob, "net_backward: no incoming gradient");
+  PXL_REQUIRE(n->pack_dgrad, "net_backward: this network packs no data-gradient weights (pxl_net_set_pack_dgrad(net, 0))");
   if (arena_bytes < n->arena_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_backward: arena too small");
   if (scratch_bytes < n->scratch_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_backward: scratch too small (%zu < %zu)", scratch_bytes, n->scratch_bytes);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -812,6 +822,7 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
   if (n->bsum_region_bytes)
     PXL_CHECK_HIP(hipMemsetAsync(at(scratch, n->bsum_region_off), 0, n->bsum_region_bytes, s));
   std::vector<char> written(n->tensors.size(), 0);
+  std::vector<char> reduced(n->bns.size(), 0);        // BN-backward sums already produced by a fused launch
   if (n->latent_seeded) {
     written[n->ops[n->head_op].d.in1] = 1;
     n->latent_seeded = false;
@@ -918,7 +929,15 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         const TensorInfo& r = n->tensors[d.in1];
         const long nelem = (long)n->B * o.H * o.W * o.Cp;
         if (written[d.in0]) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net_backward: residual main branch consumed twice");
-        if (!written[d.in1]) {
+        const BnInfo& b3 = n->bns[d.bn_in0];
+        if (!written[d.in1] && n->fuse_bn_reduce && b3.y_tensor == d.in0 && a.Cp == b3.d.C) {
+          // relu mask + the main branch BN's backward sums in one pass
+          rc = pxl_residual_bwd_reduce(dt, n->B * a.H * a.W, a.Cp, at(scratch, o.goff), at(arena, o.off), at(arena, a.off),
+                                       fat(arena, b3.coef_off), at(scratch, a.goff), at(scratch, r.goff),
+                                       fat(scratch, b3.bsum_off), stream);
+          reduced[d.bn_in0] = 1;
+          written[d.in1] = 1;
+        } else if (!written[d.in1]) {
           rc = pxl_relu_mask(dt, nelem, at(scratch, o.goff), at(arena, o.off), at(scratch, a.goff), at(scratch, r.goff), stream);
           written[d.in1] = 1;
         } else {
@@ -950,7 +969,7 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
           const float* coef = fat(arena, b.coef_off);
           // one [2C] vector per BN (the reduce kernel issues one atomic per channel per block, no replicas needed);
           // already filled when the consumer's data gradient ran with the fused reduction
-          if (b.fused_reduce_op < 0) {
+          if (b.fused_reduce_op < 0 && !reduced[d.bn_out]) {
             rc = pxl_bn_bwd_reduce(dt, M, tout.Cp, dy, at(arena, tout.off), coef, b.relu, fat(scratch, b.bsum_off), 1, stream);
             if (rc != PXL_OK) return rc;
           }

@@ -383,6 +383,11 @@ class SegNetCore(nn.Module):
     def _ensure_packed(self):
         pl = self._cur
         v = self._store.version()
+        trainable = bool(self._param_list) and self._param_list[0].requires_grad
+        if pl.pack_dgrad != trainable:      # a no-grad network (the MT teacher) needs no transposed weight copies
+            check(lib().pxl_net_set_pack_dgrad(pl.net, int(trainable)))
+            pl.pack_dgrad = trainable
+            pl.packed_version = None
         if pl.packed_version != v:
             check(lib().pxl_net_pack(pl.net, ptr(self._store.params), ptr(pl.packed), stream_ptr()))
             pl.packed_version = v
@@ -520,6 +525,7 @@ class _Plan:
         self.net = ctypes.c_void_p()
         self.packed = self.scratch = self.eval_arena = None
         self.packed_version = None
+        self.pack_dgrad = True
         self.arena_bytes = 0
         self.tuned = False
 

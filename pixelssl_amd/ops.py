@@ -130,6 +130,17 @@ def residual_fwd(y, ycoef, res, rcoef=None):
     return out
 
 
+def residual_bwd_reduce(dout, out, y, coef, second=True):
+    """relu mask of the join + bn3's backward sums in one pass -> (g, g2 | None, sums[2C])"""
+    M, Cc = dout.numel() // dout.shape[-1], dout.shape[-1]
+    g = torch.empty_like(dout)
+    g2 = torch.empty_like(dout) if second else None
+    sums = torch.zeros(2 * Cc, device=dout.device, dtype=torch.float32)
+    check(lib().pxl_residual_bwd_reduce(dtype_code(dout.dtype), M, Cc, ptr(dout), ptr(out), ptr(y), ptr(coef), ptr(g), ptr(g2),
+                                        ptr(sums), stream_ptr()))
+    return g, g2, sums
+
+
 def relu_mask(dout, out, second=False):
     g = torch.empty_like(dout)
     g2 = torch.empty_like(dout) if second else None

@@ -419,6 +419,16 @@ def test_residual_join_and_relu_mask(dtype):
     torch.cuda.synchronize()
     want = dout * (qround(ref, dtype) > 0)
     assert torch.equal(from_nhwc(g1, C), want) and torch.equal(from_nhwc(g2, C), want)
+    # the same mask fused with the main-branch BN's backward reduction (pxl_residual_bwd_reduce)
+    coef = torch.cat([torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5, yc[2 * C:3 * C], yc[3 * C:]])
+    for second in (True, False):
+        f1, f2, sums = ops.residual_bwd_reduce(to_nhwc(dout, C, dtype), to_nhwc(ref, C, dtype), to_nhwc(y, C, dtype),
+                                               coef.to(DEV), second=second)
+        torch.cuda.synchronize()
+        assert torch.equal(f1, g1) and (f2 is None or torch.equal(f2, g1))
+        xhat = (y - coef[:C].view(1, -1, 1, 1)) * coef[C:2 * C].view(1, -1, 1, 1)
+        assert rel_err(sums[:C].cpu(), want.sum(dim=(0, 2, 3))) < 1e-4
+        assert rel_err(sums[C:].cpu(), (want * xhat).sum(dim=(0, 2, 3))) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
