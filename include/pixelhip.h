@@ -442,6 +442,20 @@ int pxl_net_set_wgrad(pxl_net* net, int enable);
 #define PXL_TUNE_COUNT 5      /* key 4 = widest column group (16-byte chunks of one row per block) of those kernels */
 int pxl_tune_set(int key, int value);
 
+/* ------------------------------------------------------------------------------------------ */
+/* RCCL communicator driven from C (one per process / GPU); librccl is resolved at run time     */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct pxl_comm pxl_comm;
+int pxl_comm_available(void);                                  /* 1 if librccl could be loaded */
+int pxl_comm_unique_id(void* id128);                           /* rank 0: 128-byte id to broadcast to every rank */
+int pxl_comm_init(const void* id128, int rank, int world, pxl_comm** out);      /* collective */
+void pxl_comm_destroy(pxl_comm* comm);
+/* in-place all-reduce(sum) of n floats at device pointer buf, enqueued on `stream` */
+int pxl_comm_allreduce_sum(pxl_comm* comm, float* buf, long n, void* stream);
+/* the same with the pxl_allreduce_fn signature: pxl_net_set_sync(net, pxl_comm_allreduce_hook, comm, world) makes the
+ * Sync-BN statistics exchange a direct RCCL call from the executor (no host-language callback in the loop) */
+int pxl_comm_allreduce_hook(void* user, float* buf, int n, void* stream);
+
 /* Measurement aid (bench.py roofline leg): bracket every contraction launch of this net with HIP
  * events on the launch stream.  kind 0 = implicit-GEMM conv (forward + data gradient), 1 = weight
  * gradient.  read() synchronises on the recorded events, returns the summed kernel time, the number

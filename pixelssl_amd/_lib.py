@@ -133,6 +133,12 @@ SIGNATURES = {
     "pxl_ema_update": (_I, [_L, _P, _P, _F, _P]),
     "pxl_scale_inplace": (_I, [_L, _P, _F, _P]),
     "pxl_tune_set": (_I, [_I, _I]),
+    "pxl_comm_available": (_I, []),
+    "pxl_comm_unique_id": (_I, [_P]),
+    "pxl_comm_init": (_I, [_P, _I, _I, C.POINTER(_P)]),
+    "pxl_comm_destroy": (None, [_P]),
+    "pxl_comm_allreduce_sum": (_I, [_P, _P, _L, _P]),
+    "pxl_comm_allreduce_hook": (_I, [_P, _P, _I, _P]),
     "pxl_net_create": (_I, [_I, _I, C.POINTER(Op), _I, C.POINTER(BnDesc), _I, _I, C.POINTER(_P)]),
     "pxl_net_destroy": (None, [_P]),
     "pxl_net_plan": (_I, [_P, _I, _I, _I]),

@@ -98,18 +98,77 @@ def _sync_stats_callback(buf_ptr, n, stream):
     return 0
 
 
+_native = {"tried": False, "comm": None, "hook": None}
+
+
+def native_comm():
+    """The process's RCCL communicator driven from C (csrc/comm.cpp), or None: only with the nccl backend (one GPU per
+    rank), agreed on by ALL ranks, verified against torch.distributed once, and PXL_NATIVE_RCCL=0 disables it."""
+    if _native["tried"]:
+        return _native["comm"]
+    _native["tried"] = True
+    if not is_distributed() or dist.get_backend() != "nccl" or os.environ.get("PXL_NATIVE_RCCL", "1") == "0":
+        return None
+    import ctypes
+    from . import _lib
+    h = _lib.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ok = torch.tensor([1.0 if h.pxl_comm_available() else 0.0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)              # every rank must be able to load librccl
+    if ok.item() < 1:
+        return None
+    ident = torch.zeros(128, dtype=torch.uint8)
+    if rank() == 0:
+        _lib.check(h.pxl_comm_unique_id(ident.data_ptr()))
+    ident_d = ident.to(dev)
+    dist.broadcast(ident_d, 0)
+    ident = ident_d.cpu()
+    comm = ctypes.c_void_p()
+    rc = h.pxl_comm_init(ident.data_ptr(), rank(), world_size(), ctypes.byref(comm))
+    good = rc == 0
+    if good:                                                  # one verified exchange before anything depends on it
+        probe = torch.full((64,), float(rank() + 1), device=dev)
+        rc = h.pxl_comm_allreduce_sum(comm, probe.data_ptr(), 64, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ws = world_size()
+        good = rc == 0 and bool((probe == ws * (ws + 1) / 2).all().item())
+    ok = torch.tensor([1.0 if good else 0.0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if ok.item() < 1:
+        if comm.value:
+            h.pxl_comm_destroy(comm)
+        return None
+    _native["comm"] = comm
+    _native["hook"] = ctypes.cast(h.pxl_comm_allreduce_hook, _lib.ALLREDUCE_FN)
+    return comm
+
+
 def _post_backward(core):
+    comm = _native["comm"]
+    if comm is not None:
+        from . import _lib
+        g = core.flat.grads
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().pxl_comm_allreduce_sum(comm, g.data_ptr(), g.numel(), s))
+        _lib.check(_lib.lib().pxl_scale_inplace(g.numel(), g.data_ptr(), 1.0 / world_size(), s))
+        return
     allreduce_mean_(core.flat.grads)
 
 
 def attach(model):
-    """Wire every engine network inside `model` for multi-rank training (no-op on one rank)."""
+    """Wire every engine network inside `model` for multi-rank training (no-op on one rank): Sync-BN statistics and
+    the flat-gradient all-reduce go through the C-driven RCCL communicator when it is available (nccl backend), else
+    through torch.distributed (gloo in the CPU tests)."""
     if not is_distributed():
         return model
     from .engine import SegNetCore
     ws = world_size()
+    comm = native_comm()
     for m in model.modules():
         if isinstance(m, SegNetCore):
-            m.set_sync(_sync_stats_callback, ws)
+            if comm is not None:
+                m.set_sync_native(_native["hook"], comm, ws)
+            else:
+                m.set_sync(_sync_stats_callback, ws)
             m._post_backward_hook = _post_backward
     return model

@@ -371,7 +371,7 @@ class SegNetCore(nn.Module):
             pl.scratch = torch.empty(lib().pxl_net_scratch_bytes(pl.net), device=dev, dtype=torch.uint8)
             pl.arena_bytes = lib().pxl_net_arena_bytes(pl.net)
             if self._sync_cb is not None:
-                check(lib().pxl_net_set_sync(pl.net, self._sync_cb, None, self._sync_world))
+                check(lib().pxl_net_set_sync(pl.net, self._sync_cb, getattr(self, "_sync_user", None), self._sync_world))
             if not self._wgrad_on:
                 check(lib().pxl_net_set_wgrad(pl.net, 0))
             if self._profile_on:
@@ -413,9 +413,19 @@ class SegNetCore(nn.Module):
                 traceback.print_exc()
                 return 1
         self._sync_cb = _lib.ALLREDUCE_FN(_cb)
+        self._sync_user = None
         self._sync_world = world_size
         for pl in self._plans.values():
             check(lib().pxl_net_set_sync(pl.net, self._sync_cb, None, world_size))
+
+    def set_sync_native(self, fn, user, world_size):
+        """fn: a C function with the pxl_allreduce_fn signature (ctypes object), user: its context pointer -- the
+        Sync-BN exchange then never leaves C (dist.py wires pxl_comm_allreduce_hook + the RCCL communicator)."""
+        self._sync_cb = fn
+        self._sync_user = user
+        self._sync_world = world_size
+        for pl in self._plans.values():
+            check(lib().pxl_net_set_sync(pl.net, fn, user, world_size))
 
     # -- execution --------------------------------------------------------------------------
     def set_wgrad(self, enable):

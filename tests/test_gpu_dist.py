@@ -103,3 +103,33 @@ def test_two_ranks_one_gpu_match_full_batch_step():
         print("   worst parameters:", ["%s %.1e (|g| %.1e)" % (nm, e, nb) for e, nm, nb in per[:6]])
         assert e_l < tol and e_g < 10 * tol and e_r < tol
     del os.environ["PXL_FORCE_CLAMP_VAR"]
+
+
+def test_native_rccl_communicator_single_rank():
+    """csrc/comm.cpp: librccl resolved at run time, communicator of one rank, in-place all-reduce on a side stream and
+    through the pxl_allreduce_fn-shaped hook (what the executor calls between a conv and its BN finalize).  The
+    multi-rank agreement / verification logic of dist.native_comm() needs one GPU per rank and runs in the driver's
+    multi-GPU bench; on any failure there it falls back to the torch.distributed path these tests cover."""
+    import ctypes
+    import torch
+    from pixelssl_amd import _lib
+    h = _lib.lib()
+    assert h.pxl_comm_available() == 1
+    ident = torch.zeros(128, dtype=torch.uint8)
+    _lib.check(h.pxl_comm_unique_id(ident.data_ptr()))
+    assert ident.abs().sum().item() > 0
+    comm = ctypes.c_void_p()
+    _lib.check(h.pxl_comm_init(ident.data_ptr(), 0, 1, ctypes.byref(comm)))
+    try:
+        x = torch.arange(1000, device="cuda", dtype=torch.float32)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            _lib.check(h.pxl_comm_allreduce_sum(comm, x.data_ptr(), x.numel(), side.cuda_stream))
+            hook = ctypes.cast(h.pxl_comm_allreduce_hook, _lib.ALLREDUCE_FN)
+            assert hook(comm, x.data_ptr(), 500, side.cuda_stream) == 0
+        side.synchronize()
+        assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float32))
+        assert h.pxl_comm_allreduce_sum(comm, None, 4, None) != 0 and b"bad argument" in h.pxl_last_error()
+    finally:
+        h.pxl_comm_destroy(comm)
