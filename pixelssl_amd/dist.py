@@ -98,25 +98,15 @@ def _sync_stats_callback(buf_ptr, n, stream):
     return 0
 
 
-_native = {"tried": False, "comm": None, "hook": None}
+_native = {"tried": False, "comms": [], "hook": None, "next": 0}
+N_COMMS = max(1, int(os.environ.get("PXL_N_COMMS", "2")))
+#               # RCCL executes the collectives of ONE communicator in issue order even across streams: networks that run
+#                 concurrently on two streams (MT student / teacher, GCT l / r model) get different communicators
 
 
-def native_comm():
-    """The process's RCCL communicator driven from C (csrc/comm.cpp), or None: only with the nccl backend (one GPU per
-    rank), agreed on by ALL ranks, verified against torch.distributed once, and PXL_NATIVE_RCCL=0 disables it."""
-    if _native["tried"]:
-        return _native["comm"]
-    _native["tried"] = True
-    if not is_distributed() or dist.get_backend() != "nccl" or os.environ.get("PXL_NATIVE_RCCL", "1") == "0":
-        return None
+def _open_comm(h, dev):
     import ctypes
     from . import _lib
-    h = _lib.lib()
-    dev = torch.device("cuda", torch.cuda.current_device())
-    ok = torch.tensor([1.0 if h.pxl_comm_available() else 0.0], device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)              # every rank must be able to load librccl
-    if ok.item() < 1:
-        return None
     ident = torch.zeros(128, dtype=torch.uint8)
     if rank() == 0:
         _lib.check(h.pxl_comm_unique_id(ident.data_ptr()))
@@ -132,19 +122,44 @@ def native_comm():
         torch.cuda.synchronize()
         ws = world_size()
         good = rc == 0 and bool((probe == ws * (ws + 1) / 2).all().item())
+    return comm, good
+
+
+def native_comms():
+    """The process's RCCL communicators driven from C (csrc/comm.cpp), or []: only with the nccl backend (one GPU per
+    rank), agreed on by ALL ranks, verified against a known sum once, and PXL_NATIVE_RCCL=0 disables them."""
+    if _native["tried"]:
+        return _native["comms"]
+    _native["tried"] = True
+    if not is_distributed() or dist.get_backend() != "nccl" or os.environ.get("PXL_NATIVE_RCCL", "1") == "0":
+        return []
+    import ctypes
+    from . import _lib
+    h = _lib.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ok = torch.tensor([1.0 if h.pxl_comm_available() else 0.0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)              # every rank must be able to load librccl
+    if ok.item() < 1:
+        return []
+    comms, good = [], True
+    for _ in range(N_COMMS):
+        c, g = _open_comm(h, dev)
+        comms.append(c)
+        good = good and g
     ok = torch.tensor([1.0 if good else 0.0], device=dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if ok.item() < 1:
-        if comm.value:
-            h.pxl_comm_destroy(comm)
-        return None
-    _native["comm"] = comm
+        for c in comms:
+            if c.value:
+                h.pxl_comm_destroy(c)
+        return []
+    _native["comms"] = comms
     _native["hook"] = ctypes.cast(h.pxl_comm_allreduce_hook, _lib.ALLREDUCE_FN)
-    return comm
+    return comms
 
 
 def _post_backward(core):
-    comm = _native["comm"]
+    comm = getattr(core, "_pxl_comm", None)
     if comm is not None:
         from . import _lib
         g = core.flat.grads
@@ -163,12 +178,15 @@ def attach(model):
         return model
     from .engine import SegNetCore
     ws = world_size()
-    comm = native_comm()
+    comms = native_comms()
     for m in model.modules():
-        if isinstance(m, SegNetCore):
-            if comm is not None:
-                m.set_sync_native(_native["hook"], comm, ws)
+        if isinstance(m, SegNetCore) and not getattr(m, "_pxl_attached", False):
+            if comms:                      # networks take the communicators in creation order (identical on all ranks)
+                m._pxl_comm = comms[_native["next"] % len(comms)]
+                _native["next"] += 1
+                m.set_sync_native(_native["hook"], m._pxl_comm, ws)
             else:
                 m.set_sync(_sync_stats_callback, ws)
             m._post_backward_hook = _post_backward
+            m._pxl_attached = True
     return model
