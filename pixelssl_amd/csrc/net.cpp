@@ -36,7 +36,8 @@ int pxl_conv_wgrad_dma_eligible(const pxl_conv_desc* d, const float* in_scale);
 namespace {
 
 constexpr size_t ALIGN = 256;
-constexpr int STATS_REP = 32;   // replicas of every BN statistics vector (atomic-contention spreading)
+// replicas of every BN statistics vector (atomic-contention spreading); PXL_STATS_REP overrides (tuning experiments)
+static const int STATS_REP = [] { const char* e = getenv("PXL_STATS_REP"); const int v = e ? atoi(e) : 32; return v >= 1 && v <= 64 ? v : 32; }();
 inline size_t align_up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
 inline int pitch_of(int c) { return c <= 8 ? 8 : (c + 31) / 32 * 32; }
 
