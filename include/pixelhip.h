@@ -145,6 +145,25 @@ int pxl_bn_bwd_reduce(int dtype, int M, int C, const void* dz, const void* y, co
                       float* sums, int nrep, void* stream);
 /* bcoef [2C] = fold(sums) / count (zeros when training == 0: eval-mode BN is a fixed affine);
  * dgamma += sum dz'*xhat ; dbeta += sum dz' */
+/* One BatchNorm's finalize inputs, for the kernels that fold pxl_bn_finalize into their prologue: every block derives the
+ * (scale, shift) of its own channel group from `stats` ([nrep][2C] sums) -- or from the running statistics when
+ * training == 0 -- and the blocks of row group 0 write coef [4C] (mean, rstd, scale, shift: what backward reads) and
+ * update the running statistics, exactly as pxl_bn_finalize does. */
+typedef struct pxl_bn_fin {
+  const float* stats; int32_t nrep; float count;
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var;       /* may be NULL in training mode (no running-stat update) */
+  float momentum, eps;
+  int32_t training, clamp_var;
+  float* coef;
+} pxl_bn_fin;
+/* z = relu?(bn(y)) with the finalize folded in (replaces pxl_bn_finalize + pxl_bn_apply_fwd) */
+int pxl_bn_finalize_apply_fwd(int dtype, long M, int C, const void* y, const pxl_bn_fin* fin, int relu, void* z, void* stream);
+/* out = relu(bn_y(y) + (rfin ? bn_r(res) : res)) with both finalizes folded in (replaces up to two pxl_bn_finalize +
+ * pxl_residual_fwd); rfin == NULL: identity shortcut */
+int pxl_residual_finalize_fwd(int dtype, long M, int C, const void* y, const pxl_bn_fin* yfin, const void* res,
+                              const pxl_bn_fin* rfin, void* out, void* stream);
+
 /* Backward of the bottleneck join out = relu(bn3(y) + res) (resnet.py:44-48) fused with bn3's reduction: g = dout *
  * (out > 0) -> g (and g2 = the residual branch's copy, may be NULL); sums[0..C) += sum_m g, sums[C..2C) += sum_m g*xhat */
 int pxl_residual_bwd_reduce(int dtype, int M, int C, const void* dout, const void* out, const void* y, const float* coef,

@@ -50,6 +50,13 @@ class BnDesc(C.Structure):
                 ("momentum", C.c_float)]
 
 
+class BnFin(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("nrep", C.c_int32), ("count", C.c_float), ("gamma", C.c_void_p),
+                ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("momentum", C.c_float), ("eps", C.c_float), ("training", C.c_int32), ("clamp_var", C.c_int32),
+                ("coef", C.c_void_p)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 
 _P = C.c_void_p
@@ -73,6 +80,8 @@ SIGNATURES = {
     "pxl_bn_apply_fwd": (_I, [_I, _L, _I, _P, _P, _I, _P, _P]),
     "pxl_bn_fold_replicas": (_I, [_I, _I, _P, _P]),
     "pxl_bn_bwd_reduce": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
+    "pxl_bn_finalize_apply_fwd": (_I, [_I, _L, _I, _P, C.POINTER(BnFin), _I, _P, _P]),
+    "pxl_residual_finalize_fwd": (_I, [_I, _L, _I, _P, C.POINTER(BnFin), _P, C.POINTER(BnFin), _P, _P]),
     "pxl_residual_bwd_reduce": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pxl_bn_bwd_finalize": (_I, [_I, _P, _I, _F, _P, _P, _P, _I, _P]),
     "pxl_bn_bwd_apply": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),

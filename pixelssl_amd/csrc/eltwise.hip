@@ -13,27 +13,88 @@ inline int grid_for(long n, int block = 256) {
   return (int)g;
 }
 
+// BN finalize folded into a consumer's prologue: the block derives (scale, shift) of channels [c0, c0 + nch), nch <= 128,
+// into lsc / lsh (LDS); `writer` blocks also store coef [4C] and update the running statistics (same arithmetic as
+// bn_finalize_kernel in bn.hip).  Ends with a __syncthreads().
+__device__ __forceinline__ void block_bn_finalize(const pxl_bn_fin& f, int C, int c0, int nch, bool writer, float* lsum,
+                                                  float* lsc, float* lsh) {
+  if (f.training) {
+    for (int t = threadIdx.x; t < 2 * nch; t += 256) {      // (which, channel): coalesced over the channel index
+      const int w = t / nch, j = t - w * nch;
+      float s = 0.f;
+      for (int r = 0; r < f.nrep; ++r) s += f.stats[(size_t)r * 2 * C + (size_t)w * C + c0 + j];
+      lsum[t] = s;
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < nch; j += 256) {
+    const int c = c0 + j;
+    float mean, var;
+    if (f.training) {
+      mean = lsum[j] / f.count;
+      var = lsum[nch + j] / f.count - mean * mean;
+      if (var < 0.f) var = 0.f;
+      if (writer && f.running_mean != nullptr) {
+        const float unbiased = f.count > 1.f ? var * f.count / (f.count - 1.f) : var;
+        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean;
+        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
+      }
+    } else {
+      mean = f.running_mean[c];
+      var = f.running_var[c];
+    }
+    const float rstd = f.clamp_var ? rsqrtf(fmaxf(var, f.eps)) : rsqrtf(var + f.eps);
+    const float ga = f.gamma ? f.gamma[c] : 1.f, be = f.beta ? f.beta[c] : 0.f;
+    const float scale = ga * rstd, shift = be - mean * scale;
+    lsc[j] = scale;
+    lsh[j] = shift;
+    if (writer) {
+      f.coef[c] = mean; f.coef[C + c] = rstd; f.coef[2 * C + c] = scale; f.coef[3 * C + c] = shift;
+    }
+  }
+  __syncthreads();
+}
+
 // Per-channel-affine element-wise kernels: column-group blocks (common.h: col_geom), the channel chunk is FIXED
-// per thread so the coefficients are loaded once into registers, two rows in flight per thread.
-template <typename T>
+// per thread so the coefficients are loaded once into registers, two rows in flight per thread.  FIN: the BN finalize
+// of the operand(s) is folded into the prologue (yfin / rfin) instead of reading ready-made coefficients.
+template <typename T, bool FIN>
 __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T* __restrict__ y,
                                                            const float* __restrict__ ycoef,
                                                            const T* __restrict__ res,
                                                            const float* __restrict__ rcoef,
-                                                           T* __restrict__ out, int rows_per_group, int cgmax) {
+                                                           T* __restrict__ out, int rows_per_group, int cgmax,
+                                                           pxl_bn_fin yfin, pxl_bn_fin rfin, int has_rfin) {
   constexpr int EPC = Elem<T>::EPC;
   const ColGeom g = col_geom(C, EPC, cgmax);
   const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
   const int cc = blockIdx.x * g.cg + ccol;
   float ys[EPC], yb[EPC], rs[EPC], rb[EPC];
-  load_cvec<EPC>(ycoef + 2 * C + cc * EPC, ys);
-  load_cvec<EPC>(ycoef + 3 * C + cc * EPC, yb);
-  if (rcoef) {
-    load_cvec<EPC>(rcoef + 2 * C + cc * EPC, rs);
-    load_cvec<EPC>(rcoef + 3 * C + cc * EPC, rb);
-  } else {
+  if constexpr (FIN) {
+    __shared__ float lsum[256], lsc[128], lsh[128];
+    const int nch = g.cg * EPC, c0 = blockIdx.x * nch;
+    block_bn_finalize(yfin, C, c0, nch, blockIdx.y == 0, lsum, lsc, lsh);
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { rs[e] = 1.f; rb[e] = 0.f; }
+    for (int e = 0; e < EPC; ++e) { ys[e] = lsc[ccol * EPC + e]; yb[e] = lsh[ccol * EPC + e]; }
+    if (has_rfin) {
+      __syncthreads();
+      block_bn_finalize(rfin, C, c0, nch, blockIdx.y == 0, lsum, lsc, lsh);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { rs[e] = lsc[ccol * EPC + e]; rb[e] = lsh[ccol * EPC + e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { rs[e] = 1.f; rb[e] = 0.f; }
+    }
+  } else {
+    load_cvec<EPC>(ycoef + 2 * C + cc * EPC, ys);
+    load_cvec<EPC>(ycoef + 3 * C + cc * EPC, yb);
+    if (rcoef) {
+      load_cvec<EPC>(rcoef + 2 * C + cc * EPC, rs);
+      load_cvec<EPC>(rcoef + 3 * C + cc * EPC, rb);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { rs[e] = 1.f; rb[e] = 0.f; }
+    }
   }
   auto one = [&](const uint4& vy, const uint4& vr) -> uint4 {
     float fy[EPC], fr[EPC], v[EPC];
@@ -60,17 +121,26 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T
 }
 
 // z = relu?(y*scale + shift): the activated tensor the LDS-DMA convolutions (conv_dma.hip, wgrad) read directly
-template <typename T>
+template <typename T, bool FIN>
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(int M, int C, const T* __restrict__ y,
                                                            const float* __restrict__ coef, int relu,
-                                                           T* __restrict__ z, int rows_per_group, int cgmax) {
+                                                           T* __restrict__ z, int rows_per_group, int cgmax,
+                                                           pxl_bn_fin fin) {
   constexpr int EPC = Elem<T>::EPC;
   const ColGeom g = col_geom(C, EPC, cgmax);
   const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
   const int cc = blockIdx.x * g.cg + ccol;
   float sc[EPC], sh[EPC];
-  load_cvec<EPC>(coef + 2 * C + cc * EPC, sc);
-  load_cvec<EPC>(coef + 3 * C + cc * EPC, sh);
+  if constexpr (FIN) {
+    __shared__ float lsum[256], lsc[128], lsh[128];
+    const int nch = g.cg * EPC;
+    block_bn_finalize(fin, C, blockIdx.x * nch, nch, blockIdx.y == 0, lsum, lsc, lsh);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc[e] = lsc[ccol * EPC + e]; sh[e] = lsh[ccol * EPC + e]; }
+  } else {
+    load_cvec<EPC>(coef + 2 * C + cc * EPC, sc);
+    load_cvec<EPC>(coef + 3 * C + cc * EPC, sh);
+  }
   auto one = [&](const uint4& vy) -> uint4 {
     float f[EPC];
     Chunk<T>::unpack(vy, f);
@@ -292,12 +362,41 @@ extern "C" int pxl_residual_fwd(int dtype, long M, int C, const void* y, const f
   const ColGeom g = col_geom(C, epc, cgmax);
   const int rpg = rows_per_group((int)M, g, pxl_tune_get(2));
   const dim3 grid(g.ncg, cdiv((int)M, rpg));
+  const pxl_bn_fin none = {};
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(residual_fwd_kernel<float>, grid, dim3(256), 0, s, (int)M, C,
-                       cp<float>(y), ycoef, cp<float>(res), rcoef, mp<float>(out), rpg, cgmax);
+    hipLaunchKernelGGL((residual_fwd_kernel<float, false>), grid, dim3(256), 0, s, (int)M, C,
+                       cp<float>(y), ycoef, cp<float>(res), rcoef, mp<float>(out), rpg, cgmax, none, none, 0);
   else
-    hipLaunchKernelGGL(residual_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (int)M, C,
-                       cp<bf16_t>(y), ycoef, cp<bf16_t>(res), rcoef, mp<bf16_t>(out), rpg, cgmax);
+    hipLaunchKernelGGL((residual_fwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, (int)M, C,
+                       cp<bf16_t>(y), ycoef, cp<bf16_t>(res), rcoef, mp<bf16_t>(out), rpg, cgmax, none, none, 0);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+namespace {
+inline bool fin_ok(const pxl_bn_fin* f) {
+  return f && f->coef && f->count > 0.f && (f->training ? (f->stats != nullptr && f->nrep >= 1) : (f->running_mean && f->running_var));
+}
+}  // namespace
+
+extern "C" int pxl_residual_finalize_fwd(int dtype, long M, int C, const void* y, const pxl_bn_fin* yfin, const void* res,
+                                         const pxl_bn_fin* rfin, void* out, void* stream) {
+  PXL_REQUIRE(y && res && out && fin_ok(yfin) && (rfin == nullptr || fin_ok(rfin)), "residual_finalize_fwd: bad argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "residual_finalize_fwd: bad dtype");
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  PXL_REQUIRE(C % epc == 0, "residual_finalize_fwd: C=%d must be a multiple of %d", C, epc);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int cgmax = 16;                         // 16 chunks x EPC <= 128 channels per block (LDS coefficient arrays)
+  const ColGeom g = col_geom(C, epc, cgmax);
+  const int rpg = rows_per_group((int)M, g, pxl_tune_get(2));
+  const dim3 grid(g.ncg, cdiv((int)M, rpg));
+  const pxl_bn_fin rf = rfin ? *rfin : pxl_bn_fin{};
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL((residual_fwd_kernel<float, true>), grid, dim3(256), 0, s, (int)M, C, cp<float>(y), nullptr,
+                       cp<float>(res), nullptr, mp<float>(out), rpg, cgmax, *yfin, rf, rfin ? 1 : 0);
+  else
+    hipLaunchKernelGGL((residual_fwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, (int)M, C, cp<bf16_t>(y), nullptr,
+                       cp<bf16_t>(res), nullptr, mp<bf16_t>(out), rpg, cgmax, *yfin, rf, rfin ? 1 : 0);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -313,12 +412,34 @@ extern "C" int pxl_bn_apply_fwd(int dtype, long M, int C, const void* y, const f
   const ColGeom g = col_geom(C, epc, cgmax);
   const int rpg = rows_per_group((int)M, g, pxl_tune_get(3));
   const dim3 grid(g.ncg, cdiv((int)M, rpg));
+  const pxl_bn_fin none = {};
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(bn_apply_fwd_kernel<float>, grid, dim3(256), 0, s, (int)M, C, cp<float>(y),
-                       coef, relu, mp<float>(z), rpg, cgmax);
+    hipLaunchKernelGGL((bn_apply_fwd_kernel<float, false>), grid, dim3(256), 0, s, (int)M, C, cp<float>(y),
+                       coef, relu, mp<float>(z), rpg, cgmax, none);
   else
-    hipLaunchKernelGGL(bn_apply_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (int)M, C,
-                       cp<bf16_t>(y), coef, relu, mp<bf16_t>(z), rpg, cgmax);
+    hipLaunchKernelGGL((bn_apply_fwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, (int)M, C,
+                       cp<bf16_t>(y), coef, relu, mp<bf16_t>(z), rpg, cgmax, none);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_bn_finalize_apply_fwd(int dtype, long M, int C, const void* y, const pxl_bn_fin* fin, int relu, void* z,
+                                         void* stream) {
+  PXL_REQUIRE(y && z && fin_ok(fin), "bn_finalize_apply_fwd: bad argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "bn_finalize_apply_fwd: bad dtype");
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  PXL_REQUIRE(C % epc == 0, "bn_finalize_apply_fwd: C=%d must be a multiple of %d", C, epc);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int cgmax = 16;
+  const ColGeom g = col_geom(C, epc, cgmax);
+  const int rpg = rows_per_group((int)M, g, pxl_tune_get(3));
+  const dim3 grid(g.ncg, cdiv((int)M, rpg));
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL((bn_apply_fwd_kernel<float, true>), grid, dim3(256), 0, s, (int)M, C, cp<float>(y), nullptr, relu,
+                       mp<float>(z), rpg, cgmax, *fin);
+  else
+    hipLaunchKernelGGL((bn_apply_fwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, (int)M, C, cp<bf16_t>(y), nullptr, relu,
+                       mp<bf16_t>(z), rpg, cgmax, *fin);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

@@ -66,6 +66,10 @@ struct BnInfo {
   // the only consumer of relu(bn(y)) is a convolution whose data gradient runs on the LDS-DMA kernel: that launch
   // also produces this BN's backward sums (no separate reduce pass); -1 = no
   int fused_reduce_op = -1;
+  int fin_nrep = 1;        // replicas of the forward sums at finalize time (1 after a Sync-BN fold + all-reduce)
+  // forward: the finalize of this BN is folded into the kernel that applies it (z materialisation or the residual
+  // join that is its only consumer) instead of a pxl_bn_finalize launch
+  bool fin_in_consumer = false;
 };
 
 struct OpInfo {
@@ -119,6 +123,9 @@ struct pxl_net {
   int input_tensor = -1;
   bool latent_seeded = false;      // pxl_net_seed_latent_grad ran: the next backward starts from that gradient
   bool fuse_bn_reduce = getenv("PXL_FUSE_BN_REDUCE") == nullptr || getenv("PXL_FUSE_BN_REDUCE")[0] != '0';
+  // folding the forward finalize into its consumer removes 104 launches per pass but makes every block of the consumer
+  // re-reduce the statistics replicas: measured SLOWER on MI355X (MT 15.7 vs 15.0 ms / step), so it is opt-in
+  bool fuse_bn_finalize = getenv("PXL_FUSE_BN_FINALIZE") != nullptr && getenv("PXL_FUSE_BN_FINALIZE")[0] == '1';
   // tests: use the reference's multi-device variance formula clamp(var, eps) on a single rank too
   bool force_clamp = getenv("PXL_FORCE_CLAMP_VAR") != nullptr;
 };
@@ -463,6 +470,36 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
     b.z_off = arena;
     arena += tin.bytes;
   }
+  // forward finalize folded into its consumer: BNs that are materialised (z) or whose raw tensor feeds only one
+  // residual join
+  {
+    std::vector<int> nuse(n->tensors.size(), 0), res_use(n->tensors.size(), 0);
+    for (auto& op : n->ops) {
+      const pxl_op& d = op.d;
+      if (d.in0 >= 0) ++nuse[d.in0];
+      if (d.in1 >= 0) ++nuse[d.in1];
+      if (d.kind == PXL_OP_RESIDUAL) { ++res_use[d.in0]; if (d.in1 >= 0) ++res_use[d.in1]; }
+    }
+    for (auto& b : n->bns) {
+      b.fin_in_consumer = false;
+      if (!n->fuse_bn_finalize || b.y_tensor < 0) continue;
+      const TensorInfo& ty = n->tensors[b.y_tensor];
+      if (ty.Cp != b.d.C) continue;
+      if (b.has_z) b.fin_in_consumer = true;
+      else if (nuse[b.y_tensor] == 1 && res_use[b.y_tensor] == 1) b.fin_in_consumer = true;
+    }
+    // a residual join folds either both of its BNs or none
+    for (auto& op : n->ops) {
+      const pxl_op& d = op.d;
+      if (d.kind != PXL_OP_RESIDUAL) continue;
+      BnInfo& b0 = n->bns[d.bn_in0];
+      const bool both = !b0.has_z && b0.fin_in_consumer && (d.bn_in1 < 0 || (!n->bns[d.bn_in1].has_z && n->bns[d.bn_in1].fin_in_consumer));
+      if (!both) {
+        if (!b0.has_z) b0.fin_in_consumer = false;
+        if (d.bn_in1 >= 0 && !n->bns[d.bn_in1].has_z) n->bns[d.bn_in1].fin_in_consumer = false;
+      }
+    }
+  }
   // BN-backward reduce fused into the data gradient that writes d(relu(bn(y))): y must have exactly one consumer
   // (that convolution) and the launch must be eligible for the LDS-DMA kernel
   for (auto& b : n->bns) b.fused_reduce_op = -1;
@@ -620,6 +657,25 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
   return PXL_OK;
 }
 
+namespace {
+pxl_bn_fin make_fin(const pxl_net* n, const BnInfo& b, const float* params, float* running, void* arena, int training) {
+  pxl_bn_fin f;
+  f.stats = fat(arena, b.stats_off);
+  f.nrep = b.fin_nrep;
+  f.count = (float)b.M * n->world;
+  f.gamma = params + b.d.gamma_off;
+  f.beta = params + b.d.beta_off;
+  f.running_mean = running ? running + b.d.rmean_off : nullptr;
+  f.running_var = running ? running + b.d.rvar_off : nullptr;
+  f.momentum = b.d.momentum;
+  f.eps = b.d.eps;
+  f.training = training;
+  f.clamp_var = (n->world > 1 || n->force_clamp) ? 1 : 0;
+  f.coef = fat(arena, b.coef_off);
+  return f;
+}
+}  // namespace
+
 extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* packed, float* running,
                                const float* x, float* logits, float* prob, void* arena, size_t arena_bytes,
                                int training, void* stream) {
@@ -663,14 +719,23 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
             if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_forward: SyncBN all-reduce hook failed (%d)", rc);
             nrep = 1;
           }
-          rc = pxl_bn_finalize(b.d.C, fat(arena, b.stats_off), nrep, (float)b.M * n->world, params + b.d.gamma_off,
-                               params + b.d.beta_off, running ? running + b.d.rmean_off : nullptr,
-                               running ? running + b.d.rvar_off : nullptr, b.d.momentum, b.d.eps, training,
-                               (n->world > 1 || n->force_clamp) ? 1 : 0, fat(arena, b.coef_off), stream);
-          if (rc != PXL_OK) return rc;
-          if (b.has_z)
-            rc = pxl_bn_apply_fwd(dt, (long)n->B * tout.H * tout.W, tout.Cp, at(arena, tout.off), fat(arena, b.coef_off),
-                                  b.relu, at(arena, b.z_off), stream);
+          b.fin_nrep = nrep;
+          if (b.fin_in_consumer) {
+            if (b.has_z) {
+              const pxl_bn_fin fin = make_fin(n, b, params, running, arena, training);
+              rc = pxl_bn_finalize_apply_fwd(dt, (long)n->B * tout.H * tout.W, tout.Cp, at(arena, tout.off), &fin, b.relu,
+                                             at(arena, b.z_off), stream);
+            }                                   // else: the residual join that consumes y finalizes it
+          } else {
+            rc = pxl_bn_finalize(b.d.C, fat(arena, b.stats_off), nrep, (float)b.M * n->world, params + b.d.gamma_off,
+                                 params + b.d.beta_off, running ? running + b.d.rmean_off : nullptr,
+                                 running ? running + b.d.rvar_off : nullptr, b.d.momentum, b.d.eps, training,
+                                 (n->world > 1 || n->force_clamp) ? 1 : 0, fat(arena, b.coef_off), stream);
+            if (rc != PXL_OK) return rc;
+            if (b.has_z)
+              rc = pxl_bn_apply_fwd(dt, (long)n->B * tout.H * tout.W, tout.Cp, at(arena, tout.off), fat(arena, b.coef_off),
+                                    b.relu, at(arena, b.z_off), stream);
+          }
         }
         break;
       }
@@ -688,8 +753,16 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
         const TensorInfo& o = n->tensors[d.out];
         const float* ac = fat(arena, n->bns[d.bn_in0].coef_off);
         const float* rcoef = d.bn_in1 >= 0 ? fat(arena, n->bns[d.bn_in1].coef_off) : nullptr;
-        rc = pxl_residual_fwd(dt, (long)n->B * a.H * a.W, a.Cp, at(arena, a.off), ac, at(arena, r.off), rcoef,
-                              at(arena, o.off), stream);
+        if (n->bns[d.bn_in0].fin_in_consumer && !n->bns[d.bn_in0].has_z) {
+          const pxl_bn_fin yfin = make_fin(n, n->bns[d.bn_in0], params, running, arena, training);
+          pxl_bn_fin rfin;
+          if (d.bn_in1 >= 0) rfin = make_fin(n, n->bns[d.bn_in1], params, running, arena, training);
+          rc = pxl_residual_finalize_fwd(dt, (long)n->B * a.H * a.W, a.Cp, at(arena, a.off), &yfin, at(arena, r.off),
+                                         d.bn_in1 >= 0 ? &rfin : nullptr, at(arena, o.off), stream);
+        } else {
+          rc = pxl_residual_fwd(dt, (long)n->B * a.H * a.W, a.Cp, at(arena, a.off), ac, at(arena, r.off), rcoef,
+                                at(arena, o.off), stream);
+        }
         break;
       }
       case PXL_OP_ACT: {

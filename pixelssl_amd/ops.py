@@ -122,6 +122,30 @@ def bn_apply_fwd(y, coef, relu=True):
     return z
 
 
+def bn_fin(stats, nrep, count, gamma, beta, rmean, rvar, coef, momentum=0.1, eps=1e-5, training=True, clamp_var=False):
+    """pxl_bn_fin descriptor over device tensors (kept alive by the caller)"""
+    f = _lib.BnFin()
+    f.stats, f.nrep, f.count = ptr(stats), nrep, float(count)
+    f.gamma, f.beta, f.running_mean, f.running_var = ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar)
+    f.momentum, f.eps, f.training, f.clamp_var, f.coef = momentum, eps, int(training), int(clamp_var), ptr(coef)
+    return f
+
+
+def bn_finalize_apply_fwd(y, fin, relu=True):
+    z = torch.empty_like(y)
+    M = y.numel() // y.shape[-1]
+    check(lib().pxl_bn_finalize_apply_fwd(dtype_code(y.dtype), M, y.shape[-1], ptr(y), fin, int(relu), ptr(z), stream_ptr()))
+    return z
+
+
+def residual_finalize_fwd(y, yfin, res, rfin=None):
+    out = torch.empty_like(y)
+    M = y.numel() // y.shape[-1]
+    check(lib().pxl_residual_finalize_fwd(dtype_code(y.dtype), M, y.shape[-1], ptr(y), yfin, ptr(res), rfin, ptr(out),
+                                          stream_ptr()))
+    return out
+
+
 def residual_fwd(y, ycoef, res, rcoef=None):
     out = torch.empty_like(y)
     M = y.numel() // y.shape[-1]

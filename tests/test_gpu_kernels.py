@@ -400,6 +400,53 @@ def test_batchnorm_finalize_and_backward(dtype, C, B, H, W):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("training,clamp", [(True, False), (True, True), (False, False)])
+def test_finalize_folded_into_apply_and_residual(dtype, training, clamp):
+    """pxl_bn_finalize_apply_fwd / pxl_residual_finalize_fwd == pxl_bn_finalize followed by pxl_bn_apply_fwd /
+    pxl_residual_fwd: same outputs, same coefficient vectors (what backward reads), same running-statistics update,
+    for replicated statistics, both variance formulas and eval mode."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(31)
+    M, C, nrep = 1234, 192, 5
+    y = torch.randn(M, C, generator=g).to(DEV).to(dtype)
+    res = torch.randn(M, C, generator=g).to(DEV).to(dtype)
+
+    def fresh():
+        gg = torch.Generator().manual_seed(7)
+        yf = y.float()
+        parts = torch.stack([torch.cat([yf[i::nrep].sum(0), (yf[i::nrep] ** 2).sum(0)]) for i in range(nrep)])   # [nrep][2C]
+        return dict(stats=parts.contiguous(), gamma=(torch.rand(C, generator=gg) + 0.5).to(DEV),
+                    beta=(torch.randn(C, generator=gg) * 0.2).to(DEV), rm=(torch.randn(C, generator=gg) * 0.1).to(DEV),
+                    rv=(torch.rand(C, generator=gg) + 0.5).to(DEV))
+    a, b = fresh(), fresh()
+    coef_ref = ops.bn_finalize(a["stats"], M, a["gamma"], a["beta"], a["rm"], a["rv"], training=training, clamp_var=clamp, nrep=nrep)
+    z_ref = ops.bn_apply_fwd(y, coef_ref, relu=True)
+    coef = torch.zeros(4 * C, device=DEV)
+    fin = ops.bn_fin(b["stats"], nrep, M, b["gamma"], b["beta"], b["rm"], b["rv"], coef, training=training, clamp_var=clamp)
+    z = ops.bn_finalize_apply_fwd(y, fin, relu=True)
+    torch.cuda.synchronize()
+    assert rel_err(coef.cpu(), coef_ref.cpu()) < 1e-6
+    assert rel_err(z.float().cpu(), z_ref.float().cpu()) < (1e-6 if dtype == torch.float32 else 4e-3)
+    assert rel_err(b["rm"].cpu(), a["rm"].cpu()) < 1e-6 and rel_err(b["rv"].cpu(), a["rv"].cpu()) < 1e-6
+    # residual join with both BNs folded in (downsample block) and with the identity shortcut
+    for with_r in (True, False):
+        a, b, a2, b2 = fresh(), fresh(), fresh(), fresh()
+        c1 = ops.bn_finalize(a["stats"], M, a["gamma"], a["beta"], a["rm"], a["rv"], training=training, clamp_var=clamp, nrep=nrep)
+        c2 = ops.bn_finalize(a2["stats"], M, a2["gamma"], a2["beta"], a2["rm"], a2["rv"], training=training, clamp_var=clamp,
+                             nrep=nrep) if with_r else None
+        out_ref = ops.residual_fwd(y, c1, res, c2)
+        k1, k2 = torch.zeros(4 * C, device=DEV), torch.zeros(4 * C, device=DEV)
+        f1 = ops.bn_fin(b["stats"], nrep, M, b["gamma"], b["beta"], b["rm"], b["rv"], k1, training=training, clamp_var=clamp)
+        f2 = ops.bn_fin(b2["stats"], nrep, M, b2["gamma"], b2["beta"], b2["rm"], b2["rv"], k2, training=training,
+                        clamp_var=clamp) if with_r else None
+        out = ops.residual_finalize_fwd(y, f1, res, f2)
+        torch.cuda.synchronize()
+        assert rel_err(out.float().cpu(), out_ref.float().cpu()) < (1e-6 if dtype == torch.float32 else 4e-3)
+        assert rel_err(k1.cpu(), c1.cpu()) < 1e-6 and (not with_r or rel_err(k2.cpu(), c2.cpu()) < 1e-6)
+        assert rel_err(b["rv"].cpu(), a["rv"].cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_residual_join_and_relu_mask(dtype):
     ops = _ops()
     g = torch.Generator().manual_seed(2)

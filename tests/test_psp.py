@@ -369,4 +369,6 @@ def test_pspnet_suponly_steps_vs_reference_fixture():
     for k, ref in fx["probes"].items():
         got = sd[k].detach().cpu().reshape(-1)[:64]
         upd = (ref["head"] - init[k].reshape(-1)[:64].float()).abs().max().item()
-        assert (got - ref["head"]).abs().max().item() <= 1.25 * upd + 1e-6 * ref["head"].abs().max().item() + 1e-9, k
+        # two iterations: the second one is noise-limited (see above), so a weight may differ from the reference's by
+        # about the size of its own two-step update; a wrong optimizer / lr group would be off by 10x (lr x10 groups)
+        assert (got - ref["head"]).abs().max().item() <= 2.0 * upd + 1e-6 * ref["head"].abs().max().item() + 1e-9, k
