@@ -58,6 +58,36 @@ def test_engine_parameter_tree_matches_reference_names():
     assert sum(p.numel() for p in groups[0]) == 42500160 and sum(p.numel() for p in groups[1]) == 1548372
 
 
+def test_pspnet_and_cct_parameter_trees_and_plans():
+    """PSPNet / SSLCCT auxiliary decoder cores: reference state_dict names and shapes, lr groups, and the executor plans
+    their layer programs (new ops: adaptive pool, concat slices, PixelShuffle, HEAD with its own output size)."""
+    import torch_oracle as TO
+    import cct_oracle as CO
+    from pixelssl_amd.engine import PSPNetCore, AuxDecoderCore
+    from pixelssl_amd._lib import lib, check
+    core = PSPNetCore(device="cpu", engine_dtype=torch.bfloat16)
+    sd = core.state_dict()
+    ref = TO.pspnet_param_shapes()
+    assert set(sd.keys()) == set(ref.keys())
+    for k, shape in ref.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert sum(p.numel() for p in core.parameters()) == 65590248
+    core.load_state_dict(TO.init_pspnet_state(seed=1))
+    groups = [list(core.get_backbone_params()), list(core.get_psp_params()), list(core.get_decoder_params())]
+    assert sum(len(g) for g in groups) == len(list(core.parameters())) and all(len(g) > 0 for g in groups)
+    h = lib()
+    core._plan(8, 513, 513)
+    c, hh, ww = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    check(h.pxl_net_latent_shape(core._net, ctypes.byref(c), ctypes.byref(hh), ctypes.byref(ww)))
+    assert (c.value, hh.value, ww.value) == (512, 33, 33)                   # 'sslcct_ad_inp' = the pyramid module's output
+    assert 0 < h.pxl_net_arena_bytes(core._net) < 32 * 2 ** 30
+    dec = AuxDecoderCore(8, 512, 21, device="cpu", engine_dtype=torch.bfloat16)
+    assert {"upsample." + k for k in dec.state_dict().keys()} == set(CO.decoder_param_shapes().keys())
+    p1 = dec._plan(4, 33, 33, (513, 513))
+    p2 = dec._plan(4, 33, 33, (264, 264))                                    # I-VAT's own-resolution passes: a second plan
+    assert p1 is not p2 and dec._plan(4, 33, 33, (513, 513)) is p1 and p1.out_size == (513, 513)
+
+
 def test_plan_sizes_and_workspace_guards():
     from pixelssl_amd.engine import DeepLabV2Core
     from pixelssl_amd._lib import lib, check
