@@ -337,10 +337,17 @@ def _define_sslgct():
             self.fdgt_generator = FDGTGenerator(a, ignore_index=a.ignore_index)
 
         # ---- one task-model pass of step 1 (_task_model_iter, ssl_gct.py:401-480)
-        def _task_model_iter(self, mid, lbs, inp, gt, dc_gt, fc_mask, dc_rampup_scale):
+        def _side_stream(self):
+            if not hasattr(self, '_r_stream'):
+                on = os.environ.get('PXL_GCT_STREAMS', '1') != '0' and torch.cuda.is_available()
+                self._r_stream = torch.cuda.Stream() if on else None
+            return self._r_stream
+
+        def _task_model_iter(self, mid, lbs, inp, gt, dc_gt, fc_mask, dc_rampup_scale, resulter=None):
             a = self.args
             model, criterion = (self.l_model, self.l_criterion) if mid == 'l' else (self.r_model, self.r_criterion)
-            resulter, _ = model.forward(inp)
+            if resulter is None:
+                resulter, _ = model.forward(inp)
             self._need_pred(resulter, 'SSL_GCT')
             pred = tool.dict_value(resulter, 'pred')
             activated_pred = tool.dict_value(resulter, 'activated_pred')
@@ -360,10 +367,35 @@ def _define_sslgct():
             lbs = a.labeled_batch_size
             fd_core = self.fd_model.module.core
             dc_rampup_scale = func.sigmoid_rampup(cur_step, total_rampup_steps)
+            # The two task models never depend on each other inside an iteration (the dynamic-consistency targets come
+            # from step 0), so every l / r pair of network passes runs on two HIP streams; the flaw detector -- shared,
+            # with BN running statistics that must be updated in the reference's order -- stays on the main stream.
+            side = self._side_stream()
+            main = torch.cuda.current_stream() if side is not None else None
+
+            def pair(fn_l, fn_r):
+                if side is None:
+                    return fn_l(), fn_r()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    r = fn_r()
+                l = fn_l()
+                main.wait_stream(side)
+                return l, r
+
+            def keep(res):
+                if side is not None:
+                    for v in res.values():
+                        for t in (v if isinstance(v, (tuple, list)) else (v,)):
+                            if torch.is_tensor(t):
+                                t.record_stream(main)        # allocated on the side stream, consumed on the main one
+                return res
+
             # ---- step 0: no-grad task forwards, flaw-detector forwards whose graphs are kept for step 2
             with torch.no_grad():
-                l_prob = tool.dict_value(self.l_model.forward(inp)[0], 'activated_pred')
-                r_prob = tool.dict_value(self.r_model.forward(inp)[0], 'activated_pred')
+                l_res, r_res = pair(lambda: self.l_model.forward(inp)[0], lambda: keep(self.r_model.forward(inp)[0]))
+                l_prob = tool.dict_value(l_res, 'activated_pred')
+                r_prob = tool.dict_value(r_res, 'activated_pred')
             fd_core.set_wgrad(True)
             l_flawmap = tool.dict_value(self.fd_model.forward(inp, l_prob[0])[0], 'flawmap')
             r_flawmap = tool.dict_value(self.fd_model.forward(inp, r_prob[0])[0], 'flawmap')
@@ -372,17 +404,26 @@ def _define_sslgct():
                 r_handled = self.flawmap_handler.forward(r_flawmap)
                 l_dc_gt, r_dc_gt, l_fc_mask, r_fc_mask = self.dcgt_generator.forward(l_prob[0].detach(), r_prob[0].detach(),
                                                                                     l_handled, r_handled)
-            # ---- step 1: task models; the flaw detector is frozen (requires_grad False in the reference)
+            # ---- step 1: task models; the flaw detector is frozen (requires_grad False in the reference).  Reference
+            # order: [l: forward, losses, backward, step] then [r: ...]; the two are independent, so both forwards run
+            # side by side, then the (ordered) detector passes and losses, then ONE backward over both graphs -- the
+            # engine runs each network's backward on the stream of its forward -- and both optimizer steps.
             fd_core.set_wgrad(False)
             out = {}
-            for mid, optimizer, dc_gt, fc_mask in (('l', self.l_optimizer, l_dc_gt, l_fc_mask),
-                                                   ('r', self.r_optimizer, r_dc_gt, r_fc_mask)):
-                loss, parts = self._task_model_iter(mid, lbs, inp, gt, dc_gt, fc_mask, dc_rampup_scale)
-                optimizer.zero_grad()
-                loss.backward()
-                optimizer.step()
+            l_fwd, r_fwd = pair(lambda: self.l_model.forward(inp)[0], lambda: keep(self.r_model.forward(inp)[0]))
+            losses = []
+            for mid, resulter, dc_gt, fc_mask in (('l', l_fwd, l_dc_gt, l_fc_mask), ('r', r_fwd, r_dc_gt, r_fc_mask)):
+                loss, parts = self._task_model_iter(mid, lbs, inp, gt, dc_gt, fc_mask, dc_rampup_scale, resulter)
+                losses.append(loss)
                 for k, v in parts.items():
                     out['{0}_{1}_loss'.format(mid, k)] = v
+            self.l_optimizer.zero_grad()
+            self.r_optimizer.zero_grad()
+            torch.autograd.backward(losses)
+            if side is not None:
+                main.wait_stream(side)
+            self.l_optimizer.step()
+            self.r_optimizer.step()
             # ---- step 2: flaw detector, ground truth from the STEP-0 predictions of the labeled samples
             fd_core.set_wgrad(True)
             with torch.no_grad():
