@@ -240,11 +240,29 @@ class CutOutDecoder(_AuxDecoder):
         self.erase = erase
         self.min_vertices = 50          # `c.shape[0] > 50` contour filter of ssl_cct.py:632
 
+    def prefetch(self, output):
+        """Start the D2H copy of the predicted foreground mask (the input of the host contour search) right after the
+        main model's forward: WrappedCCTModel issues it before the other decoders are enqueued and runs the G-Cutout
+        decoders last, so that the copy is long finished when the host needs it (the reference stalls on `.cpu()`)."""
+        B, _, H, W = output.shape
+        fg = fg_mask_nearest(output, (H, W)).to(torch.uint8)
+        host = torch.empty(fg.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(fg, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._prefetched = (host, ev, fg)          # fg kept alive until the copy is done
+
     def guided_cutout(self, output, resize, erase=0.4):
         """ssl_cct.py:615-656 (use_dropout=False): host contour search on the predicted foreground mask, one erased
         window per kept contour, nearest resize to the latent size.  -> [B, h, w] float mask on the device."""
         B, _, H, W = output.shape
-        fg = fg_mask_nearest(output, (H, W)).to(torch.uint8).cpu().numpy()        # D2H + sync, like the reference
+        pre = getattr(self, '_prefetched', None)
+        if pre is not None:
+            self._prefetched = None
+            pre[1].synchronize()
+            fg = pre[0].numpy()
+        else:
+            fg = fg_mask_nearest(output, (H, W)).to(torch.uint8).cpu().numpy()    # D2H + sync, like the reference
         draws = self._take_draw()
         draws = iter(draws) if draws is not None else None
         used = []
@@ -344,10 +362,19 @@ class WrappedCCTModel(nn.Module):
             size = (ul_ad_gt.shape[2], ul_ad_gt.shape[3])
             # every decoder returns its prediction already resized (bilinear, align_corners=False) and activated: the
             # executor's HEAD kernel fuses F.interpolate + softmax (ssl_cct.py:483-484)
-            ul_ad_preds, cons = [], None
-            for ad in self.auxiliary_decoders:
+            # G-Cutout needs a host round trip: its mask copy is started first and its decoders run last (the sum of
+            # the consistency terms does not depend on the order)
+            order = list(range(len(self.auxiliary_decoders)))
+            if os.environ.get('PXL_CCT_PREFETCH', '1') != '0':
+                cuts = [i for i in order if isinstance(self.auxiliary_decoders[i], CutOutDecoder)]
+                for i in cuts:
+                    self.auxiliary_decoders[i].prefetch(ul_main_pred)
+                order = [i for i in order if i not in cuts] + cuts
+            ul_ad_preds, cons = [None] * len(order), None
+            for i in order:
+                ad = self.auxiliary_decoders[i]
                 pred, act = ad.forward(ul_ad_inp, pred_of_main_decoder=ul_main_pred, out_size=size)
-                ul_ad_preds.append(pred)
+                ul_ad_preds[i] = pred
                 term = self.cons_criterion.forward(act, ul_ad_gt)
                 cons = term if cons is None else cons + term
             resulter['ul_ad_preds'] = ul_ad_preds
