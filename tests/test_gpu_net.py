@@ -260,6 +260,43 @@ def test_shallow_trunk_eval_bn_every_gradient_tight():
     assert torch.equal(sd["backbone.bn1.running_var"].cpu(), state["backbone.bn1.running_var"])
 
 
+def test_deeplab_latent_gradient_is_seeded_into_the_executor():
+    """SSLCCT on DeepLab-v2 (task/sseg/func.py:228: 2048-channel latent): a loss on the latent handed out by
+    forward_with_latent() sends its gradient back through the executor (pxl_net_seed_latent_grad) and adds to the
+    head's.  Every parameter gradient against the oracle, both dtypes of the comparison as in the tests above."""
+    import torch_oracle as TO
+    from pixelssl_amd import functional as PF
+    state, x, gt, w = _shallow_setup(train=False)
+    hw = (x.shape[2] + 15) // 16
+    wl = torch.randn(x.shape[0], 2048, hw, hw, generator=torch.Generator().manual_seed(3)) * 1e-3
+
+    def oracle(dtype):
+        st = TO.clone_state(state)
+        for k in st:
+            if st[k].is_floating_point():
+                st[k] = st[k].to(dtype)
+        leaves = TO._param_leaves(st)
+        run = TO._with_leaves(st, leaves)
+        logits, prob, lat, _ = TO.deeplabv2_forward(run, x.to(dtype), train=False, layers=SHALLOW)
+        (TO.sseg_criterion(logits, gt).mean() + (lat * wl.to(dtype)).sum()).backward()
+        return {k: v.grad for k, v in leaves.items()}
+    o, t = oracle(torch.float32), oracle(torch.float64)
+    core = _core(torch.float32, state, backbone=SHALLOW)
+    core.train(False)
+    logits, prob, latent = core.forward_with_latent(x.to(DEV))
+    assert tuple(latent.shape) == tuple(wl.shape)
+    (PF.cross_entropy_per_sample(logits, gt.to(DEV), 255).mean() + (latent * wl.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    e = {k: p.grad.cpu() for k, p in core.named_parameters()}
+    _assert_grads_as_accurate(dict(grads=e), dict(grads=o), dict(grads=t), "latent-seeded DeepLab fp32")
+    # the latent term really contributes: without it the trunk gradient is different
+    core.flat.grads.zero_()
+    logits, _, _ = core(x.to(DEV))
+    PF.cross_entropy_per_sample(logits, gt.to(DEV), 255).mean().backward()
+    torch.cuda.synchronize()
+    assert rel(core.backbone.conv1.weight.grad.cpu(), e["backbone.conv1.weight"]) > 1e-2
+
+
 def test_shallow_trunk_train_bn_as_accurate_as_fp32_reference():
     """Train-mode BN makes the gradients of this random-init net ill conditioned: the fp32 oracle itself is
     ~1e-2 away from an fp64 run (and a 1e-7 weight perturbation moves gradients by 6e-3).  Gate: the fp32
