@@ -340,6 +340,12 @@ class WrappedCCTModel(nn.Module):
         self.param_groups = list(self.main_model.param_groups) + \
             [{'params': list(self.auxiliary_decoders.parameters()), 'lr': self.args.lr * self.args.ad_lr_scale}]
 
+    def _lanes(self, device):
+        if not hasattr(self, '_lane_streams'):
+            n = int(os.environ.get('PXL_CCT_STREAMS', '2')) if device.type == 'cuda' else 0
+            self._lane_streams = [torch.cuda.Stream(device=device) for _ in range(max(n, 0))]
+        return self._lane_streams
+
     def forward(self, inp, gt, is_unlabeled):
         resulter, debugger = {}, {}
         m_resulter, _ = self.main_model.forward(inp)
@@ -370,13 +376,33 @@ class WrappedCCTModel(nn.Module):
                 for i in cuts:
                     self.auxiliary_decoders[i].prefetch(ul_main_pred)
                 order = [i for i in order if i not in cuts] + cuts
-            ul_ad_preds, cons = [None] * len(order), None
-            for i in order:
+            # The decoders are independent between the latent and their loss term and each is a chain of ~30 small
+            # kernels: they are dealt round-robin onto the main stream and PXL_CCT_STREAMS side streams (autograd runs
+            # each decoder's backward on the stream of its forward)
+            lanes = self._lanes(ul_ad_inp.device)
+            main = torch.cuda.current_stream() if lanes else None
+            for st in lanes:
+                st.wait_stream(main)
+            ul_ad_preds, terms = [None] * len(order), []
+            for k, i in enumerate(order):
                 ad = self.auxiliary_decoders[i]
-                pred, act = ad.forward(ul_ad_inp, pred_of_main_decoder=ul_main_pred, out_size=size)
+                lane = lanes[k % (len(lanes) + 1) - 1] if lanes and k % (len(lanes) + 1) else None
+                if lane is None:
+                    pred, act = ad.forward(ul_ad_inp, pred_of_main_decoder=ul_main_pred, out_size=size)
+                    term = self.cons_criterion.forward(act, ul_ad_gt)
+                else:
+                    with torch.cuda.stream(lane):
+                        pred, act = ad.forward(ul_ad_inp, pred_of_main_decoder=ul_main_pred, out_size=size)
+                        term = self.cons_criterion.forward(act, ul_ad_gt)
+                    for t in (pred, act, term):
+                        t.record_stream(main)
                 ul_ad_preds[i] = pred
-                term = self.cons_criterion.forward(act, ul_ad_gt)
-                cons = term if cons is None else cons + term
+                terms.append(term)
+            for st in lanes:
+                main.wait_stream(st)
+            cons = terms[0]
+            for term in terms[1:]:
+                cons = cons + term
             resulter['ul_ad_preds'] = ul_ad_preds
             resulter['cons_loss'] = torch.mean(cons) / len(ul_ad_preds)
         else:
@@ -456,6 +482,9 @@ class SSLCCT(ssl_base._SSLBase):
             cons_loss = torch.zeros((), device=task_loss.device)
         loss = task_loss + cons_loss
         loss.backward()
+        lanes = getattr(self.model.module, '_lane_streams', [])
+        for st in lanes:                    # the decoders' backward ran on their lanes and wrote the flat gradient buffers
+            torch.cuda.current_stream().wait_stream(st)
         self.optimizer.step()
         if not self.args.is_epoch_lrer:
             self.lrer.step()
