@@ -463,6 +463,12 @@ class SSLCCT(ssl_base._SSLBase):
         self.lrer = lrer_funcs[0](self.optimizer)
         self.lrers = {'lrer': self.lrer}
 
+    def _labeled_stream(self):
+        if not hasattr(self, '_l_stream'):
+            on = os.environ.get('PXL_CCT_SPLIT_BACKWARD', '1') != '0' and torch.cuda.is_available()
+            self._l_stream = torch.cuda.Stream() if on else None
+        return self._l_stream
+
     def train_step(self, inp, gt, cur_step, total_rampup_steps):
         """One iteration of ssl_cct.py:226-282 on device-resident tuples -> dict(task_loss, cons_loss)."""
         lbs = self.args.labeled_batch_size
@@ -470,18 +476,44 @@ class SSLCCT(ssl_base._SSLBase):
         self.optimizer.zero_grad()
         l_gt = func.split_tensor_tuple(gt, 0, lbs)
         l_inp = func.split_tensor_tuple(inp, 0, lbs)
-        l_res, _ = self.model.forward(l_inp, l_gt, False)
-        task_loss = tool.dict_value(l_res, 'task_loss', err=True).mean()
+        has_ul = self.args.unlabeled_batch_size > 0
+        # The labeled and the unlabeled pass are separate forwards of the same model (two BN batches) whose losses are
+        # simply added: d(task + cons) = d(task) + d(cons).  The labeled pass -- forward AND backward -- runs on a side
+        # stream; the unlabeled forward starts once the labeled FORWARD is done (same running-statistics order as the
+        # reference) and overlaps with the labeled backward; the two backward passes accumulate into the same gradient
+        # buffers and stay ordered.  PXL_CCT_SPLIT_BACKWARD=0: one backward over the sum, as the reference.
+        side = self._labeled_stream() if has_ul else None
+        main = torch.cuda.current_stream() if side is not None else None
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                l_res, _ = self.model.forward(l_inp, l_gt, False)
+                task_loss = tool.dict_value(l_res, 'task_loss', err=True).mean()
+                fwd_done = torch.cuda.Event()
+                fwd_done.record()
+                task_loss.backward()
+            main.wait_event(fwd_done)
+            for v in l_res.values():
+                for t in (v if isinstance(v, (tuple, list)) else (v,)):
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
+            task_loss.record_stream(main)
+        else:
+            l_res, _ = self.model.forward(l_inp, l_gt, False)
+            task_loss = tool.dict_value(l_res, 'task_loss', err=True).mean()
         ul_res = None
-        if self.args.unlabeled_batch_size > 0:
+        if has_ul:
             ul_gt = func.split_tensor_tuple(gt, lbs, self.args.batch_size)
             ul_inp = func.split_tensor_tuple(inp, lbs, self.args.batch_size)
             ul_res, _ = self.model.forward(ul_inp, ul_gt, True)
             cons_loss = ramp * self.args.cons_scale * tool.dict_value(ul_res, 'cons_loss', err=True).mean()
         else:
             cons_loss = torch.zeros((), device=task_loss.device)
-        loss = task_loss + cons_loss
-        loss.backward()
+        if side is not None:
+            main.wait_stream(side)              # the labeled backward has finished accumulating
+            cons_loss.backward()
+        else:
+            (task_loss + cons_loss).backward()
         lanes = getattr(self.model.module, '_lane_streams', [])
         for st in lanes:                    # the decoders' backward ran on their lanes and wrote the flat gradient buffers
             torch.cuda.current_stream().wait_stream(st)
