@@ -418,6 +418,25 @@ class SegNetCore(nn.Module):
         for pl in self._plans.values():
             check(lib().pxl_net_set_sync(pl.net, self._sync_cb, None, world_size))
 
+    def twin(self):
+        """A second executor front-end over the SAME parameters / gradients / running statistics with its own plans,
+        buffers and flags (e.g. weight gradients off): lets a frozen copy of a network run (forward and input-gradient
+        backward) on one stream while the trainable one is updated on another (AdvSSL's discriminator).  Not a
+        registered sub-module: it owns no parameters."""
+        t = object.__new__(type(self))
+        nn.Module.__init__(t)
+        for k in ("_device", "_code", "num_classes", "_store", "_pb", "_ops_arr", "_bns_arr", "_param_list", "_nbt",
+                  "_anchor", "freeze_bn", "autotune", "want_prob", "has_latent", "differentiable_latent", "_profile_on"):
+            object.__setattr__(t, k, getattr(self, k))
+        object.__setattr__(t, "_plans", {})
+        object.__setattr__(t, "_cur", None)
+        object.__setattr__(t, "_sync_cb", getattr(self, "_sync_cb", None))
+        object.__setattr__(t, "_sync_user", getattr(self, "_sync_user", None))
+        object.__setattr__(t, "_sync_world", getattr(self, "_sync_world", 1))
+        object.__setattr__(t, "_wgrad_on", True)
+        t.train(self.training)
+        return t
+
     def set_sync_native(self, fn, user, world_size):
         """fn: a C function with the pxl_allreduce_fn signature (ctypes object), user: its context pointer -- the
         Sync-BN exchange then never leaves C (dist.py wires pxl_comm_allreduce_hook + the RCCL communicator)."""

@@ -143,24 +143,64 @@ class SSLADV(ssl_base._SSLBase):
         self.d_criterion = FCDiscriminatorCriterion()
         self.criterions = {'criterion': self.criterion, 'd_criterion': self.d_criterion}
 
+    def _side_stream(self):
+        if not hasattr(self, '_d_stream'):
+            on = os.environ.get('PXL_ADV_STREAMS', '1') != '0' and torch.cuda.is_available()
+            self._d_stream = torch.cuda.Stream() if on else None
+        return self._d_stream
+
     def train_step(self, inp, gt):
         """One iteration of ssl_adv.py:126-246 on device-resident tuples -> dict of detached loss scalars."""
         a = self.args
         lbs = a.labeled_batch_size
         d_core = self.d_model.module.core
-        # ---- step 1: task model; the discriminator is a fixed function here (its own gradients are discarded by
-        # the reference's d_optimizer.zero_grad() below, so they are not computed at all)
+        # Step 1 (task model, the discriminator a fixed function) and step 2 (discriminator on the DETACHED step-1
+        # predictions) only share the task forward: step 1 differentiates through a frozen twin of the discriminator
+        # (same weights, own plans, no weight gradients) on the main stream while step 2 runs -- forward, backward, Adam
+        # -- on a side stream.  PXL_ADV_STREAMS=0: strictly sequential on one stream.
+        side = self._side_stream()
+        main = torch.cuda.current_stream() if side is not None else None
+        if not hasattr(self, '_d_frozen'):
+            self._d_frozen = d_core.twin()
+            self._d_frozen.set_wgrad(False)
+        self._d_frozen.train(d_core.training)
+        # ---- step 1: task model; the discriminator's own gradients are discarded by the reference's
+        # d_optimizer.zero_grad() below, so they are not computed at all
         self.optimizer.zero_grad()
         resulter, _ = self.model.forward(inp)
         self._need_pred(resulter, 'SSL_ADV')
         pred = tool.dict_value(resulter, 'pred')
         activated_pred = tool.dict_value(resulter, 'activated_pred')
-        d_core.set_wgrad(False)
-        d_resulter, _ = self.d_model.forward(activated_pred[0])
-        confidence_map = tool.dict_value(d_resulter, 'confidence')
         l_pred = func.split_tensor_tuple(pred, 0, lbs)
         l_gt = func.split_tensor_tuple(gt, 0, lbs)
         l_inp = func.split_tensor_tuple(inp, 0, lbs)
+
+        def step2():
+            # ---- step 2: discriminator on detached predictions (fake) and one-hot ground truth (real)
+            self.d_optimizer.zero_grad()
+            fake_pred = activated_pred[0].detach() if a.unlabeled_for_discriminator else activated_pred[0][:lbs, ...].detach()
+            fake_map = tool.dict_value(self.d_model.forward(fake_pred)[0], 'confidence')
+            fp, fg = self.task_func.ssladv_preprocess_fcd_criterion(fake_map[:lbs, ...], l_gt[0], False)
+            fake_losses = [self.d_criterion.forward(fp, fg)]
+            if a.unlabeled_for_discriminator and a.unlabeled_batch_size != 0:
+                up, ug = self.task_func.ssladv_preprocess_fcd_criterion(fake_map[lbs:a.batch_size, ...], None, False)
+                fake_losses.append(self.d_criterion.forward(up, ug))
+            fake_d = a.discriminator_scale * torch.mean(torch.cat(fake_losses, dim=0))
+            real_gt = self.task_func.ssladv_convert_task_gt_to_fcd_input(l_gt[0])
+            real_map = tool.dict_value(self.d_model.forward(real_gt)[0], 'confidence')
+            rp, rg = self.task_func.ssladv_preprocess_fcd_criterion(real_map, l_gt[0], True)
+            real_d = a.discriminator_scale * torch.mean(self.d_criterion(rp, rg))
+            ((fake_d + real_d) / 2).backward()
+            self.d_optimizer.step()
+            return fake_d, real_d
+
+        # the frozen twin packs its bf16 weights from the shared fp32 parameters inside this call: it is enqueued BEFORE
+        # step 2 is released, so the discriminator's Adam update of this iteration cannot overtake it
+        confidence_map = self._d_frozen(activated_pred[0])[0]
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fake_d_loss, real_d_loss = step2()
         task_loss = torch.mean(self.criterion.forward(l_pred, l_gt, l_inp))
         zero = torch.zeros((), device=task_loss.device)
         labeled_adv_loss = unlabeled_adv_loss = zero
@@ -173,24 +213,12 @@ class SSLADV(ssl_base._SSLBase):
         loss = task_loss + labeled_adv_loss + unlabeled_adv_loss
         loss.backward()
         self.optimizer.step()
-        # ---- step 2: discriminator on detached predictions (fake) and one-hot ground truth (real)
-        d_core.set_wgrad(True)
-        self.d_optimizer.zero_grad()
-        fake_pred = activated_pred[0].detach() if a.unlabeled_for_discriminator else activated_pred[0][:lbs, ...].detach()
-        fake_map = tool.dict_value(self.d_model.forward(fake_pred)[0], 'confidence')
-        fp, fg = self.task_func.ssladv_preprocess_fcd_criterion(fake_map[:lbs, ...], l_gt[0], False)
-        fake_losses = [self.d_criterion.forward(fp, fg)]
-        if a.unlabeled_for_discriminator and a.unlabeled_batch_size != 0:
-            up, ug = self.task_func.ssladv_preprocess_fcd_criterion(fake_map[lbs:a.batch_size, ...], None, False)
-            fake_losses.append(self.d_criterion.forward(up, ug))
-        fake_d_loss = a.discriminator_scale * torch.mean(torch.cat(fake_losses, dim=0))
-        real_gt = self.task_func.ssladv_convert_task_gt_to_fcd_input(l_gt[0])
-        real_map = tool.dict_value(self.d_model.forward(real_gt)[0], 'confidence')
-        rp, rg = self.task_func.ssladv_preprocess_fcd_criterion(real_map, l_gt[0], True)
-        real_d_loss = a.discriminator_scale * torch.mean(self.d_criterion(rp, rg))
-        d_loss = (fake_d_loss + real_d_loss) / 2
-        d_loss.backward()
-        self.d_optimizer.step()
+        if side is not None:
+            main.wait_stream(side)
+            for t in (fake_d_loss, real_d_loss):
+                t.record_stream(main)
+        else:
+            fake_d_loss, real_d_loss = step2()
         self.d_lrer.step()
         if not a.is_epoch_lrer:
             self.lrer.step()
