@@ -34,6 +34,21 @@ def test_argument_errors_are_reported_not_crashed():
     assert b"dtype" in h.pxl_last_error()
     with pytest.raises(_lib.PixelHipError):
         _lib.check(h.pxl_mse_fwd(0, None, None, None, None))
+    # the later entry points refuse bad arguments before any launch, too (no GPU needed to see that)
+    assert h.pxl_adaptive_avgpool_fwd(1, 1, 33, 33, 64, 6, None, None, None) == -1 and b"adaptive_avgpool" in h.pxl_last_error()
+    assert h.pxl_upsample_slice_fwd(1, 1, 2, 2, 64, 60, 1, None, 0, 33, 33, 1, 4096, 2048, None) == -1       # C % 8 != 0
+    assert b"16-byte aligned" in h.pxl_last_error()
+    assert h.pxl_pixshuf_relu_fwd(1, 1, 4, 4, 32, 21, 1, 1, 32, None) == -1                                  # 4*C > Cp_in
+    assert h.pxl_latent_perturb(0, 512, 25, None, None, None, None, None, 1.0, None, None) == -1
+    assert h.pxl_residual_bwd_reduce(1, 10, 60, 1, 1, 1, 1, 1, None, 1, None) == -1 and b"16-byte" in h.pxl_last_error()
+    fin = _lib.BnFin()                                                          # no statistics, no coefficient output
+    assert h.pxl_bn_finalize_apply_fwd(1, 10, 64, 1, fin, 1, 1, None) == -1 and b"bn_finalize_apply_fwd" in h.pxl_last_error()
+    d2 = _lib.ConvDesc()
+    d2.dtype, d2.Cin, d2.ntaps, d2.div, d2.Kreal, d2.Cout = 0, 64, 1, 1, 64, 64                               # fp32: no LDS-DMA
+    assert h.pxl_conv_dgrad_bnreduce(d2, 1, 1, 1, None, 1, 1, 1, 1, None) == -3 and b"not eligible" in h.pxl_last_error()
+    assert h.pxl_comm_init(None, 0, 1, None) == -1 and h.pxl_comm_allreduce_sum(None, None, 4, None) == -1
+    assert h.pxl_external_contour_boxes_host(None, 4, 4, 50, None, 0, None) == -1
+    assert h.pxl_tune_set(99, 1) == -1
 
 
 def test_engine_parameter_tree_matches_reference_names():
