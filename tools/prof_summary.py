@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Summarise a rocprofv3 rocpd sqlite database (kernel trace) into a per-kernel CSV + print the top rows."""
+"""Summarise a rocprofv3 rocpd sqlite database (kernel trace) into a per-kernel CSV + print the top rows;
+`--one-step <db> [out.txt] [header]`: breakdown of one steady-state training step (window between optimizer launches)."""
 import re
 import sqlite3
 import sys
@@ -23,5 +24,55 @@ def main(db_path, out_csv=None, header="", top=30):
         print("%-86s n=%6d total=%9.3f ms avg=%8.1f us %5.1f%%" % (clean(r[0])[:86], r[1], r[2] / 1e6, r[3] / 1e3, 100 * r[2] / tot))
 
 
+def one_step(db_path, out_txt=None, marker="sgd_kernel", per_step=2, header=""):
+    """Kernel breakdown of ONE steady-state training step: the window between the last launches of `marker` of two
+    consecutive steps (`per_step` marker launches per step: one per optimizer lr group), plus the union of all kernel
+    intervals (GPU-busy time) and the per-stream busy time / gaps."""
+    db = sqlite3.connect(db_path)
+    rows = list(db.execute("select name, start, end, stream_id, queue_id from kernels order by start"))
+    marks = [i for i, r in enumerate(rows) if marker in r[0]]
+    ends = marks[per_step - 1::per_step]
+    a, b = ends[-3], ends[-2]
+    win = rows[a + 1:b + 1]
+    wall = (win[-1][2] - win[0][1]) / 1e6
+    acc = {}
+    for n, s, e, _, _ in win:
+        n = re.sub(r"\(anonymous namespace\)::", "", n)
+        n = re.sub(r"^void ", "", n).split("(")[0]
+        d = acc.setdefault(n, [0, 0])
+        d[0] += 1
+        d[1] += e - s
+    tot = sum(v[1] for v in acc.values())
+    iv = sorted((r[1], r[2]) for r in win)
+    busy, (cs, ce) = 0, iv[0]
+    for s, e in iv[1:]:
+        if s <= ce:
+            ce = max(ce, e)
+        else:
+            busy += ce - cs
+            cs, ce = s, e
+    busy += ce - cs
+    lines = ["# " + header] if header else []
+    lines += ["# ONE steady-state step (between two '%s' launches): wall window %.3f ms, SUM of kernel durations %.3f ms "
+              "(streams overlap), union of kernel intervals %.3f ms, %d launches" % (marker, wall, tot / 1e6, busy / 1e6, len(win))]
+    per = {}
+    for r in win:
+        per.setdefault((r[3], r[4]), []).append(r)
+    for k, v in per.items():
+        gaps = [v[i + 1][1] - v[i][2] for i in range(len(v) - 1)]
+        small = [g for g in gaps if 0 <= g < 20000]
+        lines.append("# stream %s: %d kernels, busy %.3f ms, gaps < 20 us: %d (sum %.3f ms)"
+                     % (k, len(v), sum(r[2] - r[1] for r in v) / 1e6, len(small), sum(small) / 1e6))
+    lines.append("Name,Calls,TotalDurationNs,AverageNs,PercentageOfSum")
+    for n, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        lines.append('"%s",%d,%d,%.1f,%.2f' % (n, c, t, t / c, 100 * t / tot))
+    if out_txt:
+        open(out_txt, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:40]))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None, sys.argv[3] if len(sys.argv) > 3 else "")
+    if len(sys.argv) > 1 and sys.argv[1] == "--one-step":
+        one_step(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None, header=sys.argv[4] if len(sys.argv) > 4 else "")
+    else:
+        main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None, sys.argv[3] if len(sys.argv) > 3 else "")
