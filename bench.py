@@ -181,7 +181,7 @@ def main():
     elapsed = t.item()
 
     # ---- roofline leg: the SAME K steps once more with a HIP event pair around every contraction launch (recorded on
-    # the launch stream).  Kept out of the timed region: ~1300 event records per step cost ~13 % of the step time.
+    # the launch stream).  Kept out of the timed region: ~850 event records per step cost ~13 % of the step time.
     kern = {}
     elapsed_ev = None
     if not a.no_kernel_events:
