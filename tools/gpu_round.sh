@@ -22,7 +22,7 @@ for s in $STAGES; do
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/stages.txt; tail -5 $OUT/smoke.log;;
     bench) timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/bench.log 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/stages.txt; tail -3 $OUT/bench.log; tail -5 $OUT/bench.err;;
     benchfast) timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench.log 2> $OUT/bench.err; echo "benchfast rc=$?" | tee -a $OUT/stages.txt; tail -3 $OUT/bench.log; tail -5 $OUT/bench.err;;
-    prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o mt -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $OLDPWD/$OUT/prof.log 2>&1); echo "prof rc=$?" | tee -a $OUT/stages.txt; find $OUT/prof -name "*stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f";;
+    prof) (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o mt -- python $OLDPWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events > $OLDPWD/$OUT/prof.log 2>&1); echo "prof rc=$?" | tee -a $OUT/stages.txt; db=$(find $OUT/prof -name "*results.db" | head -1); [ -n "$db" ] && python tools/prof_summary.py "$db" $OUT/prof/kernel_stats.csv | head -25 && python tools/prof_summary.py --one-step "$db" $OUT/prof/step_breakdown.txt | head -8;;
     convbench) timeout 600 python tools/conv_bench.py --dtype bf16 --cfgs=-1,0,1,2,4,5,6 > $OUT/convbench_bf16.log 2>&1; echo "convbench rc=$?" | tee -a $OUT/stages.txt; cat $OUT/convbench_bf16.log;;
     convbench32) timeout 600 python tools/conv_bench.py --dtype fp32 --cfgs=-1 > $OUT/convbench_fp32.log 2>&1; echo "convbench32 rc=$?" | tee -a $OUT/stages.txt; cat $OUT/convbench_fp32.log;;
   esac
