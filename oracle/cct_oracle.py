@@ -279,8 +279,8 @@ class CCTOracleTrainer(TO.OracleTrainer):
     """SSLCCT._train body (ssl_cct.py:226-300), one iteration per call, PSPNet main model.
     decoders: list of (kind, cfg dict, state dict).  Extra hp: cons_scale, cons_rampup_iters, ad_lr_scale."""
 
-    def __init__(self, state, decoders, hp):
-        super().__init__(state, hp, forward=TO.pspnet_forward)
+    def __init__(self, state, decoders, hp, forward=None):
+        super().__init__(state, hp, forward=forward or TO.pspnet_forward)      # or deeplabv2_forward (2048-ch latent)
         self.hp.update(dict(cons_scale=30.0, cons_rampup_iters=0, ad_lr_scale=10.0))
         self.hp.update(hp)
         self.decoders = decoders
@@ -293,11 +293,11 @@ class CCTOracleTrainer(TO.OracleTrainer):
         run = TO._with_leaves(self.sd, leaves)
         ad_leaves = [OrderedDict((k, v.detach().requires_grad_(True)) for k, v in sd.items()) for _, _, sd in self.decoders]
         # labeled pass, then a SEPARATE unlabeled pass through the same model (two BN batches, ssl_cct.py:248-266)
-        l_logits, _, _, _ = TO.pspnet_forward(run, x[:lbs], train=True)
+        l_logits, _, _, _ = self.forward(run, x[:lbs], train=True)
         task = TO.sseg_criterion(l_logits, gt[:lbs], hp["ignore_index"]).mean()
         out_draws = []
         if x.shape[0] > lbs:
-            u_logits, u_prob, u_lat, _ = TO.pspnet_forward(run, x[lbs:], train=True)
+            u_logits, u_prob, u_lat, _ = self.forward(run, x[lbs:], train=True)
             preds = []
             for i, (kind, cfg, _) in enumerate(self.decoders):
                 p, d = aux_forward(kind, cfg, ad_leaves[i], u_lat, u_logits.detach(), None if draws is None else draws[i])

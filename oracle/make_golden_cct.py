@@ -43,22 +43,29 @@ def head(v):
     return dict(head=v[:64].clone(), sum=float(v.double().sum()), abssum=float(v.double().abs().sum()))
 
 
-def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234):
+def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspnet"):
+    """arch = 'pspnet' (the shipped script) or 'deeplabv2' (task/sseg/func.py:228: 2048-channel latent)."""
     ref = ref_shim.load_reference()
     pixelssl = ref['pixelssl']
     from pixelssl.nn import optimizer as ropt, lrer as rlr
     batch = lbs + ubs
-    args = ref_shim.make_args('ssl_cct', dict(BASE_CFG, batch_size=batch, unlabeled_batch_size=ubs, im_size=size,
+    args = ref_shim.make_args('ssl_cct', dict(BASE_CFG, models={'model': arch}, batch_size=batch, unlabeled_batch_size=ubs, im_size=size,
                                               ignore_unlabeled=False, cons_scale=30.0, cons_rampup_epochs=5,
                                               ad_lr_scale=10.0, vat_dec_num=1, drop_dec_num=1, cut_dec_num=0,
                                               context_dec_num=1, object_dec_num=1, fd_dec_num=1, fn_dec_num=1))
     args.iters_per_epoch = 4
     task_func = ref['func'].task_func()(args)
     export = pixelssl.ssl_algorithm.__dict__['ssl_cct'].__dict__['ssl_cct']
-    algo = export(args, {'model': ref['model'].PSPNet}, {'model': ropt.sgd(args)}, {'model': rlr.polynomiallr(args)},
-                  {'model': ref['criterion'].CommonSSEGCriterion}, task_func)
-    state = TO.init_pspnet_state(seed=seed)
-    ad_states = [CO.init_decoder_state(seed + 100 + i) for i in range(len(DECODERS))]
+    psp = arch == "pspnet"
+    algo = export(args, {'model': ref['model'].PSPNet if psp else ref['model'].DeepLabV2}, {'model': ropt.sgd(args)},
+                  {'model': rlr.polynomiallr(args)}, {'model': ref['criterion'].CommonSSEGCriterion}, task_func)
+    state = TO.init_pspnet_state(seed=seed) if psp else TO.init_deeplabv2_state(seed=seed)
+    fwd = TO.pspnet_forward if psp else TO.deeplabv2_forward
+    cin = 512 if psp else 2048
+    main_probes = MAIN_PROBES if psp else ["backbone.conv1.weight", "backbone.layer4.2.conv2.weight", "backbone.layer3.11.bn2.weight",
+                                           "backbone.layer4.0.downsample.1.running_var", "classifier.conv2d_list.0.weight",
+                                           "classifier.conv2d_list.3.bias"]
+    ad_states = [CO.init_decoder_state(seed + 100 + i, in_channels=cin) for i in range(len(DECODERS))]
     wrapped = algo.model.module
     wrapped.main_model.load_state_dict(OrderedDict(("model." + k, v.clone()) for k, v in state.items()))
     kinds = [type(m).__name__ for m in wrapped.auxiliary_decoders]
@@ -79,12 +86,12 @@ def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234):
     decs = [(k, c, OrderedDict((n, v.clone()) for n, v in sd.items())) for (k, c), sd in zip(DECODERS, ad_states)]
     tr = CO.CCTOracleTrainer(TO.clone_state(state), decs,
                              dict(max_iters=args.epochs * args.iters_per_epoch, cons_scale=30.0,
-                                  cons_rampup_iters=len(loader) * 5, ad_lr_scale=10.0))
+                                  cons_rampup_iters=len(loader) * 5, ad_lr_scale=10.0), forward=fwd)
     outs = [tr.cct_step(x, gt, lbs) for x, gt in batches]
-    print("case cct:")
+    print("case cct (%s):" % arch)
     for k in meters:
         check("mean " + k, sum(o[k] for o in outs) / len(outs), meters[k])
-    for k in MAIN_PROBES:
+    for k in main_probes:
         check("main " + k, tr.sd[k], ref_main[k], rtol=2e-5)
     for i, (kind, _, sd) in enumerate(tr.decoders):
         for k in AD_PROBES:
@@ -94,21 +101,21 @@ def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234):
     tr2 = CO.CCTOracleTrainer(TO.clone_state(state),
                               [(k, c, OrderedDict((n, v.clone()) for n, v in sd.items())) for (k, c), sd in zip(DECODERS, ad_states)],
                               dict(max_iters=args.epochs * args.iters_per_epoch, cons_scale=30.0,
-                                   cons_rampup_iters=len(loader) * 5, ad_lr_scale=10.0))
+                                   cons_rampup_iters=len(loader) * 5, ad_lr_scale=10.0), forward=fwd)
     o0 = tr2.cct_step(batches[0][0], batches[0][1], lbs, draws=outs[0]["draws"])
     check("replayed draws: cons", o0["cons_loss"], outs[0]["cons_loss"])
 
     g0 = outs[0]
-    fx = dict(kind="cct", size=size, lbs=lbs, ubs=ubs, weight_seed=seed, decoder_seeds=[seed + 100 + i for i in range(len(DECODERS))],
+    fx = dict(kind="cct", arch=arch, in_channels=cin, size=size, lbs=lbs, ubs=ubs, weight_seed=seed, decoder_seeds=[seed + 100 + i for i in range(len(DECODERS))],
               decoders=DECODERS, data_seeds=[seed + 10 + i for i in range(iters)], block=16,
               max_iters=args.epochs * args.iters_per_epoch, rampup_iters=len(loader) * 5,
               meters=meters, per_iter=[dict(task_loss=o["task_loss"], cons_loss=o["cons_loss"]) for o in outs],
               draws=[o["draws"] for o in outs],
-              grads0={k: head(g0["grads"][k]) for k in MAIN_PROBES if k in g0["grads"]},
+              grads0={k: head(g0["grads"][k]) for k in main_probes if k in g0["grads"]},
               ad_grads0=[{k: head(g[k]) for k in AD_PROBES} for g in g0["ad_grads"]],
-              main_probes={k: head(ref_main[k]) for k in MAIN_PROBES},
+              main_probes={k: head(ref_main[k]) for k in main_probes},
               ad_probes=[{k: head(sd[k]) for k in AD_PROBES} for sd in ref_ads])
-    torch.save(fx, os.path.join(OUT, "cct_%d.pt" % size))
+    torch.save(fx, os.path.join(OUT, ("cct_%d.pt" if psp else "cct_deeplab_%d.pt") % size))
 
 
 if __name__ == "__main__":
@@ -117,4 +124,5 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     case_cct()
+    case_cct(arch="deeplabv2", seed=81, rng_seed=4321)
     print("golden fixtures written to", OUT)

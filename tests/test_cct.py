@@ -28,16 +28,21 @@ def rel(a, b):
 def _trainer(fx):
     import torch_oracle as TO
     import cct_oracle as CO
-    decs = [(k, c, CO.init_decoder_state(s)) for (k, c), s in zip(fx["decoders"], fx["decoder_seeds"])]
-    return CO.CCTOracleTrainer(TO.init_pspnet_state(seed=fx["weight_seed"]), decs,
+    psp = fx.get("arch", "pspnet") == "pspnet"
+    cin = fx.get("in_channels", 512)
+    decs = [(k, c, CO.init_decoder_state(s, in_channels=cin)) for (k, c), s in zip(fx["decoders"], fx["decoder_seeds"])]
+    state = TO.init_pspnet_state(seed=fx["weight_seed"]) if psp else TO.init_deeplabv2_state(seed=fx["weight_seed"])
+    return CO.CCTOracleTrainer(state, decs,
                                dict(max_iters=fx["max_iters"], cons_scale=30.0, cons_rampup_iters=fx["rampup_iters"],
-                                    ad_lr_scale=10.0))
+                                    ad_lr_scale=10.0), forward=TO.pspnet_forward if psp else TO.deeplabv2_forward)
 
 
-def test_oracle_reproduces_reference_fixture():
-    """Two SSLCCT iterations with the reference's draws replayed: logged losses + post-step weights of the reference."""
+@pytest.mark.parametrize("fixture", ["cct_65.pt", "cct_deeplab_65.pt"])
+def test_oracle_reproduces_reference_fixture(fixture):
+    """Two SSLCCT iterations with the reference's draws replayed: logged losses + post-step weights of the reference,
+    on the PSPNet main model of the shipped script and on DeepLab-v2 (2048-channel latent, task/sseg/func.py:228)."""
     import torch_oracle as TO
-    fx = torch.load(FX, weights_only=False)
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", fixture), weights_only=False)
     tr = _trainer(fx)
     B = fx["lbs"] + fx["ubs"]
     for i, s in enumerate(fx["data_seeds"]):
