@@ -218,7 +218,8 @@ def _args(**kw):
 
 
 @pytest.mark.gpu
-def test_cct_train_steps_vs_reference_fixture():
+@pytest.mark.parametrize("fixture", ["cct_65.pt", "cct_deeplab_65.pt"])
+def test_cct_train_steps_vs_reference_fixture(fixture):
     """The mirrored SSLCCT iteration (fp32 engine) with the reference's draws replayed: iteration-0 losses at 1e-3
     (task) / 2e-2 (consistency: I-VAT's direction is rounding noise in the reference, see above), iteration 1 inside
     the sanity band of the ill-conditioned random-init net; weights move like the reference's."""
@@ -227,28 +228,29 @@ def test_cct_train_steps_vs_reference_fixture():
     import pixelssl_amd as P
     from pixelssl_amd.nn import optimizer as popt, lrer as plr
     from pixelssl_amd.sseg.func import SSEGFunc
-    fx = torch.load(FX, weights_only=False)
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", fixture), weights_only=False)
+    psp = fx.get("arch", "pspnet") == "pspnet"          # the shipped script's PSPNet, or DeepLab-v2 (2048-channel latent)
     args = _args(labeled_batch_size=fx["lbs"], unlabeled_batch_size=fx["ubs"], batch_size=fx["lbs"] + fx["ubs"],
-                 iters_per_epoch=fx["max_iters"])
-    algo = P.ssl_algorithm.ssl_cct.ssl_cct(args, {"model": P.sseg.model.pspnet()}, {"model": popt.sgd(args)},
+                 iters_per_epoch=fx["max_iters"], models={"model": fx.get("arch", "pspnet")})
+    algo = P.ssl_algorithm.ssl_cct.ssl_cct(args, {"model": P.sseg.model.pspnet() if psp else P.sseg.model.deeplabv2()},
+                                          {"model": popt.sgd(args)},
                                           {"model": plr.polynomiallr(args)},
                                           {"model": P.sseg.criterion.sseg_criterion()}, SSEGFunc(args))
     wrapped = algo.model.module
     kinds = [type(m).__name__ for m in wrapped.auxiliary_decoders]
     assert kinds == ["VATDecoder", "DropOutDecoder", "ContextMaskingDecoder", "ObjectMaskingDecoder",
                      "FeatureDropDecoder", "FeatureNoiseDecoder"]
-    assert len(algo.optimizer.param_groups) == 4
-    lrs = [g["lr"] for g in algo.optimizer.param_groups]       # backbone, psp, decoder, auxiliary decoders (x ad_lr_scale)
-    assert abs(lrs[1] - 10 * lrs[0]) < 1e-12 and abs(lrs[2] - 10 * lrs[0]) < 1e-12 and abs(lrs[3] - 10.0 * lrs[0]) < 1e-12
-    init = TO.init_pspnet_state(seed=fx["weight_seed"])
+    lrs = [g["lr"] for g in algo.optimizer.param_groups]       # backbone, (psp, decoder | classifier), auxiliary decoders
+    assert len(lrs) == (4 if psp else 3) and all(abs(v - 10 * lrs[0]) < 1e-12 for v in lrs[1:])      # ad_lr_scale = 10
+    init = TO.init_pspnet_state(seed=fx["weight_seed"]) if psp else TO.init_deeplabv2_state(seed=fx["weight_seed"])
     wrapped.main_model.model.load_state_dict(init)
-    ad_init = [CO.init_decoder_state(s) for s in fx["decoder_seeds"]]
+    ad_init = [CO.init_decoder_state(s, in_channels=fx.get("in_channels", 512)) for s in fx["decoder_seeds"]]
     for m, sd in zip(wrapped.auxiliary_decoders, ad_init):
         m.load_state_dict(sd)
         m.upsample.autotune = False
     # checkpoint layout of the reference: main_model.model.* and auxiliary_decoders.k.upsample.*
     keys = set(algo.model.state_dict().keys())
-    assert "module.main_model.model.psp.bottleneck.0.weight" in keys
+    assert ("module.main_model.model.psp.bottleneck.0.weight" if psp else "module.main_model.model.classifier.conv2d_list.0.weight") in keys
     assert "module.auxiliary_decoders.3.upsample.2.conv.bias" in keys
     algo.model.train()
     B = fx["lbs"] + fx["ubs"]
