@@ -45,6 +45,42 @@ def probe(sd, prefix=""):
     return out
 
 
+def subsample(v, n=4096):
+    """Strided sample of a tensor (at most n values) -- the multi-step fixtures store these instead of 176 MB of
+    weights; the same function samples the engine's tensors in the GPU tests."""
+    v = v.detach().reshape(-1)
+    return v[::max(1, v.numel() // n)][:n].float().clone()
+
+
+def probe_update(final_sd, init_sd, keys):
+    """For the multi-step fixtures: a strided sample of every probed tensor after training, plus the L2 norm of the
+    update of that sample (||final - init||) so a test can hold the engine to a fraction of the update."""
+    out = OrderedDict()
+    for k in keys:
+        f, i = subsample(final_sd[k]), subsample(init_sd[k])
+        out[k] = dict(sample=f, update_l2=float((f.double() - i.double()).norm()),
+                      update_max=float((f.double() - i.double()).abs().max()))
+    return out
+
+
+def record_meters(algo):
+    """Every value the reference logs through `meters.update`, in order (-> per-iteration losses of its own loop)."""
+    seen = []
+    real_update = algo.meters.update
+    algo.meters.update = lambda k, v, *a: (seen.append((k, float(v))), real_update(k, v, *a))[1]
+    return seen
+
+
+def per_iteration(seen, keys, iters):
+    out = [{} for _ in range(iters)]
+    for k in keys:
+        vals = [v for kk, v in seen if kk == k]
+        assert len(vals) == iters, (k, len(vals), iters)
+        for i, v in enumerate(vals):
+            out[i][k] = v
+    return out
+
+
 def with_prefix(sd, prefix):
     return OrderedDict((prefix + k, v.clone()) for k, v in sd.items())
 
@@ -130,38 +166,46 @@ def _build_algo(name, args):
     return export(args, model_dict, opt_dict, lr_dict, crit_dict, task_func)
 
 
-def case_suponly(size=65, batch=2, seed=21, iters=2):
-    """Reference SSLNULL._train for `iters` iterations (ssl_null.py:78-144)."""
+def case_suponly(size=65, batch=2, seed=21, iters=2, gamma3=None, out=None, block=16):
+    """Reference SSLNULL._train for `iters` iterations (ssl_null.py:78-144).  gamma3: conditioned initial weights
+    (torch_oracle.condition_state) for the multi-step fixtures."""
     args = ref_shim.make_args('ssl_null', dict(BASE_CFG, batch_size=batch,
                                                unlabeled_batch_size=0, im_size=size,
                                                ignore_unlabeled=True))
-    args.iters_per_epoch = 4
+    args.iters_per_epoch = max(4, iters + 2)
     algo = _build_algo('ssl_null', args)
     state = TO.init_deeplabv2_state(seed=seed)
+    if gamma3 is not None:
+        TO.condition_state(state, gamma3)
     algo.model.module.load_state_dict(with_prefix(state, "model."))
-    batches = [TO.synthetic_batch(batch, size, batch, seed=seed + 10 + i, block=16)
+    batches = [TO.synthetic_batch(batch, size, batch, seed=seed + 10 + i, block=block)
                for i in range(iters)]
     # run the reference's own loop over the whole list (the real code path)
     loader = _ListLoader([((x,), (gt,)) for x, gt in batches])
+    seen = record_meters(algo)
     algo._train(loader, 0)
+    ref_iters = per_iteration(seen, ('task_loss',), iters)
     ref_sd = OrderedDict((k[len("module.model."):], v)
                          for k, v in algo.model.state_dict().items())
     ref_avg_loss = float(algo.meters['task_loss'].avg)
 
     tr = TO.OracleTrainer(TO.clone_state(state), dict(max_iters=args.epochs * args.iters_per_epoch))
     o_losses = [tr.suponly_step(x, gt)["task_loss"] for x, gt in batches]
-    print("case suponly:")
+    print("case suponly%s:" % ("" if gamma3 is None else " (conditioned, gamma3 = %g)" % gamma3))
     check("mean task loss", sum(o_losses) / len(o_losses), ref_avg_loss)
+    for i in range(iters):
+        check("iter %d task loss" % i, o_losses[i], ref_iters[i]['task_loss'], rtol=2e-5 if gamma3 is None else 2e-6)
     for k in PROBES:
         check("post-step " + k, tr.sd[k], ref_sd[k], rtol=2e-5)
-    fx = dict(kind="suponly", size=size, batch=batch, weight_seed=seed,
-              data_seeds=[seed + 10 + i for i in range(iters)], block=16,
+    fx = dict(kind="suponly", size=size, batch=batch, weight_seed=seed, gamma3=gamma3,
+              data_seeds=[seed + 10 + i for i in range(iters)], block=block,
               max_iters=args.epochs * args.iters_per_epoch,
-              mean_task_loss=ref_avg_loss, oracle_losses=o_losses, probes=probe(ref_sd))
-    torch.save(fx, os.path.join(OUT, "suponly_%d.pt" % size))
+              mean_task_loss=ref_avg_loss, oracle_losses=o_losses, per_iter=ref_iters, probes=probe(ref_sd),
+              updates=probe_update(ref_sd, state, PROBES))
+    torch.save(fx, os.path.join(OUT, out or "suponly_%d.pt" % size))
 
 
-def case_mt(size=65, lbs=2, ubs=2, seed=31, iters=2):
+def case_mt(size=65, lbs=2, ubs=2, seed=31, iters=2, gamma3=None, out=None, block=16):
     """Reference SSLMT._train (ssl_mt.py:124-224) with the shipped MT script's
     hyper-parameters (deeplabv2_pascalvoc_1-8_sslmt.py:23-28)."""
     batch = lbs + ubs
@@ -170,16 +214,21 @@ def case_mt(size=65, lbs=2, ubs=2, seed=31, iters=2):
                                              ignore_unlabeled=False, cons_for_labeled=False,
                                              cons_scale=1.0, cons_rampup_epochs=3,
                                              ema_decay=0.99))
-    args.iters_per_epoch = 4
+    args.iters_per_epoch = max(4, iters + 2)
     algo = _build_algo('ssl_mt', args)
     s_state = TO.init_deeplabv2_state(seed=seed)
     t_state = TO.init_deeplabv2_state(seed=seed + 1)
+    if gamma3 is not None:
+        TO.condition_state(s_state, gamma3)
+        TO.condition_state(t_state, gamma3)
     algo.s_model.module.load_state_dict(with_prefix(s_state, "model."))
     algo.t_model.module.load_state_dict(with_prefix(t_state, "model."))
-    batches = [TO.synthetic_batch(batch, size, lbs, seed=seed + 10 + i, block=16)
+    batches = [TO.synthetic_batch(batch, size, lbs, seed=seed + 10 + i, block=block)
                for i in range(iters)]
     loader = _ListLoader([((x,), (gt,)) for x, gt in batches])
+    seen = record_meters(algo)
     algo._train(loader, 0)
+    ref_iters = per_iteration(seen, ('s_task_loss', 't_task_loss', 'cons_loss'), iters)
     strip = lambda sd: OrderedDict((k[len("module.model."):], v) for k, v in sd.items())
     ref_s, ref_t = strip(algo.s_model.state_dict()), strip(algo.t_model.state_dict())
     meters = {k: float(algo.meters[k].avg) for k in ('s_task_loss', 't_task_loss', 'cons_loss')}
@@ -190,18 +239,21 @@ def case_mt(size=65, lbs=2, ubs=2, seed=31, iters=2):
                                cons_for_labeled=False, ema_decay=0.99),
                           teacher_state=TO.clone_state(t_state))
     outs = [tr.mt_step(x, gt, lbs) for x, gt in batches]
-    print("case mt:")
+    print("case mt%s:" % ("" if gamma3 is None else " (conditioned, gamma3 = %g)" % gamma3))
     for k in meters:
         check("mean " + k, sum(o[k] for o in outs) / len(outs), meters[k])
+        for i in range(iters):
+            check("iter %d %s" % (i, k), outs[i][k], ref_iters[i][k], rtol=2e-5 if gamma3 is None else 2e-6, atol=1e-9)
     for k in PROBES:
         check("student " + k, tr.sd[k], ref_s[k], rtol=2e-5)
         check("teacher " + k, tr.t_sd[k], ref_t[k], rtol=2e-5)
-    fx = dict(kind="mt", size=size, lbs=lbs, ubs=ubs, weight_seed=seed,
-              data_seeds=[seed + 10 + i for i in range(iters)], block=16,
+    fx = dict(kind="mt", size=size, lbs=lbs, ubs=ubs, weight_seed=seed, gamma3=gamma3,
+              data_seeds=[seed + 10 + i for i in range(iters)], block=block,
               max_iters=args.epochs * args.iters_per_epoch, rampup_iters=len(loader) * 3,
-              meters=meters, per_iter=[{k: o[k] for k in meters} for o in outs],
-              student_probes=probe(ref_s), teacher_probes=probe(ref_t))
-    torch.save(fx, os.path.join(OUT, "mt_%d.pt" % size))
+              meters=meters, per_iter=[{k: o[k] for k in meters} for o in outs], ref_per_iter=ref_iters,
+              student_probes=probe(ref_s), teacher_probes=probe(ref_t),
+              student_updates=probe_update(ref_s, s_state, PROBES), teacher_updates=probe_update(ref_t, t_state, PROBES))
+    torch.save(fx, os.path.join(OUT, out or "mt_%d.pt" % size))
 
 
 if __name__ == "__main__":

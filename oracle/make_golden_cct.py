@@ -21,7 +21,7 @@ sys.path.insert(0, HERE)
 import ref_shim            # noqa: E402
 import torch_oracle as TO  # noqa: E402
 import cct_oracle as CO    # noqa: E402
-from make_golden import check, _ListLoader  # noqa: E402
+from make_golden import check, _ListLoader, record_meters, per_iteration, probe_update  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
@@ -43,7 +43,7 @@ def head(v):
     return dict(head=v[:64].clone(), sum=float(v.double().sum()), abssum=float(v.double().abs().sum()))
 
 
-def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspnet"):
+def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspnet", gamma3=None, out=None, block=16):
     """arch = 'pspnet' (the shipped script) or 'deeplabv2' (task/sseg/func.py:228: 2048-channel latent)."""
     ref = ref_shim.load_reference()
     pixelssl = ref['pixelssl']
@@ -53,13 +53,15 @@ def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspne
                                               ignore_unlabeled=False, cons_scale=30.0, cons_rampup_epochs=5,
                                               ad_lr_scale=10.0, vat_dec_num=1, drop_dec_num=1, cut_dec_num=0,
                                               context_dec_num=1, object_dec_num=1, fd_dec_num=1, fn_dec_num=1))
-    args.iters_per_epoch = 4
+    args.iters_per_epoch = max(4, iters + 2)
     task_func = ref['func'].task_func()(args)
     export = pixelssl.ssl_algorithm.__dict__['ssl_cct'].__dict__['ssl_cct']
     psp = arch == "pspnet"
     algo = export(args, {'model': ref['model'].PSPNet if psp else ref['model'].DeepLabV2}, {'model': ropt.sgd(args)},
                   {'model': rlr.polynomiallr(args)}, {'model': ref['criterion'].CommonSSEGCriterion}, task_func)
     state = TO.init_pspnet_state(seed=seed) if psp else TO.init_deeplabv2_state(seed=seed)
+    if gamma3 is not None:
+        TO.condition_state(state, gamma3)
     fwd = TO.pspnet_forward if psp else TO.deeplabv2_forward
     cin = 512 if psp else 2048
     main_probes = MAIN_PROBES if psp else ["backbone.conv1.weight", "backbone.layer4.2.conv2.weight", "backbone.layer3.11.bn2.weight",
@@ -72,11 +74,13 @@ def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspne
     print("reference decoders:", kinds)
     for m, sd in zip(wrapped.auxiliary_decoders, ad_states):
         m.load_state_dict(OrderedDict((k, v.clone()) for k, v in sd.items()))
-    batches = [TO.synthetic_batch(batch, size, lbs, seed=seed + 10 + i, block=16) for i in range(iters)]
+    batches = [TO.synthetic_batch(batch, size, lbs, seed=seed + 10 + i, block=block) for i in range(iters)]
     loader = _ListLoader([((x,), (gt,)) for x, gt in batches])
 
     torch.manual_seed(rng_seed); np.random.seed(rng_seed); random.seed(rng_seed)
+    seen = record_meters(algo)
     algo._train(loader, 0)
+    ref_iters = per_iteration(seen, ('task_loss', 'cons_loss'), iters)
     meters = {k: float(algo.meters[k].avg) for k in ('task_loss', 'cons_loss')}
     ref_main = OrderedDict((k[len("model."):], v) for k, v in wrapped.main_model.state_dict().items())
     ref_ads = [m.state_dict() for m in wrapped.auxiliary_decoders]
@@ -91,6 +95,8 @@ def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspne
     print("case cct (%s):" % arch)
     for k in meters:
         check("mean " + k, sum(o[k] for o in outs) / len(outs), meters[k])
+        for i in range(iters):
+            check("iter %d %s" % (i, k), outs[i][k], ref_iters[i][k], rtol=2e-5, atol=1e-9)
     for k in main_probes:
         check("main " + k, tr.sd[k], ref_main[k], rtol=2e-5)
     for i, (kind, _, sd) in enumerate(tr.decoders):
@@ -107,7 +113,9 @@ def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspne
 
     g0 = outs[0]
     fx = dict(kind="cct", arch=arch, in_channels=cin, size=size, lbs=lbs, ubs=ubs, weight_seed=seed, decoder_seeds=[seed + 100 + i for i in range(len(DECODERS))],
-              decoders=DECODERS, data_seeds=[seed + 10 + i for i in range(iters)], block=16,
+              gamma3=gamma3, ref_per_iter=ref_iters, main_updates=probe_update(ref_main, state, main_probes),
+              ad_updates=[probe_update(sd, sd0, AD_PROBES) for sd, sd0 in zip(ref_ads, ad_states)],
+              decoders=DECODERS, data_seeds=[seed + 10 + i for i in range(iters)], block=block,
               max_iters=args.epochs * args.iters_per_epoch, rampup_iters=len(loader) * 5,
               meters=meters, per_iter=[dict(task_loss=o["task_loss"], cons_loss=o["cons_loss"]) for o in outs],
               draws=[o["draws"] for o in outs],
@@ -115,7 +123,7 @@ def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspne
               ad_grads0=[{k: head(g[k]) for k in AD_PROBES} for g in g0["ad_grads"]],
               main_probes={k: head(ref_main[k]) for k in main_probes},
               ad_probes=[{k: head(sd[k]) for k in AD_PROBES} for sd in ref_ads])
-    torch.save(fx, os.path.join(OUT, ("cct_%d.pt" if psp else "cct_deeplab_%d.pt") % size))
+    torch.save(fx, os.path.join(OUT, out or ("cct_%d.pt" if psp else "cct_deeplab_%d.pt") % size))
 
 
 if __name__ == "__main__":

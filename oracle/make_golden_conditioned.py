@@ -1,0 +1,56 @@
+"""Multi-step parity fixtures on CONDITIONED initial weights, from the REAL reference (container only).
+TEST INFRASTRUCTURE.   python oracle/make_golden_conditioned.py [case ...]
+
+Why: with the reference's own initialisers a randomly initialised ResNet-101 is a chaotic map at fixture sizes (a 1-ulp
+perturbation becomes a 1e-2 loss change after one SGD step; the reference does not reproduce its own second iteration
+between a 3-thread and an 8-thread run), so the round-1 fixtures could pin iteration 0 only.  Here the same reference
+code (`SSLNULL/SSLMT/... ._train`, shipped hyper-parameters, train-mode BN) runs SIX iterations from weights whose
+bottleneck-output BN gammas are scaled by 0.1 (torch_oracle.condition_state): fp32 and fp64 runs of the reference
+arithmetic then agree to < 1e-6 in every logged loss, and the GPU tests hold the engine to 1e-3 (losses) and 5 % of
+the update (weights) over all six iterations -- a no-op or wrong optimizer step fails by a factor of 20.
+"""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim            # noqa: E402
+
+GAMMA3 = 0.1
+ITERS = 6
+SIZE = 129
+
+
+def main(which):
+    if not ref_shim.reference_available():
+        raise SystemExit("reference tree not available; fixtures can only be generated in the build container")
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    if "suponly" in which:
+        import make_golden as MG
+        MG.case_suponly(size=SIZE, batch=4, seed=121, iters=ITERS, gamma3=GAMMA3, out="suponly_cond_%d.pt" % SIZE, block=32)
+    if "mt" in which:
+        import make_golden as MG
+        MG.case_mt(size=SIZE, lbs=2, ubs=2, seed=131, iters=ITERS, gamma3=GAMMA3, out="mt_cond_%d.pt" % SIZE, block=32)
+    if "psp" in which:
+        import make_golden_psp as MP
+        MP.case_suponly(size=SIZE, batch=4, seed=161, iters=ITERS, gamma3=GAMMA3, out="pspnet_suponly_cond_%d.pt" % SIZE, block=32)
+    if "adv" in which:
+        import make_golden_adv as MA
+        MA.main(size=SIZE, lbs=2, ubs=2, seed=141, iters=ITERS, gamma3=GAMMA3, out="adv_cond_%d.pt" % SIZE, block=32)
+    if "cutmix" in which:
+        import make_golden_cutmix as MC
+        MC.main(size=SIZE, lbs=2, ubs=4, seed=151, iters=ITERS, gamma3=GAMMA3, out="cutmix_cond_%d.pt" % SIZE, block=32)
+    if "gct" in which:
+        import make_golden_gct_train as MGT
+        MGT.main(size=SIZE, lbs=2, ubs=2, seed=171, iters=ITERS, gamma3=GAMMA3, out="gct_cond_%d.pt" % SIZE, block=32)
+    if "cct" in which:
+        import make_golden_cct as MCC
+        MCC.case_cct(size=SIZE, lbs=2, ubs=2, seed=181, iters=ITERS, rng_seed=2468, gamma3=GAMMA3, out="cct_cond_%d.pt" % SIZE,
+                     block=32)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or ["suponly", "mt", "psp", "adv", "cutmix", "gct", "cct"])

@@ -11,12 +11,12 @@ sys.path.insert(0, HERE)
 import ref_shim                 # noqa: E402
 import torch_oracle as TO       # noqa: E402
 import gct_oracle as GO         # noqa: E402
-from make_golden import BASE_CFG, _ListLoader, check, with_prefix, probe   # noqa: E402
+from make_golden import BASE_CFG, PROBES, _ListLoader, check, with_prefix, probe, probe_update   # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", "gct_129.pt")
 
 
-def main(size=129, lbs=2, ubs=2, seed=61, iters=2):
+def main(size=129, lbs=2, ubs=2, seed=61, iters=2, gamma3=None, out=None, block=16):
     ref = ref_shim.load_reference()
     pixelssl = ref["pixelssl"]
     from pixelssl.ssl_algorithm import ssl_gct as R
@@ -59,13 +59,16 @@ def main(size=129, lbs=2, ubs=2, seed=61, iters=2):
     args = ref_shim.make_args("ssl_gct", dict(BASE_CFG, batch_size=batch, unlabeled_batch_size=ubs, im_size=size,
                                               ignore_unlabeled=False, ssl_mode="gct", fc_ssl_scale=1.0, dc_ssl_scale=100.0,
                                               dc_threshold=0.6, dc_rampup_epochs=3, fd_lr=1e-4, fd_scale=10.0, mu=0.5, nu=1))
-    args.iters_per_epoch = 4
+    args.iters_per_epoch = max(4, iters + 2)
     model_dict = {"model": ref["model"].DeepLabV2}
     crit_dict = {"model": ref["criterion"].CommonSSEGCriterion}
     task_func = ref["func"].task_func()(args)
     algo = pixelssl.ssl_algorithm.ssl_gct.ssl_gct(args, model_dict, {"model": ropt.sgd(args)},
                                                   {"model": rlr.polynomiallr(args)}, crit_dict, task_func)
     l_state, r_state = TO.init_deeplabv2_state(seed=seed), TO.init_deeplabv2_state(seed=seed + 1)
+    if gamma3 is not None:
+        TO.condition_state(l_state, gamma3)
+        TO.condition_state(r_state, gamma3)
     fd1 = GO.init_fd_state(24, seed=seed + 6)
     # a freshly initialised detector outputs ~0 everywhere, FlawmapHandler then zeroes both maps and neither the
     # flaw-correction nor the right-hand consistency path is exercised: start from a detector with a lively output
@@ -75,7 +78,7 @@ def main(size=129, lbs=2, ubs=2, seed=61, iters=2):
     algo.l_model.module.load_state_dict(with_prefix(l_state, "model."))
     algo.r_model.module.load_state_dict(with_prefix(r_state, "model."))
     algo.fd_model.module.load_state_dict(fd1)
-    batches = [TO.synthetic_batch(batch, size, lbs, seed=seed + 10 + i, block=16) for i in range(iters)]
+    batches = [TO.synthetic_batch(batch, size, lbs, seed=seed + 10 + i, block=block) for i in range(iters)]
     loader = _ListLoader([((x,), (gt,)) for x, gt in batches])
     keys = ("l_task_loss", "l_fc_loss", "l_dc_loss", "r_task_loss", "r_fc_loss", "r_dc_loss", "l_fd_loss", "r_fd_loss")
     seen = []                                   # every value the reference logs, in order -> per-iteration losses
@@ -105,25 +108,32 @@ def main(size=129, lbs=2, ubs=2, seed=61, iters=2):
         check("iter0 " + k, outs[0][k], ref_iters[0][k], rtol=2e-5)
     for i in range(1, iters):
         for k in keys:
-            check("iter%d %s (band)" % (i, k), outs[i][k], ref_iters[i][k], rtol=0.35, atol=1e-3)
+            if gamma3 is None:
+                check("iter%d %s (band)" % (i, k), outs[i][k], ref_iters[i][k], rtol=0.35, atol=1e-3)
+            else:       # conditioned task models: every iteration is reproducible -- to the 1e-6 difference between
+                # this restatement's flaw detector and the reference's (measured above), which Adam's sign-like first
+                # steps and the flaw-map threshold amplify to <= 2e-3 (task / fc / fd) and <= 5e-3 (dc) over six iterations
+                check("iter%d %s" % (i, k), outs[i][k], ref_iters[i][k], rtol=1e-2 if "dc" in k else 3e-3, atol=1e-8)
     for k in ("backbone.layer3.11.conv3.weight", "classifier.conv2d_list.0.weight"):
-        check("l " + k, tr.l.sd[k], ref_l[k], rtol=2e-3)
-        check("r " + k, tr.r.sd[k], ref_r[k], rtol=2e-3)
+        check("l " + k, tr.l.sd[k], ref_l[k], rtol=2e-3 if gamma3 is None else 5e-4)
+        check("r " + k, tr.r.sd[k], ref_r[k], rtol=2e-3 if gamma3 is None else 5e-4)
     # (the stem weights are not compared: after two iterations the reference itself moves them by >10 % between
     # a 3-thread and an 8-thread run of the same code)
     fdsd = tr.fd_state()
     for k in ("ibn2.bnorm.weight", "ibn4.bnorm.running_mean", "classifier.weight", "classifier.bias"):
         check("fd " + k, fdsd[k], ref_fdsd[k], rtol=2e-2, atol=5e-7)
-    torch.save(dict(kind="gct", size=size, lbs=lbs, ubs=ubs, weight_seed=seed, fd_seed=seed + 6,
-                    data_seeds=[seed + 10 + i for i in range(iters)], block=16,
+    torch.save(dict(kind="gct", size=size, lbs=lbs, ubs=ubs, weight_seed=seed, fd_seed=seed + 6, gamma3=gamma3,
+                    l_updates=probe_update(ref_l, l_state, PROBES), r_updates=probe_update(ref_r, r_state, PROBES),
+                    fd_updates=probe_update(ref_fdsd, fd1, [k for k, v in ref_fdsd.items() if v.is_floating_point()]),
+                    data_seeds=[seed + 10 + i for i in range(iters)], block=block,
                     max_iters=args.epochs * args.iters_per_epoch, rampup_iters=len(loader) * 3, meters=meters,
                     per_iter=ref_iters, oracle_per_iter=outs, l_probes=probe(ref_l), r_probes=probe(ref_r),
                     fd_after={k: dict(head=v.reshape(-1)[:64].float().clone(), sum=float(v.double().sum()))
                               for k, v in ref_fdsd.items() if v.is_floating_point() and not
                               (k.endswith(".bias") and k.startswith("conv"))},
                     fd_scale_classifier=-3.0,
-                    standalone=standalone), OUT)
-    print("wrote", OUT, os.path.getsize(OUT), "bytes; oracle == reference")
+                    standalone=standalone), OUT if out is None else os.path.join(os.path.dirname(OUT), out))
+    print("wrote", out or OUT, os.path.getsize(OUT), "bytes; oracle == reference")
 
 
 if __name__ == "__main__":

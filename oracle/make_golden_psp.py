@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import ref_shim            # noqa: E402
 import torch_oracle as TO  # noqa: E402
-from make_golden import check, with_prefix, _ListLoader  # noqa: E402
+from make_golden import check, with_prefix, _ListLoader, record_meters, per_iteration, probe_update  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
@@ -109,17 +109,21 @@ def _build_algo(name, args):
     return export(args, model_dict, opt_dict, lr_dict, crit_dict, task_func)
 
 
-def case_suponly(size=65, batch=2, seed=61, iters=2):
+def case_suponly(size=65, batch=2, seed=61, iters=2, gamma3=None, out=None, block=16):
     """Reference SSLNULL._train on PSPNet (3 parameter groups: backbone lr, psp / decoder lr x10)."""
     args = ref_shim.make_args('ssl_null', dict(BASE_CFG, batch_size=batch, unlabeled_batch_size=0, im_size=size,
                                                ignore_unlabeled=True))
-    args.iters_per_epoch = 4
+    args.iters_per_epoch = max(4, iters + 2)
     algo = _build_algo('ssl_null', args)
     state = TO.init_pspnet_state(seed=seed)
+    if gamma3 is not None:
+        TO.condition_state(state, gamma3)
     algo.model.module.load_state_dict(with_prefix(state, "model."))
-    batches = [TO.synthetic_batch(batch, size, batch, seed=seed + 10 + i, block=16) for i in range(iters)]
+    batches = [TO.synthetic_batch(batch, size, batch, seed=seed + 10 + i, block=block) for i in range(iters)]
     loader = _ListLoader([((x,), (gt,)) for x, gt in batches])
+    seen = record_meters(algo)
     algo._train(loader, 0)
+    ref_iters = per_iteration(seen, ('task_loss',), iters)
     ref_sd = OrderedDict((k[len("module.model."):], v) for k, v in algo.model.state_dict().items())
     ref_avg_loss = float(algo.meters['task_loss'].avg)
 
@@ -128,13 +132,16 @@ def case_suponly(size=65, batch=2, seed=61, iters=2):
     o_losses = [tr.suponly_step(x, gt)["task_loss"] for x, gt in batches]
     print("case pspnet suponly:")
     check("mean task loss", sum(o_losses) / len(o_losses), ref_avg_loss)
+    for i in range(iters):
+        check("iter %d task loss" % i, o_losses[i], ref_iters[i]['task_loss'], rtol=2e-5 if gamma3 is None else 2e-6)
     for k in PROBES:
         check("post-step " + k, tr.sd[k], ref_sd[k], rtol=2e-5)
-    fx = dict(kind="pspnet_suponly", size=size, batch=batch, weight_seed=seed,
-              data_seeds=[seed + 10 + i for i in range(iters)], block=16,
+    fx = dict(kind="pspnet_suponly", size=size, batch=batch, weight_seed=seed, gamma3=gamma3,
+              data_seeds=[seed + 10 + i for i in range(iters)], block=block,
               max_iters=args.epochs * args.iters_per_epoch,
-              mean_task_loss=ref_avg_loss, oracle_losses=o_losses, probes=probe(ref_sd))
-    torch.save(fx, os.path.join(OUT, "pspnet_suponly_%d.pt" % size))
+              mean_task_loss=ref_avg_loss, oracle_losses=o_losses, per_iter=ref_iters, probes=probe(ref_sd),
+              updates=probe_update(ref_sd, state, PROBES))
+    torch.save(fx, os.path.join(OUT, out or "pspnet_suponly_%d.pt" % size))
 
 
 if __name__ == "__main__":

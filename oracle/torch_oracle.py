@@ -494,3 +494,24 @@ def synthetic_batch(batch, size, lbs, seed, num_classes=21, block=32):
     if lbs < batch:
         gt[lbs:] = -1.0
     return x, gt
+
+
+# -----------------------------------------------------------------------------
+# Conditioned initial weights for the multi-step parity fixtures
+# -----------------------------------------------------------------------------
+
+def condition_state(sd, gamma3=0.1):
+    """Scale the last BatchNorm gamma of every bottleneck (`*.bn3.weight`) in place and return `sd`.
+
+    The reference's initialisers (gamma = 1 everywhere, resnet.py:138-143) make a randomly initialised ResNet-101 a
+    chaotic map at small inputs: the residual stream grows block by block and train-mode BN over a few hundred samples
+    amplifies a 1-ulp perturbation into a 1e-2 change of the loss after one SGD step -- the reference arithmetic
+    itself (fp32 vs fp64, or 3 vs 8 CPU threads) does not reproduce its own trajectory then.  With gamma3 = 0.1 the
+    same network, same code path and same shipped hyper-parameters are well conditioned (fp32 and fp64 runs of the
+    reference arithmetic agree to < 1e-6 in every logged loss over six iterations), so multi-step parity can be held
+    to a tolerance that a missing or wrong update cannot pass.  Everything else (conv weights, ASPP, BN of the other
+    layers, running statistics) keeps the reference's distributions."""
+    for k in sd:
+        if k.endswith(".bn3.weight"):
+            sd[k] = sd[k] * gamma3
+    return sd

@@ -1,0 +1,149 @@
+"""Parity at the BASELINE size: fp32 engine vs the reference at 513 x 513 (B = 2, full ResNet-101, train-mode BN),
+DeepLab-v2 and PSPNet.  Fixtures come from the reference's own modules (oracle/make_golden_513.py), once with the
+reference's initialisers and once with conditioned weights (torch_oracle.condition_state).  Bars: north_star's 1e-3 on
+logits / loss / latent, arg-max indices bit-exact wherever the reference's top-2 margin is above the numeric noise;
+where the reference ARITHMETIC itself is further than that from the exact (fp64) result on the fixture -- each fixture
+records that gap per quantity -- the bar is 3 x the gap: the engine has to be as accurate as the reference is, it
+cannot be more reproducible than the reference's own rounding.  (Measured gaps: reference initialisers, logits 3e-4 /
+7e-4, trunk gradients 5e-2; conditioned weights, logits 2e-6 / 7e-6, trunk gradients 3e-3 -- ReLU decisions of
+pre-activations within rounding of zero.)  A bf16 row states the throughput mode's distance on the same fixtures."""
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+DEV = "cuda"
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+def _load(arch, cond=False):
+    fx = torch.load(os.path.join(GOLD, "%s_%sforward_513.pt" % (arch, "cond_" if cond else "")), weights_only=False)
+    if "argmax_zlib" in fx:
+        shape = fx["argmax_shape"]
+        fx["argmax"] = torch.from_numpy(np.frombuffer(zlib.decompress(fx["argmax_zlib"]), dtype=np.uint8).reshape(shape).copy())
+        fx["margin"] = torch.from_numpy(np.frombuffer(zlib.decompress(fx["margin_zlib"]), dtype=np.float16).reshape(shape).copy()).float()
+        fx["argmax_grid"], fx["margin_grid"] = fx["argmax"][:, ::8, ::8], fx["margin"][:, ::8, ::8]
+    return fx
+
+
+def _bar(fx, key, floor=1e-3, sub=None):
+    gap = fx["fp64_gap"][key] if sub is None else fx["fp64_gap"][key][sub]
+    return max(floor, 3.0 * gap)
+
+
+def test_fixtures_are_self_consistent():
+    """CPU: the stored arg-max map agrees with the stored logit grid, the margins are non-negative."""
+    for arch in ("deeplabv2", "pspnet"):
+        for cond in (False, True):
+            fx = _load(arch, cond)
+            assert fx["size"] == 513 and fx["batch"] == 2 and (fx.get("gamma3") is not None) == cond
+            assert torch.equal(fx["logits_grid"].argmax(1).to(torch.uint8), fx["argmax_grid"])
+            assert (fx["margin_grid"] >= 0).all()
+            assert abs(fx["prob_grid"].sum(1) - 1).max() < 1e-5
+            # conditioned weights: the reference arithmetic is 100 x closer to the exact result
+            assert fx["fp64_gap"]["logits"] < (2e-5 if cond else 2e-3)
+
+
+def _core(arch, dtype, seed, gamma3=None):
+    import torch_oracle as TO
+    from pixelssl_amd.engine import DeepLabV2Core, PSPNetCore
+    if arch == "pspnet":
+        core, state = PSPNetCore(device=DEV, engine_dtype=dtype), TO.init_pspnet_state(seed=seed)
+    else:
+        core, state = DeepLabV2Core(device=DEV, engine_dtype=dtype), TO.init_deeplabv2_state(seed=seed)
+    if gamma3 is not None:
+        TO.condition_state(state, gamma3)
+    core.load_state_dict(state)
+    core.train()
+    return core
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cond", [False, True], ids=["reference-init", "conditioned"])
+@pytest.mark.parametrize("arch", ["deeplabv2", "pspnet"])
+def test_fp32_engine_vs_reference_at_513(arch, cond):
+    import torch_oracle as TO
+    from pixelssl_amd import functional as PF
+    fx = _load(arch, cond)
+    core = _core(arch, torch.float32, fx["weight_seed"], fx.get("gamma3"))
+    x, gt = TO.synthetic_batch(fx["batch"], fx["size"], fx["batch"], seed=fx["data_seed"], block=fx["block"])
+    logits, prob, latent_fn = core(x.to(DEV))
+    ps = PF.cross_entropy_per_sample(logits, gt.to(DEV), 255)
+    ps.mean().backward()
+    torch.cuda.synchronize()
+    lg = logits.detach().cpu()
+    e_grid = rel(lg[:, :, ::8, ::8], fx["logits_grid"])
+    e_l2 = abs(lg.double().norm().item() - fx["logits_l2"]) / fx["logits_l2"]
+    print("%s 513 fp32: logits rel err on the 8-px grid %.3e, |logits| %.3e, sum %.3e"
+          % (arch, e_grid, e_l2, abs(lg.double().sum().item() - fx["logits_sum"]) / fx["logits_l2"]))
+    assert e_grid < _bar(fx, "logits") and e_l2 < 1e-3
+    assert rel(prob.detach().cpu()[:, :, ::8, ::8], fx["prob_grid"]) < _bar(fx, "logits")
+    # indices: bit-exact wherever the reference's top-2 margin exceeds the numeric noise (the bar above, in logit units)
+    am = lg.argmax(1).to(torch.uint8)
+    full = "argmax" in fx
+    ref_am, margin = (fx["argmax"], fx["margin"]) if full else (fx["argmax_grid"], fx["margin_grid"])
+    got_am = am if full else am[:, ::8, ::8]
+    agree = (got_am == ref_am).float().mean().item()
+    decided = margin > 2 * _bar(fx, "logits") * fx["logits_absmax"]
+    print("   argmax agreement %.6f %s, decided pixels %.4f of them" % (agree, "overall" if full else "on the grid", decided.float().mean().item()))
+    assert torch.equal(got_am[decided], ref_am[decided])
+    assert agree > (0.9995 if cond else 0.999) and decided.float().mean().item() > 0.9
+    # loss, latent, running statistics
+    assert rel(ps.detach().cpu(), fx["per_sample"]) < 1e-3
+    lat = latent_fn().cpu()
+    assert rel(lat.reshape(-1)[:512], fx["latent_head"]) < _bar(fx, "latent") and rel(lat[:, ::16, ::4, ::4], fx["latent_grid"]) < _bar(fx, "latent")
+    assert abs(lat.double().norm().item() - fx["latent_l2"]) < 1e-3 * fx["latent_l2"]
+    sd = core.state_dict()
+    for k, ref in fx["running"].items():
+        assert rel(sd[k].cpu().reshape(-1)[:64], ref) < 1e-3, k
+    # parameter gradients: 2e-3, or 3 x the reference arithmetic's own fp32-vs-fp64 gap on that gradient
+    named = dict(core.named_parameters())
+    for k, g in fx["grads"].items():
+        got = named[k].grad.detach().cpu().contiguous().reshape(-1)
+        gs = got[::max(1, got.numel() // 4096)][:4096]
+        e = rel(gs, g["sample"])
+        en = abs(got.double().norm().item() - g["l2"]) / g["l2"]
+        bar = _bar(fx, "grads", 2e-3, k)
+        print("   grad %-40s sample rel err %.3e  norm rel err %.3e  (bar %.1e = max(2e-3, 3 x reference fp32-vs-fp64 gap))" % (k, e, en, bar))
+        assert e < bar, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cond", [False, True], ids=["reference-init", "conditioned"])
+@pytest.mark.parametrize("arch", ["deeplabv2", "pspnet"])
+def test_bf16_engine_distance_at_513(arch, cond):
+    """Throughput mode (the benchmarked precision) on the same fixtures.  bf16 rounding (2^-9 per tensor) passes through
+    100+ layers: on the reference-initialised net, whose own fp32 arithmetic is already 3e-4 from exact, it decorrelates
+    the logits (stated, loss gated at 2e-2); on the conditioned net it is a bounded perturbation and the gate is: arg-max
+    agreement >= 99 % (DeepLab-v2, the benchmarked model; measured 99.96 %) / >= 97 % (PSPNet; measured 98.3 % -- its
+    sub-pixel decoder keeps three 21-channel logit-level tensors in bf16) of the pixels whose reference top-2 margin
+    exceeds 2 % of the logit range, logits within 4e-2 / 1e-1 (measured 2.7e-2 / 7.8e-2)."""
+    import torch_oracle as TO
+    from pixelssl_amd import functional as PF
+    fx = _load(arch, cond)
+    core = _core(arch, torch.bfloat16, fx["weight_seed"], fx.get("gamma3"))
+    x, gt = TO.synthetic_batch(fx["batch"], fx["size"], fx["batch"], seed=fx["data_seed"], block=fx["block"])
+    logits, prob, _ = core(x.to(DEV))
+    ps = PF.cross_entropy_per_sample(logits, gt.to(DEV), 255)
+    torch.cuda.synchronize()
+    lg = logits.detach().cpu()
+    e = rel(lg[:, :, ::8, ::8], fx["logits_grid"])
+    am = lg.argmax(1).to(torch.uint8)[:, ::8, ::8]
+    agree = (am == fx["argmax_grid"]).float().mean().item()
+    clear = fx["margin_grid"] > 2e-2 * fx["logits_absmax"]
+    agree_clear = (am[clear] == fx["argmax_grid"][clear]).float().mean().item()
+    le = rel(ps.detach().cpu(), fx["per_sample"])
+    print("%s 513 bf16 (%s): logits rel %.3e  argmax agreement %.4f (%.4f on the %.3f of pixels with a clear margin)  CE rel %.3e"
+          % (arch, "conditioned" if cond else "reference init", e, agree, agree_clear, clear.float().mean().item(), le))
+    assert torch.isfinite(lg).all() and le < 2e-2
+    if cond:
+        assert e < (1e-1 if arch == "pspnet" else 4e-2) and agree_clear >= (0.97 if arch == "pspnet" else 0.99) and agree > 0.9
