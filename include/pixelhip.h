@@ -437,6 +437,12 @@ int pxl_net_forward(pxl_net* net, const float* params, const void* packed, float
 /* latent (backbone feature, NCHW fp32 [B,2048,h,w]) of the last forward held in `arena` */
 int pxl_net_latent(pxl_net* net, const void* arena, float* latent, void* stream);
 int pxl_net_latent_shape(const pxl_net* net, int* C, int* h, int* w);
+/* inspection (parity tests): forward tensor `tensor` of the pass held in `arena` as NCHW fp32 [B,C,h,w]; bn >= 0 applies
+ * that BatchNorm's affine first (the pre-activation whose sign its ReLU decides -- what a torch forward hook on the
+ * reference's BN module would see, e.g. resnet.py:34-42).  tmp: pxl_net_tensor_bytes() of device scratch (bn >= 0) */
+int pxl_net_read_tensor(pxl_net* net, const void* arena, int tensor, int bn, void* tmp, float* out, void* stream);
+size_t pxl_net_tensor_bytes(const pxl_net* net, int tensor);
+int pxl_net_tensor_shape(const pxl_net* net, int tensor, int* C, int* h, int* w);
 /* accumulates parameter gradients into `grads` (same layout as params; caller zeroes when needed);
  * `training` must equal the flag of the forward pass that filled `arena` */
 int pxl_net_backward(pxl_net* net, const float* params, const void* packed, const float* dlogits,

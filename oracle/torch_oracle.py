@@ -157,19 +157,25 @@ def _bn(sd, prefix, x, train):
                         train, BN_MOMENTUM, BN_EPS)
 
 
-def resnet_forward(sd, x, train=True, prefix="backbone", layers=RESNET101):
-    """task/sseg/module/backbone/resnet.py:121-131 (+ Bottleneck.forward :30-50)."""
+def resnet_forward(sd, x, train=True, prefix="backbone", layers=RESNET101, relu=None):
+    """task/sseg/module/backbone/resnet.py:121-131 (+ Bottleneck.forward :30-50).
+
+    relu: optional `fn(site_name, pre_activation) -> activation` replacing F.relu at every ReLU of the trunk (sites
+    '<bn name>' and '<block>.out').  The parity tests use it to run this oracle with the DECISIONS (z > 0) another
+    implementation took, so that gradients can be compared free of the measure-zero set of pre-activations that sit
+    within rounding of zero (each such flip is an O(1) change of one element's gradient)."""
+    act = (lambda name, z: F.relu(z)) if relu is None else relu
     h = F.conv2d(x, sd[prefix + ".conv1.weight"], None, stride=2, padding=3)
-    h = F.relu(_bn(sd, prefix + ".bn1", h, train))
+    h = act(prefix + ".bn1", _bn(sd, prefix + ".bn1", h, train))
     h = F.max_pool2d(h, kernel_size=3, stride=2, padding=1)
     for stage in resnet101_os16_table(layers):
         for blk in stage:
             p = prefix + "." + blk["name"]
             o = F.conv2d(h, sd[p + ".conv1.weight"])
-            o = F.relu(_bn(sd, p + ".bn1", o, train))
+            o = act(p + ".bn1", _bn(sd, p + ".bn1", o, train))
             o = F.conv2d(o, sd[p + ".conv2.weight"], None, stride=blk["stride"],
                          padding=blk["dil"], dilation=blk["dil"])
-            o = F.relu(_bn(sd, p + ".bn2", o, train))
+            o = act(p + ".bn2", _bn(sd, p + ".bn2", o, train))
             o = F.conv2d(o, sd[p + ".conv3.weight"])
             o = _bn(sd, p + ".bn3", o, train)
             if blk["down"]:
@@ -177,7 +183,7 @@ def resnet_forward(sd, x, train=True, prefix="backbone", layers=RESNET101):
                 r = _bn(sd, p + ".downsample.1", r, train)
             else:
                 r = h
-            h = F.relu(o + r)
+            h = act(p + ".out", o + r)
     return h
 
 
@@ -192,12 +198,12 @@ def aspp_forward(sd, feat, prefix="classifier"):
     return out
 
 
-def deeplabv2_forward(sd, x, train=True, layers=RESNET101):
+def deeplabv2_forward(sd, x, train=True, layers=RESNET101, relu=None):
     """DeepLabV2.forward (task/sseg/module/deeplab_v2.py:29-33) followed by the
     softmax of DeepLab.forward (task/sseg/model.py:59-65).
 
     Returns (logits NCHW, softmax NCHW, latent NCHW, lowres_logits)."""
-    feat = resnet_forward(sd, x, train, layers=layers)
+    feat = resnet_forward(sd, x, train, layers=layers, relu=relu)
     low = aspp_forward(sd, feat)
     logits = F.interpolate(low, size=x.shape[2:], mode="bilinear", align_corners=True)
     return logits, F.softmax(logits, dim=1), feat, low

@@ -161,6 +161,9 @@ SIGNATURES = {
     "pxl_net_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
     "pxl_net_latent": (_I, [_P, _P, _P, _P]),
     "pxl_net_latent_shape": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "pxl_net_read_tensor": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "pxl_net_tensor_bytes": (_Z, [_P, _I]),
+    "pxl_net_tensor_shape": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "pxl_net_input_grad": (_I, [_P, _P, _P, _P]),
     "pxl_net_seed_latent_grad": (_I, [_P, _P, _Z, _P, _P]),
     "pxl_net_set_wgrad": (_I, [_P, _I]),

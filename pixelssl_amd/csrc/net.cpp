@@ -871,6 +871,35 @@ extern "C" int pxl_net_latent(pxl_net* n, const void* arena, float* latent, void
   return pxl_nhwc_to_nchw(n->dtype, at(arena, off), latent, n->B, ti.C, ti.H, ti.W, ti.Cp, stream);
 }
 
+// Inspection: forward tensor `tensor` of the pass held in `arena` as NCHW fp32; with bn >= 0 the BatchNorm's affine is
+// applied first (z = y * scale + shift, the value whose sign the ReLU after that BN decides).  `tmp` = tensor-sized
+// device scratch (needed only with bn >= 0).
+extern "C" int pxl_net_read_tensor(pxl_net* n, const void* arena, int tensor, int bn, void* tmp, float* out, void* stream) {
+  PXL_REQUIRE(n && n->planned && arena && out && tensor >= 0 && tensor < (int)n->tensors.size(), "net_read_tensor: bad argument");
+  const TensorInfo& t = n->tensors[tensor];
+  PXL_REQUIRE(t.planned, "net_read_tensor: tensor %d is not part of the plan", tensor);
+  const void* src = at(arena, t.off);
+  if (bn >= 0) {
+    PXL_REQUIRE(bn < (int)n->bns.size() && tmp && n->bns[bn].d.C == t.Cp, "net_read_tensor: BN %d does not fit tensor %d", bn, tensor);
+    int rc = pxl_bn_apply_fwd(n->dtype, (long)n->B * t.H * t.W, t.Cp, src, fat(arena, n->bns[bn].coef_off), 0, tmp, stream);
+    if (rc != PXL_OK) return rc;
+    src = tmp;
+  }
+  return pxl_nhwc_to_nchw(n->dtype, src, out, n->B, t.C, t.H, t.W, t.Cp, stream);
+}
+
+extern "C" size_t pxl_net_tensor_bytes(const pxl_net* n, int tensor) {
+  return (n && n->planned && tensor >= 0 && tensor < (int)n->tensors.size()) ? n->tensors[tensor].bytes : 0;
+}
+
+extern "C" int pxl_net_tensor_shape(const pxl_net* n, int tensor, int* C, int* h, int* w) {
+  PXL_REQUIRE(n && n->planned && tensor >= 0 && tensor < (int)n->tensors.size() && n->tensors[tensor].planned, "net_tensor_shape: bad argument");
+  if (C) *C = n->tensors[tensor].C;
+  if (h) *h = n->tensors[tensor].H;
+  if (w) *w = n->tensors[tensor].W;
+  return PXL_OK;
+}
+
 extern "C" int pxl_net_seed_latent_grad(pxl_net* n, void* scratch, size_t scratch_bytes, const float* dlatent, void* stream) {
   PXL_REQUIRE(n && n->planned && scratch && dlatent && n->head_op >= 0, "net_seed_latent_grad: bad argument");
   if (scratch_bytes < n->scratch_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_seed_latent_grad: scratch too small");

@@ -107,6 +107,8 @@ class ProgramBuilder:
         self.bns = []
         self.ntensors = 0
         self.modules = OrderedDict()      # dotted name -> (_Leaf, kind)
+        self.bn_names = []                # BN index -> dotted name
+        self.relu_sites = OrderedDict()   # site name -> (tensor id, BN index or -1): every ReLU decision of the program
 
     def tensor(self):
         self.ntensors += 1
@@ -144,6 +146,7 @@ class ProgramBuilder:
         d.C, d.gamma_off, d.beta_off, d.rmean_off, d.rvar_off = C, g, b, rm, rv
         d.eps, d.momentum = SynchronizedBatchNorm2d.eps, SynchronizedBatchNorm2d.momentum
         self.bns.append(d)
+        self.bn_names.append(name)
         self.modules[name] = "bn"
         return len(self.bns) - 1
 
@@ -159,6 +162,8 @@ class ProgramBuilder:
             op.dil[g] = dils[g]
             op.pads[g] = pads[g]
             self.modules[nm] = "conv_bias" if bias else "conv"
+        if bn_in >= 0:                     # this conv consumes relu(bn(y)): the ReLU decision of that BN
+            self.relu_sites[self.bn_names[bn_in]] = (t_in, bn_in)
         return t
 
     def act(self, t_in, slope):
@@ -178,11 +183,15 @@ class ProgramBuilder:
     def maxpool(self, t_in, bn_in):
         t = self.tensor()
         self._op(_lib.OP_MAXPOOL, in0=t_in, out=t, bn_in0=bn_in)
+        if bn_in >= 0:
+            self.relu_sites[self.bn_names[bn_in]] = (t_in, bn_in)
         return t
 
     def residual(self, t_main, bn_main, t_res, bn_res):
         t = self.tensor()
         self._op(_lib.OP_RESIDUAL, in0=t_main, in1=t_res, out=t, bn_in0=bn_main, bn_in1=bn_res)
+        # out = relu(bn3(y) + shortcut): the stored tensor is the ReLU's OUTPUT, its decision is out > 0
+        self.relu_sites[self.bn_names[bn_main].rsplit(".", 1)[0] + ".out"] = (t, -1)
         return t
 
     def avgpool(self, t_in, bins):
@@ -267,6 +276,8 @@ class SegNetCore(nn.Module):
         self.has_latent = True
         self.differentiable_latent = False   # SSLCCT: the latent handed out by forward() carries autograd history
         self._wgrad_on = True
+        self.keep_arena = False         # inspection (parity tests): keep a handle on the last forward's arena in _last_arena
+        self._last_arena = None
 
     # -- construction -----------------------------------------------------------------------
     def _finalize(self):
@@ -455,6 +466,8 @@ class SegNetCore(nn.Module):
             self._wgrad_on = bool(enable)
 
     def _forward_raw(self, x, arena, want_prob=None):
+        if self.keep_arena:
+            self._last_arena = arena
         B = x.shape[0]
         H, W = self._cur.out_size
         want_prob = self.want_prob if want_prob is None else want_prob
@@ -535,6 +548,20 @@ class SegNetCore(nn.Module):
             check(lib().pxl_net_profile_bytes(pl.net, kind, ctypes.byref(b)))
             tot += b.value
         return tot
+
+    def relu_decisions(self, arena, plan=None):
+        """name -> bool NCHW tensor of every ReLU decision of the forward pass held in `arena` (inspection for the
+        parity tests: '<bn name>' = sign of that BatchNorm's output, '<block>.out' = sign of a bottleneck's output)."""
+        pl = plan if plan is not None else self._cur
+        out = OrderedDict()
+        for name, (tid, bn) in self._pb.relu_sites.items():
+            c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            check(lib().pxl_net_tensor_shape(pl.net, tid, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)))
+            v = torch.empty(pl.shape[0], c.value, h.value, w.value, device=self._device, dtype=torch.float32)
+            tmp = torch.empty(lib().pxl_net_tensor_bytes(pl.net, tid), device=self._device, dtype=torch.uint8) if bn >= 0 else None
+            check(lib().pxl_net_read_tensor(pl.net, ptr(arena), tid, bn, ptr(tmp), ptr(v), stream_ptr()))
+            out[name] = v > 0
+        return out
 
     def latent_from(self, arena, plan=None):
         pl = plan if plan is not None else self._cur

@@ -266,16 +266,5 @@ def test_cct_train_steps_vs_reference_fixture(fixture):
         assert len(ul["ul_ad_preds"]) == 6 and tuple(ul["ul_ad_preds"][0].shape) == (fx["ubs"], 21, fx["size"], fx["size"])
         assert abs(got["task_loss"] - ref["task_loss"]) < (1e-3 if i == 0 else 0.15) * abs(ref["task_loss"])
         assert abs(got["cons_loss"] - ref["cons_loss"]) < (2e-2 if i == 0 else 0.5) * abs(ref["cons_loss"])
-    # two iterations: the second one is noise-limited, so a weight may differ from the reference's by about the size of
-    # its own two-step update (a wrong lr group -- x10 -- or a missing decoder gradient would be far outside)
-    sd = wrapped.main_model.model.state_dict()
-    for k, ref in fx["main_probes"].items():
-        got = sd[k].detach().cpu().reshape(-1)[:64]
-        upd = (ref["head"] - init[k].reshape(-1)[:64].float()).abs().max().item()
-        assert (got - ref["head"]).abs().max().item() <= 2.0 * upd + 1e-6 * ref["head"].abs().max().item() + 1e-9, k
-    for i, probes in enumerate(fx["ad_probes"]):
-        asd = wrapped.auxiliary_decoders[i].state_dict()
-        for k, ref in probes.items():
-            got = asd[k].detach().cpu().reshape(-1)[:64]
-            upd = (ref["head"] - ad_init[i][k].reshape(-1)[:64]).abs().max().item()
-            assert (got - ref["head"]).abs().max().item() <= 2.0 * upd + 1e-6 * ref["head"].abs().max().item() + 1e-9, (i, k)
+    # post-step weights / later iterations: pinned on the conditioned six-iteration fixtures (tests/test_multistep.py:
+    # losses 1e-3, weights within 5 % of the update); this ill-conditioned 65 x 65 fixture pins iteration 0 only

@@ -147,12 +147,8 @@ def test_suponly_and_mt_steps_fp32_vs_reference_meters():
     # here (atomic accumulation order differs run to run) against the oracle's 2.983, so the second iteration is
     # a sanity band, not a parity bar -- parity is pinned by iteration 0 and by the shallow-trunk tests below.
     assert abs(losses[1] - fx["oracle_losses"][1]) < 0.15 * abs(fx["oracle_losses"][1])
-    sd = algo.model.module.model.state_dict()
-    init = TO.init_deeplabv2_state(seed=fx["weight_seed"])
-    for k, ref in fx["probes"].items():
-        got = sd[k].detach().cpu().reshape(-1)[:64]
-        upd = (ref["head"] - init[k].reshape(-1)[:64]).abs().max().item()
-        assert (got - ref["head"]).abs().max().item() <= 2.0 * upd + 1e-6 * ref["head"].abs().max().item() + 1e-9, k
+    # post-step weights / later iterations: pinned on the conditioned six-iteration fixtures (tests/test_multistep.py:
+    # losses 1e-3, weights within 5 % of the update); this ill-conditioned 65 x 65 fixture pins iteration 0 only
     # ---- Mean Teacher
     fx = _load("mt_65.pt")
     args = _args(labeled_batch_size=fx["lbs"], unlabeled_batch_size=fx["ubs"], ignore_unlabeled=False,
@@ -172,12 +168,8 @@ def test_suponly_and_mt_steps_fp32_vs_reference_meters():
         print("mt iter", i, got, ref)
         for k in ref:
             assert abs(got[k] - ref[k]) < (1e-3 if i == 0 else 0.15) * abs(ref[k]) + 1e-7, (i, k)
-    t_sd = algo.t_model.module.model.state_dict()
-    t_init = TO.init_deeplabv2_state(seed=fx["weight_seed"] + 1)
-    for k, ref in fx["teacher_probes"].items():
-        got = t_sd[k].detach().cpu().reshape(-1)[:64]
-        upd = (ref["head"] - t_init[k].reshape(-1)[:64]).abs().max().item()
-        assert (got - ref["head"]).abs().max().item() <= 1.5 * upd + 1e-6 * ref["head"].abs().max().item() + 1e-9, k
+    # post-step weights / later iterations: pinned on the conditioned six-iteration fixtures (tests/test_multistep.py:
+    # losses 1e-3, weights within 5 % of the update); this ill-conditioned 65 x 65 fixture pins iteration 0 only
 
 
 SHALLOW = (2, 2, 2, 3)     # stem + 9 bottlenecks (identity + strided + dilated blocks) + ASPP: every op kind
@@ -232,8 +224,8 @@ def _engine_run(state, x, gt, w, dtype, train):
 def _assert_grads_as_accurate(e, o, t, tag, factor=3.0, slack=1e-2):
     """Every engine gradient is at most `factor` x as far from the fp64 ground truth `t` as the fp32
     reference arithmetic `o` is (+ a slack at the ReLU/max-pool mask-flip noise level: the oracle's own
-    fp32-vs-fp64 gradient distance is 1e-3..1e-2 on these nets).  A wrong or missing gradient path gives
-    O(0.1..1) errors and fails this by two orders of magnitude."""
+    fp32-vs-fp64 gradient distance is 1e-3..1e-2 on these train-mode-BN nets).  A wrong or missing gradient path
+    gives O(0.1..1) errors and fails this by two orders of magnitude."""
     rows = []
     for k in t["grads"]:
         eo, ee = rel(o["grads"][k], t["grads"][k]), rel(e["grads"][k], t["grads"][k])
@@ -243,58 +235,127 @@ def _assert_grads_as_accurate(e, o, t, tag, factor=3.0, slack=1e-2):
     assert rows[0][0] < slack, rows[:5]
 
 
+def _engine_run_with_decisions(state, x, gt, w, train, wl=None, backbone=SHALLOW):
+    """fp32 engine forward + backward, returning its gradients AND every ReLU decision it took (core.relu_decisions)."""
+    from pixelssl_amd import functional as PF
+    core = _core(torch.float32, state, backbone=backbone)
+    core.train(train)
+    core.keep_arena = True
+    if wl is None:
+        logits, prob, latent_fn = core(x.to(DEV))
+        loss = PF.cross_entropy_per_sample(logits, gt.to(DEV), 255).mean() + (prob * w.to(DEV)).sum()
+    else:
+        logits, prob, latent = core.forward_with_latent(x.to(DEV))
+        loss = PF.cross_entropy_per_sample(logits, gt.to(DEV), 255).mean() + (latent * wl.to(DEV)).sum()
+    dec = {k: v.cpu() for k, v in core.relu_decisions(core._last_arena).items()}
+    loss.backward()
+    torch.cuda.synchronize()
+    return dict(core=core, logits=logits.detach().cpu(), loss=loss.item(), decisions=dec,
+                grads={k: p.grad.cpu() for k, p in core.named_parameters()})
+
+
+def _oracle_run_with_decisions(state, x, gt, w, train, decisions, wl=None, layers=SHALLOW):
+    """fp64 oracle whose ReLUs take the given decisions (activation = z * decision): the exact gradient of the network
+    CONDITIONED on the engine's discrete choices.  Also returns where the oracle itself would have decided differently."""
+    import torch_oracle as TO
+    st = TO.clone_state(state)
+    for k in st:
+        if st[k].is_floating_point():
+            st[k] = st[k].double()
+    leaves = TO._param_leaves(st)
+    run = TO._with_leaves(st, leaves)
+    flips = {}
+
+    def act(name, z):
+        d = decisions[name]
+        own = z.detach() > 0
+        diff = own != d
+        flips[name] = (int(diff.sum()), float(z.detach()[diff].abs().max()) if diff.any() else 0.0, float(z.detach().abs().mean()), d.numel())
+        return z * d.to(z.dtype)
+    logits, prob, lat, _ = TO.deeplabv2_forward(run, x.double(), train=train, layers=layers, relu=act)
+    loss = TO.sseg_criterion(logits, gt).mean() + ((prob * w.double()).sum() if wl is None else (lat * wl.double()).sum())
+    loss.backward()
+    return dict(logits=logits.detach(), loss=loss.item(), grads={k: v.grad for k, v in leaves.items()}, flips=flips)
+
+
+def _assert_decisions_and_gradients(e, c, tag):
+    """(1) the engine's ReLU decisions differ from the exact network's only on pre-activations within rounding of
+    zero, a measure-zero set (< 1e-5 of the elements, |z| < 1e-5 of the layer's mean |z|); (2) conditioned on its
+    decisions, EVERY engine gradient is within 1e-5 of the exact one."""
+    nflip = sum(v[0] for v in c["flips"].values())
+    total = sum(v[3] for v in c["flips"].values())
+    worst_z = max((v[1] / (v[2] + 1e-30) for v in c["flips"].values()), default=0.0)
+    print("%s: %d of %d ReLU decisions differ from the exact network's (largest |z| among them: %.1e of the layer mean)"
+          % (tag, nflip, total, worst_z))
+    assert nflip <= 1e-5 * total + 2 and worst_z < 1e-5
+    rows = sorted(((rel(e["grads"][k], c["grads"][k]), k) for k in c["grads"]), reverse=True)
+    print("%s: worst gradient given the decisions: %s %.2e (median %.2e)" % (tag, rows[0][1], rows[0][0], rows[len(rows) // 2][0]))
+    assert rows[0][0] < 1e-5, rows[:5]
+
+
 def test_shallow_trunk_eval_bn_every_gradient_tight():
-    """Forward AND backward plan of the executor (every op kind, both heads of the output) against the
-    oracle at 1e-3 per parameter.  Eval-mode BN (running statistics, the freeze_bn path) keeps the
-    network well conditioned, so a wrong or missing gradient path cannot hide in numeric noise."""
+    """Forward AND backward plan of the executor (every op kind, both heads of the output), eval-mode BN (running
+    statistics: a well conditioned network), every parameter gradient at 1e-5.
+
+    Round 1 measured 3e-3 here against torch fp32's 1e-6 and could not explain it.  Root cause (tools/diag_fp32_grad*.py):
+    ReLU decisions.  A pre-activation within fp32 rounding of zero (about 1 element in 4e5 per layer) can land on either
+    side in two correct fp32 implementations; each such flip changes one element's gradient by O(1), i.e. ~1e-3 of a
+    white test gradient's norm, and the flips of ~30 layers add up.  It is not an arithmetic error of the backward
+    pass: with the engine's own decisions its gradients are exact (e.g. dbeta = sum(dout * (out > 0)) to the last bit).
+    So the comparison is made rigorous instead of loose: the fp64 oracle is run WITH the engine's decisions
+    (torch_oracle.resnet_forward(relu=...), core.relu_decisions) and the bar is 1e-5 on every gradient, plus a bound on
+    how many decisions differ from the exact network's and how close to zero those pre-activations are."""
     state, x, gt, w = _shallow_setup(train=False)
     o = _oracle_run(state, x, gt, w, torch.float32, train=False)
-    e = _engine_run(state, x, gt, w, torch.float32, train=False)
-    t = _oracle_run(state, x, gt, w, torch.float64, train=False)       # ground truth
-    assert rel(e["logits"], o["logits"]) < 1e-4
-    assert rel(e["latent"], o["latent"]) < 1e-4
+    e = _engine_run_with_decisions(state, x, gt, w, train=False)
+    c = _oracle_run_with_decisions(state, x, gt, w, False, e["decisions"])
+    assert rel(e["logits"], o["logits"]) < 1e-5
     assert abs(e["loss"] - o["loss"]) < 1e-5 * abs(o["loss"])
-    _assert_grads_as_accurate(e, o, t, "shallow eval-BN fp32")
+    _assert_decisions_and_gradients(e, c, "shallow eval-BN fp32")
     # eval mode leaves the running statistics untouched
     sd = e["core"].state_dict()
     assert torch.equal(sd["backbone.bn1.running_var"].cpu(), state["backbone.bn1.running_var"])
 
 
+def test_full_depth_resnet101_eval_bn_every_gradient_tight():
+    """The same bar on the FULL ResNet-101 + ASPP (all 320 parameter tensors, 104 convolutions): conditioned weights
+    (torch_oracle.condition_state), eval-mode BN with non-trivial running statistics, 97 x 97, B = 2."""
+    import torch_oracle as TO
+    state = TO.condition_state(TO.init_deeplabv2_state(seed=17), 0.1)
+    g = torch.Generator().manual_seed(4)
+    for k in state:
+        if k.endswith("running_mean"):
+            state[k] = torch.randn(state[k].shape, generator=g) * 0.05
+        elif k.endswith("running_var"):
+            state[k] = torch.rand(state[k].shape, generator=g) + 0.5
+    x, gt = TO.synthetic_batch(2, 97, 2, seed=18, block=16)
+    w = torch.randn(2, 21, 97, 97, generator=torch.Generator().manual_seed(1)) * 1e-3
+    e = _engine_run_with_decisions(state, x, gt, w, train=False, backbone="resnet101")
+    c = _oracle_run_with_decisions(state, x, gt, w, False, e["decisions"], layers=TO.RESNET101)
+    assert rel(e["logits"], c["logits"]) < 1e-5 and abs(e["loss"] - c["loss"]) < 1e-5 * abs(c["loss"])
+    assert len(c["grads"]) == 320
+    _assert_decisions_and_gradients(e, c, "full-depth eval-BN fp32")
+
+
 def test_deeplab_latent_gradient_is_seeded_into_the_executor():
     """SSLCCT on DeepLab-v2 (task/sseg/func.py:228: 2048-channel latent): a loss on the latent handed out by
     forward_with_latent() sends its gradient back through the executor (pxl_net_seed_latent_grad) and adds to the
-    head's.  Every parameter gradient against the oracle, both dtypes of the comparison as in the tests above."""
-    import torch_oracle as TO
+    head's.  Every parameter gradient at 1e-5 against the exact network taking the engine's ReLU decisions (see
+    test_shallow_trunk_eval_bn_every_gradient_tight)."""
     from pixelssl_amd import functional as PF
     state, x, gt, w = _shallow_setup(train=False)
     hw = (x.shape[2] + 15) // 16
     wl = torch.randn(x.shape[0], 2048, hw, hw, generator=torch.Generator().manual_seed(3)) * 1e-3
-
-    def oracle(dtype):
-        st = TO.clone_state(state)
-        for k in st:
-            if st[k].is_floating_point():
-                st[k] = st[k].to(dtype)
-        leaves = TO._param_leaves(st)
-        run = TO._with_leaves(st, leaves)
-        logits, prob, lat, _ = TO.deeplabv2_forward(run, x.to(dtype), train=False, layers=SHALLOW)
-        (TO.sseg_criterion(logits, gt).mean() + (lat * wl.to(dtype)).sum()).backward()
-        return {k: v.grad for k, v in leaves.items()}
-    o, t = oracle(torch.float32), oracle(torch.float64)
-    core = _core(torch.float32, state, backbone=SHALLOW)
-    core.train(False)
-    logits, prob, latent = core.forward_with_latent(x.to(DEV))
-    assert tuple(latent.shape) == tuple(wl.shape)
-    (PF.cross_entropy_per_sample(logits, gt.to(DEV), 255).mean() + (latent * wl.to(DEV)).sum()).backward()
-    torch.cuda.synchronize()
-    e = {k: p.grad.cpu() for k, p in core.named_parameters()}
-    _assert_grads_as_accurate(dict(grads=e), dict(grads=o), dict(grads=t), "latent-seeded DeepLab fp32")
+    e = _engine_run_with_decisions(state, x, gt, w, train=False, wl=wl)
+    c = _oracle_run_with_decisions(state, x, gt, w, False, e["decisions"], wl=wl)
+    _assert_decisions_and_gradients(e, c, "latent-seeded DeepLab fp32")
     # the latent term really contributes: without it the trunk gradient is different
+    core = e["core"]
     core.flat.grads.zero_()
     logits, _, _ = core(x.to(DEV))
     PF.cross_entropy_per_sample(logits, gt.to(DEV), 255).mean().backward()
     torch.cuda.synchronize()
-    assert rel(core.backbone.conv1.weight.grad.cpu(), e["backbone.conv1.weight"]) > 1e-2
+    assert rel(core.backbone.conv1.weight.grad.cpu(), e["grads"]["backbone.conv1.weight"]) > 1e-2
 
 
 def test_shallow_trunk_train_bn_as_accurate_as_fp32_reference():

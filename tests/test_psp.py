@@ -365,10 +365,5 @@ def test_pspnet_suponly_steps_vs_reference_fixture():
     print("pspnet suponly losses", losses, "reference (oracle)", fx["oracle_losses"])
     assert abs(losses[0] - fx["oracle_losses"][0]) < 1e-3 * abs(fx["oracle_losses"][0])
     assert abs(losses[1] - fx["oracle_losses"][1]) < 0.15 * abs(fx["oracle_losses"][1])
-    sd = algo.model.module.model.state_dict()
-    for k, ref in fx["probes"].items():
-        got = sd[k].detach().cpu().reshape(-1)[:64]
-        upd = (ref["head"] - init[k].reshape(-1)[:64].float()).abs().max().item()
-        # two iterations: the second one is noise-limited (see above), so a weight may differ from the reference's by
-        # about the size of its own two-step update; a wrong optimizer / lr group would be off by 10x (lr x10 groups)
-        assert (got - ref["head"]).abs().max().item() <= 2.0 * upd + 1e-6 * ref["head"].abs().max().item() + 1e-9, k
+    # post-step weights / later iterations: pinned on the conditioned six-iteration fixtures (tests/test_multistep.py:
+    # losses 1e-3, weights within 5 % of the update); this ill-conditioned 65 x 65 fixture pins iteration 0 only
