@@ -307,6 +307,23 @@ int pxl_bce_logits_masked_bwd(int B, long HW, const float* x, const float* task_
  * pixels whose mixed max over channels exceeds `threshold` (confidence = count / (B*HW), ssl_cutmix.py:200). */
 int pxl_cutmix_mix(int B, int C, long HW, const float* mask, const float* a, const float* b, float* out,
                    float threshold, float* count, void* stream);
+/* ssladv_preprocess_fcd_criterion as two tensors (task/sseg/func.py:137-157): pred_out = x * m, gt_out = target * m,
+ * m = (task_gt == NULL || task_gt != ignore_index); either output may be NULL.  d pred_out / d x = m: call again with
+ * x = the incoming gradient and gt_out = NULL for the backward.  total = number of elements. */
+int pxl_fcd_prepare(long total, const float* x, const float* task_gt, int ignore_index, float target, float* pred_out,
+                    float* gt_out, void* stream);
+/* FCDiscriminatorCriterion on plain tensors (ssl_adv.py:496-503): loss[b] = mean BCEWithLogits(x[b], t[b]) */
+int pxl_bce_logits_fwd(int B, long HW, const float* x, const float* t, float* loss, void* stream);
+int pxl_bce_logits_bwd(int B, long HW, const float* x, const float* t, const float* gout, float* dx, void* stream);
+/* F.softmax(x, dim=1) of an NCHW fp32 prediction (task/sseg/model.py:59-65, func.py:216-220) and its backward */
+int pxl_softmax_nchw_fwd(int N, int C, long HW, const float* x, float* p, void* stream);
+int pxl_softmax_nchw_bwd(int N, int C, long HW, const float* p, const float* dp, float* dx, void* stream);
+/* Validation metrics (task/sseg/func.py:36-80, numpy on the host in the reference).  pred NCHW fp32 [N,C,HW] (any
+ * activation: only its channel arg-max is used, np.argmax semantics), gt float class ids [N,HW]:
+ * cm[g*C + a] += #pixels with label g (0 <= g < C; 255 / -1 excluded) whose arg-max is a.  cm: C*C int64, accumulated. */
+int pxl_confusion_matrix(int N, int C, long HW, const float* pred, const float* gt, long long* cm, void* stream);
+/* out[n][pix] = arg-max over the C channels (visualisation, func.py:116-119) */
+int pxl_argmax_u8(int N, int C, long HW, const float* pred, unsigned char* out, void* stream);
 /* nn.MSELoss() (ssl_mt.py:115,182-184): out[0] = mean((a-b)^2); da = 2(a-b)/n * gout[0] */
 int pxl_mse_fwd(long n, const float* a, const float* b, float* out, void* stream);
 int pxl_mse_bwd(long n, const float* a, const float* b, const float* gout, float* da, void* stream);

@@ -124,6 +124,13 @@ SIGNATURES = {
     "pxl_bce_logits_masked_fwd": (_I, [_I, _L, _P, _P, _I, _F, _P, _P]),
     "pxl_bce_logits_masked_bwd": (_I, [_I, _L, _P, _P, _I, _F, _P, _P, _P]),
     "pxl_cutmix_mix": (_I, [_I, _I, _L, _P, _P, _P, _P, _F, _P, _P]),
+    "pxl_fcd_prepare": (_I, [_L, _P, _P, _I, _F, _P, _P, _P]),
+    "pxl_bce_logits_fwd": (_I, [_I, _L, _P, _P, _P, _P]),
+    "pxl_bce_logits_bwd": (_I, [_I, _L, _P, _P, _P, _P, _P]),
+    "pxl_softmax_nchw_fwd": (_I, [_I, _I, _L, _P, _P, _P]),
+    "pxl_softmax_nchw_bwd": (_I, [_I, _I, _L, _P, _P, _P, _P]),
+    "pxl_confusion_matrix": (_I, [_I, _I, _L, _P, _P, _P, _P]),
+    "pxl_argmax_u8": (_I, [_I, _I, _L, _P, _P, _P]),
     "pxl_mse_fwd": (_I, [_L, _P, _P, _P, _P]),
     "pxl_mse_bwd": (_I, [_L, _P, _P, _P, _P, _P]),
     "pxl_absdiff_chansum": (_I, [_I, _I, _L, _P, _P, _I, _F, _P, _P]),

@@ -227,6 +227,123 @@ extern "C" int pxl_bce_logits_masked_bwd(int B, long HW, const float* x, const f
   return PXL_OK;
 }
 
+namespace {
+// ssladv_preprocess_fcd_criterion as the reference returns it (task/sseg/func.py:137-157): two TENSORS,
+// pred_out = x * m and gt_out = target * m with m = (task_gt == NULL || task_gt != ignore).  One pass; backward of the
+// first output is dx = dout * m.
+__global__ void fcd_prepare_kernel(long total, const float* __restrict__ x, const float* __restrict__ task_gt, int ignore,
+                                   float target, float* __restrict__ pred_out, float* __restrict__ gt_out) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float m = (task_gt == nullptr || (int)task_gt[i] != ignore) ? 1.f : 0.f;
+    if (pred_out) pred_out[i] = x[i] * m;
+    if (gt_out) gt_out[i] = target * m;
+  }
+}
+// FCDiscriminatorCriterion on plain tensors (ssl_adv.py:496-503): loss[b] = mean_i BCEWithLogits(x, t)
+__global__ void bce_logits_fwd_kernel(long HW, const float* __restrict__ x, const float* __restrict__ t,
+                                      float* __restrict__ loss) {
+  const int b = blockIdx.y;
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+    const float xv = x[b * HW + i], tv = t[b * HW + i];
+    s += fmaxf(xv, 0.f) - xv * tv + log1pf(expf(-fabsf(xv)));
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(loss + b, s / (float)HW);
+}
+__global__ void bce_logits_bwd_kernel(long HW, const float* __restrict__ x, const float* __restrict__ t,
+                                      const float* __restrict__ gout, float* __restrict__ dx) {
+  const int b = blockIdx.y;
+  const float k = gout[b] / (float)HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x)
+    dx[b * HW + i] = (1.f / (1.f + expf(-x[b * HW + i])) - t[b * HW + i]) * k;
+}
+}  // namespace
+
+extern "C" int pxl_fcd_prepare(long total, const float* x, const float* task_gt, int ignore_index, float target,
+                               float* pred_out, float* gt_out, void* stream) {
+  PXL_REQUIRE(x && (pred_out || gt_out) && total > 0, "fcd_prepare: bad argument");
+  long g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(fcd_prepare_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), total, x, task_gt,
+                     ignore_index, target, pred_out, gt_out);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_bce_logits_fwd(int B, long HW, const float* x, const float* t, float* loss, void* stream) {
+  PXL_REQUIRE(x && t && loss && B > 0 && HW > 0, "bce_logits_fwd: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PXL_CHECK_HIP(hipMemsetAsync(loss, 0, (size_t)B * sizeof(float), s));
+  const int gx = (int)((HW + 256 * 8 - 1) / (256 * 8));
+  hipLaunchKernelGGL(bce_logits_fwd_kernel, dim3(gx, B), dim3(256), 0, s, HW, x, t, loss);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_bce_logits_bwd(int B, long HW, const float* x, const float* t, const float* gout, float* dx, void* stream) {
+  PXL_REQUIRE(x && t && gout && dx && B > 0 && HW > 0, "bce_logits_bwd: bad argument");
+  const int gx = (int)((HW + 256 * 8 - 1) / (256 * 8));
+  hipLaunchKernelGGL(bce_logits_bwd_kernel, dim3(gx, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), HW, x, t, gout, dx);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+namespace {
+// F.softmax(x, dim=1) on NCHW fp32 (the activation of the sseg task: task/sseg/model.py:59-65, func.py:216-220) and its
+// backward dx = p * (dp - sum_c dp * p); one thread per pixel, channel planes read in coalesced lines.
+__global__ __launch_bounds__(256) void softmax_nchw_fwd_kernel(int C, long HW, const float* __restrict__ x, float* __restrict__ p) {
+  const int n = blockIdx.y;
+  const float* xs = x + (size_t)n * C * HW;
+  float* ps = p + (size_t)n * C * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+    float v[MAXC], mx = -INFINITY, sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) { v[c] = xs[(size_t)c * HW + i]; mx = fmaxf(mx, v[c]); }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) { v[c] = expf(v[c] - mx); sum += v[c]; }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) ps[(size_t)c * HW + i] = v[c] * inv;
+  }
+}
+__global__ __launch_bounds__(256) void softmax_nchw_bwd_kernel(int C, long HW, const float* __restrict__ p,
+                                                               const float* __restrict__ dp, float* __restrict__ dx) {
+  const int n = blockIdx.y;
+  const size_t base = (size_t)n * C * HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+    float pv[MAXC], gv[MAXC], dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) { pv[c] = p[base + (size_t)c * HW + i]; gv[c] = dp[base + (size_t)c * HW + i]; dot += pv[c] * gv[c]; }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) dx[base + (size_t)c * HW + i] = pv[c] * (gv[c] - dot);
+  }
+}
+}  // namespace
+
+extern "C" int pxl_softmax_nchw_fwd(int N, int C, long HW, const float* x, float* p, void* stream) {
+  PXL_REQUIRE(x && p && N > 0 && HW > 0 && C >= 1 && C <= MAXC, "softmax_nchw_fwd: bad argument (C <= %d)", MAXC);
+  long g = (HW + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(softmax_nchw_fwd_kernel, dim3((int)g, N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), C, HW, x, p);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_softmax_nchw_bwd(int N, int C, long HW, const float* p, const float* dp, float* dx, void* stream) {
+  PXL_REQUIRE(p && dp && dx && N > 0 && HW > 0 && C >= 1 && C <= MAXC, "softmax_nchw_bwd: bad argument (C <= %d)", MAXC);
+  long g = (HW + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(softmax_nchw_bwd_kernel, dim3((int)g, N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), C, HW, p, dp, dx);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
 extern "C" int pxl_mse_fwd(long n, const float* a, const float* b, float* out, void* stream) {
   PXL_REQUIRE(a && b && out && n > 0, "mse_fwd: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

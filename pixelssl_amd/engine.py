@@ -265,6 +265,11 @@ class SegNetCore(nn.Module):
         self._store = FlatStore(self._device)
         self._pb = ProgramBuilder(self._store)
         self._plans = {}                # (B, H, W) -> _Plan: one executor instance + buffers per input shape
+        # inference-only plans (validation feeds one image per batch at its own size, task/sseg/data.py:109-123): a small
+        # LRU, untuned, no data-gradient weights -- the plan dictionary above would otherwise grow by ~0.5 GB and one
+        # autotune run per distinct validation size
+        self._eval_plans = OrderedDict()
+        self.max_eval_plans = int(os.environ.get("PXL_EVAL_PLANS", "4"))
         self._cur = None
         self._sync_cb = None
         self._sync_world = 1
@@ -319,13 +324,16 @@ class SegNetCore(nn.Module):
             mod = getattr(mod, p)
         mod.add_module(parts[-1], leaf)
 
-    def __del__(self):
-        try:
-            for pl in self._plans.values():
-                if pl.net:
-                    lib().pxl_net_destroy(pl.net)
-        except Exception:
-            pass
+    def train(self, mode=True):
+        """nn.Module.train, plus the reference's freeze_bn semantics: `freeze_bn=True` only puts the BN modules into
+        eval mode inside the constructor (deeplab_v2.py:26-27,35-40), and the first `model.train()` of `_train` switches
+        them back -- with the shipped training loops `--freeze-bn True` therefore never freezes anything.  Mirrored
+        rather than "fixed": numerics and running statistics have to follow the reference's."""
+        self.freeze_bn = False
+        return super().train(mode)
+
+    def _all_plans(self):
+        return list(self._plans.values()) + list(self._eval_plans.values())
 
     # the state of the plan in use (kept as attributes for the call sites / tests that read them)
     _net = property(lambda self: self._cur.net)
@@ -363,16 +371,22 @@ class SegNetCore(nn.Module):
         return fresh
 
     # -- planning ---------------------------------------------------------------------------
-    def _plan(self, B, H, W, out_size=None):
+    def _plan(self, B, H, W, out_size=None, inference=False):
         """Select (or create) the executor instance planned for this input shape.  Networks that see several
         batch sizes per iteration (the AdvSSL discriminator: B fake + lbs real maps) keep one plan each, so a
         backward always runs on the plan its forward used.  `out_size` = (Hout, Wout) of the HEAD when it differs
-        from the input size (SSLCCT auxiliary decoders)."""
+        from the input size (SSLCCT auxiliary decoders).  inference: a no-grad forward of a shape no training plan
+        exists for goes to the bounded LRU of untuned forward-only plans."""
         out_size = tuple(out_size) if out_size is not None else (H, W)
         key = (B, H, W) + out_size
         pl = self._plans.get(key)
+        if pl is None and inference:
+            pl = self._eval_plans.get(key)
+            if pl is not None:
+                self._eval_plans.move_to_end(key)
         if pl is None:
             pl = _Plan((B, H, W), out_size)
+            pl.inference = bool(inference)
             pb = self._pb
             check(lib().pxl_net_create(self._code, self.num_classes, self._ops_arr, len(pb.ops), self._bns_arr,
                                        len(pb.bns), pb.ntensors, ctypes.byref(pl.net)))
@@ -387,14 +401,19 @@ class SegNetCore(nn.Module):
                 check(lib().pxl_net_set_wgrad(pl.net, 0))
             if self._profile_on:
                 check(lib().pxl_net_profile(pl.net, 1))
-            self._plans[key] = pl
+            if inference:
+                self._eval_plans[key] = pl
+                while len(self._eval_plans) > max(1, self.max_eval_plans):
+                    self._eval_plans.popitem(last=False)      # its buffers / executor go when the last handle does
+            else:
+                self._plans[key] = pl
         self._cur = pl
         return pl
 
     def _ensure_packed(self):
         pl = self._cur
         v = self._store.version()
-        trainable = bool(self._param_list) and self._param_list[0].requires_grad
+        trainable = bool(self._param_list) and self._param_list[0].requires_grad and not pl.inference
         if pl.pack_dgrad != trainable:      # a no-grad network (the MT teacher) needs no transposed weight copies
             check(lib().pxl_net_set_pack_dgrad(pl.net, int(trainable)))
             pl.pack_dgrad = trainable
@@ -402,7 +421,7 @@ class SegNetCore(nn.Module):
         if pl.packed_version != v:
             check(lib().pxl_net_pack(pl.net, ptr(self._store.params), ptr(pl.packed), stream_ptr()))
             pl.packed_version = v
-        if not pl.tuned and self.autotune:
+        if not pl.tuned and self.autotune and not pl.inference:
             # per-shape tile selection, measured on this GPU (csrc/net.cpp: pxl_net_tune)
             arena = torch.zeros(pl.arena_bytes, device=self._device, dtype=torch.uint8)
             pl.scratch.zero_()
@@ -426,7 +445,7 @@ class SegNetCore(nn.Module):
         self._sync_cb = _lib.ALLREDUCE_FN(_cb)
         self._sync_user = None
         self._sync_world = world_size
-        for pl in self._plans.values():
+        for pl in self._all_plans():
             check(lib().pxl_net_set_sync(pl.net, self._sync_cb, None, world_size))
 
     def twin(self):
@@ -440,6 +459,10 @@ class SegNetCore(nn.Module):
                   "_anchor", "freeze_bn", "autotune", "want_prob", "has_latent", "differentiable_latent", "_profile_on"):
             object.__setattr__(t, k, getattr(self, k))
         object.__setattr__(t, "_plans", {})
+        object.__setattr__(t, "_eval_plans", OrderedDict())
+        object.__setattr__(t, "max_eval_plans", self.max_eval_plans)
+        object.__setattr__(t, "keep_arena", False)
+        object.__setattr__(t, "_last_arena", None)
         object.__setattr__(t, "_cur", None)
         object.__setattr__(t, "_sync_cb", getattr(self, "_sync_cb", None))
         object.__setattr__(t, "_sync_user", getattr(self, "_sync_user", None))
@@ -454,14 +477,14 @@ class SegNetCore(nn.Module):
         self._sync_cb = fn
         self._sync_user = user
         self._sync_world = world_size
-        for pl in self._plans.values():
+        for pl in self._all_plans():
             check(lib().pxl_net_set_sync(pl.net, fn, user, world_size))
 
     # -- execution --------------------------------------------------------------------------
     def set_wgrad(self, enable):
         """enable=False: backward only relays dL/dinput (a frozen discriminator inside the task model's step)."""
         if bool(enable) != self._wgrad_on:
-            for pl in self._plans.values():
+            for pl in self._all_plans():
                 check(lib().pxl_net_set_wgrad(pl.net, int(bool(enable))))
             self._wgrad_on = bool(enable)
 
@@ -492,9 +515,9 @@ class SegNetCore(nn.Module):
             raise _lib.PixelHipError("SegNetCore runs on the GPU only (input is on %s); there is no CPU path" % x.device)
         x = x.contiguous().float()
         B, _, H, W = x.shape
-        self._plan(B, H, W, out_size)
-        self._ensure_packed()
         need_graph = torch.is_grad_enabled() and (any(p.requires_grad for p in self._param_list[:1]) or x.requires_grad)
+        self._plan(B, H, W, out_size, inference=not need_graph and not self.training)
+        self._ensure_packed()
         if need_graph and self.differentiable_latent and self.has_latent:
             arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
             logits, prob, latent = _SegNetFn.apply(x, self._anchor, self, arena, True)
@@ -528,13 +551,13 @@ class SegNetCore(nn.Module):
     def profile(self, enable=True):
         """Bracket every contraction launch with HIP events (bench.py roofline leg)."""
         self._profile_on = bool(enable)
-        for pl in self._plans.values():
+        for pl in self._all_plans():
             check(lib().pxl_net_profile(pl.net, int(enable)))
 
     def profile_read(self, kind):
         """-> (kernel ms, launches, algorithmic flops) of kind 0 = conv igemm (fwd+dgrad), 1 = wgrad."""
         tot = [0.0, 0, 0.0]
-        for pl in self._plans.values():
+        for pl in self._all_plans():
             ms, n, fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
             check(lib().pxl_net_profile_read(pl.net, kind, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
             tot = [tot[0] + ms.value, tot[1] + n.value, tot[2] + fl.value]
@@ -543,7 +566,7 @@ class SegNetCore(nn.Module):
     def profile_bytes(self, kind):
         """algorithmic operand bytes of the stamped launches of `kind` since the last call"""
         tot = 0.0
-        for pl in self._plans.values():
+        for pl in self._all_plans():
             b = ctypes.c_double()
             check(lib().pxl_net_profile_bytes(pl.net, kind, ctypes.byref(b)))
             tot += b.value
@@ -584,6 +607,15 @@ class _Plan:
         self.pack_dgrad = True
         self.arena_bytes = 0
         self.tuned = False
+        self.inference = False
+
+    def __del__(self):
+        try:
+            if self.net:
+                lib().pxl_net_destroy(self.net)
+                self.net = ctypes.c_void_p()
+        except Exception:
+            pass
 
 
 class _LatentHandle:

@@ -76,3 +76,55 @@ class MSELoss(torch.nn.Module):
 
     def forward(self, a, b):
         return mse_loss(a, b)
+
+
+def confusion_matrix(pred, gt, num_classes, out=None):
+    """Device confusion matrix of the sseg validation metrics (task/sseg/func.py:41-48): pred [N,C,H,W] fp32 (activated
+    or not: only its channel arg-max counts), gt [N,1,H,W] / [N,H,W] float class ids -> int64 [C,C] with
+    cm[g][a] = #pixels labeled g (0 <= g < C) predicted a.  Accumulates into `out` when given.  Bit-exact integer counts."""
+    _gpu(pred, gt)
+    pred = pred.detach().contiguous().float()
+    gt = gt.detach().contiguous().float()
+    N, C, H, W = pred.shape
+    if C != num_classes:
+        raise ValueError("confusion_matrix: prediction has %d channels, num_classes = %d" % (C, num_classes))
+    if gt.numel() != N * H * W:
+        raise ValueError("confusion_matrix: gt %s does not match prediction %s" % (tuple(gt.shape), tuple(pred.shape)))
+    cm = out if out is not None else torch.zeros(C, C, device=pred.device, dtype=torch.int64)
+    check(lib().pxl_confusion_matrix(N, C, H * W, ptr(pred), ptr(gt), ptr(cm), stream_ptr()))
+    return cm
+
+
+def argmax_u8(pred):
+    """[N,C,H,W] fp32 -> uint8 [N,H,W] channel arg-max (np.argmax tie / NaN rules)."""
+    _gpu(pred)
+    pred = pred.detach().contiguous().float()
+    N, C, H, W = pred.shape
+    out = torch.empty(N, H, W, device=pred.device, dtype=torch.uint8)
+    check(lib().pxl_argmax_u8(N, C, H * W, ptr(pred), ptr(out), stream_ptr()))
+    return out
+
+
+class _SoftmaxChannels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _gpu(x)
+        x = x.contiguous().float()
+        N, C = x.shape[0], x.shape[1]
+        p = torch.empty_like(x)
+        check(lib().pxl_softmax_nchw_fwd(N, C, x.numel() // (N * C), ptr(x), ptr(p), stream_ptr()))
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        N, C = p.shape[0], p.shape[1]
+        dx = torch.empty_like(p)
+        check(lib().pxl_softmax_nchw_bwd(N, C, p.numel() // (N * C), ptr(p), ptr(dp.contiguous().float()), ptr(dx), stream_ptr()))
+        return dx
+
+
+def softmax_channels(x):
+    """F.softmax(x, dim=1) of an NCHW fp32 prediction (the sseg activation), differentiable."""
+    return _SoftmaxChannels.apply(x)

@@ -93,17 +93,43 @@ class _MaskedBCE(torch.autograd.Function):
         return dx, None, None, None
 
 
+class _PlainBCE(torch.autograd.Function):
+    """BCE-with-logits, mean over (1,2,3) per sample, on plain (pred, target) tensors."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred = pred.contiguous().float()
+        target = target.contiguous().float()
+        B = pred.shape[0]
+        loss = torch.empty(B, device=pred.device, dtype=torch.float32)
+        check(lib().pxl_bce_logits_fwd(B, pred.numel() // B, ptr(pred), ptr(target), ptr(loss), stream_ptr()))
+        ctx.save_for_backward(pred, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target = ctx.saved_tensors
+        B = pred.shape[0]
+        dx = torch.empty_like(pred)
+        check(lib().pxl_bce_logits_bwd(B, pred.numel() // B, ptr(pred), ptr(target), ptr(gout.contiguous().float()), ptr(dx),
+                                       stream_ptr()))
+        return dx, None
+
+
 class FCDiscriminatorCriterion(nn.Module):
-    """ssl_adv.py:496-503: BCE-with-logits, mean over (1,2,3) per sample.  `gt` is the FCDTarget descriptor the sseg
-    task hook returns (mask + target fused into the kernel)."""
+    """ssl_adv.py:496-503: `F.binary_cross_entropy_with_logits(pred, gt, reduction='none')` averaged over (1,2,3) ->
+    one value per sample, for any (pred, gt) pair of tensors.  When the pair comes from the sseg hook
+    `ssladv_preprocess_fcd_criterion` (it carries the un-masked prediction and the task labels, sseg/func.py) the mask,
+    the target and the loss run as ONE kernel on the original prediction instead of three passes."""
 
     def forward(self, pred, gt):
         if not pred.is_cuda:
             raise _lib.PixelHipError("FCDiscriminatorCriterion runs on the GPU only; there is no CPU path")
-        if not hasattr(gt, 'task_gt'):
-            raise _lib.PixelHipError("FCDiscriminatorCriterion expects the FCDTarget produced by "
-                                     "task_func.ssladv_preprocess_fcd_criterion")
-        return _MaskedBCE.apply(pred, gt.task_gt, gt.ignore_index, 1.0 if gt.is_real else 0.0)
+        src = getattr(pred, '_pxl_fcd_source', None)
+        if src is not None and getattr(gt, '_pxl_fcd_source', None) is src:
+            raw_pred, task_gt, ignore_index, is_real = src
+            return _MaskedBCE.apply(raw_pred, task_gt, ignore_index, 1.0 if is_real else 0.0)
+        return _PlainBCE.apply(pred, gt)
 
 
 class SSLADV(ssl_base._SSLBase):
@@ -249,17 +275,27 @@ class SSLADV(ssl_base._SSLBase):
         if self.args.is_epoch_lrer:
             self.lrer.step()
 
+    @torch.no_grad()
     def _validate(self, data_loader, epoch):
+        """ssl_adv.py:285-340: task model in eval mode, task loss + metrics (the discriminator's confidence map is only
+        visualised there)."""
         self.meters.reset()
         self.model.eval()
         self.d_model.eval()
         for idx, (inp, gt) in enumerate(data_loader):
+            timer = time.time()
             inp, gt = self._to_device(inp), self._to_device(gt)
             resulter, _ = self.model.forward(inp)
             self._need_pred(resulter, 'SSL_ADV')
             pred = tool.dict_value(resulter, 'pred')
             self.meters.update('task_loss', torch.mean(self.criterion.forward(pred, gt, inp)).detach())
             self.task_func.metrics(tool.dict_value(resulter, 'activated_pred'), gt, inp, self.meters, id_str='task')
+            self.meters.update('batch_time', time.time() - timer)
+            if idx % self.args.log_freq == 0:
+                logger.log_info('step: [{0}][{1}/{2}]\tbatch-time: {3:.3f}\n  task-{4}\t=>\ttask-loss: {5:.6f}\t'
+                                .format(epoch + 1, idx, len(data_loader), self.meters['batch_time'].avg, self.args.task,
+                                        float(self.meters['task_loss'].avg)))
+        self._log_validation_metrics(['task'])
 
     def _save_checkpoint(self, epoch):
         state = {'algorithm': self.NAME, 'epoch': epoch, 'model': self.model.state_dict(),

@@ -72,6 +72,19 @@ class _SSLBase:
         dev = torch.device('cuda', torch.cuda.current_device())
         return tuple(t.to(dev, non_blocking=True) for t in tensors)
 
+    def _log_validation_metrics(self, id_strs):
+        """The 'Validation metrics' banner every reference _validate ends with (e.g. ssl_mt.py:285-294): all meters
+        whose key contains TaskFunc.METRIC_STR, grouped by the id_str prefix they were recorded under."""
+        info = {k: '' for k in id_strs}
+        for key in sorted(list(self.meters.keys())):
+            if self.task_func.METRIC_STR in key:
+                for id_str in info:
+                    if key.startswith(id_str):
+                        info[id_str] += '{0}: {1:.6}\t'.format(key, self.meters[key])
+        logger.log_info('Validation metrics:\n' + ''.join(
+            '  {0}-metrics\t=>\t{1}\n'.format(k, v.replace('_', '-')) for k, v in info.items()))
+        return info
+
     @staticmethod
     def _need_pred(resulter, name):
         if 'pred' not in resulter.keys() or 'activated_pred' not in resulter.keys():

@@ -467,11 +467,15 @@ def _define_sslgct():
                 self.l_lrer.step()
                 self.r_lrer.step()
 
+        @torch.no_grad()
         def _validate(self, data_loader, epoch):
+            """ssl_gct.py:300-361: both task models in eval mode, task loss + metrics of each (the flaw-detector /
+            consistency terms the reference also evaluates on the validation set are logging only and are not computed)."""
             self.meters.reset()
             for m in (self.l_model, self.r_model, self.fd_model):
                 m.eval()
             for idx, (inp, gt) in enumerate(data_loader):
+                timer = time.time()
                 inp, gt = self._to_device(inp), self._to_device(gt)
                 for mid, model, criterion in (('l', self.l_model, self.l_criterion), ('r', self.r_model, self.r_criterion)):
                     resulter, _ = model.forward(inp)
@@ -479,6 +483,13 @@ def _define_sslgct():
                     self.meters.update(mid + '_task_loss',
                                        torch.mean(criterion.forward(tool.dict_value(resulter, 'pred'), gt, inp)).detach())
                     self.task_func.metrics(tool.dict_value(resulter, 'activated_pred'), gt, inp, self.meters, id_str=mid)
+                self.meters.update('batch_time', time.time() - timer)
+                if idx % self.args.log_freq == 0:
+                    logger.log_info('step: [{0}][{1}/{2}]\tbatch-time: {3:.3f}\n'
+                                    '  l-{4}\t=>\tl-task-loss: {5:.6f}\n  r-{4}\t=>\tr-task-loss: {6:.6f}\n'
+                                    .format(epoch + 1, idx, len(data_loader), self.meters['batch_time'].avg, self.args.task,
+                                            float(self.meters['l_task_loss'].avg), float(self.meters['r_task_loss'].avg)))
+            self._log_validation_metrics(['l', 'r'])
 
         def _save_checkpoint(self, epoch):
             state = {'algorithm': self.NAME, 'epoch': epoch}

@@ -156,18 +156,35 @@ class SSLMT(ssl_base._SSLBase):
         if self.args.is_epoch_lrer:
             self.s_lrer.step()
 
+    @torch.no_grad()
     def _validate(self, data_loader, epoch):
+        """ssl_mt.py:226-294: student and teacher in eval mode, task losses, the consistency loss and the metrics of both."""
         self.meters.reset()
         self.s_model.eval()
         self.t_model.eval()
         for idx, (inp, gt) in enumerate(data_loader):
+            timer = time.time()
             inp, gt = self._to_device(inp), self._to_device(gt)
+            preds = {}
             for tag, model in (('student', self.s_model), ('teacher', self.t_model)):
                 resulter, _ = model.forward(inp)
                 self._need_pred(resulter, 'SSL_MT')
                 pred = tool.dict_value(resulter, 'pred')
+                preds[tag] = (pred, tool.dict_value(resulter, 'activated_pred'))
                 self.meters.update(tag[0] + '_task_loss', torch.mean(self.s_criterion.forward(pred, gt, inp)).detach())
-                self.task_func.metrics(tool.dict_value(resulter, 'activated_pred'), gt, inp, self.meters, id_str=tag)
+            cons_loss = self.args.cons_scale * torch.mean(self.cons_criterion(preds['student'][0][0], preds['teacher'][0][0].detach()))
+            self.meters.update('cons_loss', cons_loss.detach())
+            self.task_func.metrics(preds['student'][1], gt, inp, self.meters, id_str='student')
+            self.task_func.metrics(preds['teacher'][1], gt, inp, self.meters, id_str='teacher')
+            self.meters.update('batch_time', time.time() - timer)
+            if idx % self.args.log_freq == 0:
+                logger.log_info('step: [{0}][{1}/{2}]\tbatch-time: {3:.3f}\n'
+                                '  student-{4}\t=>\ts-task-loss: {5:.6f}\ts-cons-loss: {6:.6f}\n'
+                                '  teacher-{4}\t=>\tt-task-loss: {7:.6f}\n'
+                                .format(epoch + 1, idx, len(data_loader), self.meters['batch_time'].avg, self.args.task,
+                                        float(self.meters['s_task_loss'].avg), float(self.meters['cons_loss'].avg),
+                                        float(self.meters['t_task_loss'].avg)))
+        self._log_validation_metrics(['student', 'teacher'])
 
     def _save_checkpoint(self, epoch):
         state = {'algorithm': self.NAME, 'epoch': epoch, 's_model': self.s_model.state_dict(),

@@ -77,16 +77,25 @@ class SSLNULL(ssl_base._SSLBase):
         if self.args.is_epoch_lrer:
             self.lrer.step()
 
+    @torch.no_grad()
     def _validate(self, data_loader, epoch):
+        """ssl_null.py:146-187: eval-mode forward (running BN statistics) at whatever size the loader yields."""
         self.meters.reset()
         self.model.eval()
         for idx, (inp, gt) in enumerate(data_loader):
+            timer = time.time()
             inp, gt = self._to_device(inp), self._to_device(gt)
             resulter, _ = self.model.forward(inp)
             self._need_pred(resulter, 'SSL_NULL')
             pred = tool.dict_value(resulter, 'pred')
             self.meters.update('task_loss', torch.mean(self.criterion.forward(pred, gt, inp)).detach())
             self.task_func.metrics(tool.dict_value(resulter, 'activated_pred'), gt, inp, self.meters, id_str='task')
+            self.meters.update('batch_time', time.time() - timer)
+            if idx % self.args.log_freq == 0:
+                logger.log_info('step: [{0}][{1}/{2}]\tbatch-time: {3:.3f}\n  task-{4}\t=>\ttask-loss: {5:.6f}\t'
+                                .format(epoch + 1, idx, len(data_loader), self.meters['batch_time'].avg, self.args.task,
+                                        float(self.meters['task_loss'].avg)))
+        self._log_validation_metrics(['task'])
 
     def _save_checkpoint(self, epoch):
         state = {'algorithm': self.NAME, 'epoch': epoch, 'model': self.model.state_dict(),
