@@ -5,7 +5,7 @@ constants, `ssl_algorithm`, `nn`, `model_template` / `criterion_template` / `fun
 `SynchronizedBatchNorm2d`, `log_*`, `str2bool`.  Everything heavy runs in libpixelhip.so
 (hand-written HIP for gfx950); importing the package does not need a GPU, running a model does.
 """
-from .utils import REGRESSION, CLASSIFICATION, log_info, log_warn, log_err, str2bool
+from .utils import REGRESSION, CLASSIFICATION, log_info, log_warn, log_err, str2bool, str2intlist
 from . import utils
 from . import nn
 from .nn import SynchronizedBatchNorm2d, patch_replication_callback, GaussianNoiseLayer

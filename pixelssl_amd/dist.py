@@ -31,6 +31,8 @@ def world_size():
 def local_device():
     """This rank's GPU: LOCAL_RANK, or PXL_FORCE_DEVICE (tests run two gloo ranks on one GPU)."""
     forced = os.environ.get('PXL_FORCE_DEVICE')
+    if forced == 'cpu':         # structure-only use (parameter trees, checkpoints): nothing can be executed there
+        return torch.device('cpu')
     return torch.device('cuda', int(forced if forced is not None else os.environ.get('LOCAL_RANK', '0')))
 
 
@@ -42,8 +44,8 @@ def init_from_env(backend=None):
     backend = os.environ.get('PXL_DIST_BACKEND', backend)      # tests: two gloo ranks on one GPU
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if backend == 'nccl':
-        torch.cuda.set_device(local_device())
+    if torch.cuda.is_available() and local_device().type == 'cuda':
+        torch.cuda.set_device(local_device())       # inputs (_to_device) and statistic views follow the current device
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     dist.init_process_group(backend=backend)
 

@@ -114,6 +114,13 @@ class ProgramBuilder:
         self.ntensors += 1
         return self.ntensors - 1
 
+    def reserve(self, *names):
+        """Fix the position of modules in the parameter order before they are built: the reference's optimizers index
+        their state by the position of a parameter in `module.parameters()` (conv before its BN, resnet.py:18-27), and an
+        optimizer state_dict has to load across the two implementations (ssl_mt.py:296-322)."""
+        for n in names:
+            self.modules.setdefault(n, None)
+
     def _op(self, kind, **kw):
         op = Op()
         op.kind = kind
@@ -228,7 +235,8 @@ def build_resnet_trunk(pb, prefix, layers, output_stride=16):
     else:
         raise NotImplementedError("output_stride %r" % output_stride)
     x = pb.input(3)
-    bn1 = pb.bn(prefix + ".bn1", 64)       # declared after conv1 in the state_dict; names are what matter
+    pb.reserve(prefix + ".conv1")
+    bn1 = pb.bn(prefix + ".bn1", 64)
     y = pb.conv(prefix + ".conv1", x, -1, 3, 64, 7, 2, 1, 3, bn_out=bn1, need_dgrad=False)
     h = pb.maxpool(y, bn1)
     cin = 64
@@ -237,6 +245,7 @@ def build_resnet_trunk(pb, prefix, layers, output_stride=16):
             p = "%s.layer%d.%d" % (prefix, li + 1, b)
             stride = strides[li] if b == 0 else 1
             dil = dilations[li] * ((1, 2, 4)[b] if li == 3 else 1)
+            pb.reserve(p + ".conv1", p + ".bn1", p + ".conv2", p + ".bn2", p + ".conv3", p + ".bn3")
             b1 = pb.bn(p + ".bn1", planes)
             y1 = pb.conv(p + ".conv1", h, -1, cin, planes, 1, 1, 1, 0, bn_out=b1)
             b2 = pb.bn(p + ".bn2", planes)
@@ -244,6 +253,7 @@ def build_resnet_trunk(pb, prefix, layers, output_stride=16):
             b3 = pb.bn(p + ".bn3", planes * 4)
             y3 = pb.conv(p + ".conv3", y2, b2, planes, planes * 4, 1, 1, 1, 0, bn_out=b3)
             if b == 0 and (stride != 1 or cin != planes * 4):
+                pb.reserve(p + ".downsample.0")
                 bd = pb.bn(p + ".downsample.1", planes * 4)
                 yd = pb.conv(p + ".downsample.0", h, -1, cin, planes * 4, 1, stride, 1, 0, bn_out=bd)
                 h = pb.residual(y3, b3, yd, bd)
@@ -783,9 +793,11 @@ class PSPNetCore(SegNetCore):
         cat = pb.concat(feat, c, c + oc * len(PSP_BINS))
         for i, bins in enumerate(PSP_BINS):
             pooled = pb.avgpool(feat, bins)
+            pb.reserve("psp.stages.%d.1" % i)
             b = pb.bn("psp.stages.%d.2" % i, oc)
             y = pb.conv("psp.stages.%d.1" % i, pooled, -1, c, oc, 1, 1, 1, 0, bn_out=b)
             pb.upcat(y, b, cat, c + i * oc, oc)
+        pb.reserve("psp.bottleneck.0")
         bb = pb.bn("psp.bottleneck.1", oc)
         px = pb.conv("psp.bottleneck.0", cat, -1, c + oc * len(PSP_BINS), oc, 3, 1, 1, 1, bn_out=bb)
         low = build_subpixel_decoder(pb, "decoder", px, bb, oc, num_classes, upscale=8)

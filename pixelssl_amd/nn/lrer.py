@@ -1,19 +1,66 @@
-"""LR scheduler factories (pixelssl/nn/lrer.py).  Only the iteration-based polynomial decay is on the
-hot path: lr_t = base * (1 - it/max_it)^power, stepped once per iteration (host scalar math)."""
+"""LR scheduler factories (pixelssl/nn/lrer.py:14-179).  The iteration-based polynomial decay is the one on the hot
+path: lr_t = base * (1 - it/max_it)^power, stepped once per iteration (host scalar math); the epoch schedulers are
+torch's, handed the fused optimizer (they only touch `param_groups[i]['lr']`)."""
 import math
 
+from torch.optim import lr_scheduler
 from torch.optim.lr_scheduler import LRScheduler
 
-from ..utils import logger
+from ..utils import logger, cmd
 
-EPOCH_LRERS = []
+EPOCH_LRERS = ['steplr', 'multisteplr', 'exponentiallr', 'cosineannealinglr']
 ITER_LRERS = ['polynomiallr']
 VALID_LRER = EPOCH_LRERS + ITER_LRERS
 
 
 def add_parser_arguments(parser):
-    parser.add_argument('--last-epoch', type=int, default=-1, metavar='', help='lr scheduler - index of last epoch')
-    parser.add_argument('--power', type=float, default=-1, metavar='', help='lr scheduler - power (polynomiallr)')
+    """Same flags and the '-1 = scheduler default' convention as the reference parser (lrer.py:19-44)."""
+    parser.add_argument('--last-epoch', type=int, default=-1, metavar='', help='lr scheduler - index of last epoch [all]')
+    parser.add_argument('--step-size', type=int, default=-1, metavar='', help='lr scheduler - decay period in epochs [steplr]')
+    parser.add_argument('--milestones', type=cmd.str2intlist, default=[], metavar='', help='lr scheduler - epoch indices [multisteplr]')
+    parser.add_argument('--gamma', type=float, default=-1, metavar='', help='lr scheduler - decay factor [steplr, multisteplr, exponentiallr]')
+    parser.add_argument('--T-max', type=int, default=-1, metavar='', help='lr scheduler - maximum number of epochs [cosineannealinglr]')
+    parser.add_argument('--eta-min', type=float, default=-1, metavar='', help='lr scheduler - minimum learning rate [cosineannealinglr]')
+    parser.add_argument('--power', type=float, default=-1, metavar='', help='lr scheduler - power [polynomiallr]')
+
+
+def steplr(args):
+    args.step_size = args.epochs if args.step_size == -1 else args.step_size
+    args.gamma = 0.1 if args.gamma == -1 else args.gamma
+
+    def steplr_wrapper(optimizer):
+        return lr_scheduler.StepLR(optimizer, step_size=args.step_size, gamma=args.gamma, last_epoch=args.last_epoch)
+
+    return steplr_wrapper
+
+
+def multisteplr(args):
+    args.milestones = list(range(1, args.epochs)) if args.milestones == [] else args.milestones
+    args.gamma = 0.1 if args.gamma == -1 else args.gamma
+
+    def multisteplr_wrapper(optimizer):
+        return lr_scheduler.MultiStepLR(optimizer, milestones=args.milestones, gamma=args.gamma, last_epoch=args.last_epoch)
+
+    return multisteplr_wrapper
+
+
+def exponentiallr(args):
+    args.gamma = 0.1 if args.gamma == -1 else args.gamma
+
+    def exponentiallr_wrapper(optimizer):
+        return lr_scheduler.ExponentialLR(optimizer, gamma=args.gamma, last_epoch=args.last_epoch)
+
+    return exponentiallr_wrapper
+
+
+def cosineannealinglr(args):
+    args.T_max = args.epochs if args.T_max == -1 else args.T_max
+    args.eta_min = 0 if args.eta_min == -1 else args.eta_min
+
+    def cosineannealinglr_wrapper(optimizer):
+        return lr_scheduler.CosineAnnealingLR(optimizer, T_max=args.T_max, eta_min=args.eta_min, last_epoch=args.last_epoch)
+
+    return cosineannealinglr_wrapper
 
 
 class PolynomialLR(LRScheduler):

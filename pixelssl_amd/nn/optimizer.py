@@ -8,7 +8,7 @@ from ..utils import cmd
 from .. import _lib
 from .. import ops
 
-VALID_OPTIMIZER = ['sgd']
+VALID_OPTIMIZER = ['sgd', 'adam']
 
 
 def add_parser_arguments(parser):
@@ -46,7 +46,78 @@ def _segments(params):
     return runs
 
 
-class FusedSGD(Optimizer):
+def _flat_view(store, buf, p):
+    """The slice of a flat per-store buffer (momentum, Adam moments) that belongs to parameter `p`, shaped like it."""
+    _, off, n = p._pxl_flat
+    v = buf[off:off + n]
+    if p.dim() == 4:                       # stored [O][kh][kw][I], exposed OIHW like the parameter itself
+        o, i, kh, kw = p.shape
+        return v.view(o, kh, kw, i).permute(0, 3, 1, 2)
+    return v.view(p.shape)
+
+
+class _FlatStateMixin:
+    """state_dict / load_state_dict in torch's per-parameter format for optimizers whose state lives in flat buffers
+    on the FlatStore: checkpoints written here load into torch.optim.SGD / Adam of the reference (and vice versa:
+    ssl_mt.py:296-322 saves `optimizer.state_dict()` and restores it on --resume)."""
+
+    _STATE_KEYS = ()          # (state_dict key, store attribute)
+
+    def _param_list(self):
+        return [p for g in self.param_groups for p in g['params']]
+
+    def state_dict(self):
+        sd = Optimizer.state_dict(self)
+        state = {}
+        if self._steps_taken > 0:
+            for idx, p in enumerate(self._param_list()):
+                store = p._pxl_flat[0]
+                entry = {k: _flat_view(store, getattr(store, attr), p).detach().clone().contiguous()
+                         for k, attr in self._STATE_KEYS}
+                entry.update(self._extra_state())
+                state[idx] = entry
+        sd['state'] = state
+        return sd
+
+    def load_state_dict(self, state_dict):
+        groups = state_dict['param_groups']
+        if len(groups) != len(self.param_groups) or any(len(g['params']) != len(mine['params'])
+                                                        for g, mine in zip(groups, self.param_groups)):
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters")
+        for g, mine in zip(groups, self.param_groups):
+            for k, v in g.items():
+                if k != 'params':
+                    mine[k] = v
+        params = self._param_list()
+        state = state_dict.get('state', {})
+        for store in self._stores.values():
+            for _, attr in self._STATE_KEYS:
+                getattr(store, attr).zero_()
+        steps = 0
+        with torch.no_grad():
+            for idx, p in enumerate(params):
+                entry = state.get(idx, state.get(str(idx)))
+                if not entry:
+                    continue
+                store = p._pxl_flat[0]
+                for k, attr in self._STATE_KEYS:
+                    if entry.get(k) is not None:
+                        _flat_view(store, getattr(store, attr), p).copy_(entry[k].to(store.params.device))
+                steps = max(steps, self._steps_of(entry))
+        self._steps_taken = steps
+        self._after_load(steps)
+
+    def _extra_state(self):
+        return {}
+
+    def _steps_of(self, entry):
+        return 1
+
+    def _after_load(self, steps):
+        pass
+
+
+class FusedSGD(_FlatStateMixin, Optimizer):
     """torch.optim.SGD semantics (momentum, weight decay, no dampening/nesterov):
     d = g + wd*p ; buf = m*buf + d ; p -= lr*buf   (buf starts at 0, identical to torch's first step)."""
 
@@ -65,10 +136,14 @@ class FusedSGD(Optimizer):
         for store in self._stores.values():
             if not hasattr(store, 'momentum'):
                 store.momentum = torch.zeros_like(store.params)
+        self._steps_taken = 0
+
+    _STATE_KEYS = (('momentum_buffer', 'momentum'),)
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        self._steps_taken += 1
         for group, runs in zip(self.param_groups, self._runs):
             for store, off, n in runs:
                 ops.sgd_step(store.params[off:off + n], store.grads[off:off + n], store.momentum[off:off + n],
@@ -83,12 +158,17 @@ class FusedSGD(Optimizer):
             store.grads.zero_()
 
 
-class FusedAdam(Optimizer):
-    """torch.optim.Adam semantics (no weight decay / amsgrad) as one fused launch per contiguous run of the flat
-    parameter buffer: the discriminator optimizer of AdvSSL (ssl_adv.py:101-102, betas (0.9, 0.99))."""
+class FusedAdam(_FlatStateMixin, Optimizer):
+    """torch.optim.Adam semantics (L2 weight decay folded into the gradient, no amsgrad) as one fused launch per
+    contiguous run of the flat parameter buffer: the discriminator optimizer of AdvSSL (ssl_adv.py:101-102, betas
+    (0.9, 0.99)) and the `adam` factory."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+    _STATE_KEYS = (('exp_avg', 'exp_avg'), ('exp_avg_sq', 'exp_avg_sq'))
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if weight_decay not in (0, 0.0):
+            raise NotImplementedError('FusedAdam implements weight_decay = 0 (what every shipped script uses)')
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0.0))
         self._runs = []
         for group in self.param_groups:
             group['params'] = list(group['params'])
@@ -102,11 +182,23 @@ class FusedAdam(Optimizer):
                 store.exp_avg = torch.zeros_like(store.params)
                 store.exp_avg_sq = torch.zeros_like(store.params)
         self._step = 0
+        self._steps_taken = 0
+
+    def _extra_state(self):
+        return {'step': torch.tensor(float(self._step))}
+
+    def _steps_of(self, entry):
+        st = entry.get('step', 0)
+        return int(st.item() if torch.is_tensor(st) else st)
+
+    def _after_load(self, steps):
+        self._step = steps
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         self._step += 1
+        self._steps_taken = self._step
         for group, runs in zip(self.param_groups, self._runs):
             b1, b2 = group['betas']
             for store, off, n in runs:
@@ -134,3 +226,18 @@ def sgd(args):
                         weight_decay=args.weight_decay, nesterov=args.nesterov)
 
     return sgd_wrapper
+
+
+def adam(args):
+    """`adam(args)` factory (pixelssl/nn/optimizer.py:103-122) on the fused kernel."""
+    args.lr = 0.001 if args.lr == -1 else args.lr
+    args.beta1 = 0.9 if args.beta1 == -1 else args.beta1
+    args.beta2 = 0.999 if args.beta2 == -1 else args.beta2
+    args.eps = 1e-08 if args.eps == -1 else args.eps
+    args.weight_decay = 0.0 if args.weight_decay == -1 else args.weight_decay
+
+    def adam_wrapper(param_groups):
+        return FusedAdam(param_groups, lr=args.lr, betas=(args.beta1, args.beta2), eps=args.eps,
+                         weight_decay=args.weight_decay)
+
+    return adam_wrapper

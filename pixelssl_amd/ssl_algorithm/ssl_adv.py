@@ -47,21 +47,15 @@ class FCDiscriminator(nn.Module):
     def __init__(self, in_channels, engine_dtype=torch.float32):
         super().__init__()
         core = FCDiscriminatorCore(in_channels, device=pdist.local_device(), engine_dtype=engine_dtype)
-        self.core = core
-        for name in ("conv1", "conv2", "conv3", "conv4", "classifier"):     # reference attribute names
+        # the executor front-end stays outside the module registry; its leaves carry the reference's attribute names, so
+        # the state_dict of this module and of every wrapper around it (`module.conv1.weight`) is the reference's
+        object.__setattr__(self, 'core', core)
+        for name in ("conv1", "conv2", "conv3", "conv4", "classifier"):
             self.add_module(name, getattr(core, name))
 
-    def state_dict(self, *a, **k):
-        return self.core.state_dict(*a, **k)
-
-    def load_state_dict(self, sd, strict=True):
-        return self.core.load_state_dict(sd, strict=strict)
-
-    def parameters(self, recurse=True):
-        return self.core.parameters(recurse)
-
-    def named_parameters(self, *a, **k):
-        return self.core.named_parameters(*a, **k)
+    def train(self, mode=True):
+        self.core.train(mode)
+        return super().train(mode)
 
     def forward(self, task_pred):
         conf, _, _ = self.core(task_pred)
@@ -312,4 +306,8 @@ class SSLADV(ssl_base._SSLBase):
                            .format(self.NAME, found))
         self.model.load_state_dict(checkpoint['model'])
         self.d_model.load_state_dict(checkpoint['d_model'])
+        self.optimizer.load_state_dict(checkpoint['optimizer'])      # ssl_adv.py:380-385
+        self.d_optimizer.load_state_dict(checkpoint['d_optimizer'])
+        self.lrer.load_state_dict(checkpoint['lrer'])
+        self.d_lrer.load_state_dict(checkpoint['d_lrer'])
         return checkpoint['epoch']

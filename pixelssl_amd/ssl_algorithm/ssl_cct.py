@@ -571,6 +571,8 @@ class SSLCCT(ssl_base._SSLBase):
             logger.log_err('Unmatched SSL algorithm format in checkpoint => required: {0} - given: {1}\n'
                            .format(self.NAME, found))
         self.model.load_state_dict(checkpoint['model'])
+        self.optimizer.load_state_dict(checkpoint['optimizer'])      # ssl_cct.py:374-376
+        self.lrer.load_state_dict(checkpoint['lrer'])
         self.main_model = self.model.module.main_model
         self.auxiliary_decoders = self.model.module.auxiliary_decoders
         return checkpoint['epoch']

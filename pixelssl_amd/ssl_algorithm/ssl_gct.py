@@ -229,19 +229,17 @@ class FlawDetector(nn.Module):
         super().__init__()
         from ..engine import FlawDetectorCore
         from .. import dist as pdist
-        self.core = FlawDetectorCore(in_channels, device=pdist.local_device(), engine_dtype=engine_dtype)
+        core = FlawDetectorCore(in_channels, device=pdist.local_device(), engine_dtype=engine_dtype)
+        # the executor front-end stays outside the module registry: its leaves (conv1, ibn1.bnorm, ..., classifier) are
+        # registered under the reference's attribute names, so state_dict / load_state_dict / parameters() of this module
+        # and of every wrapper around it (`module.conv1.weight`, ssl_gct.py:367-369) are the reference's
+        object.__setattr__(self, 'core', core)
+        for name, child in core.named_children():
+            self.add_module(name, child)
 
-    def state_dict(self, *a, **k):
-        return self.core.state_dict(*a, **k)
-
-    def load_state_dict(self, sd, strict=True):
-        return self.core.load_state_dict(sd, strict=strict)
-
-    def parameters(self, recurse=True):
-        return self.core.parameters(recurse)
-
-    def named_parameters(self, *a, **k):
-        return self.core.named_parameters(*a, **k)
+    def train(self, mode=True):
+        self.core.train(mode)
+        return super().train(mode)
 
     def forward(self, task_inp, task_pred):
         x = torch.cat(tuple(task_inp) + (task_pred,), dim=1)
@@ -503,12 +501,13 @@ def _define_sslgct():
             if found != self.NAME:
                 logger.log_err('Unmatched SSL algorithm format in checkpoint => required: {0} - given: {1}\n'
                                .format(self.NAME, found))
-            for k, v in self.models.items():
-                v.load_state_dict(checkpoint[k])
+            for k, v in list(self.models.items()) + list(self.optimizers.items()) + list(self.lrers.items()):
+                v.load_state_dict(checkpoint[k])                      # ssl_gct.py:389-397: models, optimizers, lrers
             return checkpoint['epoch']
 
     return _SSLGCT
 
 
 SSLGCT = _define_sslgct()
+SSLGCT.__name__ = SSLGCT.__qualname__ = 'SSLGCT'
 NAME = SSLGCT.NAME

@@ -200,6 +200,8 @@ class SSLMT(ssl_base._SSLBase):
                            .format(self.NAME, found))
         self.s_model.load_state_dict(checkpoint['s_model'])
         self.t_model.load_state_dict(checkpoint['t_model'])
+        self.s_optimizer.load_state_dict(checkpoint['s_optimizer'])  # ssl_mt.py:318-320
+        self.s_lrer.load_state_dict(checkpoint['s_lrer'])
         return checkpoint['epoch']
 
     def _update_ema_variables(self, s_model, t_model, ema_decay, cur_step):

@@ -109,4 +109,6 @@ class SSLNULL(ssl_base._SSLBase):
             logger.log_err('Unmatched SSL algorithm format in checkpoint => required: {0} - given: {1}\n'
                            .format(self.NAME, found))
         self.model.load_state_dict(checkpoint['model'])
+        self.optimizer.load_state_dict(checkpoint['optimizer'])      # momentum buffers + lr groups (ssl_null.py:214-216)
+        self.lrer.load_state_dict(checkpoint['lrer'])                # cur_iter of the polynomial schedule
         return checkpoint['epoch']
