@@ -447,6 +447,9 @@ int pxl_net_tune(pxl_net* net, const float* params, const void* packed, float* g
                  size_t arena_bytes, void* scratch, size_t scratch_bytes, void* stream);
 /* repack params -> packed (call after every parameter update) */
 int pxl_net_pack(pxl_net* net, const float* params, void* packed, void* stream);
+/* the same in two independent halves: which bit 0 = forward operand layout + biases (read by pxl_net_forward), bit 1 =
+ * transposed data-gradient layout (first read by pxl_net_backward: pack it on a side stream next to the forward) */
+int pxl_net_pack_parts(pxl_net* net, const float* params, void* packed, int which, void* stream);
 /* x NCHW fp32 [B,3,H,W] -> logits/prob NCHW fp32 [B,classes,H,W]; training selects batch statistics
  * (+ running-stat update) vs running statistics; the arena keeps what backward needs. */
 int pxl_net_forward(pxl_net* net, const float* params, const void* packed, float* running, const float* x,

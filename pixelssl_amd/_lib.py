@@ -165,6 +165,7 @@ SIGNATURES = {
     "pxl_net_set_sync": (_I, [_P, ALLREDUCE_FN, _P, _I]),
     "pxl_net_tune": (_I, [_P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
     "pxl_net_pack": (_I, [_P, _P, _P, _P]),
+    "pxl_net_pack_parts": (_I, [_P, _P, _P, _I, _P]),
     "pxl_net_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
     "pxl_net_latent": (_I, [_P, _P, _P, _P]),
     "pxl_net_latent_shape": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),

@@ -40,6 +40,7 @@ struct DmaArgs {
   int B, Hi, Wi, Cin;
   int Ho, Wo, Cout, Kreal;
   int ntaps, so;
+  int div_shift;     // data gradient of a stride-2 convolution: source pixel = (oy + dy, ox + dx) / 2 where both are even
   int M, Ktot, nk;
   int tiles_m, tiles_n;
   float* ws;         // split-K: pre-zeroed fp32 [M][Cout] accumulation buffer (blockIdx.y = K slice), else nullptr
@@ -83,11 +84,33 @@ __device__ __forceinline__ void wait_chunk(u32x4 (&fa)[TMI], u32x4 (&fw)[TNI], f
     asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fw[0]), "+a"(acc[0][0]), "+a"(acc[0][1]) : "n"(N));
   else if constexpr (TMI == 1 && TNI == 2)
     asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(fa[0]), "+v"(fw[0]), "+v"(fw[1]), "+a"(acc[0][0]), "+a"(acc[1][0]) : "n"(N));
-  else
+  else if constexpr (TMI == 2 && TNI == 2)
     asm volatile("s_waitcnt lgkmcnt(%8)"
                  : "+v"(fa[0]), "+v"(fa[1]), "+v"(fw[0]), "+v"(fw[1]), "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]),
                    "+a"(acc[1][1])
                  : "n"(N));
+  // tall tiles (one wave column: WM = 1, WN = 4): TNI = 1, TMI = 3 .. 6 pixel tiles per wave
+  else if constexpr (TMI == 3 && TNI == 1)
+    asm volatile("s_waitcnt lgkmcnt(%7)"
+                 : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fw[0]), "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2])
+                 : "n"(N));
+  else if constexpr (TMI == 4 && TNI == 1)
+    asm volatile("s_waitcnt lgkmcnt(%9)"
+                 : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fw[0]), "+a"(acc[0][0]), "+a"(acc[0][1]),
+                   "+a"(acc[0][2]), "+a"(acc[0][3])
+                 : "n"(N));
+  else if constexpr (TMI == 5 && TNI == 1)
+    asm volatile("s_waitcnt lgkmcnt(%11)"
+                 : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fw[0]), "+a"(acc[0][0]),
+                   "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[0][4])
+                 : "n"(N));
+  else {
+    static_assert(TMI == 6 && TNI == 1, "wait_chunk: unsupported wave tile");
+    asm volatile("s_waitcnt lgkmcnt(%13)"
+                 : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fw[0]), "+a"(acc[0][0]),
+                   "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[0][4]), "+a"(acc[0][5])
+                 : "n"(N));
+  }
 }
 template <int I, int N, int STRIDE, int BASE> struct FragLoad {
   static __device__ __forceinline__ void run(u32x4 (&f)[N], unsigned addr) {
@@ -109,7 +132,8 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   constexpr int TPR = BN / 8;                // threads per output row on the read-back pass
   constexpr int RPP = 256 / TPR;             // rows per pass
   constexpr int NPASS = BM / RPP;
-  static_assert(WM * WN == 4 && TMI >= 1 && TNI >= 1 && TMI <= 2 && TNI <= 2, "tile");
+  static_assert(WM * WN == 4 && TMI >= 1 && TNI >= 1 && ((TMI <= 2 && TNI <= 2) || (TNI == 1 && TMI <= 6)), "tile");
+  static_assert(BM % RPP == 0, "epilogue rows per pass must divide the tile");
   static_assert(NST * SB >= BM * TP + 4 * BN * 8, "epilogue staging must fit in the ring");
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -130,7 +154,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   // ---- loader coordinates: DMA instruction g = wave + 4*q covers tile rows 8g .. 8g+7, lane -> (row, 16-byte slot)
   const int lrow = lane >> 3, lslot = lane & 7;
   unsigned voffA[LA], voffB[LB];
-  int a_pix[LA], a_iy[LA], a_ix[LA];
+  int a_pix[LA], a_iy[LA], a_ix[LA], a_img[LA];
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int q = 0; q < LA; ++q) {
@@ -144,12 +168,14 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
       const int ox = r - oy * p.Wo;
       a_iy[q] = oy * p.so;
       a_ix[q] = ox * p.so;
-      a_pix[q] = ((b * p.Hi + a_iy[q]) * p.Wi + a_ix[q]) * p.Cin * 2 + chunk * 16;
+      a_img[q] = b * p.Hi * p.Wi * p.Cin * 2 + chunk * 16;
+      a_pix[q] = a_img[q] + (a_iy[q] * p.Wi + a_ix[q]) * p.Cin * 2;
       voffA[q] = (unsigned)a_pix[q];
     } else {
       a_iy[q] = -(1 << 20);
       a_ix[q] = 0;
       a_pix[q] = 0;
+      a_img[q] = 0;
       voffA[q] = OOB;
     }
   }
@@ -172,11 +198,23 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
       const int tp = p.taps[min(t, p.ntaps - 1)];
       const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
       const int tapoff = (dy * p.Wi + dx) * p.Cin * 2;
+      if (p.div_shift == 0) {
 #pragma unroll
-      for (int q = 0; q < LA; ++q) {
-        const int iy = a_iy[q] + dy, ix = a_ix[q] + dx;
-        const bool ok = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
-        voffA[q] = ok ? (unsigned)(a_pix[q] + tapoff) : OOB;
+        for (int q = 0; q < LA; ++q) {
+          const int iy = a_iy[q] + dy, ix = a_ix[q] + dx;
+          const bool ok = ((unsigned)iy < (unsigned)p.Hi) && ((unsigned)ix < (unsigned)p.Wi);
+          voffA[q] = ok ? (unsigned)(a_pix[q] + tapoff) : OOB;
+        }
+      } else {
+        // stride-2 data gradient: only the (pixel, tap) pairs whose source coordinate is even exist; the others are
+        // out-of-range lanes (zero fill) like padding -- 3/4 of a 3x3 tap set, but the tile still streams by DMA
+#pragma unroll
+        for (int q = 0; q < LA; ++q) {
+          const int ny = a_iy[q] + dy, nx = a_ix[q] + dx;
+          const int iy = ny >> 1, ix = nx >> 1;
+          const bool ok = ((ny | nx) & 1) == 0 && ny >= 0 && nx >= 0 && iy < p.Hi && ix < p.Wi;
+          voffA[q] = ok ? (unsigned)(a_img[q] + (iy * p.Wi + ix) * p.Cin * 2) : OOB;
+        }
       }
     }
   };
@@ -248,9 +286,11 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      if (kk == 0) wait_chunk<3 * (TMI + TNI)>(fa[0], fw[0], acc);
-      if (kk == 1) wait_chunk<2 * (TMI + TNI)>(fa[1], fw[1], acc);
-      if (kk == 2) wait_chunk<1 * (TMI + TNI)>(fa[2], fw[2], acc);
+      // (lgkmcnt is a 4-bit counter on gfx950: a wait for "more than 15 outstanding" is a wait for 15)
+      constexpr int PER = TMI + TNI;
+      if (kk == 0) wait_chunk<(3 * PER > 15 ? 15 : 3 * PER)>(fa[0], fw[0], acc);
+      if (kk == 1) wait_chunk<(2 * PER > 15 ? 15 : 2 * PER)>(fa[1], fw[1], acc);
+      if (kk == 2) wait_chunk<(1 * PER > 15 ? 15 : 1 * PER)>(fa[2], fw[2], acc);
       if (kk == 3) wait_chunk<0>(fa[3], fw[3], acc);
       if constexpr (!(ABL & 2)) {
 #pragma unroll
@@ -464,13 +504,18 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
 extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_scale, const void* workspace) {
   (void)workspace;
   if (d->dtype != PXL_BF16 || in_scale != nullptr) return 0;
-  if (d->Cin % 64 != 0 || d->Cout % 8 != 0 || d->div != 1) return 0;
+  if (d->Cin % 64 != 0 || d->Cout % 8 != 0 || (d->div != 1 && d->div != 2)) return 0;
+  if (d->div == 2 && d->out_stride != 1) return 0;
   if ((long)d->Kreal * d->ntaps * d->Cin * 2 >= (1L << 31)) return 0;
   return 1;
 }
 
 // tile configurations 8..: 8 = 128x128, 9 = 128(pixels)x64, 10 = 64x128, 11 = 64x64 with a 3-stage LDS ring;
-// 12..15 the same with 4 stages, 16..19 with 2 stages (more blocks per CU)
+// 12..15 the same with 4 stages, 16..19 with 2 stages (more blocks per CU);
+// 20..27: tall tiles 96 / 160 / 192 / 256 (pixels) x 128 with ONE wave column (WM = 1, WN = 4): M = 8 * 33 * 33 = 8712 is
+// 68.06 tiles of 128 and 136.1 tiles of 64 -- every ResNet-101 stage-3/4 launch ends with a nearly empty last wave of
+// workgroups (274 on 256 CUs).  96-row tiles give 91 x N/128 workgroups (182 for N = 256: one wave at 1.17x the tile
+// traffic instead of two), 160 / 192 rows fit N = 512 / 2048 the same way.  20..23 = 3 stages, 24..27 = 2 stages
 namespace { int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes, void* stream); }
 
 extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
@@ -509,6 +554,7 @@ int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes,
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.Kreal = d->Kreal;
   a.ntaps = d->ntaps; a.so = d->out_stride;
+  a.div_shift = d->div == 2 ? 1 : 0;
   a.M = d->B * d->Ho * d->Wo;
   a.Ktot = d->ntaps * d->Cin;
   a.nk = a.Ktot / 64;
@@ -522,6 +568,7 @@ int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes,
   bool gather = false;
   for (int t = 0; t < d->ntaps; ++t) gather |= d->dy[t] != 0 || d->dx[t] != 0;
   gather |= d->ntaps != 1;
+  gather |= d->div != 1;
   gather |= (d->Ho - 1) * d->out_stride >= d->Hi || (d->Wo - 1) * d->out_stride >= d->Wi;
   int cfg = d->tile_cfg;
   if (cfg < 8) {
@@ -543,6 +590,14 @@ int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes,
     case 17: return launch_dma<128, 64, 2, 2, 2>(a, gather, sk, ws_bytes, s);
     case 18: return launch_dma<64, 128, 2, 2, 2>(a, gather, sk, ws_bytes, s);
     case 19: return launch_dma<64, 64, 2, 2, 2>(a, gather, sk, ws_bytes, s);
+    case 20: return launch_dma<96, 128, 1, 4, 3>(a, gather, sk, ws_bytes, s);
+    case 21: return launch_dma<160, 128, 1, 4, 3>(a, gather, sk, ws_bytes, s);
+    case 22: return launch_dma<192, 128, 1, 4, 3>(a, gather, sk, ws_bytes, s);
+    case 23: return launch_dma<128, 128, 1, 4, 3>(a, gather, sk, ws_bytes, s);
+    case 24: return launch_dma<96, 128, 1, 4, 2>(a, gather, sk, ws_bytes, s);
+    case 25: return launch_dma<160, 128, 1, 4, 2>(a, gather, sk, ws_bytes, s);
+    case 26: return launch_dma<192, 128, 1, 4, 2>(a, gather, sk, ws_bytes, s);
+    case 27: return launch_dma<128, 128, 1, 4, 2>(a, gather, sk, ws_bytes, s);
     // timing ablations (garbage results): 64x128 3-stage gather kernel, 100 + ABL bits
     case 100: return launch_abl<64, 128, 3, 0>(a, s);
     case 101: return launch_abl<64, 128, 3, 1>(a, s);

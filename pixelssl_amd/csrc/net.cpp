@@ -37,7 +37,9 @@ namespace {
 
 constexpr size_t ALIGN = 256;
 // replicas of every BN statistics vector (atomic-contention spreading); PXL_STATS_REP overrides (tuning experiments)
-static const int STATS_REP = [] { const char* e = getenv("PXL_STATS_REP"); const int v = e ? atoi(e) : 32; return v >= 1 && v <= 64 ? v : 32; }();
+// (4 since round 2: with the finalize folded into the kernel that applies the BN, every block of that kernel reduces the
+// replicas itself -- 32 made that slower than a separate finalize launch, 4 makes it faster: MT 15.17 -> 14.98 ms / step)
+static const int STATS_REP = [] { const char* e = getenv("PXL_STATS_REP"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
 inline size_t align_up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
 inline int pitch_of(int c) { return c <= 8 ? 8 : (c + 31) / 32 * 32; }
 
@@ -123,9 +125,10 @@ struct pxl_net {
   int input_tensor = -1;
   bool latent_seeded = false;      // pxl_net_seed_latent_grad ran: the next backward starts from that gradient
   bool fuse_bn_reduce = getenv("PXL_FUSE_BN_REDUCE") == nullptr || getenv("PXL_FUSE_BN_REDUCE")[0] != '0';
-  // folding the forward finalize into its consumer removes 104 launches per pass but makes every block of the consumer
-  // re-reduce the statistics replicas: measured SLOWER on MI355X (MT 15.7 vs 15.0 ms / step), so it is opt-in
-  bool fuse_bn_finalize = getenv("PXL_FUSE_BN_FINALIZE") != nullptr && getenv("PXL_FUSE_BN_FINALIZE")[0] == '1';
+  // folding the forward finalize into its consumer removes 104 launches per pass; every block of the consumer re-reduces
+  // the statistics replicas, which was slower with 32 replicas (round 1: 15.7 vs 15.0 ms / step) and is faster with 4
+  // (round 2: 14.98 vs 15.17): on by default, PXL_FUSE_BN_FINALIZE=0 restores the separate pxl_bn_finalize launches
+  bool fuse_bn_finalize = getenv("PXL_FUSE_BN_FINALIZE") == nullptr || getenv("PXL_FUSE_BN_FINALIZE")[0] != '0';
   // tests: use the reference's multi-device variance formula clamp(var, eps) on a single rank too
   bool force_clamp = getenv("PXL_FORCE_CLAMP_VAR") != nullptr;
 };
@@ -514,7 +517,7 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
     for (size_t i = 0; i < n->ops.size(); ++i) {
       OpInfo& op = n->ops[i];
       const pxl_op& d = op.d;
-      if (d.kind != PXL_OP_CONV || d.bn_in0 < 0 || !d.need_dgrad || d.stride != 1) continue;
+      if (d.kind != PXL_OP_CONV || d.bn_in0 < 0 || !d.need_dgrad) continue;     // (stride-2 data gradients run on the DMA kernel too)
       BnInfo& b = n->bns[d.bn_in0];
       const TensorInfo& tin = n->tensors[d.in0];
       if (b.y_tensor != d.in0 || uses[d.in0] != 1 || tin.Cp != tin.C || tin.C != b.d.C) continue;
@@ -533,8 +536,11 @@ extern "C" size_t pxl_net_packed_bytes(const pxl_net* n) { return n && n->planne
 extern "C" size_t pxl_net_arena_bytes(const pxl_net* n) { return n && n->planned ? n->arena_bytes : 0; }
 extern "C" size_t pxl_net_scratch_bytes(const pxl_net* n) { return n && n->planned ? n->scratch_bytes : 0; }
 
-extern "C" int pxl_net_pack(pxl_net* n, const float* params, void* packed, void* stream) {
-  PXL_REQUIRE(n && n->planned && params && packed, "net_pack: bad argument (plan first)");
+// which: bit 0 = forward operand layout (+ summed biases), bit 1 = transposed data-gradient layout.  The two halves are
+// independent: the host packs the forward half on the stream of the forward pass and the data-gradient half, which is
+// first read by the backward pass, on a side stream that overlaps the forward.
+extern "C" int pxl_net_pack_parts(pxl_net* n, const float* params, void* packed, int which, void* stream) {
+  PXL_REQUIRE(n && n->planned && params && packed && (which & 3) != 0, "net_pack: bad argument (plan first)");
   std::vector<pxl_pack_item> items;
   for (auto& op : n->ops) {
     const pxl_op& d = op.d;
@@ -542,16 +548,18 @@ extern "C" int pxl_net_pack(pxl_net* n, const float* params, void* packed, void*
     const TensorInfo& tin = n->tensors[d.in0];
     const TensorInfo& tout = n->tensors[d.out];
     const int tpg = d.kh * d.kw;
+    const bool want_t = (which & 2) && d.need_dgrad && n->pack_dgrad;
     for (int g = 0; g < d.ngroups; ++g) {
+      if (!(which & 1) && !want_t) continue;
       pxl_pack_item it;
       it.src_off = d.w_off[g];
-      it.wf_off = (int64_t)op.wf_off;
-      it.wt_off = (d.need_dgrad && n->pack_dgrad) ? (int64_t)op.wt_off : -1;
+      it.wf_off = (which & 1) ? (int64_t)op.wf_off : -1;
+      it.wt_off = want_t ? (int64_t)op.wt_off : -1;
       it.K = d.cout; it.T = tpg; it.C = d.cin;
       it.Cp = tin.Cp; it.T_total = op.ntaps; it.t_off = g * tpg; it.Kp = tout.Cp;
       items.push_back(it);
     }
-    if (d.b_off[0] >= 0) {
+    if ((which & 1) && d.b_off[0] >= 0) {
       const float* b[4] = {nullptr, nullptr, nullptr, nullptr};
       for (int g = 0; g < d.ngroups; ++g) b[g] = d.b_off[g] >= 0 ? params + d.b_off[g] : nullptr;
       int rc = pxl_vec_sum4(d.cout, fat(packed, op.bias_off), b[0], b[1], b[2], b[3], stream);
@@ -559,6 +567,10 @@ extern "C" int pxl_net_pack(pxl_net* n, const float* params, void* packed, void*
     }
   }
   return pxl_pack_weights_batched(n->dtype, params, packed, items.data(), (int)items.size(), stream);
+}
+
+extern "C" int pxl_net_pack(pxl_net* n, const float* params, void* packed, void* stream) {
+  return pxl_net_pack_parts(n, params, packed, 3, stream);
 }
 
 namespace {
@@ -607,9 +619,10 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
     {
       int best_cfg = -1; float best = 1e30f;
       const bool dma = pxl_conv_dma_eligible(&op.fwd, sc, nullptr) != 0;
-      for (int cfg = dma ? 8 : 0; cfg < (dma ? 20 : 8); ++cfg) {
+      for (int cfg = dma ? 8 : 0; cfg < (dma ? 28 : 8); ++cfg) {
         if (!dma && (cfg & 3) == 3 && tout.Cp > 64) continue;
         if (dma && cfg >= 12 && cfg < 16) continue;          // 4-stage rings never won on the ResNet shapes
+        if (dma && cfg >= 20 && tout.Cp < 128) continue;     // tall tiles are 128 channels wide
         pxl_conv_desc q = op.fwd; q.tile_cfg = cfg;
         float t = time_launch([&]() { return pxl_conv_igemm(&q, cin.ptr, at(packed, op.wf_off), at(arena, tout.off),
                                                             sc, sh, bias, nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr,
@@ -623,9 +636,10 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
     if (d.need_dgrad && n->pack_dgrad) {
       int best_cfg = -1; float best = 1e30f;
       const bool dma = pxl_conv_dma_eligible(&op.bwd, nullptr, nullptr) != 0;
-      for (int cfg = dma ? 8 : 0; cfg < (dma ? 20 : 8); ++cfg) {
+      for (int cfg = dma ? 8 : 0; cfg < (dma ? 28 : 8); ++cfg) {
         if (!dma && (cfg & 3) == 3 && tin.Cp > 64) continue;
         if (dma && cfg >= 12 && cfg < 16) continue;
+        if (dma && cfg >= 20 && tin.Cp < 128) continue;
         pxl_conv_desc q = op.bwd; q.tile_cfg = cfg;
         float t = time_launch([&]() { return pxl_conv_igemm(&q, at(scratch, tout.goff), at(packed, op.wt_off), at(scratch, tin.goff),
                                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream); },
@@ -934,7 +948,14 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
     const char* e = getenv("PXL_SIDE_STREAM");
     n->use_side = (e && e[0] == '0') ? 0 : 1;
     if (n->use_side) {
-      PXL_CHECK_HIP(hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
+      // the weight-gradient stream is off the critical path (its results are needed at the optimizer step): lowest
+      // priority, so that the data-gradient chain on the caller's stream wins the CUs it can use.  PXL_SIDE_PRIO=0: default
+      int lo = 0, hi = 0;
+      const char* pe = getenv("PXL_SIDE_PRIO");
+      if ((pe == nullptr || pe[0] != '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+        PXL_CHECK_HIP(hipStreamCreateWithPriority(&n->side, hipStreamNonBlocking, lo));
+      else
+        PXL_CHECK_HIP(hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
       PXL_CHECK_HIP(hipEventCreateWithFlags(&n->join_ev, hipEventDisableTiming));
       n->fork_ev.assign(n->ops.size(), nullptr);
     }

@@ -183,14 +183,17 @@ extern "C" int pxl_pack_weights_batched(int dtype, const float* params, void* pa
   for (int base = 0; base < n; base += 64) {
     const int cnt = n - base < 64 ? n - base : 64;
     PackBatch f, t;
-    f.n = cnt; t.n = 0;
+    f.n = 0; t.n = 0;
     int fb = 0, tb = 0;
     for (int i = 0; i < cnt; ++i) {
       const pxl_pack_item& it = items[base + i];
       PXL_REQUIRE(it.Cp >= it.C && it.t_off + it.T <= it.T_total, "pack_weights_batched: bad padding in item %d", base + i);
-      f.it[i] = it;
-      f.start[i] = fb;
-      fb += (int)(((long)it.K * it.T * it.Cp + 2047) / 2048);
+      if (it.wf_off >= 0) {              // (wf_off < 0: only the transposed copy of this tensor is wanted)
+        f.it[f.n] = it;
+        f.start[f.n] = fb;
+        fb += (int)(((long)it.K * it.T * it.Cp + 2047) / 2048);
+        ++f.n;
+      }
       if (it.wt_off >= 0) {
         PXL_REQUIRE(it.Kp >= it.K, "pack_weights_batched: bad Kp in item %d", base + i);
         t.it[t.n] = it;
@@ -199,7 +202,7 @@ extern "C" int pxl_pack_weights_batched(int dtype, const float* params, void* pa
         ++t.n;
       }
     }
-    f.start[cnt] = fb;
+    f.start[f.n] = fb;
     t.start[t.n] = tb;
     if (fb > 0) {
       if (dtype == PXL_F32) hipLaunchKernelGGL(pack_fwd_batched_kernel<float>, dim3(fb), dim3(256), 0, s, params, pk, f);

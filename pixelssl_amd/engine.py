@@ -429,9 +429,25 @@ class SegNetCore(nn.Module):
             pl.pack_dgrad = trainable
             pl.packed_version = None
         if pl.packed_version != v:
-            check(lib().pxl_net_pack(pl.net, ptr(self._store.params), ptr(pl.packed), stream_ptr()))
+            # forward operands on this stream; the transposed data-gradient copies are first read by the backward pass, so
+            # they are packed on a low-priority side stream next to the forward (event: pl.wt_ready)
+            side = self._pack_stream() if (trainable and torch.is_grad_enabled()) else None
+            if side is None:
+                check(lib().pxl_net_pack(pl.net, ptr(self._store.params), ptr(pl.packed), stream_ptr()))
+                pl.wt_ready = None
+            else:
+                cur = torch.cuda.current_stream()
+                check(lib().pxl_net_pack_parts(pl.net, ptr(self._store.params), ptr(pl.packed), 1, stream_ptr()))
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    check(lib().pxl_net_pack_parts(pl.net, ptr(self._store.params), ptr(pl.packed), 2, stream_ptr()))
+                    pl.wt_ready = torch.cuda.Event()
+                    pl.wt_ready.record()
+                pl.wt_waiters = set()
             pl.packed_version = v
         if not pl.tuned and self.autotune and not pl.inference:
+            if pl.wt_ready is not None:
+                torch.cuda.current_stream().wait_event(pl.wt_ready)
             # per-shape tile selection, measured on this GPU (csrc/net.cpp: pxl_net_tune)
             arena = torch.zeros(pl.arena_bytes, device=self._device, dtype=torch.uint8)
             pl.scratch.zero_()
@@ -442,6 +458,12 @@ class SegNetCore(nn.Module):
             self._store.grads.copy_(keep)
             del arena
         pl.tuned = True
+
+    def _pack_stream(self):
+        if not hasattr(self, "_pk_stream"):
+            on = os.environ.get("PXL_PACK_STREAM", "1") != "0" and self._device.type == "cuda"
+            object.__setattr__(self, "_pk_stream", torch.cuda.Stream(device=self._device, priority=1) if on else None)
+        return self._pk_stream
 
     def set_sync(self, callback, world_size):
         """callback(buf_ptr:int, n:int, stream:int) -> int ; installs the SyncBN statistics hook."""
@@ -618,6 +640,7 @@ class _Plan:
         self.arena_bytes = 0
         self.tuned = False
         self.inference = False
+        self.wt_ready = None         # event: the data-gradient weight copies of `packed` are complete (side-stream pack)
 
     def __del__(self):
         try:
@@ -663,6 +686,8 @@ class _SegNetFn(torch.autograd.Function):
         core.ensure_grad_views()
         s = core._store
         pl = ctx.plan
+        if pl.wt_ready is not None:
+            torch.cuda.current_stream().wait_event(pl.wt_ready)
         if dlatent is not None:
             dlatent = dlatent.contiguous().float()
             check(lib().pxl_net_seed_latent_grad(pl.net, ptr(pl.scratch), pl.scratch.numel(), ptr(dlatent), stream_ptr()))

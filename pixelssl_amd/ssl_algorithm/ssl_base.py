@@ -56,6 +56,22 @@ class _SSLBase:
         raise NotImplementedError
 
     # shared helpers -------------------------------------------------------------------------
+    def _enqueue_worker(self):
+        """One helper thread that ENQUEUES an independent network pass on its own HIP stream while the caller's thread
+        enqueues the pass on the critical path.  An executor pass is one C call issuing ~220 launches (~1 ms of host
+        time); issued back to back from one thread, the second network's stream sits idle for that long at every step
+        (measured: a 1 - 3.7 ms hole at the head of each MT step).  ctypes drops the GIL for the call, the HIP runtime
+        is thread-safe, torch's current stream is thread-local.  PXL_ENQUEUE_THREAD=0 turns it off."""
+        import os
+        if not hasattr(self, '_enq_pool'):
+            on = os.environ.get('PXL_ENQUEUE_THREAD', '1') != '0'
+            if on:
+                from concurrent.futures import ThreadPoolExecutor
+                self._enq_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='pxl-enqueue')
+            else:
+                self._enq_pool = None
+        return self._enq_pool
+
     @staticmethod
     def _single_component(name, *dicts):
         if not all(len(d) == 1 for d in dicts):

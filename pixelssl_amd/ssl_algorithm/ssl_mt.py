@@ -69,7 +69,10 @@ class SSLMT(ssl_base._SSLBase):
         if not hasattr(self, '_t_stream'):
             import os
             on = os.environ.get('PXL_TEACHER_STREAM', '1') != '0' and torch.cuda.is_available()
-            self._t_stream = torch.cuda.Stream() if on else None
+            # lowest priority: the teacher's no-grad forward only has to be done by the time the consistency loss is
+            # formed; the student's forward is the critical path (PXL_SIDE_PRIO=0: default priority)
+            prio = 0 if os.environ.get('PXL_SIDE_PRIO', '1') == '0' else 1
+            self._t_stream = torch.cuda.Stream(priority=prio) if on else None
         return self._t_stream
 
     def train_step(self, inp, gt, cur_step, total_rampup_steps):
@@ -97,17 +100,29 @@ class SSLMT(ssl_base._SSLBase):
         # stream, and runs concurrently with the student forward (each network's kernels are ~1 workgroup per CU
         # and latency-bound, two in flight fill each other's bubbles).  PXL_TEACHER_STREAM=0 keeps one stream.
         side = self._teacher_stream()
+        fut = None
         if side is not None:
             main = torch.cuda.current_stream()
             side.wait_stream(main)          # inputs and the EMA-updated teacher weights are ready
-            with torch.cuda.stream(side):
-                t_resulter, t_pred, t_task_loss = teacher_pass()
+            dev = torch.cuda.current_device()
+
+            def on_side():
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(side):
+                    return teacher_pass()
+            pool = self._enqueue_worker()
+            if pool is not None:            # a helper thread enqueues the teacher while this one enqueues the student
+                fut = pool.submit(on_side)
+            else:
+                t_resulter, t_pred, t_task_loss = on_side()
         s_resulter, _ = self.s_model.forward(s_inp)
         self._need_pred(s_resulter, 'SSL_MT')
         s_pred = tool.dict_value(s_resulter, 'pred')
         s_task_loss = torch.mean(self.s_criterion.forward(func.split_tensor_tuple(s_pred, 0, lbs), l_gt,
                                                           func.split_tensor_tuple(s_inp, 0, lbs)))
         if side is not None:
+            if fut is not None:
+                t_resulter, t_pred, t_task_loss = fut.result()
             main.wait_stream(side)
             outs = [t_task_loss]
             for v in t_resulter.values():

@@ -46,6 +46,10 @@ def test_resume_continues_the_uninterrupted_run(tmp_path):
                   resume=os.path.join(str(tmp_path), "checkpoint_0.ckpt"))
     b = _mt(args2)
     assert b.load_checkpoint() == 0
+    # bit-exact restore: re-saving the loaded state gives the same optimizer tensors
+    re = b.s_optimizer.state_dict()["state"]
+    assert all(torch.equal(re[i]["momentum_buffer"].cpu(), ck["s_optimizer"]["state"][i]["momentum_buffer"].cpu()) for i in re)
+    assert all(torch.equal(v.cpu(), ck["s_model"][k].cpu()) for k, v in b.s_model.state_dict().items())
     b.s_model.train(), b.t_model.train()
     assert b.s_lrer.cur_iter == 4 and [g["lr"] for g in b.s_optimizer.param_groups] == [g["lr"] for g in ck["s_optimizer"]["param_groups"]]
     got, _, _ = b.train_step((batches[3][0].to(DEV),), (batches[3][1].to(DEV),), 3, fx["rampup_iters"])
@@ -53,8 +57,10 @@ def test_resume_continues_the_uninterrupted_run(tmp_path):
     for k in want:
         assert abs(got[k].item() - want[k].item()) <= 2e-6 * abs(want[k].item()) + 1e-9, (k, got[k].item(), want[k].item())
     pa, pb = a.s_model.module.model.flat, b.s_model.module.model.flat
-    assert (pa.params - pb.params).abs().max().item() <= 1e-6 * pa.params.abs().max().item()
-    assert (pa.momentum - pb.momentum).abs().max().item() <= 1e-5 * pa.momentum.abs().max().item()
+    # the fourth step is computed twice: fp32 atomics order and ReLU decisions at rounding level differ run to run, which
+    # moves the gradient by ~3e-4 (L2) -- the restored state itself is bit-exact (checked above)
+    assert (pa.params - pb.params).norm().item() <= 1e-6 * pa.params.norm().item()
+    assert (pa.momentum - pb.momentum).norm().item() <= 2e-3 * pa.momentum.norm().item()
     # a resumed run that dropped the optimizer state (the round-1 bug: models only) would restart momentum at zero and
     # the schedule at cur_iter 0 -- both visible here
     assert pb.momentum.abs().max().item() > 0 and b.s_lrer.cur_iter == 5

@@ -112,7 +112,7 @@ DMA_CASES = [
 
 
 @pytest.mark.parametrize("case", DMA_CASES, ids=[c[0] for c in DMA_CASES])
-@pytest.mark.parametrize("cfg", [-1, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [-1, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27])
 def test_conv_dma_forward_and_dgrad(case, cfg):
     """LDS-DMA kernel: forward (every tile configuration, 3- and 4-stage rings), bias + addend + BN statistics
     on the coalesced read-back pass, and the data gradient of stride-1 convolutions."""
@@ -153,14 +153,15 @@ def test_conv_dma_forward_and_dgrad(case, cfg):
     dy = qround(torch.randn(y0.shape, generator=g), dtype)
     y0.backward(dy)
     dx = torch.empty(B, H, W, cip, device=DEV, dtype=dtype)
+    # (stride-2 data gradients run on the DMA kernel too: odd source coordinates are zero-fill lanes)
     bdesc = ops.conv_desc(dtype, B, Ho, Wo, cop, H, W, cip, Cin, [(-a, -b) for a, b in taps], out_stride=1, div=s,
-                          tile_cfg=cfg if (s == 1 and cop % 64 == 0) else -1)
+                          tile_cfg=cfg if cop % 64 == 0 else -1)
     ops.conv_igemm(bdesc, to_nhwc(dy, cop, dtype), wt, dx)
     torch.cuda.synchronize()
     assert rel_err(from_nhwc(dx, Cin), x.grad) < TOL[dtype], "dgrad %s cfg %d" % (name, cfg)
 
 
-@pytest.mark.parametrize("cfg", [-1, 8, 10, 11, 18])
+@pytest.mark.parametrize("cfg", [-1, 8, 10, 11, 18, 20, 21, 26])
 @pytest.mark.parametrize("shape", [(2, 128, 64, 17, 19, 3, 1, 1), (3, 64, 256, 9, 13, 1, 1, 0), (2, 192, 128, 12, 12, 3, 2, 2)])
 def test_conv_dgrad_with_fused_bn_backward_reduce(shape, cfg):
     """pxl_conv_dgrad_bnreduce == pxl_conv_igemm (data gradient) followed by pxl_bn_bwd_reduce over the tensor just
