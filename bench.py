@@ -12,7 +12,9 @@ iteration (ssl_mt.py:131-220): student fwd + CE, teacher fwd (no-grad, train-mod
 consistency, backward, fused SGD step, EMA teacher update, poly-LR step; inputs are resident in HBM
 before the timed region.  `roofline` is measured live with HIP events bracketing every launch of
 the dominant contraction kernel on its launch stream; `cpu_baseline` times the CPU oracle
-(oracle/torch_oracle.py, a port pinned bit-exact to the reference) on a bounded sample.
+(oracle/torch_oracle.py, a port pinned bit-exact to the reference) on a bounded sample; `miou_vs_ref`
+scores the engine's and the oracle's predictions of the same weights with the reference's mIoU.
+Only those two legs touch oracle/ (the checker); the timed region and its inputs do not.
 """
 import argparse
 import json
@@ -38,7 +40,10 @@ def parse():
     p.add_argument("--ubs", type=int, default=4, help="unlabeled samples per GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-events", action="store_true")
-    p.add_argument("--cpu-sample-steps", type=int, default=2)
+    p.add_argument("--cpu-sample-steps", type=int, default=10, help="timed steps of the SupOnly B=2 CPU baseline (SURVEY.md 8d)")
+    p.add_argument("--cpu-warmup", type=int, default=3)
+    p.add_argument("--cpu-budget-s", type=float, default=45.0, help="the CPU legs stop adding timed steps past this budget")
+    p.add_argument("--no-miou", action="store_true")
     return p.parse_args()
 
 
@@ -70,29 +75,91 @@ def make_args(a, world):
     return ns
 
 
+def _cpu_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def _timed_cpu_steps(step, warmup, steps, budget_s):
+    """warm-up + up to `steps` timed calls; stops early (never below 2 timed steps) when the budget is used up"""
+    for _ in range(warmup):
+        step()
+    done, t0 = 0, time.time()
+    while done < steps:
+        step()
+        done += 1
+        if done >= 2 and time.time() - t0 > budget_s:
+            break
+    return done, time.time() - t0
+
+
 def cpu_baseline(a):
-    """Reference CPU path (port): the oracle's MT step at the same image size on a bounded batch."""
+    """Reference CPU path (kind "port": the oracle, pinned bit-exact to the reference).  Two legs on this box's host cores:
+    `cpu_baseline` = the benchmarked workload (MT step, 2 + 2 images at 513 x 513) on a bounded sample, and
+    `config1` inside it = BASELINE.json configs[0] / SURVEY.md 8d: SupOnly, B = 2, 3 warm-up + 10 timed iterations."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch_oracle as TO
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     torch.set_num_threads(threads)
+    hp = dict(max_iters=20000, cons_rampup_iters=3000)
+    # ---- config 1: SupOnly, DeepLab-v2, B = 2
+    tr = TO.OracleTrainer(TO.init_deeplabv2_state(seed=0), hp)
+    x, gt = TO.synthetic_batch(2, a.size, 2, seed=5)
+    n1, dt1 = _timed_cpu_steps(lambda: tr.suponly_step(x, gt), a.cpu_warmup, a.cpu_sample_steps, a.cpu_budget_s)
+    config1 = {"value": round(2 * n1 / dt1, 4), "unit": "img/s", "workload": "SupOnly sseg, DeepLab-v2/ResNet-101, 2x%dx%d" % (a.size, a.size),
+               "sample": "%d warm-up + %d timed iterations" % (a.cpu_warmup, n1), "s_per_iter": round(dt1 / n1, 3)}
+    # ---- the benchmarked workload on a bounded batch
     lbs, ubs = (2, 2) if a.algo == "mt" else (2, 0)
-    tr = TO.OracleTrainer(TO.init_deeplabv2_state(seed=0), dict(max_iters=20000, cons_rampup_iters=3000),
-                          teacher_state=TO.init_deeplabv2_state(seed=1) if a.algo == "mt" else None)
-    x, gt = TO.synthetic_batch(lbs + ubs, a.size, lbs, seed=5)
-    step = (lambda: tr.mt_step(x, gt, lbs)) if a.algo == "mt" else (lambda: tr.suponly_step(x, gt))
-    step()                                    # warm-up (allocator, oneDNN primitives)
-    t0 = time.time()
-    for _ in range(a.cpu_sample_steps):
-        step()
-    dt = time.time() - t0
-    return {"value": round((lbs + ubs) * a.cpu_sample_steps / dt, 4), "unit": "img/s", "cores": threads,
-            "kind": "port",
-            "sample": "%d timed %s steps (after 1 warm-up) of the CPU oracle at %dx%d, batch %d+%d, fp32, "
-                      "torch %s, %d threads" % (a.cpu_sample_steps, "MT" if a.algo == "mt" else "SupOnly (DeepLab-v2)", a.size, a.size, lbs, ubs,
-                                                torch.__version__, threads)}
+    if a.algo == "mt":
+        tr = TO.OracleTrainer(TO.init_deeplabv2_state(seed=0), hp, teacher_state=TO.init_deeplabv2_state(seed=1))
+        x, gt = TO.synthetic_batch(lbs + ubs, a.size, lbs, seed=5)
+        n2, dt2 = _timed_cpu_steps(lambda: tr.mt_step(x, gt, lbs), 1, 3, a.cpu_budget_s / 2)
+    else:
+        n2, dt2 = n1, dt1
+    return {"value": round((lbs + ubs) * n2 / dt2, 4), "unit": "img/s", "cores": threads, "kind": "port",
+            "cpu": "%s, %d logical cores (%d torch threads)" % (_cpu_name(), cores, threads),
+            "sample": "%d timed %s steps (after %d warm-up) of the CPU oracle at %dx%d, batch %d+%d, fp32, torch %s"
+                      % (n2, "MT" if a.algo == "mt" else "SupOnly (DeepLab-v2)", 1 if a.algo == "mt" else a.cpu_warmup,
+                         a.size, a.size, lbs, ubs, torch.__version__),
+            "config1": config1}
+
+
+def miou_vs_oracle(core, a):
+    """BASELINE.json metric, second half ("mIoU vs ref"): the engine's eval-mode prediction (running BN statistics, the
+    benchmarked precision) and the CPU oracle's on the SAME weights and the same synthetic validation batch, scored with
+    the reference's confusion-matrix mIoU (task/sseg/func.py:36-80).  Random-init weights: the absolute value means
+    nothing, the DIFFERENCE is the parity figure."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_oracle as TO
+    import metrics_oracle as MO
+    from pixelssl_amd import functional as PF
+    from pixelssl_amd.utils.synthetic import synthetic_batch
+    x, gt = synthetic_batch(2, a.size, 2, seed=4242)
+    state = {k: v.detach().float().cpu().clone() for k, v in core.state_dict().items()}
+    was_training = core.training
+    core.eval()
+    with torch.no_grad():
+        logits, prob, _ = core(x.to(core.flat.params.device))
+        cm_e = PF.confusion_matrix(prob, gt.to(prob.device), 21).cpu().numpy()
+    core.train(was_training)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.no_grad():
+        o_logits, o_prob, _, _ = TO.deeplabv2_forward(state, x, train=False)
+    cm_o = MO.confusion_matrix(o_prob.numpy(), gt.numpy(), 21)
+    me, mo = MO.metrics(cm_e), MO.metrics(cm_o)
+    agree = float((logits.argmax(1).cpu() == o_logits.argmax(1)).float().mean())
+    return {"engine": round(me["mIoU"], 6), "oracle": round(mo["mIoU"], 6), "abs_diff": round(abs(me["mIoU"] - mo["mIoU"]), 6),
+            "argmax_agreement": round(agree, 5), "pixels": int(cm_o.sum()),
+            "note": "eval-mode forward of the trained student (%s engine) vs the fp32 CPU oracle on the same weights, 2x%dx%d "
+                    "synthetic validation batch" % (a.dtype, a.size, a.size)}
 
 
 def main():
@@ -102,7 +169,7 @@ def main():
     import pixelssl_amd as P
     from pixelssl_amd import dist as pdist
     from pixelssl_amd.nn import optimizer as popt, lrer as plr
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from pixelssl_amd.utils.synthetic import synthetic_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -142,11 +209,10 @@ def main():
         algo.model.train()
 
     # synthetic data, resident in HBM before timing; 4 distinct batches cycled
-    import torch_oracle as TO
     per_gpu = a.lbs + (a.ubs if a.algo != "suponly" else 0)
     batches = []
     for i in range(4):
-        x, gt = TO.synthetic_batch(per_gpu, a.size, a.lbs, seed=1234 + rank * 1000 + i)
+        x, gt = synthetic_batch(per_gpu, a.size, a.lbs, seed=1234 + rank * 1000 + i)
         batches.append(((x.to(dev),), (gt.to(dev),)))
 
     def one_step(it):
@@ -222,24 +288,30 @@ def main():
                                                       a.size, a.size, a.lbs, per_gpu - a.lbs),
                           "algorithm": "ssl_" + {"mt": "mt", "adv": "adv", "gct": "gct", "cct": "cct", "suponly": "null"}[a.algo], "global_batch": gb,
                           "im_size": a.size, "parallelism": "dp%d" % world, "sync_bn": world > 1},
-               "final_losses": loss_vals}
+               "final_losses": loss_vals,
+               # multi-rank: ranks on the C-driven RCCL communicators (0 = torch.distributed carries the exchanges) and the
+               # gradient buckets all-reduced from inside the last backward pass (overlapped with it)
+               "rccl_ranks": pdist.rccl_ranks(), "grad_buckets": int(cores[0].grad_buckets())}
         if elapsed_ev is not None:
             out["ms_per_step_with_kernel_events"] = round(1e3 * elapsed_ev / a.steps, 3)
         if kern:
             dom = max(kern, key=lambda k: kern[k]["total_ms"])
             peak = MFMA_PEAK_TFLOPS[a.dtype]
-            # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in
-            # separate rocprofv3 runs of this same command, tools/pmc_traffic.py -> profiles/traffic.json)
-            traffic = None
+            # HBM bytes per launch of the dominant kernel: NOT measured by this run (PMC counters need their own rocprofv3
+            # passes) -- read from profiles/traffic.json, which tools/pmc_traffic.py wrote from two `rocprofv3 --pmc` runs
+            # of this same command (FETCH_SIZE doubled per the gfx950 note of the guide); traffic_source says which
+            traffic, traffic_source = None, None
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
                 key = "conv_dma_kernel" if dom.startswith("conv_dma") else "conv_wgrad_dma_kernel"
-                traffic = tj["kernels"][key]["traffic_bytes_per_launch"] if a.algo == "mt" and a.dtype == "bf16" else None
+                if a.algo == "mt" and a.dtype == "bf16":
+                    traffic = tj["kernels"][key]["traffic_bytes_per_launch"]
+                    traffic_source = "profiles/traffic.json (%s)" % tj.get("measured", "separate rocprofv3 --pmc passes")
             except Exception:
                 traffic = None
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["achieved_tflops"],
                                "peak": peak, "unit": "TFLOP/s", "frac": round(kern[dom]["achieved_tflops"] / peak, 4),
-                               "traffic": traffic, "avg_launch_us": kern[dom]["avg_us"],
+                               "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": kern[dom]["avg_us"],
                                "algorithmic_gflop_per_launch": kern[dom]["algorithmic_gflop_per_launch"],
                                "algorithmic_bytes_per_launch": int(kern[dom]["algorithmic_mbytes_per_launch"] * 1e6),
                                "measured": "second pass of the same K steps with per-launch HIP events (outside the timed region)",
@@ -251,6 +323,8 @@ def main():
             # CCT: 3 x F_P (150.74 GFLOP) per image through the PSPNet, decoders ~0.05 GFLOP each
             flop_img = {"mt": 449.9e9, "adv": 435.0e9, "gct": 1291.2e9, "suponly": 337.1e9, "cct": 452.6e9}[a.algo]
             out["step_mfma_frac"] = round(out["value"] * flop_img / world / (peak * 1e12), 4) if a.size == 513 else None
+        if world == 1 and not a.no_miou and a.algo in ("mt", "suponly") and a.size == 513:
+            out["miou_vs_ref"] = miou_vs_oracle(cores[0], a)
         if world == 1 and not a.no_cpu_baseline:
             del algo
             torch.cuda.empty_cache()

@@ -441,6 +441,14 @@ size_t pxl_net_packed_bytes(const pxl_net* net);     /* persistent packed-weight
 size_t pxl_net_arena_bytes(const pxl_net* net);      /* activations saved between fwd and bwd      */
 size_t pxl_net_scratch_bytes(const pxl_net* net);    /* backward gradient buffers                  */
 int pxl_net_set_sync(pxl_net* net, pxl_allreduce_fn fn, void* user, int world_size);
+/* Gradient exchange overlapped with the backward pass (replaces nn.DataParallel's reduction, pixelssl/nn/func.py:54-62):
+ * pxl_net_backward all-reduces (fn: in-place sum on the given stream; then x 1/world_size) the flat gradient buffer
+ * `grads[0, total_floats)` in contiguous buckets of >= bucket_floats floats, each as soon as every kernel writing into it
+ * has been issued, on its own communication stream; the caller's stream waits for the last bucket before the call's
+ * work is considered done.  bucket_floats = 0: one exchange at the end.  fn = NULL: off.  Use a communicator of its own
+ * for fn (RCCL runs the collectives of one communicator in issue order, a bucket must not queue behind Sync-BN). */
+int pxl_net_set_grad_sync(pxl_net* net, pxl_allreduce_fn fn, void* user, int world_size, long bucket_floats, long total_floats);
+int pxl_net_grad_buckets(const pxl_net* net);        /* buckets issued by the last pxl_net_backward */
 /* autotune: time every tile configuration of every contraction on the planned shapes and keep the
  * fastest (call once after plan + pack; clobbers arena / scratch / grads contents; synchronises) */
 int pxl_net_tune(pxl_net* net, const float* params, const void* packed, float* grads, void* arena,

@@ -163,6 +163,8 @@ SIGNATURES = {
     "pxl_net_arena_bytes": (_Z, [_P]),
     "pxl_net_scratch_bytes": (_Z, [_P]),
     "pxl_net_set_sync": (_I, [_P, ALLREDUCE_FN, _P, _I]),
+    "pxl_net_set_grad_sync": (_I, [_P, ALLREDUCE_FN, _P, _I, _L, _L]),
+    "pxl_net_grad_buckets": (_I, [_P]),
     "pxl_net_tune": (_I, [_P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
     "pxl_net_pack": (_I, [_P, _P, _P, _P]),
     "pxl_net_pack_parts": (_I, [_P, _P, _P, _I, _P]),

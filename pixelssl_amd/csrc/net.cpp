@@ -120,6 +120,18 @@ struct pxl_net {
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
   int use_side = -1;
+  // gradient exchange overlapped with the backward pass: contiguous buckets of the flat gradient buffer are all-reduced
+  // on a communication stream as soon as every kernel that writes into them has been issued (north_star: "RCCL all-reduce
+  // of gradients over xGMI overlapped with backward"; replaces nn.DataParallel's reduction, pixelssl/nn/func.py:54-62)
+  pxl_allreduce_fn grad_sync = nullptr;
+  void* grad_user = nullptr;
+  long grad_bucket = 0;            // floats per bucket
+  long grad_total = 0;             // floats in the flat gradient buffer
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_main_ev = nullptr, comm_side_ev = nullptr, comm_done_ev = nullptr;
+  std::vector<long> op_lo;         // per op: lowest flat offset (floats) its backward writes a gradient to, or -1
+  bool bucket_ok = false;          // parameter offsets grow with the op index: suffixes of the op list = suffixes of the buffer
+  int grad_buckets_last = 0;       // buckets issued by the last backward (tests / bench)
   bool wgrad_on = true;
   bool pack_dgrad = true;          // false: pxl_net_pack skips the transposed (data-gradient) weights (no-grad networks)
   int input_tensor = -1;
@@ -271,6 +283,8 @@ extern "C" void pxl_net_destroy(pxl_net* net) {
   for (auto e : net->fork_ev) if (e) (void)hipEventDestroy(e);
   if (net->join_ev) (void)hipEventDestroy(net->join_ev);
   if (net->side) (void)hipStreamDestroy(net->side);
+  for (hipEvent_t e : {net->comm_main_ev, net->comm_side_ev, net->comm_done_ev}) if (e) (void)hipEventDestroy(e);
+  if (net->comm_stream) (void)hipStreamDestroy(net->comm_stream);
   delete net;
 }
 
@@ -281,6 +295,19 @@ extern "C" int pxl_net_set_sync(pxl_net* net, pxl_allreduce_fn fn, void* user, i
   net->world = world_size;
   return PXL_OK;
 }
+
+extern "C" int pxl_net_set_grad_sync(pxl_net* net, pxl_allreduce_fn fn, void* user, int world_size, long bucket_floats,
+                                     long total_floats) {
+  PXL_REQUIRE(net && world_size >= 1 && bucket_floats >= 0 && total_floats >= 0, "net_set_grad_sync: bad argument");
+  net->grad_sync = fn;
+  net->grad_user = user;
+  net->world = world_size;
+  net->grad_bucket = bucket_floats;
+  net->grad_total = total_floats;
+  return PXL_OK;
+}
+
+extern "C" int pxl_net_grad_buckets(const pxl_net* net) { return net ? net->grad_buckets_last : 0; }
 
 extern "C" int pxl_net_profile(pxl_net* net, int enable) {
   PXL_REQUIRE(net, "net_profile: null net");
@@ -523,6 +550,25 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
       if (b.y_tensor != d.in0 || uses[d.in0] != 1 || tin.Cp != tin.C || tin.C != b.d.C) continue;
       if (!pxl_conv_dma_eligible(&op.bwd, nullptr, nullptr)) continue;
       b.fused_reduce_op = (int)i;
+    }
+  }
+  // lowest gradient offset written by each op's backward, and whether those grow with the op index
+  n->op_lo.assign(n->ops.size(), -1);
+  n->bucket_ok = true;
+  {
+    long prev = -1;
+    for (size_t i = 0; i < n->ops.size(); ++i) {
+      const pxl_op& d = n->ops[i].d;
+      long lo = -1;
+      auto take = [&](long off) { if (off >= 0 && (lo < 0 || off < lo)) lo = off; };
+      if (d.kind == PXL_OP_CONV) {
+        for (int g = 0; g < d.ngroups; ++g) { take(d.w_off[g]); take(d.b_off[g]); }
+        if (d.bn_out >= 0) { take(n->bns[d.bn_out].d.gamma_off); take(n->bns[d.bn_out].d.beta_off); }
+      } else if (d.kind == PXL_OP_IBN && d.bn_out >= 0) {
+        take(n->bns[d.bn_out].d.gamma_off); take(n->bns[d.bn_out].d.beta_off);
+      }
+      n->op_lo[i] = lo;
+      if (lo >= 0) { if (lo <= prev) n->bucket_ok = false; prev = lo; }
     }
   }
   n->arena_bytes = arena;
@@ -961,6 +1007,37 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
     }
   }
   bool forked = false;
+  // ---- overlapped gradient exchange (multi-rank): flush [lo, hi) of the flat gradient buffer once every kernel writing
+  // into it has been issued -- the communication stream waits for the main and the weight-gradient stream at that point
+  const bool bucketing = n->grad_sync && n->world > 1 && n->wgrad_on && n->grad_total > 0;
+  long grad_hi = n->grad_total;
+  n->grad_buckets_last = 0;
+  if (bucketing && !n->comm_stream) {
+    PXL_CHECK_HIP(hipStreamCreateWithFlags(&n->comm_stream, hipStreamNonBlocking));
+    PXL_CHECK_HIP(hipEventCreateWithFlags(&n->comm_main_ev, hipEventDisableTiming));
+    PXL_CHECK_HIP(hipEventCreateWithFlags(&n->comm_side_ev, hipEventDisableTiming));
+    PXL_CHECK_HIP(hipEventCreateWithFlags(&n->comm_done_ev, hipEventDisableTiming));
+  }
+  auto flush = [&](long lo) -> int {
+    if (!bucketing || lo >= grad_hi) return PXL_OK;
+    PXL_CHECK_HIP(hipEventRecord(n->comm_main_ev, s));
+    PXL_CHECK_HIP(hipStreamWaitEvent(n->comm_stream, n->comm_main_ev, 0));
+    if (forked) {
+      PXL_CHECK_HIP(hipEventRecord(n->comm_side_ev, n->side));
+      PXL_CHECK_HIP(hipStreamWaitEvent(n->comm_stream, n->comm_side_ev, 0));
+    }
+    // (the hook takes an int count: buckets are far below 2^31 floats)
+    for (long o = lo; o < grad_hi; o += (1L << 30)) {
+      const long cnt = grad_hi - o < (1L << 30) ? grad_hi - o : (1L << 30);
+      const int rc = n->grad_sync(n->grad_user, grads + o, (int)cnt, n->comm_stream);
+      if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_backward: gradient all-reduce hook failed (%d)", rc);
+    }
+    const int rc2 = pxl_scale_inplace(grad_hi - lo, grads + lo, 1.0f / (float)n->world, n->comm_stream);
+    if (rc2 != PXL_OK) return rc2;
+    grad_hi = lo;
+    ++n->grad_buckets_last;
+    return PXL_OK;
+  };
 
   for (int i = (int)n->ops.size() - 1; i >= 0; --i) {
     OpInfo& op = n->ops[i];
@@ -1154,6 +1231,17 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         break;
     }
     if (rc != PXL_OK) return rc;
+    // everything that writes gradients at or above op_lo[i] has now been issued
+    if (bucketing && n->bucket_ok && n->grad_bucket > 0 && n->op_lo[i] >= 0 && grad_hi - n->op_lo[i] >= n->grad_bucket) {
+      rc = flush(n->op_lo[i]);
+      if (rc != PXL_OK) return rc;
+    }
+  }
+  if (bucketing) {                               // the rest of the buffer (or all of it when bucketing is off)
+    int rc = flush(0);
+    if (rc != PXL_OK) return rc;
+    PXL_CHECK_HIP(hipEventRecord(n->comm_done_ev, n->comm_stream));
+    PXL_CHECK_HIP(hipStreamWaitEvent(s, n->comm_done_ev, 0));
   }
   if (forked) {                                  // join: every weight gradient is complete before the caller goes on
     PXL_CHECK_HIP(hipEventRecord(n->join_ev, n->side));

@@ -100,7 +100,12 @@ def _sync_stats_callback(buf_ptr, n, stream):
     return 0
 
 
-_native = {"tried": False, "comms": [], "hook": None, "next": 0}
+_native = {"tried": False, "comms": [], "hook": None, "next": 0, "grad_comm": None}
+# floats per gradient bucket: 8 M floats = 32 MB (DeepLab-v2's 176 MB gradient = 6 buckets, issued in reverse layer order
+# while the backward pass is still running).  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of
+# 32 MB over 8 GPUs moves 2 * 7/8 * 32 MB per link, ~0.4 ms at link speed -- large enough to be bandwidth-bound, small
+# enough that the last bucket (the stem's) is the only one the optimizer step waits for.
+GRAD_BUCKET_FLOATS = int(float(os.environ.get("PXL_GRAD_BUCKET_MB", "32")) * (1 << 20) / 4)
 N_COMMS = max(1, int(os.environ.get("PXL_N_COMMS", "2")))
 #               # RCCL executes the collectives of ONE communicator in issue order even across streams: networks that run
 #                 concurrently on two streams (MT student / teacher, GCT l / r model) get different communicators
@@ -155,12 +160,34 @@ def native_comms():
             if c.value:
                 h.pxl_comm_destroy(c)
         return []
+    # one more communicator for the gradient buckets: RCCL runs the collectives of ONE communicator in issue order even
+    # across streams, and a bucket waiting for its weight gradients must not block the Sync-BN exchanges behind it
+    gc, g = _open_comm(h, dev)
+    ok = torch.tensor([1.0 if g else 0.0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    _native["grad_comm"] = gc if ok.item() >= 1 else None
     _native["comms"] = comms
     _native["hook"] = ctypes.cast(h.pxl_comm_allreduce_hook, _lib.ALLREDUCE_FN)
     return comms
 
 
+def rccl_ranks():
+    """Ranks of the C-driven RCCL communicators (0 = the exchanges go through torch.distributed)."""
+    return world_size() if _native["comms"] else 0
+
+
+def _grad_sync_callback(buf_ptr, n, stream):
+    """torch.distributed path of the bucketed gradient exchange (gloo in the CPU-launched tests): all-reduce(sum) of the
+    bucket on the executor's communication stream."""
+    t = torch.as_tensor(_DevView(buf_ptr, n), device=torch.device('cuda', torch.cuda.current_device()))
+    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream))):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return 0
+
+
 def _post_backward(core):
+    if getattr(core, "_grad_sync", None) is not None:
+        return                              # the executor exchanged the buckets from inside pxl_net_backward
     comm = getattr(core, "_pxl_comm", None)
     if comm is not None:
         from . import _lib
@@ -190,5 +217,19 @@ def attach(model):
             else:
                 m.set_sync(_sync_stats_callback, ws)
             m._post_backward_hook = _post_backward
+            if os.environ.get("PXL_GRAD_OVERLAP", "1") != "0":
+                if comms and _native["grad_comm"] is not None:
+                    m.set_grad_sync(_native["hook"], _native["grad_comm"], ws, GRAD_BUCKET_FLOATS)
+                elif not comms:
+                    def _cb(user, buf, n, stream):
+                        try:
+                            return int(_grad_sync_callback(buf, n, stream) or 0)
+                        except Exception:   # never unwind through C
+                            import traceback
+                            traceback.print_exc()
+                            return 1
+                    from . import _lib
+                    m._grad_cb = _lib.ALLREDUCE_FN(_cb)
+                    m.set_grad_sync(m._grad_cb, None, ws, GRAD_BUCKET_FLOATS)
             m._pxl_attached = True
     return model

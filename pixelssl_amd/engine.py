@@ -407,6 +407,9 @@ class SegNetCore(nn.Module):
             pl.arena_bytes = lib().pxl_net_arena_bytes(pl.net)
             if self._sync_cb is not None:
                 check(lib().pxl_net_set_sync(pl.net, self._sync_cb, getattr(self, "_sync_user", None), self._sync_world))
+            gs = getattr(self, "_grad_sync", None)
+            if gs is not None:
+                check(lib().pxl_net_set_grad_sync(pl.net, gs[0], gs[1], gs[2], gs[3], self._store.np))
             if not self._wgrad_on:
                 check(lib().pxl_net_set_wgrad(pl.net, 0))
             if self._profile_on:
@@ -480,6 +483,21 @@ class SegNetCore(nn.Module):
         for pl in self._all_plans():
             check(lib().pxl_net_set_sync(pl.net, self._sync_cb, None, world_size))
 
+    def set_grad_sync(self, fn, user, world_size, bucket_floats):
+        """Overlapped gradient exchange (csrc/net.cpp: pxl_net_set_grad_sync): fn = a ctypes pxl_allreduce_fn (in-place
+        sum on the given stream), user = its context; the executor all-reduces buckets of the flat gradient buffer from
+        inside pxl_net_backward.  fn = None turns it off."""
+        self._grad_sync = None if fn is None else (fn, user, int(world_size), int(bucket_floats))
+        for pl in self._all_plans():
+            if fn is None:
+                check(lib().pxl_net_set_grad_sync(pl.net, _lib.ALLREDUCE_FN(), None, 1, 0, 0))
+            else:
+                check(lib().pxl_net_set_grad_sync(pl.net, fn, user, int(world_size), int(bucket_floats), self._store.np))
+
+    def grad_buckets(self):
+        """buckets the last backward of the current plan exchanged (0 on one rank)"""
+        return lib().pxl_net_grad_buckets(self._cur.net) if self._cur is not None else 0
+
     def twin(self):
         """A second executor front-end over the SAME parameters / gradients / running statistics with its own plans,
         buffers and flags (e.g. weight gradients off): lets a frozen copy of a network run (forward and input-gradient
@@ -499,6 +517,7 @@ class SegNetCore(nn.Module):
         object.__setattr__(t, "_sync_cb", getattr(self, "_sync_cb", None))
         object.__setattr__(t, "_sync_user", getattr(self, "_sync_user", None))
         object.__setattr__(t, "_sync_world", getattr(self, "_sync_world", 1))
+        object.__setattr__(t, "_grad_sync", None)          # a twin never owns the gradient exchange
         object.__setattr__(t, "_wgrad_on", True)
         t.train(self.training)
         return t

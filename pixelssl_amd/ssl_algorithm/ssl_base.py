@@ -61,10 +61,13 @@ class _SSLBase:
         enqueues the pass on the critical path.  An executor pass is one C call issuing ~220 launches (~1 ms of host
         time); issued back to back from one thread, the second network's stream sits idle for that long at every step
         (measured: a 1 - 3.7 ms hole at the head of each MT step).  ctypes drops the GIL for the call, the HIP runtime
-        is thread-safe, torch's current stream is thread-local.  PXL_ENQUEUE_THREAD=0 turns it off."""
+        is thread-safe, torch's current stream is thread-local.  PXL_ENQUEUE_THREAD=0 turns it off.
+        Single-rank only: with Sync-BN the two passes would issue collectives from two threads, whose interleaving differs
+        from rank to rank (a torch.distributed group is not thread-safe; two RCCL communicators can dead-lock on it)."""
         import os
+        from .. import dist as pdist
         if not hasattr(self, '_enq_pool'):
-            on = os.environ.get('PXL_ENQUEUE_THREAD', '1') != '0'
+            on = os.environ.get('PXL_ENQUEUE_THREAD', '1') != '0' and not pdist.is_distributed()
             if on:
                 from concurrent.futures import ThreadPoolExecutor
                 self._enq_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='pxl-enqueue')

@@ -22,8 +22,10 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
+    # 0.25 MB gradient buckets: the 8.9 M-parameter test trunk is exchanged in > 10 buckets issued from inside the backward
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), PXL_FORCE_DEVICE="0", PXL_DIST_BACKEND="gloo", PXL_AUTOTUNE="0")
+                      LOCAL_RANK=str(rank), PXL_FORCE_DEVICE="0", PXL_DIST_BACKEND="gloo", PXL_AUTOTUNE="0",
+                      PXL_GRAD_BUCKET_MB="0.25")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     sys.path.insert(0, os.path.join(root, "oracle"))
@@ -50,6 +52,12 @@ def _worker(rank, world, port, q):
         # numpy arrays are pickled by value (torch tensors would be passed as shared-memory handles that die with the worker)
         out[str(dtype)] = dict(logits=logits.detach().float().cpu().numpy(), grads=core.flat.grads.detach().cpu().numpy().copy(),
                                rmean=core.flat.running.detach().cpu().numpy().copy())
+        assert core.grad_buckets() > 10, core.grad_buckets()         # the exchange ran bucketed, inside pxl_net_backward
+        # a second backward into the same (already averaged) buffers: accumulation stays exact (mean of identical = same)
+        logits2, _, _ = core(x[sl].cuda())
+        PF.cross_entropy_per_sample(logits2, gt[sl].cuda(), 255).mean().backward()
+        torch.cuda.synchronize()
+        out[str(dtype)]["grads2"] = core.flat.grads.detach().cpu().numpy().copy()
     dist.barrier()
     q.put((rank, out))
     dist.barrier()
@@ -89,6 +97,8 @@ def test_two_ranks_one_gpu_match_full_batch_step():
         r0, r1 = ({k: torch.from_numpy(v) for k, v in res[r][str(dtype)].items()} for r in (0, 1))
         # both ranks hold the same averaged gradient, equal to the full-batch gradient
         assert rel(r0["grads"], r1["grads"]) < 1e-6
+        # accumulating a second backward on top of the exchanged buffers doubles the gradient (2 x the same batch)
+        assert rel(r0["grads2"], 2 * r0["grads"]) < (2e-3 if dtype == torch.float32 else 6e-2) and rel(r0["grads2"], r1["grads2"]) < 1e-6
         e_g = rel(r0["grads"], core.flat.grads.detach().cpu())
         e_l = rel(torch.cat([r0["logits"], r1["logits"]]), logits.detach().cpu())
         e_r = rel(r0["rmean"], core.flat.running.detach().cpu())
@@ -133,3 +143,25 @@ def test_native_rccl_communicator_single_rank():
         assert h.pxl_comm_allreduce_sum(comm, None, 4, None) != 0 and b"bad argument" in h.pxl_last_error()
     finally:
         h.pxl_comm_destroy(comm)
+
+
+def test_bench_two_ranks_on_one_gpu_through_torchrun():
+    """`bench.py --gpus 2` launched exactly like the driver does (torch.distributed.run, 127.0.0.1), with the gloo
+    backend and both ranks on cuda:0 (RCCL refuses two ranks on one GPU): the full ResNet-101 MT step at 513 x 513,
+    1 + 1 images per rank, Sync-BN statistics exchange, bucketed gradient exchange inside the backward pass, max-over-
+    ranks timing -- the multi-rank code path of the benchmark end to end, falling back from the C-driven RCCL
+    communicators to torch.distributed (rccl_ranks = 0) as it must when they cannot be opened."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PXL_FORCE_DEVICE="0", PXL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--lbs", "1", "--ubs", "1", "--no-kernel-events"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 4 and d["config"]["sync_bn"] is True
+    assert d["rccl_ranks"] == 0 and d["grad_buckets"] >= 5          # 176 MB of gradients in 32 MB buckets
+    assert d["value"] > 0 and all(v == v and abs(v) < 1e6 for v in d["final_losses"].values())
