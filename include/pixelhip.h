@@ -120,6 +120,12 @@ int pxl_pack_weights_batched(int dtype, const float* params, void* packed, const
 /* layout conversion at the API edge: NCHW fp32 <-> NHWC engine dtype (channel pitch Cp >= C) */
 int pxl_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W, int Cp, void* stream);
 int pxl_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H, int W, int Cp, void* stream);
+/* input pipeline on the device (task/sseg/data.py:150-182 Normalize + ToTensor): uint8 image crops [B,H,W,C] ->
+ * (x / 255 - mean[c]) / std[c] as fp32 NCHW with numpy's rounding (float32 division, then double-precision subtract and
+ * divide each rounded to float32); mean / std: device pointers to C doubles.  pxl_u8_to_f32: label maps, the byte
+ * `marker` (< 0: none) becoming `marker_value` (the stand-in of the reference's -1 "unlabeled" plane, data.py:104-105). */
+int pxl_normalize_u8(int B, int C, long HW, const unsigned char* src, const double* mean, const double* stdv, float* dst, void* stream);
+int pxl_u8_to_f32(long n, const unsigned char* src, float* dst, int marker, float marker_value, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* BatchNorm (training-mode, cross-device statistics)                                          */

@@ -12,7 +12,7 @@ from .nn import SynchronizedBatchNorm2d, patch_replication_callback, GaussianNoi
 from . import ssl_algorithm
 from .ssl_algorithm import SSL_NULL, SSL_MT, SSL_ADV, SSL_CUTMIX, SSL_GCT, SSL_CCT, SSL_ALGORITHMS
 from . import task_template
-from .task_template import model_template, criterion_template, func_template
+from .task_template import model_template, criterion_template, func_template, data_template
 from . import functional
 from . import sseg
 

@@ -76,6 +76,8 @@ SIGNATURES = {
     "pxl_pack_weights_batched": (_I, [_I, _P, _P, C.POINTER(PackItem), _I, _P]),
     "pxl_nchw_to_nhwc": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "pxl_nhwc_to_nchw": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "pxl_normalize_u8": (_I, [_I, _I, _L, _P, _P, _P, _P, _P]),
+    "pxl_u8_to_f32": (_I, [_L, _P, _P, _I, _F, _P]),
     "pxl_bn_finalize": (_I, [_I, _P, _I, _F, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P]),
     "pxl_bn_apply_fwd": (_I, [_I, _L, _I, _P, _P, _I, _P, _P]),
     "pxl_bn_fold_replicas": (_I, [_I, _I, _P, _P]),

@@ -248,3 +248,50 @@ extern "C" int pxl_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
+
+namespace {
+// Input pipeline, device side (task/sseg/data.py:150-182 `Normalize` + `ToTensor`): uint8 HWC crops -> normalised fp32 NCHW.
+// numpy semantics of the reference, bit for bit: `img /= 255.0` is a float32 division; `img -= mean` and `img /= std`
+// take float64 tuples, i.e. compute in double and round to float32 after each step.
+__global__ __launch_bounds__(256) void normalize_u8_kernel(long HW, int C, const unsigned char* __restrict__ src,
+                                                          const double* __restrict__ mean, const double* __restrict__ stdv,
+                                                          float* __restrict__ dst) {
+  const int b = blockIdx.y;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long)gridDim.x * 256) {
+    for (int c = 0; c < C; ++c) {
+      float v = (float)src[((size_t)b * HW + i) * C + c] / 255.0f;
+      v = (float)((double)v - mean[c]);
+      v = (float)((double)v / stdv[c]);
+      dst[((size_t)b * C + c) * HW + i] = v;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(long n, const unsigned char* __restrict__ src, float* __restrict__ dst,
+                                                        int marker, float marker_value) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int v = src[i];
+    dst[i] = v == marker ? marker_value : (float)v;
+  }
+}
+}  // namespace
+
+extern "C" int pxl_normalize_u8(int B, int C, long HW, const unsigned char* src, const double* mean, const double* stdv,
+                                float* dst, void* stream) {
+  PXL_REQUIRE(src && mean && stdv && dst && B > 0 && C > 0 && C <= 4 && HW > 0, "normalize_u8: bad argument");
+  long g = (HW + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(normalize_u8_kernel, dim3((int)g, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), HW, C, src, mean,
+                     stdv, dst);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_u8_to_f32(long n, const unsigned char* src, float* dst, int marker, float marker_value, void* stream) {
+  PXL_REQUIRE(src && dst && n > 0, "u8_to_f32: bad argument");
+  long g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(u8_to_f32_kernel, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, src, dst, marker,
+                     marker_value);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
