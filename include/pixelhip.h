@@ -163,6 +163,12 @@ typedef struct pxl_bn_fin {
   int32_t training, clamp_var;
   float* coef;
 } pxl_bn_fin;
+/* Forward convolution (LDS-DMA kernel) whose LAST workgroup finalizes the BatchNorm of its output from the statistics the
+ * launch itself accumulated: stats [desc->stats_rep][2*Kreal] and *counter (uint32) caller-zeroed; fin as above (its
+ * stats / nrep fields are ignored, training must be 1).  Replaces pxl_conv_igemm + pxl_bn_finalize for one rank (with
+ * Sync-BN the statistics are all-reduced between the two).  PXL_ERR_UNSUPPORTED: use pxl_conv_igemm + pxl_bn_finalize. */
+int pxl_conv_dma_finalize(const pxl_conv_desc* desc, const void* in, const void* w, void* out, const float* bias,
+                          float* stats, const pxl_bn_fin* fin, unsigned* counter, void* stream);
 /* z = relu?(bn(y)) with the finalize folded in (replaces pxl_bn_finalize + pxl_bn_apply_fwd) */
 int pxl_bn_finalize_apply_fwd(int dtype, long M, int C, const void* y, const pxl_bn_fin* fin, int relu, void* z, void* stream);
 /* out = relu(bn_y(y) + (rfin ? bn_r(res) : res)) with both finalizes folded in (replaces up to two pxl_bn_finalize +

@@ -82,6 +82,7 @@ SIGNATURES = {
     "pxl_bn_apply_fwd": (_I, [_I, _L, _I, _P, _P, _I, _P, _P]),
     "pxl_bn_fold_replicas": (_I, [_I, _I, _P, _P]),
     "pxl_bn_bwd_reduce": (_I, [_I, _I, _I, _P, _P, _P, _I, _P, _I, _P]),
+    "pxl_conv_dma_finalize": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.POINTER(BnFin), _P, _P]),
     "pxl_bn_finalize_apply_fwd": (_I, [_I, _L, _I, _P, C.POINTER(BnFin), _I, _P, _P]),
     "pxl_residual_finalize_fwd": (_I, [_I, _L, _I, _P, C.POINTER(BnFin), _P, C.POINTER(BnFin), _P, _P]),
     "pxl_residual_bwd_reduce": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),

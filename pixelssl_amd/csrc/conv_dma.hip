@@ -45,6 +45,10 @@ struct DmaArgs {
   int tiles_m, tiles_n;
   float* ws;         // split-K: pre-zeroed fp32 [M][Cout] accumulation buffer (blockIdx.y = K slice), else nullptr
   int nk_per;        // K steps per slice
+  // forward with batch statistics: the LAST workgroup to finish turns the completed [sum, sumsq] into the BatchNorm
+  // coefficients (what pxl_bn_finalize does), so no finalize launch and no replica reduction in the consumers
+  pxl_bn_fin fin;    // fin.coef == nullptr: off
+  unsigned* fin_counter;
   unsigned in_bytes, w_bytes;
   int taps[64];      // (dy << 16) | (dx & 0xffff)
 };
@@ -439,6 +443,43 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
       }
     }
   }
+  if (p.fin.coef != nullptr && has_stats && !has_bnr) {
+    // last-block-done.  The statistics are device-scope atomics (performed at the memory side, never cached): a thread's
+    // `s_waitcnt vmcnt(0)` means its atomics have been performed, the barrier extends that to the block, and only then
+    // does thread 0 draw the ticket.  The block holding the last ticket reads every replica with agent-scope loads (past
+    // its L1; no other block of this launch ever read those lines, so no L2 holds them).  No __threadfence(): a full
+    // agent fence per block writes back the L2 and made the whole step 1.8x slower when it was tried here.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int mine = 0;
+    if (tid == 0) mine = atomicAdd(p.fin_counter, 1u) == (unsigned)(gridDim.x * gridDim.y) - 1u;
+    const int is_last = __syncthreads_or(mine);
+    if (is_last) {
+      const int C = p.Kreal;
+      for (int c = tid; c < C; c += 256) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < p.stats_rep; ++r) {
+          s1 += __hip_atomic_load(p.stats + (size_t)r * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s2 += __hip_atomic_load(p.stats + (size_t)r * 2 * C + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const float mean = s1 / p.fin.count;
+        float var = s2 / p.fin.count - mean * mean;
+        if (var < 0.f) var = 0.f;
+        if (p.fin.running_mean != nullptr) {
+          const float unbiased = p.fin.count > 1.f ? var * p.fin.count / (p.fin.count - 1.f) : var;
+          p.fin.running_mean[c] = (1.f - p.fin.momentum) * p.fin.running_mean[c] + p.fin.momentum * mean;
+          p.fin.running_var[c] = (1.f - p.fin.momentum) * p.fin.running_var[c] + p.fin.momentum * unbiased;
+        }
+        const float rstd = p.fin.clamp_var ? rsqrtf(fmaxf(var, p.fin.eps)) : rsqrtf(var + p.fin.eps);
+        const float g = p.fin.gamma ? p.fin.gamma[c] : 1.f, b = p.fin.beta ? p.fin.beta[c] : 0.f;
+        const float scale = g * rstd;
+        p.fin.coef[c] = mean;
+        p.fin.coef[C + c] = rstd;
+        p.fin.coef[2 * C + c] = scale;
+        p.fin.coef[3 * C + c] = b - mean * scale;
+      }
+    }
+  }
 }
 
 template <int BM, int BN, int NST, int ABL>
@@ -448,9 +489,10 @@ int launch_abl(const DmaArgs& a, hipStream_t stream) {
   p.tiles_n = cdiv(p.Cout, BN);
   p.ws = nullptr;
   p.nk_per = p.nk;
+  p.fin.coef = nullptr;
   constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
   PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, 2, 2, NST, true, ABL>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
   hipLaunchKernelGGL((conv_dma_kernel<BM, BN, 2, 2, NST, true, ABL>), dim3(p.tiles_m * p.tiles_n), dim3(256), smem, stream, p);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
@@ -483,9 +525,9 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
   static bool raised[2] = {false, false};
   if (!raised[gather ? 1 : 0]) {
     if (gather) PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     else PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     raised[gather ? 1 : 0] = true;
   }
   if (gather)
@@ -525,8 +567,27 @@ extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* 
   a.ws = reinterpret_cast<float*>(workspace);
   a.nk_per = 0;
   a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0;
+  a.fin.coef = nullptr; a.fin_counter = nullptr;
   const int sk = d->split_k;
   return conv_dma_launch(d, a, sk, ws_bytes, stream);
+}
+
+// Forward convolution with batch statistics AND the BatchNorm finalize: `stats` ([stats_rep][2*Kreal], caller-zeroed)
+// receives the sums as in pxl_conv_igemm, and the workgroup that finishes last computes what pxl_bn_finalize would
+// (fin->coef, running statistics) from them -- `counter` is one caller-zeroed uint32 per launch.  fin->stats / nrep are
+// ignored (the launch's own stats / stats_rep are used).  PXL_ERR_UNSUPPORTED when the LDS-DMA kernel cannot run the
+// descriptor or the launch would split K.
+extern "C" int pxl_conv_dma_finalize(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
+                                     float* stats, const pxl_bn_fin* fin, unsigned* counter, void* stream) {
+  PXL_REQUIRE(d && in && w && out && stats && fin && fin->coef && counter && fin->count > 0.f, "conv_dma_finalize: bad argument");
+  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || (d->tile_cfg >= 0 && d->tile_cfg < 8) || !fin->training)
+    return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_finalize: descriptor is not eligible for the LDS-DMA kernel");
+  DmaArgs a;
+  a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
+  a.ws = nullptr; a.nk_per = 0;
+  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0;
+  a.fin = *fin; a.fin_counter = counter;
+  return conv_dma_launch(d, a, 1, 0, stream);
 }
 
 // Data gradient with the BatchNorm-backward reduction of its output fused into the epilogue: din = dgrad(dy) (+ addend)
@@ -542,6 +603,7 @@ extern "C" int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, c
   DmaArgs a;
   a.in = dy; a.w = wt; a.out = din; a.bias = nullptr; a.addend = addend; a.stats = bn_sums;
   a.ws = nullptr; a.nk_per = 0;
+  a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = bn_relu;
   pxl_conv_desc q = *d;
   q.stats_rep = 1;

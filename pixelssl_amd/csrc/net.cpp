@@ -24,6 +24,8 @@
 #include "common.h"
 
 extern "C" {
+int pxl_conv_dma_finalize(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias, float* stats,
+                          const pxl_bn_fin* fin, unsigned* counter, void* stream);
 int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
                             const void* bn_y, const float* bn_coef, int bn_relu, float* bn_sums, void* stream);
 int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream);
@@ -72,6 +74,8 @@ struct BnInfo {
   // forward: the finalize of this BN is folded into the kernel that applies it (z materialisation or the residual
   // join that is its only consumer) instead of a pxl_bn_finalize launch
   bool fin_in_consumer = false;
+  size_t cnt_off = 0;      // arena (inside the statistics region, zeroed with it): the last-block-done ticket counter
+  bool fin_by_conv = false;   // this pass: the producing convolution's last workgroup finalized the BN
 };
 
 struct OpInfo {
@@ -141,6 +145,11 @@ struct pxl_net {
   // the statistics replicas, which was slower with 32 replicas (round 1: 15.7 vs 15.0 ms / step) and is faster with 4
   // (round 2: 14.98 vs 15.17): on by default, PXL_FUSE_BN_FINALIZE=0 restores the separate pxl_bn_finalize launches
   bool fuse_bn_finalize = getenv("PXL_FUSE_BN_FINALIZE") == nullptr || getenv("PXL_FUSE_BN_FINALIZE")[0] != '0';
+  // the producing convolution's last workgroup finalizes the BatchNorm (conv_dma.hip: pxl_conv_dma_finalize); one rank only
+  // (Sync-BN all-reduces the statistics between the convolution and the finalize).  Measured negative result, kept
+  // opt-in (PXL_CONV_FINALIZE=1): the ticket atomic + two extra barriers in EVERY workgroup's epilogue cost more than
+  // the consumer-side fold saves -- MT 15.3-15.5 ms / step vs 14.8 (and 26.7 ms with a __threadfence() per block)
+  bool conv_finalize = getenv("PXL_CONV_FINALIZE") != nullptr && getenv("PXL_CONV_FINALIZE")[0] == '1';
   // tests: use the reference's multi-device variance formula clamp(var, eps) on a single rank too
   bool force_clamp = getenv("PXL_FORCE_CLAMP_VAR") != nullptr;
 };
@@ -351,7 +360,10 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
   size_t arena = 0, scratch = 0, packed = 0;
   // BN statistics first (contiguous -> one memset per pass)
   n->stats_region_off = arena;
-  for (auto& b : n->bns) { b.stats_off = arena; arena += align_up(STATS_REP * 2 * (size_t)b.d.C * 4); }
+  for (auto& b : n->bns) {
+    b.stats_off = arena; arena += align_up(STATS_REP * 2 * (size_t)b.d.C * 4);
+    b.cnt_off = arena; arena += ALIGN;
+  }
   n->stats_region_bytes = arena - n->stats_region_off;
   for (auto& b : n->bns) { b.coef_off = arena; arena += align_up(4 * (size_t)b.d.C * 4); }
   n->bsum_region_off = scratch;
@@ -762,14 +774,30 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
         const float* sc = cin.sc; const float* sh = cin.sh;
         float* stats = (d.bn_out >= 0 && training) ? fat(arena, n->bns[d.bn_out].stats_off) : nullptr;
         const float* bias = d.b_off[0] >= 0 ? fat(packed, op.bias_off) : nullptr;
+        bool fin_by_conv = false;
         {
           Timed t(n, s, 0, conv_flops(n, d, tout));
           if (n->profile) n->prof_bytes[0] += conv_bytes(n, d, tin, tout, false);
-          rc = pxl_conv_igemm(&op.fwd, cin.ptr, at(packed, op.wf_off), at(arena, tout.off), sc, sh, bias,
-                              nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr, op.ws_bytes, stream);
+          if (stats && n->conv_finalize && !(n->sync && n->world > 1) && n->dtype == PXL_BF16 && !op.ws_bytes &&
+              pxl_conv_dma_eligible(&op.fwd, sc, nullptr) && (op.fwd.tile_cfg < 0 || op.fwd.tile_cfg >= 8)) {
+            BnInfo& b = n->bns[d.bn_out];
+            pxl_bn_fin fin = make_fin(n, b, params, running, arena, training);
+            rc = pxl_conv_dma_finalize(&op.fwd, cin.ptr, at(packed, op.wf_off), at(arena, tout.off), bias, stats, &fin,
+                                       reinterpret_cast<unsigned*>(at(arena, b.cnt_off)), stream);
+            fin_by_conv = rc == PXL_OK;
+          }
+          if (!fin_by_conv)
+            rc = pxl_conv_igemm(&op.fwd, cin.ptr, at(packed, op.wf_off), at(arena, tout.off), sc, sh, bias,
+                                nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr, op.ws_bytes, stream);
         }
         if (rc != PXL_OK) return rc;
-        if (d.bn_out >= 0) {
+        if (d.bn_out >= 0) n->bns[d.bn_out].fin_by_conv = fin_by_conv;
+        if (d.bn_out >= 0 && fin_by_conv) {
+          BnInfo& b = n->bns[d.bn_out];
+          if (b.has_z)
+            rc = pxl_bn_apply_fwd(dt, (long)n->B * tout.H * tout.W, tout.Cp, at(arena, tout.off), fat(arena, b.coef_off),
+                                  b.relu, at(arena, b.z_off), stream);
+        } else if (d.bn_out >= 0) {
           BnInfo& b = n->bns[d.bn_out];
           int nrep = STATS_REP;
           if (training && n->sync && n->world > 1) {
@@ -813,7 +841,9 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
         const TensorInfo& o = n->tensors[d.out];
         const float* ac = fat(arena, n->bns[d.bn_in0].coef_off);
         const float* rcoef = d.bn_in1 >= 0 ? fat(arena, n->bns[d.bn_in1].coef_off) : nullptr;
-        if (n->bns[d.bn_in0].fin_in_consumer && !n->bns[d.bn_in0].has_z) {
+        // (a residual join finalizes either both of its BatchNorms or none: both convolutions took the same path)
+        if (n->bns[d.bn_in0].fin_in_consumer && !n->bns[d.bn_in0].has_z && !n->bns[d.bn_in0].fin_by_conv &&
+            !(d.bn_in1 >= 0 && n->bns[d.bn_in1].fin_by_conv)) {
           const pxl_bn_fin yfin = make_fin(n, n->bns[d.bn_in0], params, running, arena, training);
           pxl_bn_fin rfin;
           if (d.bn_in1 >= 0) rfin = make_fin(n, n->bns[d.bn_in1], params, running, arena, training);

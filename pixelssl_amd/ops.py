@@ -42,6 +42,13 @@ def conv_igemm(desc, x, w, out, in_scale=None, in_shift=None, bias=None, addend=
     return out
 
 
+def conv_dma_finalize(desc, x, w, out, stats, fin, counter, bias=None):
+    """forward conv (LDS-DMA kernel) whose last workgroup finalizes the BN of its output; raises when not eligible"""
+    _require_cuda(x, w, out, stats, counter)
+    check(lib().pxl_conv_dma_finalize(desc, ptr(x), ptr(w), ptr(out), ptr(bias), ptr(stats), fin, ptr(counter), stream_ptr()))
+    return out
+
+
 def conv_dgrad_bnreduce(desc, dy, wt, din, bn_y, bn_coef, bn_relu, bn_sums, addend=None):
     """data gradient + fused BN-backward reduction of its output (LDS-DMA kernel); raises when not eligible"""
     _require_cuda(dy, wt, din, bn_y, bn_coef, bn_sums)

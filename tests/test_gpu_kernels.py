@@ -161,6 +161,49 @@ def test_conv_dma_forward_and_dgrad(case, cfg):
     assert rel_err(from_nhwc(dx, Cin), x.grad) < TOL[dtype], "dgrad %s cfg %d" % (name, cfg)
 
 
+@pytest.mark.parametrize("cfg", [-1, 8, 10, 18, 20, 24, 26])
+@pytest.mark.parametrize("case", DMA_CASES[:7], ids=[c[0] for c in DMA_CASES[:7]])
+def test_conv_with_last_block_bn_finalize(case, cfg):
+    """pxl_conv_dma_finalize == pxl_conv_igemm + pxl_bn_finalize: same output, same (mean, rstd, scale, shift), same
+    running statistics -- the workgroup that draws the last ticket sees every other workgroup's statistics atomics.
+    Repeated launches (fresh counters) give the same coefficients: no stale reads."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    name, B, Cin, Cout, H, W, k, s, d, p = case
+    g = torch.Generator().manual_seed(_seed(name) + 3)
+    x = qround(torch.randn(B, Cin, H, W, generator=g) + 0.3, dtype)
+    w = qround(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype)
+    gamma, beta = (torch.rand(Cout, generator=g) + 0.5).to(DEV), (torch.randn(Cout, generator=g) * 0.2).to(DEV)
+    Ho, Wo = (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
+    cip, cop = _pitch(Cin), _pitch(Cout)
+    taps = ops.fwd_taps(k, k, d, p)
+    xd = to_nhwc(x, cip, dtype)
+    wf, _ = pack_w(w, dtype, cip)
+    nrep, count = 4, float(B * Ho * Wo)
+    desc = ops.conv_desc(dtype, B, H, W, cip, Ho, Wo, cop, Cout, taps, out_stride=s, tile_cfg=cfg, stats_rep=nrep)
+    # reference path: conv + statistics, then the finalize launch
+    out_a = torch.empty(B, Ho, Wo, cop, device=DEV, dtype=dtype)
+    st_a = torch.zeros(nrep, 2 * Cout, device=DEV)
+    rm_a, rv_a = torch.full((Cout,), 0.25, device=DEV), torch.full((Cout,), 1.5, device=DEV)
+    ops.conv_igemm(desc, xd, wf, out_a, stats=st_a)
+    coef_a = ops.bn_finalize(st_a, count, gamma, beta, rm_a, rv_a, nrep=nrep)
+    for trial in range(3):
+        out_b = torch.empty_like(out_a)
+        st_b = torch.zeros(nrep, 2 * Cout, device=DEV)
+        cnt = torch.zeros(4, device=DEV, dtype=torch.int32)
+        rm_b, rv_b = torch.full((Cout,), 0.25, device=DEV), torch.full((Cout,), 1.5, device=DEV)
+        coef_b = torch.full((4 * Cout,), float("nan"), device=DEV)
+        fin = ops.bn_fin(st_b, nrep, count, gamma, beta, rm_b, rv_b, coef_b)
+        ops.conv_dma_finalize(desc, xd, wf, out_b, st_b, fin, cnt)
+        torch.cuda.synchronize()
+        assert torch.equal(out_a, out_b)
+        assert torch.isfinite(coef_b).all()
+        # the sums differ only in fp32 atomic order
+        assert rel_err(coef_b.cpu(), coef_a.cpu()) < 2e-6, (name, cfg, trial)
+        assert rel_err(rm_b.cpu(), rm_a.cpu()) < 2e-6 and rel_err(rv_b.cpu(), rv_a.cpu()) < 2e-6
+        assert cnt[0].item() > 0
+
+
 @pytest.mark.parametrize("cfg", [-1, 8, 10, 11, 18, 20, 21, 26])
 @pytest.mark.parametrize("shape", [(2, 128, 64, 17, 19, 3, 1, 1), (3, 64, 256, 9, 13, 1, 1, 0), (2, 192, 128, 12, 12, 3, 2, 2)])
 def test_conv_dgrad_with_fused_bn_backward_reduce(shape, cfg):
