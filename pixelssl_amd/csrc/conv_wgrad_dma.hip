@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WDmaArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wc = wave & 1;
 
-  const int tile = blockIdx.x;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);      // workgroups of one XCD (one L2) share the dY columns of an n-tile
   const int tn = tile / p.tiles_c, tcg = tile % p.tiles_c;
   const int tap = tcg / p.ctiles_per_tap;
   const int c0 = (tcg % p.ctiles_per_tap) * BC;

@@ -14,19 +14,33 @@ import sys
 from collections import defaultdict
 
 
-def per_kernel(d):
+TAIL = {"conv_dma_kernel": 250, "conv_wgrad_dma_kernel": 90, "conv_igemm_kernel": 6}     # launches of ONE step at least
+
+
+def per_kernel(d, tail=True):
+    """kernel name -> counter values in dispatch order; with `tail`, only the last launches of the contraction kernels are
+    kept (the final training step: the run's earlier launches are the autotune candidates of every tile configuration)"""
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    if rows and "Dispatch_Id" in rows[0]:
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     acc = defaultdict(list)
-    for r in csv.DictReader(open(f)):
+    for r in rows:
         n = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"]).split("<")[0].split("(")[0]
         acc[n].append(float(r["Counter_Value"]))
+    if tail:
+        for k, keep in TAIL.items():
+            if k in acc:
+                acc[k] = acc[k][-keep:]
     return acc
 
 
 def main(fetch_dir, write_dir, out):
     fe, wr = per_kernel(fetch_dir), per_kernel(write_dir)
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace -- python bench.py --steps 1 --warmup 1 "
-                     "--no-cpu-baseline --no-kernel-events (PXL_AUTOTUNE=0), MT 8x513x513 bf16",
+                     "--no-cpu-baseline --no-kernel-events --no-miou, MT 8x513x513 bf16, autotuned tiles; contraction kernels: "
+                     "the last launches of the run only (the final training step)",
+           "measured": "two separate rocprofv3 --pmc passes of this command, tools/r02_call13.sh",
            "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads)",
            "kernels": {}}
     for k in sorted(set(fe) | set(wr), key=lambda k: -(2 * sum(fe.get(k, [0])) + sum(wr.get(k, [0])))):
