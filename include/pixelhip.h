@@ -93,6 +93,15 @@ int pxl_conv_igemm(const pxl_conv_desc* desc, const void* in, const void* w, voi
 int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
                             const void* bn_y, const float* bn_coef, int bn_relu, float* bn_sums, void* stream);
 
+/* Data gradient that COMPLETES the gradient of a residual join's output (Bottleneck `out += residual; relu(out)`,
+ * resnet.py:43-48), with the join's backward fused into the epilogue: g = dgrad(dy) (+ addend); din = g * (join_out > 0)
+ * -- the masked gradient is what both branches of the join receive -- and bn_sums[0..C) += sum_m din, bn_sums[C..2C) +=
+ * sum_m din * xhat(bn_y) for the main branch's last BatchNorm (bn3, no ReLU of its own).  Stands in for
+ * pxl_residual_bwd_reduce (3 tensor reads + 2 writes in a launch of its own).  LDS-DMA kernel only, else
+ * PXL_ERR_UNSUPPORTED. */
+int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
+                              const void* join_out, const void* bn_y, const float* bn_coef, float* bn_sums, void* stream);
+
 /* dw[k][t][c] += sum_m dy[m][k] * act(in)[m,t,c]   (fp32, atomically accumulated: zero dw first
  * unless accumulating).  `desc` describes the FORWARD conv (in = its input, Ho/Wo/Cout = dy).
  * creal = real input channels (<= Cin pitch), dw_cpitch = channel pitch of dw.
@@ -306,6 +315,15 @@ int pxl_ce_fwd(int N, int C, int HW, const float* logits, const float* gt, int i
                void* stream);
 int pxl_ce_bwd(int N, int C, int HW, const float* logits, const float* gt, int ignore_index, const float* gout,
                float* dlogits, void* stream);
+
+/* d(task + consistency)/d(logits) of a mean-teacher style step in one pass (ssl_mt.py:166-196: CE on the labeled
+ * samples' `pred`, MSE between the student's and the teacher's `pred`): samples [0, n_ce) get pxl_ce_bwd's term (gt
+ * [n_ce][HW], g_ce [n_ce]), samples [mse_lo, mse_hi) get pxl_mse_bwd's term against target ([N][C][HW], indexed like
+ * logits; g_mse [1]; mean over (mse_hi - mse_lo)*C*HW elements); everything else is zero.  Bit-identical to the two
+ * kernels + the slice-padding and the sum autograd would do.  g_ce / g_mse may be NULL (term absent). */
+int pxl_ce_mse_bwd(int N, int C, int HW, const float* logits, const float* gt, int ignore_index, int n_ce,
+                   const float* g_ce, const float* target, int mse_lo, int mse_hi, const float* g_mse,
+                   float* dlogits, void* stream);
 /* FCDiscriminatorCriterion (ssl_adv.py:496-503) fused with ssladv_preprocess_fcd_criterion (task/sseg/func.py:
  * 137-157): x = discriminator logits [B][1][HW], task_gt = float labels [B][1][HW] or NULL (unlabeled: nothing
  * masked), target = 1 (real) / 0 (fake).  Pixels whose label is ignore_index get x := 0, t := 0 and still count in

@@ -71,6 +71,7 @@ SIGNATURES = {
     "pxl_version": (_I, []),
     "pxl_conv_igemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "pxl_conv_dgrad_bnreduce": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "pxl_conv_dgrad_joinreduce": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pxl_conv_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _I, _P]),
     "pxl_pack_weights": (_I, [_I, _P, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P]),
     "pxl_pack_weights_batched": (_I, [_I, _P, _P, C.POINTER(PackItem), _I, _P]),
@@ -124,6 +125,7 @@ SIGNATURES = {
     "pxl_upsample_softmax_bwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "pxl_ce_fwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P]),
     "pxl_ce_bwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "pxl_ce_mse_bwd": (_I, [_I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
     "pxl_bce_logits_masked_fwd": (_I, [_I, _L, _P, _P, _I, _F, _P, _P]),
     "pxl_bce_logits_masked_bwd": (_I, [_I, _L, _P, _P, _I, _F, _P, _P, _P]),
     "pxl_cutmix_mix": (_I, [_I, _I, _L, _P, _P, _P, _P, _F, _P, _P]),

@@ -37,6 +37,9 @@ struct DmaArgs {
   const void* bn_y;
   const float* bn_coef;
   int bn_relu;
+  // ... of a residual join: the tensor being written is d(join output); gd = din * (bn_mask > 0) (bn_mask = the join's
+  // post-ReLU output), the MASKED gradient is what gets stored, bn_y / bn_coef belong to the main branch's last BN
+  const void* bn_mask;
   int B, Hi, Wi, Cin;
   int Ho, Wo, Cout, Kreal;
   int ntaps, so;
@@ -358,6 +361,8 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   const bool has_stats = p.stats != nullptr && !(ABL & 32);
   const bf16_t* __restrict__ gbny = reinterpret_cast<const bf16_t*>(p.bn_y);
   const bool has_bnr = has_stats && gbny != nullptr;
+  const bf16_t* __restrict__ gmask = reinterpret_cast<const bf16_t*>(p.bn_mask);
+  const bool has_mask = has_bnr && gmask != nullptr;
   float bn_mean[8], bn_rstd[8], bn_sc[8], bn_sh[8];
   if (has_bnr && ncol) {
     load_cvec<8>(p.bn_coef + n, bn_mean);
@@ -393,7 +398,19 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
           v = Chunk<bf16_t>::pack(f);
           if (has_stats) Chunk<bf16_t>::unpack(v, f);     // statistics of the stored (rounded) values
         }
-        if (has_bnr) {
+        if (has_mask) {
+          float fy[8], fm[8];
+          Chunk<bf16_t>::unpack(*reinterpret_cast<const uint4*>(gbny + o), fy);
+          Chunk<bf16_t>::unpack(*reinterpret_cast<const uint4*>(gmask + o), fm);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float gd = fm[e] > 0.f ? f[e] : 0.f;
+            f[e] = gd;
+            s1[e] += gd;
+            s2[e] += gd * (fy[e] - bn_mean[e]) * bn_rstd[e];
+          }
+          v = Chunk<bf16_t>::pack(f);
+        } else if (has_bnr) {
           float fy[8];
           Chunk<bf16_t>::unpack(*reinterpret_cast<const uint4*>(gbny + o), fy);
 #pragma unroll
@@ -566,7 +583,7 @@ extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* 
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = addend; a.stats = stats;
   a.ws = reinterpret_cast<float*>(workspace);
   a.nk_per = 0;
-  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0;
+  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   const int sk = d->split_k;
   return conv_dma_launch(d, a, sk, ws_bytes, stream);
@@ -585,7 +602,7 @@ extern "C" int pxl_conv_dma_finalize(const pxl_conv_desc* d, const void* in, con
   DmaArgs a;
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
   a.ws = nullptr; a.nk_per = 0;
-  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0;
+  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin = *fin; a.fin_counter = counter;
   return conv_dma_launch(d, a, 1, 0, stream);
 }
@@ -604,7 +621,27 @@ extern "C" int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, c
   a.in = dy; a.w = wt; a.out = din; a.bias = nullptr; a.addend = addend; a.stats = bn_sums;
   a.ws = nullptr; a.nk_per = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
-  a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = bn_relu;
+  a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = bn_relu; a.bn_mask = nullptr;
+  pxl_conv_desc q = *d;
+  q.stats_rep = 1;
+  return conv_dma_launch(&q, a, 1, 0, stream);
+}
+
+// Data gradient that completes the gradient of a residual join's output, with the join's backward fused into the
+// epilogue: g = dgrad(dy) (+ addend); din = g * (join_out > 0) -- the ReLU after the join -- and bn_sums[0..C) +=
+// sum_m din, bn_sums[C..2C) += sum_m din * xhat(bn_y) for the main branch's last BatchNorm (the one without a ReLU of its
+// own).  Replaces pxl_residual_bwd_reduce (3 tensor reads + 2 writes) by two extra reads in this epilogue.
+extern "C" int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
+                                         const void* join_out, const void* bn_y, const float* bn_coef, float* bn_sums,
+                                         void* stream) {
+  PXL_REQUIRE(d && dy && wt && din && join_out && bn_y && bn_coef && bn_sums, "conv_dgrad_joinreduce: null argument");
+  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || d->Kreal != d->Cout || (d->tile_cfg >= 0 && d->tile_cfg < 8))
+    return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dgrad_joinreduce: descriptor is not eligible for the LDS-DMA kernel");
+  DmaArgs a;
+  a.in = dy; a.w = wt; a.out = din; a.bias = nullptr; a.addend = addend; a.stats = bn_sums;
+  a.ws = nullptr; a.nk_per = 0;
+  a.fin.coef = nullptr; a.fin_counter = nullptr;
+  a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = 0; a.bn_mask = join_out;
   pxl_conv_desc q = *d;
   q.stats_rep = 1;
   return conv_dma_launch(&q, a, 1, 0, stream);

@@ -89,12 +89,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WDmaArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wc = wave & 1;
 
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);      // workgroups of one XCD (one L2) share the dY columns of an n-tile
+  // workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest): remap the WHOLE 2-D grid so that one
+  // XCD (one L2) runs consecutive (split, tile) pairs = every output tile of the same pixel slice; the slice's dY and Z
+  // rows (m_per_split x (Cout + Cin) x 2 B, 1-3 MB) are then fetched from HBM once per XCD instead of once per tile
+  const int lid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int tile = lid % gridDim.x;
+  const int split = lid / gridDim.x;
   const int tn = tile / p.tiles_c, tcg = tile % p.tiles_c;
   const int tap = tcg / p.ctiles_per_tap;
   const int c0 = (tcg % p.ctiles_per_tap) * BC;
   const int n0 = tn * BN;
-  const int m_begin = blockIdx.y * p.m_per_split;
+  const int m_begin = split * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
   const int nks = (m_end - m_begin + BKP - 1) / BKP;
 

@@ -77,6 +77,61 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(int C, int HW, const float*
   }
 }
 
+// d(task loss + consistency loss)/d(logits) in ONE pass over the [N][C][HW] logits of a mean-teacher style step:
+// samples n < n_ce carry the cross-entropy term of ce_bwd_kernel (gt holds n_ce maps), samples mse_lo <= n < mse_hi the
+// term s * (logits - target), s = g_mse[0] * two_inv_n, of mse_bwd_kernel; every element is written exactly once (zeros
+// where neither applies).  Same expressions, same rounding as the two separate kernels followed by autograd's add.
+__global__ __launch_bounds__(256) void ce_mse_bwd_kernel(int C, int HW, const float* __restrict__ logits,
+                                                         const float* __restrict__ gt, int ignore_index, int n_ce,
+                                                         const float* __restrict__ g_ce, const float* __restrict__ target,
+                                                         int mse_lo, int mse_hi, const float* __restrict__ g_mse,
+                                                         float two_inv_n, float* __restrict__ dlogits) {
+  const int n = blockIdx.y;
+  const float* lg = logits + (size_t)n * C * HW;
+  float* dl = dlogits + (size_t)n * C * HW;
+  const bool ce = n < n_ce && g_ce != nullptr;
+  const bool mse = n >= mse_lo && n < mse_hi && g_mse != nullptr;
+  const float* tg = mse ? target + (size_t)n * C * HW : nullptr;
+  const float gs = ce ? g_ce[n] / (float)HW : 0.f;
+  const float ms = mse ? g_mse[0] * two_inv_n : 0.f;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    bool valid = false;
+    int label = -1;
+    if (ce) {
+      label = (int)gt[(size_t)n * HW + p];
+      valid = !(label == ignore_index || label < 0 || label >= C);
+    }
+    float v[MAXC], x[MAXC];
+    if (valid || mse) {
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) x[c] = lg[(size_t)c * HW + p];
+    }
+    float inv = 0.f;
+    if (valid) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) mx = fmaxf(mx, x[c]);
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) { v[c] = expf(x[c] - mx); sum += v[c]; }
+      inv = gs / sum;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) {
+        float g = valid ? v[c] * inv - (c == label ? gs : 0.f) : 0.f;
+        if (mse) {
+          const float m = ms * (x[c] - tg[(size_t)c * HW + p]);
+          g = ce ? g + m : m;
+        }
+        dl[(size_t)c * HW + p] = g;
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void mse_fwd_kernel(long n4, long n, const float* __restrict__ a,
                                                       const float* __restrict__ b, float inv_n,
                                                       float* __restrict__ out) {
@@ -121,6 +176,23 @@ extern "C" int pxl_ce_fwd(int N, int C, int HW, const float* logits, const float
   int gx = cdiv(HW, 256);
   if (gx > 512) gx = 512;
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(gx, N), dim3(256), 0, s, C, HW, logits, gt, ignore_index, loss);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_ce_mse_bwd(int N, int C, int HW, const float* logits, const float* gt, int ignore_index, int n_ce,
+                              const float* g_ce, const float* target, int mse_lo, int mse_hi, const float* g_mse,
+                              float* dlogits, void* stream) {
+  PXL_REQUIRE(logits && dlogits && N > 0 && n_ce >= 0 && n_ce <= N, "ce_mse_bwd: bad argument");
+  PXL_REQUIRE(C >= 1 && C <= MAXC, "ce_mse_bwd: C=%d unsupported (max %d)", C, MAXC);
+  PXL_REQUIRE(g_ce == nullptr || n_ce == 0 || gt != nullptr, "ce_mse_bwd: cross-entropy term without label maps");
+  PXL_REQUIRE(mse_lo >= 0 && mse_lo <= mse_hi && mse_hi <= N, "ce_mse_bwd: bad consistency range [%d, %d)", mse_lo, mse_hi);
+  PXL_REQUIRE(g_mse == nullptr || mse_hi == mse_lo || target != nullptr, "ce_mse_bwd: consistency term without a target");
+  int gx = cdiv(HW, 256);
+  if (gx > 1024) gx = 1024;
+  const long cnt = (long)(mse_hi - mse_lo) * C * HW;
+  hipLaunchKernelGGL(ce_mse_bwd_kernel, dim3(gx, N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), C, HW, logits, gt,
+                     ignore_index, n_ce, g_ce, target, mse_lo, mse_hi, g_mse, cnt > 0 ? 2.0f / (float)cnt : 0.f, dlogits);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

@@ -28,6 +28,8 @@ int pxl_conv_dma_finalize(const pxl_conv_desc* d, const void* in, const void* w,
                           const pxl_bn_fin* fin, unsigned* counter, void* stream);
 int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
                             const void* bn_y, const float* bn_coef, int bn_relu, float* bn_sums, void* stream);
+int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
+                              const void* join_out, const void* bn_y, const float* bn_coef, float* bn_sums, void* stream);
 int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream);
 int pxl_residual_bwd_reduce(int dtype, int M, int C, const void* dout, const void* out, const void* y, const float* coef,
                             void* g, void* g2, float* sums, void* stream);
@@ -89,6 +91,9 @@ struct OpInfo {
   // IBNorm op: arena [B][2][C] sums + [2*nb] folded BN part + [B][4][C] coefficients; scratch: the backward twins
   size_t ibn_sums = 0, ibn_bn = 0, ibn_coef = 0, ibn_bsums = 0, ibn_bbn = 0;
   size_t ws_off = 0, ws_bytes = 0;               // arena: split-K fp32 workspace (small-N, long-K convs)
+  // CONV: this op's data gradient is the last contribution to the gradient of residual join `join_op`'s output and
+  // performs that join's backward in its epilogue; RESIDUAL: the convolution that does it (-1 = separate launch)
+  int join_op = -1, join_conv = -1;
 };
 
 }  // namespace
@@ -120,6 +125,7 @@ struct pxl_net {
   // backward runs the weight gradients on a second stream, concurrently with the data gradients (both only read
   // dy): the contraction kernels of this network are ~1 workgroup per CU and latency-bound, two in flight fill
   // each other's bubbles.  Created lazily; PXL_SIDE_STREAM=0 disables it.
+  int fork_every = getenv("PXL_FORK_EVERY") ? atoi(getenv("PXL_FORK_EVERY")) : 3;   // convolutions per fork event (>= 1)
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
@@ -141,6 +147,9 @@ struct pxl_net {
   int input_tensor = -1;
   bool latent_seeded = false;      // pxl_net_seed_latent_grad ran: the next backward starts from that gradient
   bool fuse_bn_reduce = getenv("PXL_FUSE_BN_REDUCE") == nullptr || getenv("PXL_FUSE_BN_REDUCE")[0] != '0';
+  // backward of a residual join (ReLU mask + the main branch BN's sums) inside the data gradient that completes the
+  // gradient of the join's output (PXL_FUSE_JOIN=0: separate pxl_residual_bwd_reduce launch)
+  bool fuse_join = getenv("PXL_FUSE_JOIN") == nullptr || getenv("PXL_FUSE_JOIN")[0] != '0';
   // folding the forward finalize into its consumer removes 104 launches per pass; every block of the consumer re-reduces
   // the statistics replicas, which was slower with 32 replicas (round 1: 15.7 vs 15.0 ms / step) and is faster with 4
   // (round 2: 14.98 vs 15.17): on by default, PXL_FUSE_BN_FINALIZE=0 restores the separate pxl_bn_finalize launches
@@ -562,6 +571,38 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
       if (b.y_tensor != d.in0 || uses[d.in0] != 1 || tin.Cp != tin.C || tin.C != b.d.C) continue;
       if (!pxl_conv_dma_eligible(&op.bwd, nullptr, nullptr)) continue;
       b.fused_reduce_op = (int)i;
+    }
+  }
+  // residual joins whose backward runs in the epilogue of the data gradient that completes d(join output): that
+  // convolution must be the FIRST consumer of the output in program order (= the last contribution in the backward
+  // pass), read it as a plain operand and run on the LDS-DMA kernel; every other consumer must be a convolution or the
+  // identity input of the next join (they only add their share before it)
+  for (auto& op : n->ops) op.join_op = op.join_conv = -1;
+  if (n->dtype == PXL_BF16 && n->fuse_bn_reduce && n->fuse_join) {
+    for (size_t j = 0; j < n->ops.size(); ++j) {
+      const pxl_op& dj = n->ops[j].d;
+      if (dj.kind != PXL_OP_RESIDUAL || dj.bn_in0 < 0) continue;
+      const BnInfo& b3 = n->bns[dj.bn_in0];
+      const TensorInfo& a = n->tensors[dj.in0];
+      const TensorInfo& o = n->tensors[dj.out];
+      if (b3.y_tensor != dj.in0 || b3.relu || a.Cp != b3.d.C || o.Cp != o.C || o.C != b3.d.C) continue;
+      int first = -1;
+      bool ok = true;
+      for (size_t c = j + 1; c < n->ops.size() && ok; ++c) {
+        const pxl_op& dc = n->ops[c].d;
+        const bool uses = dc.in0 == dj.out || dc.in1 == dj.out;
+        if (!uses) continue;
+        if (first < 0) first = (int)c;
+        if (dc.kind == PXL_OP_CONV) ok = dc.in0 == dj.out && dc.need_dgrad;
+        else if (dc.kind == PXL_OP_RESIDUAL) ok = dc.in1 == dj.out && dc.in0 != dj.out;
+        else ok = false;
+      }
+      if (!ok || first < 0) continue;
+      OpInfo& oc = n->ops[first];
+      if (oc.d.kind != PXL_OP_CONV || oc.d.bn_in0 >= 0 || oc.d.ngroups != 1 || oc.join_op >= 0) continue;
+      if (!pxl_conv_dma_eligible(&oc.bwd, nullptr, nullptr) || oc.bwd.Kreal != oc.bwd.Cout || oc.bwd.Cout != o.C) continue;
+      oc.join_op = (int)j;
+      n->ops[j].join_conv = first;
     }
   }
   // lowest gradient offset written by each op's backward, and whether those grow with the op index
@@ -1016,6 +1057,20 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
     PXL_CHECK_HIP(hipMemsetAsync(at(scratch, n->bsum_region_off), 0, n->bsum_region_bytes, s));
   std::vector<char> written(n->tensors.size(), 0);
   std::vector<char> reduced(n->bns.size(), 0);        // BN-backward sums already produced by a fused launch
+  // where the gradient of a tensor currently lives: its own buffer, or -- after a fused residual join -- the buffer of
+  // the join's output, which both branches then READ (nothing is copied); settle() materialises it for ops that
+  // accumulate in place
+  std::vector<size_t> gsrc(n->tensors.size());
+  for (size_t t = 0; t < n->tensors.size(); ++t) gsrc[t] = n->tensors[t].goff;
+  std::vector<char> join_done(n->ops.size(), 0);
+  auto settle = [&](int t) -> int {
+    if (t < 0 || gsrc[t] == n->tensors[t].goff) return PXL_OK;
+    const TensorInfo& ti = n->tensors[t];
+    PXL_CHECK_HIP(hipMemcpyAsync(at(scratch, ti.goff), at(scratch, gsrc[t]), (size_t)n->B * ti.H * ti.W * ti.Cp * n->esize,
+                                 hipMemcpyDeviceToDevice, s));
+    gsrc[t] = ti.goff;
+    return PXL_OK;
+  };
   if (n->latent_seeded) {
     written[n->ops[n->head_op].d.in1] = 1;
     n->latent_seeded = false;
@@ -1069,10 +1124,50 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
     return PXL_OK;
   };
 
+  std::vector<int> pending_w;        // convolutions whose dy is final on the main stream, weight gradient not yet issued
+  std::vector<size_t> wsrc(n->ops.size(), 0);     // dy location of a queued convolution without BN (may be an alias)
+  auto issue_wgrads = [&](int at_op) -> int {
+    if (pending_w.empty()) return PXL_OK;
+    hipStream_t ws = s;
+    if (n->use_side) {                                     // fork: every queued dy is final on the main stream from here on
+      if (!n->fork_ev[at_op]) PXL_CHECK_HIP(hipEventCreateWithFlags(&n->fork_ev[at_op], hipEventDisableTiming));
+      PXL_CHECK_HIP(hipEventRecord(n->fork_ev[at_op], s));
+      PXL_CHECK_HIP(hipStreamWaitEvent(n->side, n->fork_ev[at_op], 0));
+      ws = n->side;
+      forked = true;
+    }
+    for (int k : pending_w) {
+      OpInfo& opk = n->ops[k];
+      const pxl_op& dk = opk.d;
+      const TensorInfo& tik = n->tensors[dk.in0];
+      const TensorInfo& tok = n->tensors[dk.out];
+      const int Mk = n->B * tok.H * tok.W;
+      const void* dyk = at(scratch, dk.bn_out >= 0 ? tok.goff : wsrc[k]);
+      const ConvIn cin = conv_input(n, dk, arena);
+      for (int g = 0; g < dk.ngroups; ++g) {
+        int rc;
+        {
+          Timed t(n, ws, 1, conv_flops(n, dk, tok) / dk.ngroups);
+          if (n->profile) n->prof_bytes[1] += conv_bytes(n, dk, tik, tok, true) / dk.ngroups;
+          rc = pxl_conv_wgrad(&opk.grp[g], cin.ptr, cin.sc, cin.sh, dyk, grads + dk.w_off[g], dk.cin, dk.cin, ws);
+        }
+        if (rc != PXL_OK) return rc;
+        if (dk.b_off[g] >= 0) {
+          rc = pxl_colsum(dt, Mk, tok.Cp, dk.cout, dyk, grads + dk.b_off[g], ws);
+          if (rc != PXL_OK) return rc;
+        }
+      }
+    }
+    pending_w.clear();
+    return PXL_OK;
+  };
   for (int i = (int)n->ops.size() - 1; i >= 0; --i) {
     OpInfo& op = n->ops[i];
     const pxl_op& d = op.d;
     int rc = PXL_OK;
+    if (d.kind != PXL_OP_CONV && d.kind != PXL_OP_RESIDUAL && d.kind != PXL_OP_INPUT) {
+      for (int t : {d.in0, d.in1, d.out}) { rc = settle(t); if (rc != PXL_OK) return rc; }
+    }
     switch (d.kind) {
       case PXL_OP_HEAD: {
         const TensorInfo& low = n->tensors[d.in0];
@@ -1161,6 +1256,26 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         const long nelem = (long)n->B * o.H * o.W * o.Cp;
         if (written[d.in0]) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net_backward: residual main branch consumed twice");
         const BnInfo& b3 = n->bns[d.bn_in0];
+        if (join_done[i]) {
+          // o's gradient buffer already holds the masked gradient and b3's sums are complete (the consumer's data
+          // gradient did it): both branches read it from there
+          gsrc[d.in0] = o.goff;
+          if (!written[d.in1]) {
+            gsrc[d.in1] = o.goff;
+            written[d.in1] = 1;
+          } else {
+            rc = settle(d.in1);
+            if (rc != PXL_OK) return rc;
+            rc = pxl_add_inplace(dt, nelem, at(scratch, r.goff), at(scratch, o.goff), stream);
+          }
+          reduced[d.bn_in0] = 1;
+          written[d.in0] = 1;
+          break;
+        }
+        rc = settle(d.out);
+        if (rc != PXL_OK) return rc;
+        rc = settle(d.in1);
+        if (rc != PXL_OK) return rc;
         if (!written[d.in1] && n->fuse_bn_reduce && b3.y_tensor == d.in0 && a.Cp == b3.d.C) {
           // relu mask + the main branch BN's backward sums in one pass
           rc = pxl_residual_bwd_reduce(dt, n->B * a.H * a.W, a.Cp, at(scratch, o.goff), at(arena, o.off), at(arena, a.off),
@@ -1195,13 +1310,16 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         if (!written[d.out]) return pxl_set_error(PXL_ERR_ARG, "net_backward: conv op %d output has no gradient", i);
         const int M = n->B * tout.H * tout.W;
         void* dy = at(scratch, tout.goff);
+        const void* dy_in = at(scratch, gsrc[d.out]);      // (a fused residual join leaves it in the join output's buffer)
+        if (d.bn_out < 0) dy = const_cast<void*>(dy_in);
+        wsrc[i] = gsrc[d.out];
         if (d.bn_out >= 0) {
           BnInfo& b = n->bns[d.bn_out];
           const float* coef = fat(arena, b.coef_off);
           // one [2C] vector per BN (the reduce kernel issues one atomic per channel per block, no replicas needed);
           // already filled when the consumer's data gradient ran with the fused reduction
           if (b.fused_reduce_op < 0 && !reduced[d.bn_out]) {
-            rc = pxl_bn_bwd_reduce(dt, M, tout.Cp, dy, at(arena, tout.off), coef, b.relu, fat(scratch, b.bsum_off), 1, stream);
+            rc = pxl_bn_bwd_reduce(dt, M, tout.Cp, dy_in, at(arena, tout.off), coef, b.relu, fat(scratch, b.bsum_off), 1, stream);
             if (rc != PXL_OK) return rc;
           }
           float* dgam = grads + b.d.gamma_off;
@@ -1215,44 +1333,43 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
             rc = n->sync(n->sync_user, fat(scratch, b.bsum_off), 2 * b.d.C, stream);
             if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_backward: SyncBN all-reduce hook failed (%d)", rc);
           }
-          rc = pxl_bn_bwd_apply_fused(dt, M, tout.Cp, dy, at(arena, tout.off), coef, fat(scratch, b.bsum_off),
+          rc = pxl_bn_bwd_apply_fused(dt, M, tout.Cp, dy_in, at(arena, tout.off), coef, fat(scratch, b.bsum_off),
                                       (float)b.M * n->world, training, b.relu, dgam, dbet, dy, stream);
           if (rc != PXL_OK) return rc;
         }
         const ConvIn cin = conv_input(n, d, arena);
         const float* sc = cin.sc; const float* sh = cin.sh;
-        hipStream_t ws = s;
-        if (n->use_side && d.need_dgrad && n->wgrad_on) {       // fork: dy is final on the main stream from here on
-          if (!n->fork_ev[i]) PXL_CHECK_HIP(hipEventCreateWithFlags(&n->fork_ev[i], hipEventDisableTiming));
-          PXL_CHECK_HIP(hipEventRecord(n->fork_ev[i], s));
-          PXL_CHECK_HIP(hipStreamWaitEvent(n->side, n->fork_ev[i], 0));
-          ws = n->side;
-          forked = true;
-        }
-        for (int g = 0; g < d.ngroups && n->wgrad_on; ++g) {
-          {
-            Timed t(n, ws, 1, conv_flops(n, d, tout) / d.ngroups);
-            if (n->profile) n->prof_bytes[1] += conv_bytes(n, d, tin, tout, true) / d.ngroups;
-            rc = pxl_conv_wgrad(&op.grp[g], cin.ptr, sc, sh, dy, grads + d.w_off[g], d.cin, d.cin, ws);
-          }
-          if (rc != PXL_OK) return rc;
-          if (d.b_off[g] >= 0) {
-            rc = pxl_colsum(dt, M, tout.Cp, d.cout, dy, grads + d.b_off[g], ws);
-            if (rc != PXL_OK) return rc;
-          }
+        // weight gradients: queued, and issued on the side stream in groups -- one fork event per `fork_every`
+        // convolutions instead of one per convolution (an event record between two kernels of the main stream costs a
+        // 6-7 us bubble there; dy buffers and activations stay valid until the end of the pass, so the weight gradients
+        // can start any time after their dy is final)
+        (void)sc; (void)sh;
+        if (n->wgrad_on) {
+          pending_w.push_back(i);
+          const bool now = !n->use_side || !d.need_dgrad || (int)pending_w.size() >= (n->fork_every < 1 ? 1 : n->fork_every);
+          if (now) { rc = issue_wgrads(i); if (rc != PXL_OK) return rc; }
         }
         if (d.need_dgrad) {
           void* din = at(scratch, tin.goff);
           Timed t(n, s, 0, conv_flops(n, d, tout));
           if (n->profile) n->prof_bytes[0] += conv_bytes(n, d, tin, tout, false);
-          if (d.bn_in0 >= 0 && n->bns[d.bn_in0].fused_reduce_op == i) {
+          const void* addend = written[d.in0] ? at(scratch, gsrc[d.in0]) : nullptr;
+          if (op.join_op >= 0) {
+            const pxl_op& dj = n->ops[op.join_op].d;
+            const BnInfo& b3 = n->bns[dj.bn_in0];
+            rc = pxl_conv_dgrad_joinreduce(&op.bwd, dy, at(packed, op.wt_off), din, addend, at(arena, tin.off),
+                                           at(arena, n->tensors[dj.in0].off), fat(arena, b3.coef_off),
+                                           fat(scratch, b3.bsum_off), stream);
+            join_done[op.join_op] = 1;
+          } else if (d.bn_in0 >= 0 && n->bns[d.bn_in0].fused_reduce_op == i) {
             const BnInfo& bi = n->bns[d.bn_in0];
-            rc = pxl_conv_dgrad_bnreduce(&op.bwd, dy, at(packed, op.wt_off), din, written[d.in0] ? din : nullptr,
+            rc = pxl_conv_dgrad_bnreduce(&op.bwd, dy, at(packed, op.wt_off), din, addend,
                                          at(arena, tin.off), fat(arena, bi.coef_off), bi.relu, fat(scratch, bi.bsum_off), stream);
           } else {
             rc = pxl_conv_igemm(&op.bwd, dy, at(packed, op.wt_off), din, nullptr, nullptr, nullptr,
-                                written[d.in0] ? din : nullptr, nullptr, nullptr, 0, stream);
+                                addend, nullptr, nullptr, 0, stream);
           }
+          gsrc[d.in0] = tin.goff;
           written[d.in0] = 1;
         }
         break;
@@ -1263,9 +1380,15 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
     if (rc != PXL_OK) return rc;
     // everything that writes gradients at or above op_lo[i] has now been issued
     if (bucketing && n->bucket_ok && n->grad_bucket > 0 && n->op_lo[i] >= 0 && grad_hi - n->op_lo[i] >= n->grad_bucket) {
+      rc = issue_wgrads(i);
+      if (rc != PXL_OK) return rc;
       rc = flush(n->op_lo[i]);
       if (rc != PXL_OK) return rc;
     }
+  }
+  {
+    int rc = issue_wgrads(0);                    // (only when the program does not end in a convolution without data gradient)
+    if (rc != PXL_OK) return rc;
   }
   if (bucketing) {                               // the rest of the buffer (or all of it when bucketing is off)
     int rc = flush(0);

@@ -57,6 +57,14 @@ def conv_dgrad_bnreduce(desc, dy, wt, din, bn_y, bn_coef, bn_relu, bn_sums, adde
     return din
 
 
+def conv_dgrad_joinreduce(desc, dy, wt, din, join_out, bn_y, bn_coef, bn_sums, addend=None):
+    """data gradient completing d(residual join output) + the join's backward (ReLU mask, bn3 sums) in its epilogue"""
+    _require_cuda(dy, wt, din, join_out, bn_y, bn_coef, bn_sums)
+    check(lib().pxl_conv_dgrad_joinreduce(desc, ptr(dy), ptr(wt), ptr(din), ptr(addend), ptr(join_out), ptr(bn_y),
+                                          ptr(bn_coef), ptr(bn_sums), stream_ptr()))
+    return din
+
+
 def conv_wgrad(desc, x, dy, dw, creal, dw_cpitch, in_scale=None, in_shift=None):
     _require_cuda(x, dy, dw)
     check(lib().pxl_conv_wgrad(desc, ptr(x), ptr(in_scale), ptr(in_shift), ptr(dy), ptr(dw), creal, dw_cpitch,

@@ -21,3 +21,10 @@ class CommonSSEGCriterion(criterion_template.TaskCriterion):
             logger.log_err('DeepLab criterion for semantic segmentation requires\t=>\t'
                            'len(pred) == 1 \t len(gt) == 1 \t len(inp) == 1\n')
         return PF.cross_entropy_per_sample(pred[0], gt[0], self.args.ignore_index)
+
+    def with_consistency(self, pred, gt, ce_values, target, lo, hi):
+        """Engine extension (not in the reference): this criterion on the first len(ce_values) samples of `pred` AND
+        nn.MSELoss()(pred[lo:hi], target[lo:hi]) with one fused backward; `ce_values` = self.forward(...) computed
+        under no_grad on the same samples.  SSL algorithms use it when the criterion offers it and fall back to the
+        two separate losses otherwise."""
+        return PF.task_consistency(pred[0], gt[0], ce_values, target, lo, hi, self.args.ignore_index)

@@ -67,11 +67,10 @@ class SSLMT(ssl_base._SSLBase):
 
     def _teacher_stream(self):
         if not hasattr(self, '_t_stream'):
-            import os
             on = os.environ.get('PXL_TEACHER_STREAM', '1') != '0' and torch.cuda.is_available()
-            # lowest priority: the teacher's no-grad forward only has to be done by the time the consistency loss is
-            # formed; the student's forward is the critical path (PXL_SIDE_PRIO=0: default priority)
-            prio = 0 if os.environ.get('PXL_SIDE_PRIO', '1') == '0' else 1
+            # PXL_TEACHER_PRIO=-1: high priority (the student waits for the teacher's logits before the consistency loss;
+            # in the traces the teacher pass ends 0.5 ms after the student's when both have the same priority)
+            prio = int(os.environ.get('PXL_TEACHER_PRIO', '0'))
             self._t_stream = torch.cuda.Stream(priority=prio) if on else None
         return self._t_stream
 
@@ -118,8 +117,19 @@ class SSLMT(ssl_base._SSLBase):
         s_resulter, _ = self.s_model.forward(s_inp)
         self._need_pred(s_resulter, 'SSL_MT')
         s_pred = tool.dict_value(s_resulter, 'pred')
-        s_task_loss = torch.mean(self.s_criterion.forward(func.split_tensor_tuple(s_pred, 0, lbs), l_gt,
-                                                          func.split_tensor_tuple(s_inp, 0, lbs)))
+        # fused task + consistency gradient (one launch writes d(pred) once) when the criterion pair allows it:
+        # CommonSSEGCriterion.with_consistency + the engine's MSELoss, a single `pred` tensor.  PXL_FUSE_MT_LOSS=0 disables
+        cons_range = (0, s_pred[0].shape[0]) if self.args.cons_for_labeled else \
+            ((lbs, s_pred[0].shape[0]) if self.args.unlabeled_batch_size > 0 else None)
+        fuse = (cons_range is not None and len(s_pred) == 1 and hasattr(self.s_criterion, 'with_consistency')
+                and type(self.cons_criterion) is MSELoss and os.environ.get('PXL_FUSE_MT_LOSS', '1') != '0')
+        if fuse:
+            with torch.no_grad():       # launched now: overlaps the tail of the teacher pass
+                ce_values = self.s_criterion.forward(func.split_tensor_tuple(s_pred, 0, lbs), l_gt,
+                                                     func.split_tensor_tuple(s_inp, 0, lbs))
+        else:
+            s_task_loss = torch.mean(self.s_criterion.forward(func.split_tensor_tuple(s_pred, 0, lbs), l_gt,
+                                                              func.split_tensor_tuple(s_inp, 0, lbs)))
         if side is not None:
             if fut is not None:
                 t_resulter, t_pred, t_task_loss = fut.result()
@@ -132,7 +142,10 @@ class SSLMT(ssl_base._SSLBase):
         else:
             t_resulter, t_pred, t_task_loss = teacher_pass()
         t_pseudo_gt = t_pred[0].detach()
-        if self.args.cons_for_labeled:
+        if fuse:
+            ce, cons_loss = self.s_criterion.with_consistency(s_pred, l_gt, ce_values, t_pseudo_gt, *cons_range)
+            s_task_loss = torch.mean(ce)
+        elif self.args.cons_for_labeled:
             cons_loss = self.cons_criterion(s_pred[0], t_pseudo_gt)
         elif self.args.unlabeled_batch_size > 0:
             cons_loss = self.cons_criterion(s_pred[0][lbs:, ...], t_pseudo_gt[lbs:, ...])

@@ -240,6 +240,42 @@ def test_conv_dgrad_with_fused_bn_backward_reduce(shape, cfg):
             assert rel_err(sums.cpu(), rs.cpu()) < 1e-4, (shape, cfg, relu, addend is not None)
 
 
+@pytest.mark.parametrize("cfg", [-1, 9, 10, 18, 20, 26])
+@pytest.mark.parametrize("shape", [(2, 128, 64, 17, 19, 1, 1, 0), (3, 64, 256, 9, 13, 1, 1, 0), (2, 256, 128, 12, 12, 3, 1, 1)])
+def test_conv_dgrad_with_fused_residual_join_backward(shape, cfg):
+    """pxl_conv_dgrad_joinreduce == pxl_conv_igemm (data gradient + addend) followed by pxl_residual_bwd_reduce: the stored
+    tensor is the ReLU-masked gradient (bit-identical) and the sums are bn3's [sum g, sum g * xhat]."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    B, Cin, Cout, H, W, k, d, p = shape
+    g = torch.Generator().manual_seed(B * 100 + Cin + k + 7)
+    w = qround(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype)
+    taps = ops.fwd_taps(k, k, d, p)
+    Ho, Wo = H + 2 * p - d * (k - 1), W + 2 * p - d * (k - 1)
+    dy = to_nhwc(qround(torch.randn(B, Cout, Ho, Wo, generator=g), dtype), Cout, dtype)
+    _, wt = pack_w(w, dtype, Cin, kp=Cout)
+    y = to_nhwc(qround(torch.randn(B, Cin, H, W, generator=g), dtype), Cin, dtype)            # bn3's input
+    out = to_nhwc(qround(torch.relu(torch.randn(B, Cin, H, W, generator=g)), dtype), Cin, dtype)    # the join's output
+    add = to_nhwc(qround(torch.randn(B, Cin, H, W, generator=g), dtype), Cin, dtype)
+    coef = torch.cat([torch.randn(Cin, generator=g) * 0.1, torch.rand(Cin, generator=g) + 0.5,
+                      torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3]).to(DEV)
+    bdesc = ops.conv_desc(dtype, B, Ho, Wo, Cout, H, W, Cin, Cin, [(-a, -b) for a, b in taps], out_stride=1, div=1, tile_cfg=cfg)
+    from pixelssl_amd._lib import lib, check, ptr, stream_ptr, dtype_code
+    for addend in (None, add):
+        full = torch.empty(B, H, W, Cin, device=DEV, dtype=dtype)
+        ops.conv_igemm(bdesc, dy, wt, full, addend=addend)
+        ref = torch.empty_like(full)
+        rs = torch.zeros(2 * Cin, device=DEV)
+        check(lib().pxl_residual_bwd_reduce(dtype_code(dtype), B * H * W, Cin, ptr(full), ptr(out), ptr(y), ptr(coef), ptr(ref),
+                                            None, ptr(rs), stream_ptr()))
+        got = torch.empty_like(full)
+        sums = torch.zeros(2 * Cin, device=DEV)
+        ops.conv_dgrad_joinreduce(bdesc, dy, wt, got, out, y, coef, sums, addend=addend)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref) and (got == 0).float().mean().item() > 0.3
+        assert rel_err(sums.cpu(), rs.cpu()) < 1e-4, (shape, cfg, addend is not None)
+
+
 WDMA_CASES = [
     # name, B, Cin, Cout, H, W, k, stride, dil, pad   (Cin % 128 == 0: conv_wgrad_dma.hip)
     ("wdma_1x1", 3, 256, 72, 9, 13, 1, 1, 1, 0),
@@ -604,6 +640,42 @@ def test_cross_entropy_and_mse_losses():
     torch.cuda.synchronize()
     assert abs(m.item() - r.item()) < 1e-5 * abs(r.item())
     assert rel_err(ad.grad.cpu(), a.grad) < 1e-5
+
+
+@pytest.mark.parametrize("rng", [(2, 5), (0, 5), (3, 3)], ids=["unlabeled-only", "all-samples", "no-consistency"])
+def test_fused_task_and_consistency_gradient_is_bit_identical(rng):
+    """PF.task_consistency (one backward launch) == CE on pred[:lbs] + MSE on pred[lo:hi] + autograd's slice padding and
+    sum: same loss values, bit-identical d(pred), odd sizes, ignore labels."""
+    from pixelssl_amd import functional as PF
+    g = torch.Generator().manual_seed(12)
+    N, C, H, W, lbs = 5, 21, 33, 29, 2
+    lo, hi = rng
+    pred = (torch.randn(N, C, H, W, generator=g) * 3).to(DEV)
+    target = (torch.randn(N, C, H, W, generator=g) * 3).to(DEV)
+    gt = torch.randint(0, C, (lbs, 1, H, W), generator=g).float()
+    gt[0, 0, :7] = 255.0
+    gt = gt.to(DEV)
+    scale = 0.37
+    a = pred.clone().requires_grad_(True)
+    task = PF.cross_entropy_per_sample(a[:lbs], gt, 255).mean()
+    cons = scale * PF.mse_loss(a[lo:hi], target[lo:hi]) if hi > lo else torch.zeros((), device=DEV)
+    (task + cons).backward()
+    b = pred.clone().requires_grad_(True)
+    with torch.no_grad():
+        ce_values = PF.cross_entropy_per_sample(b[:lbs], gt, 255)
+    ce, mse = PF.task_consistency(b, gt, ce_values, target, lo, hi, 255)
+    (ce.mean() + scale * mse).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(ce.detach(), ce_values) and abs(ce.mean().item() - task.item()) == 0
+    assert mse.item() == (cons.item() / scale if hi > lo else 0.0) or abs(mse.item() * scale - cons.item()) < 1e-7 * abs(cons.item())
+    assert torch.equal(a.grad, b.grad)
+    # only one of the two losses is differentiated
+    c = pred.clone().requires_grad_(True)
+    ce, mse = PF.task_consistency(c, gt, ce_values, target, lo, hi, 255)
+    ce.mean().backward()
+    d = pred.clone().requires_grad_(True)
+    PF.cross_entropy_per_sample(d[:lbs], gt, 255).mean().backward()
+    assert torch.equal(c.grad, d.grad)
 
 
 def test_sgd_and_ema_flat_updates():
