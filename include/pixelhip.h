@@ -367,6 +367,10 @@ int pxl_mse_bwd(long n, const float* a, const float* b, const float* gout, float
  * with FDGTGenerator.forward's abs/sum (ssl_algorithm/ssl_gct.py:715-716). */
 int pxl_absdiff_chansum(int B, int C, long HW, const float* pred, const float* gt, int ignore_index, float mu,
                         float* out, void* stream);
+/* ... against a dense target gt [B][C][HW] (the explicit one-hot of the reference's task hook): FDGTGenerator's
+ * `torch.sum(torch.abs(gt - pred), dim=1, keepdim=True) * mu`, ssl_gct.py:703. */
+int pxl_absdiff_chansum_dense(int B, int C, long HW, const float* pred, const float* gt, float mu, float* out,
+                              void* stream);
 /* explicit one-hot [B][C][HW] with ignored pixels all-zero (task/sseg/func.py:159-168, 179-192) */
 int pxl_onehot_ignore(int B, int C, long HW, const float* gt, int ignore_index, float* out, void* stream);
 /* GaussianBlurLayer (nn/module/gaussian_blur.py:31-61) of single-channel maps: separable evaluation of the rank-1
@@ -514,6 +518,26 @@ int pxl_net_seed_latent_grad(pxl_net* net, void* scratch, size_t scratch_bytes, 
 /* gradient w.r.t. the network input of the last backward (NCHW fp32 [B,Cin,H,W]); the first convolution of the
  * program must have need_dgrad = 1 (discriminator / flaw detector: the input is the task model's softmax) */
 int pxl_net_input_grad(pxl_net* net, const void* scratch, float* dx, void* stream);
+
+/* Concatenation on load (FlawDetector.forward: torch.cat((inp, pred), dim=1), ssl_gct.py:578): the NEXT pxl_net_forward
+ * gathers its input from `nparts` (<= 4) NCHW fp32 tensors of chans[k] channels each instead of `x` (which may then be
+ * NULL); cleared by that pass.  pxl_net_input_grad_parts writes the input gradient as one NCHW tensor per part
+ * (dsts[k] == NULL: not needed) -- what autograd's cat-backward + .contiguous() would produce. */
+int pxl_net_set_input_parts(pxl_net* net, int nparts, const float* const* srcs, const int* chans);
+int pxl_net_input_grad_parts(pxl_net* net, const void* scratch, int nparts, float* const* dsts, const int* chans,
+                             void* stream);
+/* Stem patches: im2col of a few-channel NCHW fp32 input, P[(b, oy, ox)][(ky*kw + kx)*C + c] (zero outside the image and
+ * for k >= kh*kw*C; row pitch Kp, a multiple of 8) in the engine dtype.  With them the 7x7 / stride-2 / 3-channel stem
+ * (resnet.py:100-101 `conv1`) is a 1x1 convolution over Kp channels for the LDS-DMA kernels, forward and weight gradient;
+ * the k order equals the master weight layout [Cout][kh][kw][C].  pxl_net uses it for a first convolution that needs no
+ * data gradient (bf16 engine; PXL_STEM_PATCHES=0 keeps the gathering kernel). */
+int pxl_stem_patches(int dtype, const float* x, void* P, int B, int C, int H, int W, int kh, int kw, int stride, int pad,
+                     int Ho, int Wo, int Kp, void* stream);
+/* the two data movements behind them (NCHW fp32 parts <-> NHWC engine tensor with channel pitch Cp) */
+int pxl_nchw_parts_to_nhwc(int dtype, int nparts, const float* const* srcs, const int* chans, void* y, int B, int H,
+                           int W, int Cp, void* stream);
+int pxl_nhwc_to_nchw_parts(int dtype, const void* x, int nparts, float* const* dsts, const int* chans, int B, int H,
+                           int W, int Cp, void* stream);
 /* enable = 0: pxl_net_pack skips the transposed (data-gradient) weight copies -- networks that only run forward (the
  * Mean-Teacher teacher); pxl_net_backward then refuses to run */
 int pxl_net_set_pack_dgrad(pxl_net* net, int enable);

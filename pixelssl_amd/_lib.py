@@ -139,6 +139,7 @@ SIGNATURES = {
     "pxl_mse_fwd": (_I, [_L, _P, _P, _P, _P]),
     "pxl_mse_bwd": (_I, [_L, _P, _P, _P, _P, _P]),
     "pxl_absdiff_chansum": (_I, [_I, _I, _L, _P, _P, _I, _F, _P, _P]),
+    "pxl_absdiff_chansum_dense": (_I, [_I, _I, _L, _P, _P, _F, _P, _P]),
     "pxl_onehot_ignore": (_I, [_I, _I, _L, _P, _I, _P, _P]),
     "pxl_gauss_sep_reflect": (_I, [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "pxl_clamp_min0_inplace": (_I, [_L, _P, _P]),
@@ -180,6 +181,11 @@ SIGNATURES = {
     "pxl_net_tensor_bytes": (_Z, [_P, _I]),
     "pxl_net_tensor_shape": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "pxl_net_input_grad": (_I, [_P, _P, _P, _P]),
+    "pxl_net_set_input_parts": (_I, [_P, _I, _P, _P]),
+    "pxl_net_input_grad_parts": (_I, [_P, _P, _I, _P, _P, _P]),
+    "pxl_stem_patches": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "pxl_nchw_parts_to_nhwc": (_I, [_I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "pxl_nhwc_to_nchw_parts": (_I, [_I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
     "pxl_net_seed_latent_grad": (_I, [_P, _P, _Z, _P, _P]),
     "pxl_net_set_wgrad": (_I, [_P, _I]),
     "pxl_net_set_pack_dgrad": (_I, [_P, _I]),

@@ -37,6 +37,21 @@ __global__ void absdiff_chansum_kernel(int B, int C, long HW, const float* __res
   }
 }
 
+// the same against a dense target [B][C][HW] (the one-hot tensor the reference's task hook builds, or a regression target):
+// torch.sum(torch.abs(gt - pred), dim=1) * mu with torch's channel order of summation (ssl_gct.py:703)
+__global__ void absdiff_chansum_dense_kernel(int B, int C, long HW, const float* __restrict__ pred,
+                                             const float* __restrict__ gt, float mu, float* __restrict__ out) {
+  const long total = (long)B * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / HW, p = i - b * HW;
+    const float* pp = pred + b * C * HW + p;
+    const float* gg = gt + b * C * HW + p;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += fabsf(gg[(long)c * HW] - pp[(long)c * HW]);
+    out[i] = s * mu;
+  }
+}
+
 // explicit one-hot tensor [B][C][HW] (ssladv / sslgct task hooks): 1 at the label's class, 0 for ignored pixels
 __global__ void onehot_kernel(int B, int C, long HW, const float* __restrict__ gt, int ignore, float* __restrict__ out) {
   const long total = (long)B * C * HW;
@@ -207,6 +222,15 @@ extern "C" int pxl_absdiff_chansum(int B, int C, long HW, const float* pred, con
   PXL_REQUIRE(pred && gt && out && B > 0 && C > 0 && HW > 0, "absdiff_chansum: bad argument");
   hipLaunchKernelGGL(absdiff_chansum_kernel, dim3(g1((long)B * HW)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      B, C, HW, pred, gt, ignore_index, mu, out);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_absdiff_chansum_dense(int B, int C, long HW, const float* pred, const float* gt, float mu, float* out,
+                                         void* stream) {
+  PXL_REQUIRE(pred && gt && out && B > 0 && C > 0 && HW > 0, "absdiff_chansum_dense: bad argument");
+  hipLaunchKernelGGL(absdiff_chansum_dense_kernel, dim3(g1((long)B * HW)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     B, C, HW, pred, gt, mu, out);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

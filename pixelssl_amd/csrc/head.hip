@@ -77,12 +77,19 @@ __global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(int C, int H, in
                                                                 const float* __restrict__ dprob,
                                                                 const float* __restrict__ prob,
                                                                 float* __restrict__ tmp) {
-  extern __shared__ float g[];   // [C][W+1]
+  extern __shared__ float g[];   // [C][W+1], then per full-res column: i0, i1 (int) and l1 (float)
   const int y = blockIdx.x, b = blockIdx.y;
   const size_t plane = (size_t)H * W;
   const size_t base = (size_t)b * C * plane + (size_t)y * W;
   const int ld = W + 1;
+  int* ci0 = reinterpret_cast<int*>(g + (size_t)C * ld);
+  int* ci1 = ci0 + W;
+  float* cl1 = reinterpret_cast<float*>(ci1 + W);
   for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    int i0, i1;
+    float l1;
+    src_coord(x, sx, align, w, i0, i1, l1);      // once per column (the reduction below used to redo it 2 * C times)
+    ci0[x] = i0; ci1[x] = i1; cl1[x] = l1;
     float dot = 0.f;
     if (dprob != nullptr) {
       for (int c = 0; c < C; ++c) dot += dprob[base + c * plane + x] * prob[base + c * plane + x];
@@ -105,12 +112,10 @@ __global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(int C, int H, in
     if (xhi > W - 1) xhi = W - 1;
     float acc = 0.f;
     for (int x = xlo; x <= xhi; ++x) {
-      int i0, i1;
-      float l1;
-      src_coord(x, sx, align, w, i0, i1, l1);
+      const float l1 = cl1[x];
       float wgt = 0.f;
-      if (i0 == x0) wgt += 1.f - l1;
-      if (i1 == x0) wgt += l1;
+      if (ci0[x] == x0) wgt += 1.f - l1;
+      if (ci1[x] == x0) wgt += l1;
       acc += wgt * g[c * ld + x];
     }
     tmp[(((size_t)b * H + y) * w + x0) * C + c] = acc;
@@ -192,7 +197,7 @@ extern "C" int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, 
   const float sy = align ? (float)(h - 1) / (float)(H - 1) : (float)h / (float)H;
   const float sx = align ? (float)(w - 1) / (float)(W - 1) : (float)w / (float)W;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const size_t smem = (size_t)C * (W + 1) * sizeof(float);
+  const size_t smem = (size_t)C * (W + 1) * sizeof(float) + (size_t)W * 3 * sizeof(float);
   PXL_REQUIRE(smem <= 64 * 1024, "upsample_softmax_bwd: row too wide for LDS staging (W=%d)", W);
   hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(H, B), dim3(256), smem, s, C, H, W, w, sx, align, dlogits, dprob,
                      prob, (float*)workspace);

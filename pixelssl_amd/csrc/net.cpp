@@ -31,6 +31,12 @@ int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, const void* 
 int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
                               const void* join_out, const void* bn_y, const float* bn_coef, float* bn_sums, void* stream);
 int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream);
+int pxl_stem_patches(int dtype, const float* x, void* P, int B, int C, int H, int W, int kh, int kw, int stride, int pad,
+                     int Ho, int Wo, int Kp, void* stream);
+int pxl_nchw_parts_to_nhwc(int dtype, int nparts, const float* const* srcs, const int* chans, void* y, int B, int H, int W,
+                           int Cp, void* stream);
+int pxl_nhwc_to_nchw_parts(int dtype, const void* x, int nparts, float* const* dsts, const int* chans, int B, int H, int W,
+                           int Cp, void* stream);
 int pxl_residual_bwd_reduce(int dtype, int M, int C, const void* dout, const void* out, const void* y, const float* coef,
                             void* g, void* g2, float* sums, void* stream);
 int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_scale, const void* workspace);
@@ -94,6 +100,12 @@ struct OpInfo {
   // CONV: this op's data gradient is the last contribution to the gradient of residual join `join_op`'s output and
   // performs that join's backward in its epilogue; RESIDUAL: the convolution that does it (-1 = separate launch)
   int join_op = -1, join_conv = -1;
+  // stem in patch mode (bf16 engine): the convolution reads the network input, has few input channels and needs no data
+  // gradient -> its im2col patches [M][patch_Kp] are written once per forward (arena) and the convolution runs as a 1x1
+  // convolution over patch_Kp channels on the LDS-DMA kernels, forward and weight gradient
+  bool patch = false;
+  size_t patch_off = 0;
+  int patch_K = 0, patch_Kp = 0;
 };
 
 }  // namespace
@@ -125,7 +137,12 @@ struct pxl_net {
   // backward runs the weight gradients on a second stream, concurrently with the data gradients (both only read
   // dy): the contraction kernels of this network are ~1 workgroup per CU and latency-bound, two in flight fill
   // each other's bubbles.  Created lazily; PXL_SIDE_STREAM=0 disables it.
-  int fork_every = getenv("PXL_FORK_EVERY") ? atoi(getenv("PXL_FORK_EVERY")) : 3;   // convolutions per fork event (>= 1)
+  bool stem_patches = getenv("PXL_STEM_PATCHES") == nullptr || getenv("PXL_STEM_PATCHES")[0] != '0';
+  bool input_needed = true;              // some op reads the NHWC copy of the input (false: only patch-mode convolutions)
+  int in_parts = 0;                      // > 0: the next forward gathers its input from these tensors
+  const float* in_src[4] = {nullptr, nullptr, nullptr, nullptr};
+  int in_chans[4] = {0, 0, 0, 0};
+  int fork_every = getenv("PXL_FORK_EVERY") ? atoi(getenv("PXL_FORK_EVERY")) : 1;   // convolutions per fork event (>= 1)
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
@@ -224,9 +241,11 @@ struct Timed {
 // operand a convolution (forward and weight gradient) reads: the raw tensor, the materialised relu(bn(y)),
 // or the raw tensor + the fused (scale, shift) prologue
 struct ConvIn { const void* ptr; const float* sc; const float* sh; };
-inline ConvIn conv_input(const pxl_net* n, const pxl_op& d, const void* arena) {
+inline ConvIn conv_input(const pxl_net* n, const OpInfo& op, const void* arena) {
+  const pxl_op& d = op.d;
   const TensorInfo& tin = n->tensors[d.in0];
   const unsigned char* base = reinterpret_cast<const unsigned char*>(arena);
+  if (op.patch) return {base + op.patch_off, nullptr, nullptr};
   if (d.bn_in0 < 0) return {base + tin.off, nullptr, nullptr};
   const BnInfo& b = n->bns[d.bn_in0];
   if (b.has_z) return {base + b.z_off, nullptr, nullptr};
@@ -411,7 +430,22 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
         int rc = build_conv_descs(n, op, n->tensors[d.in0], n->tensors[d.out]);
         if (rc != PXL_OK) return rc;
         const TensorInfo& tout = n->tensors[d.out];
-        op.wf_off = packed; packed += align_up((size_t)d.cout * op.ntaps * tin.Cp * n->esize);
+        op.patch = false;
+        if (n->stem_patches && n->dtype == PXL_BF16 && d.in0 == n->input_tensor && !d.need_dgrad && d.ngroups == 1 &&
+            d.bn_in0 < 0 && d.kh * d.kw > 1 && d.cin * d.kh * d.kw <= 256 && tout.Cp % 8 == 0) {
+          op.patch = true;
+          op.patch_K = d.cin * d.kh * d.kw;
+          op.patch_Kp = (op.patch_K + 63) / 64 * 64;
+          op.patch_off = arena; arena += align_up((size_t)B * ho * wo * op.patch_Kp * n->esize);
+          pxl_conv_desc f = op.fwd;
+          f.Hi = ho; f.Wi = wo; f.Cin = op.patch_Kp; f.ntaps = 1; f.out_stride = 1; f.div = 1; f.relu_in = 0;
+          f.dy[0] = f.dx[0] = 0;
+          op.fwd = f;
+          op.grp[0] = f;
+          op.wf_off = packed; packed += align_up((size_t)d.cout * op.patch_Kp * n->esize);
+        } else {
+          op.wf_off = packed; packed += align_up((size_t)d.cout * op.ntaps * tin.Cp * n->esize);
+        }
         if (d.need_dgrad) { op.wt_off = packed; packed += align_up((size_t)tin.Cp * op.ntaps * tout.Cp * n->esize); }
         if (d.b_off[0] >= 0) { op.bias_off = packed; packed += align_up((size_t)d.cout * 4); }
         if (d.bn_out < 0 && tout.Cp <= 32) {     // few output tiles + long reduction: allow split-K
@@ -573,6 +607,12 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
       b.fused_reduce_op = (int)i;
     }
   }
+  n->input_needed = false;
+  for (auto& op : n->ops) {
+    const pxl_op& d = op.d;
+    if (d.kind == PXL_OP_INPUT) continue;
+    if ((d.in0 == n->input_tensor && !(d.kind == PXL_OP_CONV && op.patch)) || d.in1 == n->input_tensor) n->input_needed = true;
+  }
   // residual joins whose backward runs in the epilogue of the data gradient that completes d(join output): that
   // convolution must be the FIRST consumer of the output in program order (= the last contribution in the backward
   // pass), read it as a plain operand and run on the LDS-DMA kernel; every other consumer must be a convolution or the
@@ -656,6 +696,7 @@ extern "C" int pxl_net_pack_parts(pxl_net* n, const float* params, void* packed,
       it.wt_off = want_t ? (int64_t)op.wt_off : -1;
       it.K = d.cout; it.T = tpg; it.C = d.cin;
       it.Cp = tin.Cp; it.T_total = op.ntaps; it.t_off = g * tpg; it.Kp = tout.Cp;
+      if (op.patch) { it.T = 1; it.C = op.patch_K; it.Cp = op.patch_Kp; it.T_total = 1; it.t_off = 0; }   // master [Cout][kh*kw*C] as is
       items.push_back(it);
     }
     if ((which & 1) && d.b_off[0] >= 0) {
@@ -710,7 +751,7 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
     if (d.kind != PXL_OP_CONV) continue;
     const TensorInfo& tin = n->tensors[d.in0];
     const TensorInfo& tout = n->tensors[d.out];
-    const ConvIn cin = conv_input(n, d, arena);
+    const ConvIn cin = conv_input(n, op, arena);
     const float* sc = cin.sc; const float* sh = cin.sh;
     float* stats = d.bn_out >= 0 ? fat(arena, n->bns[d.bn_out].stats_off) : nullptr;
     const float* bias = d.b_off[0] >= 0 ? fat(packed, op.bias_off) : nullptr;
@@ -756,8 +797,9 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
         if (cfg == 2 && d.cout > 64) continue;
         if (cfg >= 3 && cfg < 8) continue;
         pxl_conv_desc q = op.grp[g]; q.tile_cfg = cfg;
+        const int creal = op.patch ? op.patch_K : d.cin;
         float t = time_launch([&]() { return pxl_conv_wgrad(&q, cin.ptr, sc, sh, at(scratch, tout.goff),
-                                                            grads + d.w_off[g], d.cin, d.cin, stream); }, s, a, b, reps);
+                                                            grads + d.w_off[g], creal, creal, stream); }, s, a, b, reps);
         if (t < 0) { rc_all = PXL_ERR_HIP; continue; }
         if (t < best) { best = t; best_cfg = cfg; }
       }
@@ -792,7 +834,7 @@ pxl_bn_fin make_fin(const pxl_net* n, const BnInfo& b, const float* params, floa
 extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* packed, float* running,
                                const float* x, float* logits, float* prob, void* arena, size_t arena_bytes,
                                int training, void* stream) {
-  PXL_REQUIRE(n && n->planned && params && packed && x && logits && arena, "net_forward: bad argument (plan first)");
+  PXL_REQUIRE(n && n->planned && params && packed && (x || n->in_parts > 0) && logits && arena, "net_forward: bad argument (plan first)");
   if (arena_bytes < n->arena_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_forward: arena too small (%zu < %zu)", arena_bytes, n->arena_bytes);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (training && n->stats_region_bytes)
@@ -805,17 +847,32 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
     switch (d.kind) {
       case PXL_OP_INPUT: {
         const TensorInfo& t = n->tensors[d.out];
-        rc = pxl_nchw_to_nhwc(dt, x, at(arena, t.off), n->B, t.C, t.H, t.W, t.Cp, stream);
+        if (!n->input_needed && n->in_parts == 0) break;      // only patch-mode convolutions read the input: from `x` directly
+        if (n->in_parts > 0) {
+          int C = 0;
+          for (int k = 0; k < n->in_parts; ++k) C += n->in_chans[k];
+          if (C != t.C) return pxl_set_error(PXL_ERR_ARG, "net_forward: input parts hold %d channels, the program expects %d", C, t.C);
+          rc = pxl_nchw_parts_to_nhwc(dt, n->in_parts, n->in_src, n->in_chans, at(arena, t.off), n->B, t.H, t.W, t.Cp, stream);
+          n->in_parts = 0;
+        } else {
+          rc = pxl_nchw_to_nhwc(dt, x, at(arena, t.off), n->B, t.C, t.H, t.W, t.Cp, stream);
+        }
         break;
       }
       case PXL_OP_CONV: {
         const TensorInfo& tin = n->tensors[d.in0];
         const TensorInfo& tout = n->tensors[d.out];
-        const ConvIn cin = conv_input(n, d, arena);
+        const ConvIn cin = conv_input(n, op, arena);
         const float* sc = cin.sc; const float* sh = cin.sh;
         float* stats = (d.bn_out >= 0 && training) ? fat(arena, n->bns[d.bn_out].stats_off) : nullptr;
         const float* bias = d.b_off[0] >= 0 ? fat(packed, op.bias_off) : nullptr;
         bool fin_by_conv = false;
+        if (op.patch) {
+          if (x == nullptr) return pxl_set_error(PXL_ERR_ARG, "net_forward: the patch-mode stem reads ONE NCHW input tensor");
+          rc = pxl_stem_patches(dt, x, at(arena, op.patch_off), n->B, d.cin, tin.H, tin.W, d.kh, d.kw, d.stride, d.pads[0],
+                                tout.H, tout.W, op.patch_Kp, stream);
+          if (rc != PXL_OK) return rc;
+        }
         {
           Timed t(n, s, 0, conv_flops(n, d, tout));
           if (n->profile) n->prof_bytes[0] += conv_bytes(n, d, tin, tout, false);
@@ -974,6 +1031,26 @@ extern "C" int pxl_net_set_pack_dgrad(pxl_net* net, int enable) {
   PXL_REQUIRE(net, "net_set_pack_dgrad: null net");
   net->pack_dgrad = enable != 0;
   return PXL_OK;
+}
+
+// The next forward pass gathers its input from `nparts` NCHW fp32 tensors concatenated along the channels (FlawDetector:
+// image + task prediction, ssl_gct.py:578) instead of one tensor; cleared by that pass.
+extern "C" int pxl_net_set_input_parts(pxl_net* n, int nparts, const float* const* srcs, const int* chans) {
+  PXL_REQUIRE(n && nparts >= 0 && nparts <= 4 && (nparts == 0 || (srcs && chans)), "net_set_input_parts: bad argument");
+  n->in_parts = nparts;
+  for (int k = 0; k < nparts; ++k) { n->in_src[k] = srcs[k]; n->in_chans[k] = chans[k]; }
+  return PXL_OK;
+}
+
+// input gradient split into one NCHW tensor per concatenated part (NULL = not needed)
+extern "C" int pxl_net_input_grad_parts(pxl_net* n, const void* scratch, int nparts, float* const* dsts, const int* chans,
+                                        void* stream) {
+  PXL_REQUIRE(n && n->planned && scratch && dsts && chans && n->input_tensor >= 0, "net_input_grad_parts: bad argument");
+  const TensorInfo& t = n->tensors[n->input_tensor];
+  int C = 0;
+  for (int k = 0; k < nparts; ++k) C += chans[k];
+  PXL_REQUIRE(C == t.C, "net_input_grad_parts: parts hold %d channels, the input has %d", C, t.C);
+  return pxl_nhwc_to_nchw_parts(n->dtype, at(scratch, t.goff), nparts, dsts, chans, n->B, t.H, t.W, t.Cp, stream);
 }
 
 extern "C" int pxl_net_input_grad(pxl_net* n, const void* scratch, float* dx, void* stream) {
@@ -1143,13 +1220,14 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
       const TensorInfo& tok = n->tensors[dk.out];
       const int Mk = n->B * tok.H * tok.W;
       const void* dyk = at(scratch, dk.bn_out >= 0 ? tok.goff : wsrc[k]);
-      const ConvIn cin = conv_input(n, dk, arena);
+      const ConvIn cin = conv_input(n, opk, arena);
       for (int g = 0; g < dk.ngroups; ++g) {
         int rc;
         {
           Timed t(n, ws, 1, conv_flops(n, dk, tok) / dk.ngroups);
           if (n->profile) n->prof_bytes[1] += conv_bytes(n, dk, tik, tok, true) / dk.ngroups;
-          rc = pxl_conv_wgrad(&opk.grp[g], cin.ptr, cin.sc, cin.sh, dyk, grads + dk.w_off[g], dk.cin, dk.cin, ws);
+          const int creal = opk.patch ? opk.patch_K : dk.cin;       // (patch mode: dw[Cout][1][kh*kw*C] = the master layout)
+          rc = pxl_conv_wgrad(&opk.grp[g], cin.ptr, cin.sc, cin.sh, dyk, grads + dk.w_off[g], creal, creal, ws);
         }
         if (rc != PXL_OK) return rc;
         if (dk.b_off[g] >= 0) {
@@ -1337,12 +1415,13 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
                                       (float)b.M * n->world, training, b.relu, dgam, dbet, dy, stream);
           if (rc != PXL_OK) return rc;
         }
-        const ConvIn cin = conv_input(n, d, arena);
+        const ConvIn cin = conv_input(n, op, arena);
         const float* sc = cin.sc; const float* sh = cin.sh;
-        // weight gradients: queued, and issued on the side stream in groups -- one fork event per `fork_every`
-        // convolutions instead of one per convolution (an event record between two kernels of the main stream costs a
-        // 6-7 us bubble there; dy buffers and activations stay valid until the end of the pass, so the weight gradients
-        // can start any time after their dy is final)
+        // weight gradients: queued, and issued on the side stream in groups of `fork_every` convolutions (PXL_FORK_EVERY,
+        // default 1).  An event record between two kernels of the main stream costs a 6-7 us bubble there, and dy buffers
+        // and activations stay valid until the end of the pass, so the weight gradients could start later in larger
+        // groups -- measured (MT 8x513x513, 20 steps): 1 -> 14.04 ms, 3 -> 14.2, 6 -> 14.2: the earlier start of the
+        // weight gradients is worth more than the saved bubbles
         (void)sc; (void)sh;
         if (n->wgrad_on) {
           pending_w.push_back(i);

@@ -116,6 +116,84 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
   }
 }
 
+// Stem patches (im2col of a few-channel input, once per forward): x NCHW fp32 [B][C][H][W] -> P [B*Ho*Wo][Kp] in the
+// engine dtype, P[m][(ky*kw + kx)*C + c] = x[b][c][oy*stride - pad + ky][ox*stride - pad + kx] (0 outside the image and
+// for k >= kh*kw*C).  The 7x7 / stride-2 / 3-channel stem then IS a 1x1 convolution over Kp = 192 channels for the
+// LDS-DMA kernels (forward and weight gradient); the k order equals the master weight layout [Cout][kh][kw][C].
+template <typename T>
+__global__ __launch_bounds__(256) void stem_patches_kernel(const float* __restrict__ x, T* __restrict__ P, int B, int C, int H,
+                                                           int W, int kh, int kw, int stride, int pad, int Ho, int Wo, int Kp) {
+  const int K = kh * kw * C;
+  const int chunks = Kp / 8;
+  const long total = (long)B * Ho * Wo * chunks;
+  const long plane = (long)H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % chunks);
+    const long m = i / chunks;
+    const int ox = (int)(m % Wo);
+    const int oy = (int)((m / Wo) % Ho);
+    const long b = m / ((long)Wo * Ho);
+    const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
+    float v[8];
+    int k = ch * 8;
+    int tap = k / C, c = k - tap * C;
+    int ky = tap / kw, kx = tap - ky * kw;
+#pragma unroll
+    for (int e = 0; e < 8; ++e, ++k) {
+      float f = 0.f;
+      if (k < K) {
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) f = x[(b * C + c) * plane + (long)iy * W + ix];
+      }
+      v[e] = f;
+      if (++c == C) { c = 0; if (++kx == kw) { kx = 0; ++ky; } }
+    }
+    T* dst = P + m * Kp + ch * 8;
+    if constexpr (sizeof(T) == 2) {
+      *reinterpret_cast<uint4*>(dst) = Chunk<bf16_t>::pack(v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[e] = from_f<T>(v[e]);
+    }
+  }
+}
+
+// the same with the channels gathered from up to 4 NCHW tensors (concatenation along C on load: no torch.cat copy)
+struct NchwParts { const float* src[4]; int chans[4]; int n; };
+template <typename T>
+__global__ void nchw_parts_to_nhwc_kernel(const NchwParts ps, T* __restrict__ y, int B, int H, int W, int Cp) {
+  const long HW = (long)H * W, total = (long)B * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long hw = i % HW, b = i / HW;
+    int c = 0;
+    for (int k = 0; k < ps.n; ++k)
+      for (int cc = 0; cc < ps.chans[k]; ++cc, ++c) y[i * Cp + c] = from_f<T>(ps.src[k][(b * ps.chans[k] + cc) * HW + hw]);
+    for (; c < Cp; ++c) y[i * Cp + c] = from_f<T>(0.f);
+  }
+}
+// NHWC gradient -> one NCHW fp32 tensor per part (NULL = that part needs none), 32 x 32 tiles through LDS
+struct NchwOutParts { float* dst[4]; int chans[4]; int n; };
+template <typename T>
+__global__ void nhwc_to_nchw_parts_kernel(const T* __restrict__ x, const NchwOutParts ps, int C, int HW, int Cp) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    tile[r][tx] = (p < HW && c < C) ? to_f(x[((long)b * HW + p) * Cp + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int c = c0 + r;
+    const int p = p0 + tx;
+    if (c >= C || p >= HW) continue;
+    int k = 0;
+    while (k < ps.n && c >= ps.chans[k]) { c -= ps.chans[k]; ++k; }
+    if (k < ps.n && ps.dst[k] != nullptr) ps.dst[k][((long)b * ps.chans[k] + c) * HW + p] = tile[tx][r];
+  }
+}
+
 // NHWC [B][H][W][Cp] (first C channels) -> NCHW fp32, tiled through LDS (32 pixels x 32 channels)
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int C, int HW, int Cp) {
@@ -229,6 +307,74 @@ extern "C" int pxl_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16_t*)y, B, C, H, W, Cp);
   else
     return pxl_set_error(PXL_ERR_ARG, "nchw_to_nhwc: bad dtype %d", dtype);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_stem_patches(int dtype, const float* x, void* P, int B, int C, int H, int W, int kh, int kw, int stride,
+                                int pad, int Ho, int Wo, int Kp, void* stream) {
+  PXL_REQUIRE(x && P && B > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && Ho > 0 && Wo > 0, "stem_patches: bad argument");
+  PXL_REQUIRE(Kp % 8 == 0 && Kp >= kh * kw * C, "stem_patches: pitch %d does not hold %d x %d x %d", Kp, kh, kw, C);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)B * Ho * Wo * (Kp / 8);
+  int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(stem_patches_kernel<float>, dim3(grid), dim3(256), 0, s, x, (float*)P, B, C, H, W, kh, kw, stride, pad, Ho,
+                       Wo, Kp);
+  else if (dtype == PXL_BF16)
+    hipLaunchKernelGGL(stem_patches_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, (bf16_t*)P, B, C, H, W, kh, kw, stride, pad,
+                       Ho, Wo, Kp);
+  else
+    return pxl_set_error(PXL_ERR_ARG, "stem_patches: bad dtype %d", dtype);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_nchw_parts_to_nhwc(int dtype, int nparts, const float* const* srcs, const int* chans, void* y, int B,
+                                     int H, int W, int Cp, void* stream) {
+  PXL_REQUIRE(srcs && chans && y && nparts >= 1 && nparts <= 4, "nchw_parts_to_nhwc: bad argument");
+  NchwParts ps;
+  ps.n = nparts;
+  int C = 0;
+  for (int k = 0; k < 4; ++k) {
+    ps.src[k] = k < nparts ? srcs[k] : nullptr;
+    ps.chans[k] = k < nparts ? chans[k] : 0;
+    if (k < nparts) { PXL_REQUIRE(srcs[k] && chans[k] > 0, "nchw_parts_to_nhwc: empty part %d", k); C += chans[k]; }
+  }
+  PXL_REQUIRE(Cp >= C, "nchw_parts_to_nhwc: %d channels do not fit the pitch %d", C, Cp);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)B * H * W;
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(nchw_parts_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, ps, (float*)y, B, H, W, Cp);
+  else if (dtype == PXL_BF16)
+    hipLaunchKernelGGL(nchw_parts_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, ps, (bf16_t*)y, B, H, W, Cp);
+  else
+    return pxl_set_error(PXL_ERR_ARG, "nchw_parts_to_nhwc: bad dtype %d", dtype);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_nhwc_to_nchw_parts(int dtype, const void* x, int nparts, float* const* dsts, const int* chans, int B,
+                                      int H, int W, int Cp, void* stream) {
+  PXL_REQUIRE(x && dsts && chans && nparts >= 1 && nparts <= 4, "nhwc_to_nchw_parts: bad argument");
+  NchwOutParts ps;
+  ps.n = nparts;
+  int C = 0;
+  for (int k = 0; k < 4; ++k) {
+    ps.dst[k] = k < nparts ? dsts[k] : nullptr;
+    ps.chans[k] = k < nparts ? chans[k] : 0;
+    if (k < nparts) { PXL_REQUIRE(chans[k] > 0, "nhwc_to_nchw_parts: empty part %d", k); C += chans[k]; }
+  }
+  PXL_REQUIRE(Cp >= C, "nhwc_to_nchw_parts: %d channels exceed the pitch %d", C, Cp);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int HW = H * W;
+  dim3 grid(cdiv(HW, 32), cdiv(C, 32), B);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_parts_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ps, C, HW, Cp);
+  else if (dtype == PXL_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_parts_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ps, C, HW, Cp);
+  else
+    return pxl_set_error(PXL_ERR_ARG, "nhwc_to_nchw_parts: bad dtype %d", dtype);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

@@ -539,9 +539,15 @@ class SegNetCore(nn.Module):
                 check(lib().pxl_net_set_wgrad(pl.net, int(bool(enable))))
             self._wgrad_on = bool(enable)
 
-    def _forward_raw(self, x, arena, want_prob=None):
+    def _forward_raw(self, x, arena, want_prob=None, parts=None):
+        """`parts`: NCHW tensors whose channel concatenation is the input (gathered by the input op itself: no torch.cat
+        copy); `x` is then parts[0]."""
         if self.keep_arena:
             self._last_arena = arena
+        if parts is not None and len(parts) > 1:
+            srcs = (ctypes.c_void_p * len(parts))(*[t.data_ptr() for t in parts])
+            chans = (ctypes.c_int * len(parts))(*[t.shape[1] for t in parts])
+            check(lib().pxl_net_set_input_parts(self._net, len(parts), srcs, chans))
         B = x.shape[0]
         H, W = self._cur.out_size
         want_prob = self.want_prob if want_prob is None else want_prob
@@ -562,25 +568,31 @@ class SegNetCore(nn.Module):
 
     def forward(self, x, out_size=None):
         """x: NCHW fp32 on the GPU -> (logits, softmax, latent_fn) with autograd attached."""
-        if not x.is_cuda:
-            raise _lib.PixelHipError("SegNetCore runs on the GPU only (input is on %s); there is no CPU path" % x.device)
-        x = x.contiguous().float()
+        parts = tuple(x) if isinstance(x, (tuple, list)) else (x,)     # several tensors = their concatenation along C
+        for t in parts:
+            if not t.is_cuda:
+                raise _lib.PixelHipError("SegNetCore runs on the GPU only (input is on %s); there is no CPU path" % t.device)
+        parts = tuple(t.contiguous().float() for t in parts)
+        if len(parts) > 4 or any(t.shape[0] != parts[0].shape[0] or t.shape[2:] != parts[0].shape[2:] for t in parts):
+            raise ValueError("SegNetCore: at most 4 input parts of the same batch and spatial size")
+        x = parts[0]
         B, _, H, W = x.shape
-        need_graph = torch.is_grad_enabled() and (any(p.requires_grad for p in self._param_list[:1]) or x.requires_grad)
+        need_graph = torch.is_grad_enabled() and (any(p.requires_grad for p in self._param_list[:1]) or
+                                                  any(t.requires_grad for t in parts))
         self._plan(B, H, W, out_size, inference=not need_graph and not self.training)
         self._ensure_packed()
         if need_graph and self.differentiable_latent and self.has_latent:
             arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
-            logits, prob, latent = _SegNetFn.apply(x, self._anchor, self, arena, True)
+            logits, prob, latent = _SegNetFn.apply(x, self._anchor, self, arena, True, *parts[1:])
             return logits, prob, (lambda: latent)
         if need_graph:
             arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
-            logits, prob, _ = _SegNetFn.apply(x, self._anchor, self, arena, False)
+            logits, prob, _ = _SegNetFn.apply(x, self._anchor, self, arena, False, *parts[1:])
         else:
             if self._cur.eval_arena is None:
                 self._cur.eval_arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
             arena = self._cur.eval_arena
-            logits, prob = self._forward_raw(x, arena)
+            logits, prob = self._forward_raw(x, arena, parts=parts)
         return logits, prob, (_LatentHandle(self, arena, self._cur) if self.has_latent else None)
 
     def forward_with_latent(self, x):
@@ -680,11 +692,13 @@ class _LatentHandle:
 
 class _SegNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, anchor, core, arena, with_latent):
-        logits, prob = core._forward_raw(x, arena)
+    def forward(ctx, x, anchor, core, arena, with_latent, *more_parts):
+        parts = (x,) + tuple(more_parts)
+        logits, prob = core._forward_raw(x, arena, parts=parts)
         ctx.core, ctx.arena, ctx.plan = core, arena, core._cur
         ctx.bn_training = bool(core.training and not core.freeze_bn)
         ctx.x_shape = tuple(x.shape)
+        ctx.part_shapes = [tuple(t.shape) for t in parts]
         ctx.save_for_backward(prob)
         ctx.set_materialize_grads(False)
         latent = core.latent_from(arena) if with_latent else None
@@ -694,8 +708,9 @@ class _SegNetFn(torch.autograd.Function):
     def backward(ctx, dlogits, dprob, dlatent):
         core = ctx.core
         (prob,) = ctx.saved_tensors
+        nextra = len(ctx.part_shapes) - 1
         if dlogits is None and dprob is None and dlatent is None:
-            return None, None, None, None, None
+            return (None,) * (5 + nextra)
         if dlogits is None and dprob is None:           # only the latent carries a gradient
             dlogits = torch.zeros((ctx.x_shape[0], core.num_classes) + ctx.plan.out_size, device=core._device)
         if dlogits is not None:
@@ -713,15 +728,23 @@ class _SegNetFn(torch.autograd.Function):
         check(lib().pxl_net_backward(pl.net, ptr(s.params), ptr(pl.packed), ptr(dlogits), ptr(dprob), ptr(prob),
                                      ptr(s.grads), ptr(ctx.arena), ctx.arena.numel(), ptr(pl.scratch),
                                      pl.scratch.numel(), int(ctx.bn_training), stream_ptr()))
-        dx = None
-        if ctx.needs_input_grad[0]:        # discriminator / flaw detector: gradient w.r.t. the task model's softmax
+        dx, dextra = None, [None] * nextra
+        want = [ctx.needs_input_grad[0]] + [ctx.needs_input_grad[5 + k] for k in range(nextra)]
+        if nextra and any(want):           # concatenated input: one NCHW gradient per part that asks for it
+            outs = [torch.empty(shp, device=core._device, dtype=torch.float32) if w else None
+                    for shp, w in zip(ctx.part_shapes, want)]
+            dsts = (ctypes.c_void_p * len(outs))(*[t.data_ptr() if t is not None else None for t in outs])
+            chans = (ctypes.c_int * len(outs))(*[shp[1] for shp in ctx.part_shapes])
+            check(lib().pxl_net_input_grad_parts(pl.net, ptr(pl.scratch), len(outs), dsts, chans, stream_ptr()))
+            dx, dextra = outs[0], outs[1:]
+        elif ctx.needs_input_grad[0]:      # discriminator / flaw detector: gradient w.r.t. the task model's softmax
             dx = torch.empty(ctx.x_shape, device=core._device, dtype=torch.float32)
             check(lib().pxl_net_input_grad(pl.net, ptr(pl.scratch), ptr(dx), stream_ptr()))
         hook = getattr(core, "_post_backward_hook", None)
         if hook is not None and core._wgrad_on:
             hook(core)
         ctx.arena = None
-        return dx, None, None, None, None
+        return (dx, None, None, None, None) + tuple(dextra)
 
 
 class DeepLabV2Core(SegNetCore):

@@ -154,12 +154,15 @@ class FDGTGenerator(nn.Module):
         _gpu(pred, gt)
         pred = pred.detach().contiguous()
         B, C, H, W = pred.shape
+        diff = torch.empty(B, 1, H, W, device=pred.device, dtype=torch.float32)
         if gt.shape[1] == 1 and C != 1:
-            diff = torch.empty(B, 1, H, W, device=pred.device, dtype=torch.float32)
             check(lib().pxl_absdiff_chansum(B, C, H * W, ptr(pred), ptr(gt.contiguous().float()), self.ignore_index,
                                             float(self.args.mu), ptr(diff), stream_ptr()))
         else:
-            diff = torch.sum(torch.abs(gt - pred), dim=1, keepdim=True) * self.args.mu
+            if gt.shape != pred.shape:
+                raise ValueError('FDGTGenerator: gt %s vs pred %s' % (tuple(gt.shape), tuple(pred.shape)))
+            check(lib().pxl_absdiff_chansum_dense(B, C, H * W, ptr(pred), ptr(gt.detach().contiguous().float()),
+                                                  float(self.args.mu), ptr(diff), stream_ptr()))
         diff = self.blur(diff)
         for _ in range(self.args.nu):
             dil = torch.empty_like(diff)
@@ -242,8 +245,8 @@ class FlawDetector(nn.Module):
         return super().train(mode)
 
     def forward(self, task_inp, task_pred):
-        x = torch.cat(tuple(task_inp) + (task_pred,), dim=1)
-        flawmap, _, _ = self.core(x)
+        # concatenation along the channels happens in the executor's input op (no torch.cat copy, ssl_gct.py:578)
+        flawmap, _, _ = self.core(tuple(task_inp) + (task_pred,))
         assert flawmap.shape[2:] == task_pred.shape[2:]
         return {'flawmap': flawmap}, {}
 
