@@ -28,13 +28,19 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(int C, int HW, const float*
   const float* lg = logits + (size_t)n * C * HW;
   float acc = 0.f;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
-    const int label = (int)gt[(size_t)n * HW + p];
-    if (label == ignore_index || label < 0 || label >= C) continue;
+    // label and channel planes are requested together (the label used to gate the plane loads: two dependent HBM
+    // round trips per pixel)
+    const float lab_f = gt[(size_t)n * HW + p];
     float v[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) v[c] = lg[(size_t)c * HW + p];
+    const int label = (int)lab_f;
+    if (label == ignore_index || label < 0 || label >= C) continue;
     float mx = -INFINITY;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
-      if (c < C) { v[c] = lg[(size_t)c * HW + p]; mx = fmaxf(mx, v[c]); }
+      if (c < C) mx = fmaxf(mx, v[c]);
     float sum = 0.f, pick = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
@@ -124,8 +130,9 @@ __global__ __launch_bounds__(256) void ce_mse_bwd_kernel(int C, int HW, const fl
       if (c < C) {
         float g = valid ? v[c] * inv - (c == label ? gs : 0.f) : 0.f;
         if (mse) {
-          const float m = ms * (x[c] - tg[(size_t)c * HW + p]);
-          g = ce ? g + m : m;
+          // explicit roundings: no fma contraction across the two terms (bit-identical to the separate kernels + add)
+          const float m = __fmul_rn(ms, x[c] - tg[(size_t)c * HW + p]);
+          g = ce ? __fadd_rn(g, m) : m;
         }
         dl[(size_t)c * HW + p] = g;
       }
