@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(int C, int HW, const float*
       const float inv = gs / sum;
 #pragma unroll
       for (int c = 0; c < MAXC; ++c)
-        if (c < C) dl[(size_t)c * HW + p] = v[c] * inv - (c == label ? gs : 0.f);
+        if (c < C) dl[(size_t)c * HW + p] = __fmaf_rn(v[c], inv, c == label ? -gs : 0.f);   // (one rounding, spelled out: pxl_ce_mse_bwd must match bit for bit)
     } else {
 #pragma unroll
       for (int c = 0; c < MAXC; ++c)
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void ce_mse_bwd_kernel(int C, int HW, const fl
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
       if (c < C) {
-        float g = valid ? v[c] * inv - (c == label ? gs : 0.f) : 0.f;
+        float g = valid ? __fmaf_rn(v[c], inv, c == label ? -gs : 0.f) : 0.f;
         if (mse) {
           // explicit roundings: no fma contraction across the two terms (bit-identical to the separate kernels + add)
           const float m = __fmul_rn(ms, x[c] - tg[(size_t)c * HW + p]);

@@ -164,15 +164,25 @@ __global__ __launch_bounds__(256) void stem_patches_kernel(const float* __restri
     const long b = m / ((long)Wo * Ho);
     const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
     T* row = tile + pl * pitch_e;
+    const int rowlen = kw * C;                       // elements of one kernel row: (kx, c) pairs, c fastest
     for (int ky = part; ky < kh; ky += NPART) {
       const int iy = iy0 + ky;
       const bool yok = (unsigned)iy < (unsigned)H;
-      for (int kx = 0; kx < kw; ++kx) {
-        const int ix = ix0 + kx;
-        const bool ok = yok && (unsigned)ix < (unsigned)W;
-        const float* src = x + (b * C) * plane + (long)iy * W + ix;
-        T* dst = row + (ky * kw + kx) * C;
-        for (int c = 0; c < C; ++c) dst[c] = from_f<T>(ok ? src[c * plane] : 0.f);
+      const float* src = x + (b * C) * plane + (long)iy * W + ix0;
+      T* dst = row + ky * rowlen;
+      // 8 independent loads in flight per thread (a plain loop over the run-time (kx, c) kept ONE: 365 us)
+      int kx = 0, c = 0;
+      for (int j0 = 0; j0 < rowlen; j0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool ok = yok && j0 + u < rowlen && (unsigned)(ix0 + kx) < (unsigned)W;
+          v[u] = ok ? src[c * plane + kx] : 0.f;
+          if (++c == C) { c = 0; ++kx; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j0 + u < rowlen) dst[j0 + u] = from_f<T>(v[u]);
       }
     }
   }
