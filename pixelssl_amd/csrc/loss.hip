@@ -92,6 +92,9 @@ __global__ __launch_bounds__(256) void ce_mse_bwd_kernel(int C, int HW, const fl
                                                          const float* __restrict__ g_ce, const float* __restrict__ target,
                                                          int mse_lo, int mse_hi, const float* __restrict__ g_mse,
                                                          float two_inv_n, float* __restrict__ dlogits) {
+  // hipcc contracts a * b + c into one fma by default and HIP's __fmul_rn / __fadd_rn are plain operators, i.e. no
+  // barrier against that: the sum of the two terms below must round twice, like the separate kernels + autograd's add
+#pragma clang fp contract(off)
   const int n = blockIdx.y;
   const float* lg = logits + (size_t)n * C * HW;
   float* dl = dlogits + (size_t)n * C * HW;
