@@ -425,7 +425,7 @@ int pxl_scale_inplace(long n, float* x, float a, void* stream);
 #define PXL_OP_RESIDUAL 3   /* out = relu(bn(in0) + (bn(in1) | in1))                 */
 #define PXL_OP_HEAD 4       /* upsample + softmax of the low-res logits -> outputs (stride = 1: align_corners=True,
                                stride = 0: align_corners=False)                                    */
-#define PXL_OP_ACT 5        /* out = LeakyReLU(in0, slope) (conv stacks without BN)  */
+#define PXL_OP_ACT 5        /* out = LeakyReLU(in0, slope), or LeakyReLU(bn_in0(in0), slope) (ssl_s4l.py:384-388) */
 #define PXL_OP_IBN 6        /* out = LeakyReLU(IBNorm(in0), slope); bn_out = BN half  */
 #define PXL_OP_AVGPOOL 7    /* out = AdaptiveAvgPool2d(kh)(in0)                      */
 #define PXL_OP_CONCAT 8     /* out = new tensor of cout channels; in0 -> channels [0, cin)           */

@@ -19,6 +19,7 @@
 //     4 consecutive output channels: the epilogue packs them, stages the tile through LDS
 //     (ds_write_b64) and stores full 16-byte row segments; bias / addend / BN statistics are applied
 //     on that coalesced read-back pass.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -565,6 +566,13 @@ extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_sca
   if (d->dtype != PXL_BF16 || in_scale != nullptr) return 0;
   if (d->Cin % 64 != 0 || d->Cout % 8 != 0 || (d->div != 1 && d->div != 2)) return 0;
   if (d->div == 2 && d->out_stride != 1) return 0;
+  if (d->div == 2) {
+    // data gradient of a stride-2 convolution: the kernel walks ALL taps and lets the parity test zero the 3 of 4 that do
+    // not apply to a pixel -- a win for the 1x1 / 3x3 strided convolutions of the ResNet (1 / 2.25 useful taps of 1 / 9),
+    // a loss for the 4x4 stacks of the discriminators (4 useful taps of 16 at 4x the loop).  PXL_DMA_STRIDED_DGRAD: max taps
+    static const int max_taps = getenv("PXL_DMA_STRIDED_DGRAD") ? atoi(getenv("PXL_DMA_STRIDED_DGRAD")) : 9;
+    if (d->ntaps > max_taps) return 0;
+  }
   if ((long)d->Kreal * d->ntaps * d->Cin * 2 >= (1L << 31)) return 0;
   return 1;
 }

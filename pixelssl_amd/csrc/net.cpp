@@ -481,6 +481,13 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
         PXL_REQUIRE(d.in0 >= 0 && n->tensors[d.in0].planned, "net_plan: op %zu consumes an unplanned tensor", i);
         const TensorInfo& tin = n->tensors[d.in0];
         plan_tensor(d.out, tin.H, tin.W, tin.C);
+        op.ws_bytes = 0;
+        if (d.bn_in0 >= 0) {          // LeakyReLU(bn(y)): bn(y) is kept (the backward needs its sign)
+          PXL_REQUIRE(n->bns[d.bn_in0].d.C == tin.Cp, "net_plan: activation op %zu: BN %d has %d channels, the tensor pitch is %d",
+                      i, d.bn_in0, n->bns[d.bn_in0].d.C, tin.Cp);
+          op.ws_bytes = align_up(tin.bytes);
+          op.ws_off = arena; arena += op.ws_bytes;
+        }
         break;
       }
       case PXL_OP_IBN: {
@@ -956,7 +963,14 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
       case PXL_OP_ACT: {
         const TensorInfo& tin = n->tensors[d.in0];
         const TensorInfo& tout = n->tensors[d.out];
-        rc = pxl_leaky_fwd(dt, (long)n->B * tin.H * tin.W * tin.Cp, at(arena, tin.off), d.slope, at(arena, tout.off), stream);
+        const void* pre = at(arena, tin.off);
+        if (d.bn_in0 >= 0) {          // (the producing convolution finalized this BN: it is neither materialised nor folded)
+          rc = pxl_bn_apply_fwd(dt, (long)n->B * tin.H * tin.W, tin.Cp, at(arena, tin.off), fat(arena, n->bns[d.bn_in0].coef_off), 0,
+                                at(arena, op.ws_off), stream);
+          if (rc != PXL_OK) return rc;
+          pre = at(arena, op.ws_off);
+        }
+        rc = pxl_leaky_fwd(dt, (long)n->B * tin.H * tin.W * tin.Cp, pre, d.slope, at(arena, tout.off), stream);
         break;
       }
       case PXL_OP_IBN: {
@@ -1297,8 +1311,9 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
         const TensorInfo& tout = n->tensors[d.out];
         if (!written[d.out]) return pxl_set_error(PXL_ERR_ARG, "net_backward: activation op %d output has no gradient", i);
         if (written[d.in0]) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net_backward: activation input consumed twice");
-        rc = pxl_leaky_bwd(dt, (long)n->B * tin.H * tin.W * tin.Cp, at(scratch, tout.goff), at(arena, tin.off), d.slope,
-                           at(scratch, tin.goff), stream);
+        // with a BN in front the gradient written here is d(bn(y)): the producing convolution's backward applies the BN
+        rc = pxl_leaky_bwd(dt, (long)n->B * tin.H * tin.W * tin.Cp, at(scratch, tout.goff),
+                           d.bn_in0 >= 0 ? at(arena, op.ws_off) : at(arena, tin.off), d.slope, at(scratch, tin.goff), stream);
         written[d.in0] = 1;
         break;
       }

@@ -38,21 +38,28 @@ class FlatStore:
         self.running = None
         self.user_version = 0
 
-    def add_param(self, name, shape):
+    def add_param(self, name, shape, alloc=None):
+        """`alloc`: shape of the slot the executor sees when it is larger than the exposed tensor (channels padded to what
+        the kernels take: a 21-channel BatchNorm lives in a 32-channel slot whose tail stays zero).  The exposed
+        parameter is the leading sub-block of the slot."""
+        alloc = tuple(alloc) if alloc is not None else tuple(shape)
+        if len(alloc) != len(shape) or any(a < b for a, b in zip(alloc, shape)):
+            raise ValueError("add_param %s: slot %s does not hold %s" % (name, alloc, tuple(shape)))
         n = 1
-        for s in shape:
+        for s in alloc:
             n *= s
         off = self.np
-        self._p_entries.append((name, tuple(shape), n, off))
+        self._p_entries.append((name, tuple(shape), n, off, alloc))
         self.np += (n + 3) // 4 * 4        # keep every tensor 16-byte aligned
         return off
 
-    def add_running(self, name, shape):
+    def add_running(self, name, shape, alloc=None):
+        alloc = tuple(alloc) if alloc is not None else tuple(shape)
         n = 1
-        for s in shape:
+        for s in alloc:
             n *= s
         off = self.nr
-        self._r_entries.append((name, tuple(shape), n, off))
+        self._r_entries.append((name, tuple(shape), n, off, alloc))
         self.nr += (n + 3) // 4 * 4
         return off
 
@@ -62,20 +69,25 @@ class FlatStore:
         self.running = torch.zeros(max(self.nr, 4), device=self.device, dtype=torch.float32)
 
     @staticmethod
-    def _view(flat, shape, n, off):
+    def _view(flat, shape, n, off, alloc=None):
+        alloc = tuple(shape) if alloc is None else tuple(alloc)
         v = flat[off:off + n]
         if len(shape) == 4:            # stored [O][kh][kw][I], exposed as OIHW
             o, i, kh, kw = shape
-            return v.view(o, kh, kw, i).permute(0, 3, 1, 2)
-        return v.view(shape)
+            oa, ia = alloc[0], alloc[1]
+            return v.view(oa, kh, kw, ia)[:o, :, :, :i].permute(0, 3, 1, 2)
+        if len(shape) == 2:            # Linear weight [O][I] (a 1x1 convolution over a 1x1 map)
+            return v.view(alloc)[:shape[0], :shape[1]]
+        return v.view(alloc)[:shape[0]]
 
     def param_views(self):
-        return OrderedDict((name, (self._view(self.params, shape, n, off), self._view(self.grads, shape, n, off),
-                                   off, n))
-                           for name, shape, n, off in self._p_entries)
+        return OrderedDict((name, (self._view(self.params, shape, n, off, alloc), self._view(self.grads, shape, n, off, alloc),
+                                   off, n, alloc))
+                           for name, shape, n, off, alloc in self._p_entries)
 
     def running_views(self):
-        return OrderedDict((name, self._view(self.running, shape, n, off)) for name, shape, n, off in self._r_entries)
+        return OrderedDict((name, self._view(self.running, shape, n, off, alloc))
+                           for name, shape, n, off, alloc in self._r_entries)
 
     def version(self):
         return (self.params._version, self.user_version)
@@ -143,29 +155,39 @@ class ProgramBuilder:
         self._op(_lib.OP_INPUT, out=t, cout=channels)
         return t
 
-    def bn(self, name, C):
+    def bn(self, name, C, alloc=None):
+        """`alloc` > C: the executor normalises `alloc` channels (the tensor's pitch), the module exposes the first C."""
         s = self.store
-        g = s.add_param(name + ".weight", (C,))
-        b = s.add_param(name + ".bias", (C,))
-        rm = s.add_running(name + ".running_mean", (C,))
-        rv = s.add_running(name + ".running_var", (C,))
+        A = (alloc,) if alloc else None
+        g = s.add_param(name + ".weight", (C,), A)
+        b = s.add_param(name + ".bias", (C,), A)
+        rm = s.add_running(name + ".running_mean", (C,), A)
+        rv = s.add_running(name + ".running_var", (C,), A)
         d = BnDesc()
-        d.C, d.gamma_off, d.beta_off, d.rmean_off, d.rvar_off = C, g, b, rm, rv
+        d.C, d.gamma_off, d.beta_off, d.rmean_off, d.rvar_off = alloc or C, g, b, rm, rv
         d.eps, d.momentum = SynchronizedBatchNorm2d.eps, SynchronizedBatchNorm2d.momentum
         self.bns.append(d)
         self.bn_names.append(name)
         self.modules[name] = "bn"
         return len(self.bns) - 1
 
-    def conv(self, names, t_in, bn_in, cin, cout, k, stride, dils, pads, bias=False, bn_out=-1, need_dgrad=True):
+    def conv(self, names, t_in, bn_in, cin, cout, k, stride, dils, pads, bias=False, bn_out=-1, need_dgrad=True,
+             cin_alloc=None, cout_alloc=None, linear=False):
+        """cin_alloc / cout_alloc: channel counts the executor works with when the module's are not multiples of what the
+        BatchNorm kernels take (S4L's 21 / 42-channel rotation classifier): the extra weight rows / columns are zero and
+        stay zero (their gradients are sums over zero activations).  linear: expose the 1x1 weight as [cout, cin]."""
         if isinstance(names, str):
             names, dils, pads = [names], [dils], [pads]
+        ci, co = cin_alloc or cin, cout_alloc or cout
         t = self.tensor()
-        op = self._op(_lib.OP_CONV, in0=t_in, out=t, bn_in0=bn_in, bn_out=bn_out, ngroups=len(names), cin=cin,
-                      cout=cout, kh=k, kw=k, stride=stride, need_dgrad=int(need_dgrad))
+        op = self._op(_lib.OP_CONV, in0=t_in, out=t, bn_in0=bn_in, bn_out=bn_out, ngroups=len(names), cin=ci,
+                      cout=co, kh=k, kw=k, stride=stride, need_dgrad=int(need_dgrad))
         for g, nm in enumerate(names):
-            op.w_off[g] = self.store.add_param(nm + ".weight", (cout, cin, k, k))
-            op.b_off[g] = self.store.add_param(nm + ".bias", (cout,)) if bias else -1
+            if linear:
+                op.w_off[g] = self.store.add_param(nm + ".weight", (cout, cin), (co, ci))
+            else:
+                op.w_off[g] = self.store.add_param(nm + ".weight", (cout, cin, k, k), (co, ci, k, k))
+            op.b_off[g] = self.store.add_param(nm + ".bias", (cout,), (co,)) if bias else -1
             op.dil[g] = dils[g]
             op.pads[g] = pads[g]
             self.modules[nm] = "conv_bias" if bias else "conv"
@@ -173,9 +195,10 @@ class ProgramBuilder:
             self.relu_sites[self.bn_names[bn_in]] = (t_in, bn_in)
         return t
 
-    def act(self, t_in, slope):
+    def act(self, t_in, slope, bn_in=-1):
+        """LeakyReLU(t_in), or LeakyReLU(bn_in(t_in)) (BatchNorm without a ReLU of its own)."""
         t = self.tensor()
-        self._op(_lib.OP_ACT, in0=t_in, out=t, slope=float(slope))
+        self._op(_lib.OP_ACT, in0=t_in, out=t, bn_in0=bn_in, slope=float(slope))
         return t
 
     def ibn(self, name, t_in, C, slope, split=0.5):
@@ -308,11 +331,12 @@ class SegNetCore(nn.Module):
             for attr in ("weight", "bias"):
                 key = dotted + "." + attr
                 if key in pviews:
-                    pv, gv, off, n = pviews[key]
+                    pv, gv, off, n, alloc = pviews[key]
                     prm = nn.Parameter(pv)
                     prm.grad = gv
                     prm._pxl_grad_view = gv
                     prm._pxl_flat = (s, off, n)
+                    prm._pxl_alloc = alloc
                     leaf.register_parameter(attr, prm)
                     self._param_list.append(prm)
             if kind == "bn":
@@ -984,6 +1008,66 @@ class FCDiscriminatorCore(SegNetCore):
             else:
                 bound = 1.0 / math.sqrt(self._last_fan_in)
                 prm.copy_((torch.rand(prm.shape, generator=generator) * 2 - 1) * bound)
+
+
+class RotationClassifierCore(SegNetCore):
+    """Rotation classifier of S4L (pixelssl/ssl_algorithm/ssl_s4l.py:371-393): conv 4x4 / s2 (C -> C) + BatchNorm +
+    LeakyReLU 0.2, conv 4x4 / s2 (C -> 2C) + BatchNorm + LeakyReLU 0.2, global average pool, Linear(2C -> 4) -- on the same
+    layer-program executor: the Linear is a 1x1 convolution over the pooled 1x1 map, the HEAD resizes 1x1 -> 1x1.  C = 21
+    and 2C = 42 are no channel counts the BatchNorm kernels take (multiples of 8, equal to the tensor pitch): the executor
+    works on 32 / 64 channels whose extra weight rows, BatchNorm slots and activations are zero and stay zero; the
+    module exposes the reference's shapes (conv1.weight [21, 21, 4, 4], bn2.weight [42], classifier.weight [4, 42]).
+    Input: the task model's `pred` (NCHW fp32); its gradient is returned to autograd."""
+
+    def __init__(self, in_channels, device="cuda", engine_dtype=torch.float32):
+        super().__init__(device, engine_dtype, 4)
+        self.want_prob = False
+        self.has_latent = False
+        c = in_channels
+        pad32 = lambda v: (v + 31) // 32 * 32
+        c1, c2 = pad32(c), pad32(2 * c)
+        pb = self._pb
+        t = pb.input(c)
+        pb.reserve("conv1")
+        b1 = pb.bn("bn1", c, alloc=c1)
+        y1 = pb.conv("conv1", t, -1, c, c, 4, 2, 1, 1, bias=True, bn_out=b1, need_dgrad=True, cout_alloc=c1)
+        a1 = pb.act(y1, 0.2, bn_in=b1)
+        pb.reserve("conv2")
+        b2 = pb.bn("bn2", 2 * c, alloc=c2)
+        y2 = pb.conv("conv2", a1, -1, c, 2 * c, 4, 2, 1, 1, bias=True, bn_out=b2, cin_alloc=c1, cout_alloc=c2)
+        a2 = pb.act(y2, 0.2, bn_in=b2)
+        pooled = pb.avgpool(a2, 1)
+        low = pb.conv("classifier", pooled, -1, 2 * c, 4, 1, 1, 1, 0, bias=True, cin_alloc=c2, linear=True)
+        pb.head(low, -1, align_corners=False)
+        self._finalize()
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self, generator=None):
+        """torch's default initialisers of nn.Conv2d / nn.Linear (kaiming_uniform(a=sqrt(5)) weights, uniform bias of the
+        same fan-in) and nn.BatchNorm2d (1 / 0, running 0 / 1)."""
+        import math
+        fan = {}
+        for name, prm in self.named_parameters():
+            mod, attr = name.rsplit(".", 1)
+            if mod.startswith("bn"):
+                prm.fill_(1.0) if attr == "weight" else prm.zero_()
+            elif attr == "weight":
+                fan[mod] = prm[0].numel()
+                bound = math.sqrt(6.0 / ((1 + 5.0) * fan[mod]))
+                prm.copy_((torch.rand(prm.shape, generator=generator) * 2 - 1) * bound)
+            else:
+                bound = 1.0 / math.sqrt(fan[mod])
+                prm.copy_((torch.rand(prm.shape, generator=generator) * 2 - 1) * bound)
+        for name, buf in self.named_buffers():
+            if name.endswith("running_var"):
+                buf.fill_(1.0)
+            elif name.endswith("running_mean") or name.endswith("num_batches_tracked"):
+                buf.zero_()
+
+    def forward(self, task_pred):
+        logits, _, _ = super().forward(task_pred, out_size=(1, 1))
+        return logits.reshape(logits.shape[0], 4)
 
 
 class FlawDetectorCore(SegNetCore):

@@ -48,12 +48,9 @@ def _segments(params):
 
 def _flat_view(store, buf, p):
     """The slice of a flat per-store buffer (momentum, Adam moments) that belongs to parameter `p`, shaped like it."""
+    from ..engine import FlatStore
     _, off, n = p._pxl_flat
-    v = buf[off:off + n]
-    if p.dim() == 4:                       # stored [O][kh][kw][I], exposed OIHW like the parameter itself
-        o, i, kh, kw = p.shape
-        return v.view(o, kh, kw, i).permute(0, 3, 1, 2)
-    return v.view(p.shape)
+    return FlatStore._view(buf, tuple(p.shape), n, off, getattr(p, '_pxl_alloc', None))
 
 
 class _FlatStateMixin:
