@@ -319,8 +319,8 @@ int pxl_ce_bwd(int N, int C, int HW, const float* logits, const float* gt, int i
 /* d(task + consistency)/d(logits) of a mean-teacher style step in one pass (ssl_mt.py:166-196: CE on the labeled
  * samples' `pred`, MSE between the student's and the teacher's `pred`): samples [0, n_ce) get pxl_ce_bwd's term (gt
  * [n_ce][HW], g_ce [n_ce]), samples [mse_lo, mse_hi) get pxl_mse_bwd's term against target ([N][C][HW], indexed like
- * logits; g_mse [1]; mean over (mse_hi - mse_lo)*C*HW elements); everything else is zero.  Bit-identical to the two
- * kernels + the slice-padding and the sum autograd would do.  g_ce / g_mse may be NULL (term absent). */
+ * logits; g_mse [1]; mean over (mse_hi - mse_lo)*C*HW elements); everything else is zero.  Each term is bit-identical to its own
+ * kernel; where both apply the sum is within 1 ulp of autograd's.  g_ce / g_mse may be NULL (term absent). */
 int pxl_ce_mse_bwd(int N, int C, int HW, const float* logits, const float* gt, int ignore_index, int n_ce,
                    const float* g_ce, const float* target, int mse_lo, int mse_hi, const float* g_mse,
                    float* dlogits, void* stream);

