@@ -10,7 +10,7 @@ from . import utils
 from . import nn
 from .nn import SynchronizedBatchNorm2d, patch_replication_callback, GaussianNoiseLayer
 from . import ssl_algorithm
-from .ssl_algorithm import SSL_NULL, SSL_MT, SSL_ADV, SSL_CUTMIX, SSL_GCT, SSL_CCT, SSL_ALGORITHMS
+from .ssl_algorithm import SSL_NULL, SSL_MT, SSL_ADV, SSL_CUTMIX, SSL_GCT, SSL_CCT, SSL_S4L, SSL_ALGORITHMS
 from . import task_template
 from .task_template import model_template, criterion_template, func_template, data_template
 from . import functional

@@ -207,7 +207,8 @@ extern "C" int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, 
   PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "upsample_softmax_bwd: bad dtype");
   if (ws_bytes < pxl_upsample_bwd_workspace(B, w, C, H))
     return pxl_set_error(PXL_ERR_WORKSPACE, "upsample_softmax_bwd: workspace too small");
-  PXL_REQUIRE(H > 1 && W > 1 && h > 1 && w > 1, "upsample_softmax_bwd: degenerate sizes");
+  // (1 x 1 -> 1 x 1 is the identity resize of a pooled classifier head, ssl_s4l.py:389-391; align_corners needs H, W > 1)
+  PXL_REQUIRE(H >= 1 && W >= 1 && h >= 1 && w >= 1 && (!align_corners || (H > 1 && W > 1)), "upsample_softmax_bwd: degenerate sizes");
   const int align = align_corners ? 1 : 0;
   const float sy = align ? (float)(h - 1) / (float)(H - 1) : (float)h / (float)H;
   const float sx = align ? (float)(w - 1) / (float)(W - 1) : (float)w / (float)W;

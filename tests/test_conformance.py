@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import ref_shim  # noqa: E402
 
 needs_reference = pytest.mark.skipif(not ref_shim.reference_available(), reason="reference tree not present on this box")
-ALGOS = ["ssl_null", "ssl_mt", "ssl_adv", "ssl_cutmix", "ssl_gct", "ssl_cct"]
+ALGOS = ["ssl_null", "ssl_mt", "ssl_adv", "ssl_cutmix", "ssl_gct", "ssl_cct", "ssl_s4l"]
 
 
 def _params(fn):
@@ -99,7 +99,7 @@ def test_algorithm_modules_match_the_reference():
             assert _params(getattr(rc, meth)) == _params(getattr(oc, meth)), (a, meth)
     assert P.SSL_NULL == ref.SSL_NULL and P.SSL_MT == ref.SSL_MT and P.SSL_ADV == ref.SSL_ADV
     assert P.SSL_GCT == ref.SSL_GCT and P.SSL_CCT == ref.SSL_CCT and P.SSL_CUTMIX == ref.SSL_CUTMIX
-    assert set(P.SSL_ALGORITHMS) == set(ref.SSL_ALGORITHMS) - {"ssl_s4l"}        # S4L: SURVEY.md 8f rank 4, not built
+    assert set(P.SSL_ALGORITHMS) == set(ref.SSL_ALGORITHMS) and P.SSL_S4L == ref.SSL_S4L
     assert P.REGRESSION == ref.REGRESSION and P.CLASSIFICATION == ref.CLASSIFICATION
 
 
