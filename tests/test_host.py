@@ -162,7 +162,7 @@ def test_polynomial_lr_matches_oracle_schedule():
 def test_helpers_and_registry():
     import pixelssl_amd as P
     from pixelssl_amd.nn import func
-    assert P.SSL_ALGORITHMS == ["ssl_null", "ssl_mt", "ssl_adv", "ssl_cutmix", "ssl_gct", "ssl_cct"]
+    assert P.SSL_ALGORITHMS == ["ssl_null", "ssl_mt", "ssl_adv", "ssl_cutmix", "ssl_gct", "ssl_cct", "ssl_s4l"]
     for name in P.SSL_ALGORITHMS:      # lookup convention of task_template/proxy.py:433
         assert callable(P.ssl_algorithm.__dict__[name].__dict__[name])
         assert callable(P.ssl_algorithm.__dict__[name].add_parser_arguments)
