@@ -40,7 +40,7 @@ def main(fetch_dir, write_dir, out):
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace -- python bench.py --steps 1 --warmup 1 "
                      "--no-cpu-baseline --no-kernel-events --no-miou, MT 8x513x513 bf16, autotuned tiles; contraction kernels: "
                      "the last launches of the run only (the final training step)",
-           "measured": "two separate rocprofv3 --pmc passes of this command, tools/r02_call20.sh (round 2, final state)",
+           "measured": "two separate rocprofv3 --pmc passes of this command, tools/r02_call26.sh (round 2, final state)",
            "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads)",
            "kernels": {}}
     for k in sorted(set(fe) | set(wr), key=lambda k: -(2 * sum(fe.get(k, [0])) + sum(wr.get(k, [0])))):
