@@ -568,9 +568,10 @@ extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_sca
   if (d->div == 2 && d->out_stride != 1) return 0;
   if (d->div == 2) {
     // data gradient of a stride-2 convolution: the kernel walks ALL taps and lets the parity test zero the 3 of 4 that do
-    // not apply to a pixel -- a win for the 1x1 / 3x3 strided convolutions of the ResNet (1 / 2.25 useful taps of 1 / 9),
-    // a loss for the 4x4 stacks of the discriminators (4 useful taps of 16 at 4x the loop).  PXL_DMA_STRIDED_DGRAD: max taps
-    static const int max_taps = getenv("PXL_DMA_STRIDED_DGRAD") ? atoi(getenv("PXL_DMA_STRIDED_DGRAD")) : 9;
+    // not apply to a pixel.  Measured a win for the 1x1 / 3x3 strided convolutions of the ResNet (125 -> 48 us) and still
+    // slightly ahead of the gathering kernel for the 4x4 stacks of the discriminators (AdvSSL 31.5 vs 32.4 ms, GCT 54.0 vs
+    // 55.4 ms in the same call).  PXL_DMA_STRIDED_DGRAD=<max taps> restricts it.
+    static const int max_taps = getenv("PXL_DMA_STRIDED_DGRAD") ? atoi(getenv("PXL_DMA_STRIDED_DGRAD")) : 64;
     if (d->ntaps > max_taps) return 0;
   }
   if ((long)d->Kreal * d->ntaps * d->Cin * 2 >= (1L << 31)) return 0;

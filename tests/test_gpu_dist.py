@@ -120,7 +120,11 @@ def _compare_with_full_batch(res, state, x, gt, rel):
         print("   in order:", ["%s %.0e" % (nm.replace("backbone.", ""), e) for e, nm, nb in per if nm.endswith("weight")])
         per.sort(reverse=True)
         print("   worst parameters:", ["%s %.1e (|g| %.1e)" % (nm, e, nb) for e, nm, nb in per[:6]])
-        assert e_l < tol and e_g < 10 * tol and e_r < tol
+        # gradients: the two runs sum the BN statistics in different orders (per-rank sums + all-reduce vs one pass, fp32
+        # atomics), so a pre-activation within rounding of zero can take the other ReLU branch: measured 3.6e-6 (no flip),
+        # 5.6e-4 and 2.7e-3 (one flip each) over repeated runs of this very test -- the decision-level noise analysed in
+        # tests/test_gpu_net.py; logits and running statistics stay at rounding level
+        assert e_l < tol and e_g < (5e-3 if dtype == torch.float32 else 10 * tol) and e_r < tol
 
 
 def test_native_rccl_communicator_single_rank():
