@@ -84,16 +84,11 @@ class WrappedS4LModel(nn.Module):
         resulter, debugger = {}, {}
         t_resulter, _ = self.task_model.forward(inp)
         if 'pred' not in t_resulter.keys() or 'activated_pred' not in t_resulter.keys():
-            logger.log_err('In SSL_S4L, the \'resulter\' dict returned by the task model should contain the following keys:\n'
-                           '   (1) \'pred\'\t=>\tunactivated task predictions\n'
-                           '   (2) \'activated_pred\'\t=>\tactivated task predictions\n'
-                           'We need both of them since some losses include the activation functions,\n'
-                           'e.g., the CrossEntropyLoss has contained SoftMax\n')
+            logger.log_err('SSL_S4L needs both \'pred\' (un-activated) and \'activated_pred\' in the task model\'s resulter:\n'
+                           'the task criterion activates on its own (CrossEntropyLoss contains the SoftMax), metrics do not\n')
         if 'ssls4l_rc_inp' not in t_resulter.keys():
-            logger.log_err('In SSL_S4L, the \'resulter\' dict returned by the task model should contain the key:\n'
-                           '    \'ssls4l_rc_inp\'\t=>\tinputs of the rotation classifier (a 4-dim tensor)\n'
-                           'It can be the feature map encoded by the task model or the output of the task model\n'
-                           'Please add the key \'ssls4l_rc_inp\' in your task model\'s resulter\n')
+            logger.log_err('SSL_S4L needs \'ssls4l_rc_inp\' in the task model\'s resulter: the 4-dim tensor the rotation\n'
+                           'classifier reads (a feature map of the task model or its prediction)\n')
         rc_inp = tool.dict_value(t_resulter, 'ssls4l_rc_inp')
         resulter['pred'] = tool.dict_value(t_resulter, 'pred')
         resulter['activated_pred'] = tool.dict_value(t_resulter, 'activated_pred')
@@ -110,11 +105,9 @@ class SSLS4L(ssl_base._SSLBase):
         self.task_model = self.rotation_classifier = None
         self.model = self.optimizer = self.lrer = self.criterion = self.rotation_criterion = None
         if self.args.rotation_scale < 0:
-            logger.log_err('The argument - rotation_scale - is not set (or invalid)\n'
-                           'Please set - rotation_scale >= 0 - for training\n')
+            logger.log_err('SSL_S4L: --rotation-scale must be set to a value >= 0\n')
         if self.args.rotated_sup_scale < 0:
-            logger.log_err('The argument - rotated_sup_scale - is not set (or invalid)\n'
-                           'Please set - rotated_sup_scale >= 0 - for training\n')
+            logger.log_err('SSL_S4L: --rotated-sup-scale must be set to a value >= 0\n')
 
     def _build(self, model_funcs, optimizer_funcs, lrer_funcs, criterion_funcs, task_func):
         self.task_func = task_func
@@ -137,10 +130,8 @@ class SSLS4L(ssl_base._SSLBase):
         self.args.batch_size *= 2
         self.args.labeled_batch_size *= 2
         self.args.unlabeled_batch_size *= 2
-        logger.log_info('In SSL_S4L algorithm, batch size are doubled: \n'
-                        '  Total labeled batch size: {1}\n'
-                        '  Total unlabeled batch size: {2}\n'
-                        .format(self.args.lr, self.args.labeled_batch_size, self.args.unlabeled_batch_size))
+        logger.log_info('SSL_S4L doubles the batch (one rotated copy per sample): labeled {0}, unlabeled {1}\n'
+                        .format(self.args.labeled_batch_size, self.args.unlabeled_batch_size))
         self._algorithm_warn()
 
     # -- one iteration -------------------------------------------------------------------------------------------
@@ -274,37 +265,30 @@ class SSLS4L(ssl_base._SSLBase):
             rotation_gt[bs:] = torch.from_numpy(rotation_angles.astype(np.int64)).to(rotation_gt.device)
         return inp, gt + (rotation_gt,)
 
+    # angle index of _rotate_tensor (ssl_s4l.py:347-355) -> quarter turns of torch.rot90 over (H, W): 1 = clockwise
+    _QUARTER_TURNS = {0: 0, 1: -1, 2: 2, 3: 1}
+
     def _with_rotated(self, t, angles):
-        assert t.shape[0] == len(angles)
-        out = torch.empty((2 * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=torch.float32)
-        out[:t.shape[0]] = t
-        for s, a in enumerate(angles):
-            out[t.shape[0] + s] = self._rotate_tensor(t[s], angle_idx=int(a))
+        """[bs, ...] -> [2 * bs, ...]: the batch followed by one rotated copy per sample (copies that share an angle are
+        produced by ONE rot90 over the sub-batch)."""
+        bs = t.shape[0]
+        assert bs == len(angles) and t.shape[-1] == t.shape[-2], 'S4L rotates by quarter turns: square inputs'
+        out = torch.empty((2 * bs,) + tuple(t.shape[1:]), device=t.device, dtype=torch.float32)
+        out[:bs] = t
+        for a in sorted(set(int(v) for v in angles)):
+            idx = torch.as_tensor([i for i, v in enumerate(angles) if int(v) == a], device=t.device)
+            out[bs + idx] = torch.rot90(t[idx].float(), self._QUARTER_TURNS[a], (-2, -1))
         return out
 
     def _rotate_tensor(self, tensor, angle_idx):
-        if angle_idx == 1:
-            tensor = tensor.transpose(1, 2).flip(2)
-        elif angle_idx == 2:
-            tensor = tensor.flip(2).flip(1)
-        elif angle_idx == 3:
-            tensor = tensor.transpose(1, 2).flip(1)
-        return tensor
+        """One [C, H, W] tensor, same convention (kept for callers of the reference's helper)."""
+        return torch.rot90(tensor, self._QUARTER_TURNS[int(angle_idx)], (-2, -1))
 
     def _inp_warn(self):
-        logger.log_warn('More than one ground truth of the task model is given in SSL_S4L\n'
-                        'You try to train the task model with more than one (pred & gt) pairs\n'
-                        'Please make sure that:\n'
-                        '  (1) The prediction tuple has the same size as the ground truth tuple\n'
-                        '  (2) The elements with the same index in the two tuples are corresponding\n'
-                        '  (3) All elements in the ground truth tuple should be 4-dim tensors since S4L\n'
-                        '      will rotate them to match the rotated inputs\n'
-                        'Please implement a new SSL algorithm if you want a variant of SSL_S4L that\n'
-                        'supports other formants (not 4-dim tensor) of the ground truth\n')
+        logger.log_warn('SSL_S4L received several task ground truths: predictions and ground truths are paired by index,\n'
+                        'and every ground truth must be a 4-dim tensor (it is rotated together with its input);\n'
+                        'other ground-truth formats need their own SSL algorithm\n')
 
     def _algorithm_warn(self):
-        logger.log_warn('This SSL_S4L algorithm reproduces the SSL algorithm from the paper:\n'
-                        '  \'S4L: Self-Supervised Semi-Supervised Learning\'\n'
-                        'The main differences between this implementation and the original paper are:\n'
-                        '  (1) This is an implementation for pixel-wise vision tasks\n'
-                        '  (2) This implementation only supports the 4-angle (0, 90, 180, 270) rotation-based self-supervised pretext task\n')
+        logger.log_warn('SSL_S4L follows \'S4L: Self-Supervised Semi-Supervised Learning\' adapted to pixel-wise tasks;\n'
+                        'only the 4-angle rotation pretext task (0 / 90 / 180 / 270 degrees) is implemented\n')
