@@ -178,3 +178,30 @@ def test_helpers_and_registry():
     P.sseg.model.add_parser_arguments(parser)
     a = P.utils.cmd.parse_args(parser, {"lr": 0.00025, "cons_for_labeled": False, "ema_decay": 0.99})
     assert a.lr == 0.00025 and a.cons_for_labeled is False and a.backbone == "resnet101"
+
+
+def test_attach_reaches_executors_kept_outside_the_module_registry(monkeypatch):
+    """dist.attach: FCDiscriminator / FlawDetector / RotationClassifer register the LEAVES of their executor under the
+    reference's names and keep the executor itself out of `modules()`; multi-rank wiring (Sync-BN hook, gradient
+    exchange) must still reach it -- a missed network trains on un-averaged gradients without any error."""
+    os.environ.setdefault("PXL_FORCE_DEVICE", "cpu")
+    import torch
+    from pixelssl_amd import dist as pdist
+    from pixelssl_amd.engine import SegNetCore
+    from pixelssl_amd.ssl_algorithm.ssl_s4l import RotationClassifer
+    from pixelssl_amd.ssl_algorithm.ssl_adv import FCDiscriminator
+    monkeypatch.setattr(pdist, "is_distributed", lambda: True)
+    monkeypatch.setattr(pdist, "world_size", lambda: 2)
+    monkeypatch.setattr(pdist, "native_comms", lambda: [])
+    wired = []
+    monkeypatch.setattr(SegNetCore, "set_sync", lambda self, cb, ws: wired.append(("sync", id(self), ws)))
+    monkeypatch.setattr(SegNetCore, "set_grad_sync", lambda self, fn, user, ws, bucket: wired.append(("grad", id(self), ws)))
+    model = torch.nn.ModuleDict(dict(rc=RotationClassifer(21), d=FCDiscriminator(21)))
+    assert not any(isinstance(m, SegNetCore) for m in model.modules())          # invisible to a plain modules() walk
+    pdist.attach(model)
+    for core in (model["rc"].core, model["d"].core):
+        assert getattr(core, "_pxl_attached", False) and ("sync", id(core), 2) in wired and ("grad", id(core), 2) in wired
+        assert core._post_backward_hook is pdist._post_backward
+    n = len(wired)
+    pdist.attach(model)                                                           # idempotent
+    assert len(wired) == n
