@@ -49,6 +49,17 @@ def test_argument_errors_are_reported_not_crashed():
     assert h.pxl_comm_init(None, 0, 1, None) == -1 and h.pxl_comm_allreduce_sum(None, None, 4, None) == -1
     assert h.pxl_external_contour_boxes_host(None, 4, 4, 50, None, 0, None) == -1
     assert h.pxl_tune_set(99, 1) == -1
+    # round-2 entry points
+    assert h.pxl_stem_patches(1, 1, 1, 2, 3, 33, 33, 7, 7, 2, 3, 17, 17, 144, None) == -1 and b"pitch" in h.pxl_last_error()   # 147 > 144
+    assert h.pxl_stem_patches(1, None, 1, 2, 3, 33, 33, 7, 7, 2, 3, 17, 17, 192, None) == -1
+    assert h.pxl_ce_mse_bwd(4, 21, 100, 1, 1, 255, 5, 1, 1, 0, 4, 1, 1, None) == -1                        # n_ce > N
+    assert h.pxl_ce_mse_bwd(4, 21, 100, 1, 1, 255, 2, 1, 1, 3, 2, 1, 1, None) == -1 and b"consistency range" in h.pxl_last_error()
+    assert h.pxl_ce_mse_bwd(4, 21, 100, 1, None, 255, 2, 1, 1, 2, 4, 1, 1, None) == -1 and b"label maps" in h.pxl_last_error()
+    assert h.pxl_nchw_parts_to_nhwc(1, 5, 1, 1, 1, 2, 8, 8, 32, None) == -1                                 # > 4 parts
+    assert h.pxl_conv_dgrad_joinreduce(d2, 1, 1, 1, None, None, 1, 1, 1, None) == -1                         # no join output
+    assert h.pxl_conv_dgrad_joinreduce(d2, 1, 1, 1, None, 1, 1, 1, 1, None) == -3 and b"not eligible" in h.pxl_last_error()
+    assert h.pxl_confusion_matrix(0, 21, 100, None, None, None, None) == -1
+    assert h.pxl_absdiff_chansum_dense(1, 21, 100, None, 1, 1.0, 1, None) == -1
 
 
 def test_engine_parameter_tree_matches_reference_names():
