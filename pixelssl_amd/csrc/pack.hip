@@ -138,72 +138,46 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
 // engine dtype, P[m][(ky*kw + kx)*C + c] = x[b][c][oy*stride - pad + ky][ox*stride - pad + kx] (0 outside the image and
 // for k >= kh*kw*C).  The 7x7 / stride-2 / 3-channel stem then IS a 1x1 convolution over Kp = 192 channels for the
 // LDS-DMA kernels (forward and weight gradient); the k order equals the master weight layout [Cout][kh][kw][C].
-// One block = PB consecutive output pixels.  Phase 1: lane <-> pixel, so that for a fixed (ky, kx, c) the 64 lanes of a
-// wave read one image row at `stride` elements distance (coalesced; the chunk-per-lane version touched ~24 cache lines
-// per wave-load and ran at 1.4 TB/s); the values go to an LDS tile [PB][Kp] whose row pitch is odd in 32-bit words.
-// Phase 2: the tile leaves as full 16-byte row segments.
-template <typename T, int PB>
-__global__ __launch_bounds__(256) void stem_patches_kernel(const float* __restrict__ x, T* __restrict__ P, long M, int C, int H,
+template <typename T>
+__global__ __launch_bounds__(256) void stem_patches_kernel(const float* __restrict__ x, T* __restrict__ P, int B, int C, int H,
                                                            int W, int kh, int kw, int stride, int pad, int Ho, int Wo, int Kp) {
-  extern __shared__ unsigned lds_w[];
-  constexpr int EPW = 4 / (int)sizeof(T);               // elements per 32-bit word
-  const int pitch_w = Kp / EPW + 1;                     // words per tile row (odd: Kp / EPW is even)
-  T* tile = reinterpret_cast<T*>(lds_w);
-  const int pitch_e = pitch_w * EPW;
-  const long m0 = (long)blockIdx.x * PB;
   const int K = kh * kw * C;
+  const int chunks = Kp / 8;
+  const long total = (long)B * Ho * Wo * chunks;
   const long plane = (long)H * W;
-  constexpr int NPART = 256 / PB;
-  const int pl = threadIdx.x % PB, part = threadIdx.x / PB;
-  const long m = m0 + pl;
-  // zero the padding columns k in [K, Kp) once
-  for (int q = threadIdx.x; q < PB * (Kp - K); q += 256) tile[(q / (Kp - K)) * pitch_e + K + q % (Kp - K)] = from_f<T>(0.f);
-  if (m < M) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % chunks);
+    const long m = i / chunks;
     const int ox = (int)(m % Wo);
     const int oy = (int)((m / Wo) % Ho);
     const long b = m / ((long)Wo * Ho);
     const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
-    T* row = tile + pl * pitch_e;
-    const int rowlen = kw * C;                       // elements of one kernel row: (kx, c) pairs, c fastest
-    for (int ky = part; ky < kh; ky += NPART) {
-      const int iy = iy0 + ky;
-      const bool yok = (unsigned)iy < (unsigned)H;
-      const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
-      const float* src = x + (b * C) * plane + (long)iyc * W;
-      T* dst = row + ky * rowlen;
-      // NB independent loads in flight per thread (one whole 7 x 3 kernel row).  They are UNCONDITIONAL (clamped
-      // coordinates, the value is zeroed afterwards): a guarded load is a branch, every branch join waits for the loads
-      // before it, and the kernel ran with one load in flight (365-400 us instead of the 203 MB it writes)
-      constexpr int NB = 24;
-      int kx = 0, c = 0;
-      for (int j0 = 0; j0 < rowlen; j0 += NB) {
-        float v[NB];
-        unsigned okm = 0u;
+    float v[8];
+    int k = ch * 8;
+    int tap = k / C, c = k - tap * C;
+    int ky = tap / kw, kx = tap - ky * kw;
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const int ix = ix0 + kx;
-          if (yok && (unsigned)ix < (unsigned)W) okm |= 1u << u;
-          const int ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-          v[u] = src[c * plane + ixc];
-          if (++c == C) { c = 0; ++kx; }
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u)
-          if (j0 + u < rowlen) dst[j0 + u] = from_f<T>((okm >> u) & 1u ? v[u] : 0.f);
+    for (int e = 0; e < 8; ++e, ++k) {
+      float f = 0.f;
+      if (k < K) {
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) f = x[(b * C + c) * plane + (long)iy * W + ix];
       }
+      v[e] = f;
+      if (++c == C) { c = 0; if (++kx == kw) { kx = 0; ++ky; } }
+    }
+    T* dst = P + m * Kp + ch * 8;
+    if constexpr (sizeof(T) == 2) {
+      *reinterpret_cast<uint4*>(dst) = Chunk<bf16_t>::pack(v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[e] = from_f<T>(v[e]);
     }
   }
-  __syncthreads();
-  const int chunks = Kp * (int)sizeof(T) / 16;          // 16-byte segments per row
-  const int wpc = 4;                                    // words per segment
-  for (int q = threadIdx.x; q < PB * chunks; q += 256) {
-    const int r = q / chunks, ch = q - r * chunks;
-    if (m0 + r >= M) break;
-    const unsigned* w = lds_w + r * pitch_w + ch * wpc;
-    uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
-    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(P) + ((m0 + r) * (long)Kp) * sizeof(T) + (size_t)ch * 16) = v;
-  }
 }
+// (Two LDS-transposing variants of this kernel -- lane <-> pixel gathers into a [pixels][Kp] tile, 8 and 24 loads in
+// flight -- were measured at 365-400 us against 134-146 us for this direct one, both networks running it at once; the
+// direct form stays.)
 
 // the same with the channels gathered from up to 4 NCHW tensors (concatenation along C on load: no torch.cat copy)
 struct NchwParts { const float* src[4]; int chans[4]; int n; };
@@ -363,22 +337,16 @@ extern "C" int pxl_stem_patches(int dtype, const float* x, void* P, int B, int C
   PXL_REQUIRE(x && P && B > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && Ho > 0 && Wo > 0, "stem_patches: bad argument");
   PXL_REQUIRE(Kp % 8 == 0 && Kp >= kh * kw * C, "stem_patches: pitch %d does not hold %d x %d x %d", Kp, kh, kw, C);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const long M = (long)B * Ho * Wo;
-  if (dtype == PXL_F32) {
-    constexpr int PB = 64;
-    const size_t smem = (size_t)PB * (Kp + 1) * 4;
-    PXL_REQUIRE(smem <= 64 * 1024, "stem_patches: row pitch %d too wide", Kp);
-    hipLaunchKernelGGL((stem_patches_kernel<float, PB>), dim3((unsigned)((M + PB - 1) / PB)), dim3(256), smem, s, x, (float*)P, M,
-                       C, H, W, kh, kw, stride, pad, Ho, Wo, Kp);
-  } else if (dtype == PXL_BF16) {
-    constexpr int PB = 128;
-    const size_t smem = (size_t)PB * (Kp / 2 + 1) * 4;
-    PXL_REQUIRE(smem <= 64 * 1024, "stem_patches: row pitch %d too wide", Kp);
-    hipLaunchKernelGGL((stem_patches_kernel<bf16_t, PB>), dim3((unsigned)((M + PB - 1) / PB)), dim3(256), smem, s, x, (bf16_t*)P,
-                       M, C, H, W, kh, kw, stride, pad, Ho, Wo, Kp);
-  } else {
+  const long total = (long)B * Ho * Wo * (Kp / 8);
+  int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(stem_patches_kernel<float>, dim3(grid), dim3(256), 0, s, x, (float*)P, B, C, H, W, kh, kw, stride, pad, Ho,
+                       Wo, Kp);
+  else if (dtype == PXL_BF16)
+    hipLaunchKernelGGL(stem_patches_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, (bf16_t*)P, B, C, H, W, kh, kw, stride, pad,
+                       Ho, Wo, Kp);
+  else
     return pxl_set_error(PXL_ERR_ARG, "stem_patches: bad dtype %d", dtype);
-  }
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
