@@ -44,6 +44,8 @@ def parse():
     p.add_argument("--cpu-warmup", type=int, default=3)
     p.add_argument("--cpu-budget-s", type=float, default=45.0, help="the CPU legs stop adding timed steps past this budget")
     p.add_argument("--no-miou", action="store_true")
+    p.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32_parity_mode leg (the engine mode that meets the 1e-3 parity bar)")
+    p.add_argument("--fp32-steps", type=int, default=5)
     return p.parse_args()
 
 
@@ -162,25 +164,10 @@ def miou_vs_oracle(core, a):
                     "synthetic validation batch" % (a.dtype, a.size, a.size)}
 
 
-def main():
-    a = parse()
-    import torch
-    import torch.distributed as dist
+def build_algo(a, args):
+    """-> (algorithm, executor cores) of the workload `a.algo` (plugin API: pixelssl_amd.ssl_algorithm.*)"""
     import pixelssl_amd as P
-    from pixelssl_amd import dist as pdist
     from pixelssl_amd.nn import optimizer as popt, lrer as plr
-    from pixelssl_amd.utils.synthetic import synthetic_batch
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if world != a.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
-    torch.cuda.set_device(pdist.local_device())
-    pdist.init_from_env("nccl")
-    dev = pdist.local_device()
-
-    args = make_args(a, world)
     factories = ({"model": P.sseg.model.deeplabv2()}, {"model": popt.sgd(args)}, {"model": plr.polynomiallr(args)},
                  {"model": P.sseg.criterion.sseg_criterion()})
     if a.algo == "mt":
@@ -208,13 +195,10 @@ def main():
         cores = [algo.model.module.model]
         algo.model.train()
 
-    # synthetic data, resident in HBM before timing; 4 distinct batches cycled
-    per_gpu = a.lbs + (a.ubs if a.algo != "suponly" else 0)
-    batches = []
-    for i in range(4):
-        x, gt = synthetic_batch(per_gpu, a.size, a.lbs, seed=1234 + rank * 1000 + i)
-        batches.append(((x.to(dev),), (gt.to(dev),)))
+    return algo, cores
 
+
+def make_step(a, args, algo, batches):
     def one_step(it):
         inp, gt = batches[it % len(batches)]
         if a.algo == "mt":
@@ -224,6 +208,71 @@ def main():
         if a.algo == "cct":
             return algo.train_step(inp, gt, it, 5 * args.iters_per_epoch)[0]
         return algo.train_step(inp, gt)[0]
+    return one_step
+
+
+def fp32_parity_leg(a, world, batches, fence):
+    """The SAME workload on the fp32 engine -- the mode that meets north_star's 1e-3 parity bar (tests/test_parity_513.py,
+    tests/test_multistep.py::test_mt_at_the_baseline_configuration[fp32]) -- timed like the headline figure (barrier +
+    synchronize on both sides, K steps), reported next to it: img/s and the whole-step fraction of the 157.3 TFLOP/s
+    fp32 MFMA peak (v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation)."""
+    import copy
+    import torch
+    a32 = copy.copy(a)
+    a32.dtype = "fp32"
+    args = make_args(a32, world)
+    algo, cores = build_algo(a32, args)
+    step = make_step(a32, args, algo, batches)
+    warm = 2
+    for it in range(warm):
+        step(it)
+    fence()
+    t0 = time.perf_counter()
+    for it in range(warm, warm + a.fp32_steps):
+        step(it)
+    fence()
+    dt = time.perf_counter() - t0
+    per_gpu = a.lbs + (a.ubs if a.algo != "suponly" else 0)
+    flop_img = {"mt": 449.9e9, "adv": 435.0e9, "gct": 1291.2e9, "suponly": 337.1e9, "cct": 452.6e9}[a.algo]
+    val = per_gpu * world * a.fp32_steps / dt
+    del algo, cores
+    torch.cuda.empty_cache()
+    return {"dtype": "fp32", "value": round(val, 3), "unit": "img/s", "ms_per_step": round(1e3 * dt / a.fp32_steps, 3),
+            "steps": a.fp32_steps, "warmup": warm, "peak": MFMA_PEAK_TFLOPS["fp32"],
+            "step_mfma_frac": round(val * flop_img / world / (MFMA_PEAK_TFLOPS["fp32"] * 1e12), 4) if a.size == 513 else None,
+            "note": "fp32 engine (fp32 operands, products and accumulation on v_mfma_f32_32x32x2_f32): the mode whose logits / "
+                    "losses / weights are within 1e-3 of the reference (parity tests); same workload, same timing protocol"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    import pixelssl_amd as P
+    from pixelssl_amd import dist as pdist
+    from pixelssl_amd.nn import optimizer as popt, lrer as plr
+    from pixelssl_amd.utils.synthetic import synthetic_batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != a.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(pdist.local_device())
+    pdist.init_from_env("nccl")
+    dev = pdist.local_device()
+
+    args = make_args(a, world)
+    algo, cores = build_algo(a, args)
+
+    # synthetic data (SURVEY.md 8d), resident in HBM before timing; 4 distinct batches cycled
+    per_gpu = a.lbs + (a.ubs if a.algo != "suponly" else 0)
+    batches = []
+    for i in range(4):
+        x, gt = synthetic_batch(per_gpu, a.size, a.lbs, seed=1234 + rank * 1000 + i)
+        batches.append(((x.to(dev),), (gt.to(dev),)))
+
+    one_step = make_step(a, args, algo, batches)
 
     def fence():
         torch.cuda.synchronize()
@@ -325,8 +374,17 @@ def main():
             out["step_mfma_frac"] = round(out["value"] * flop_img / world / (peak * 1e12), 4) if a.size == 513 else None
         if world == 1 and not a.no_miou and a.algo in ("mt", "suponly") and a.size == 513:
             out["miou_vs_ref"] = miou_vs_oracle(cores[0], a)
+    do_fp32 = a.dtype == "bf16" and not a.no_fp32_leg and world == 1      # (scaling runs stay the headline workload only)
+    if do_fp32:
+        del algo, one_step
+        cores = None
+        torch.cuda.empty_cache()
+        leg = fp32_parity_leg(a, world, batches, fence)
+    if rank == 0:
+        if do_fp32:
+            out["fp32_parity_mode"] = leg
         if world == 1 and not a.no_cpu_baseline:
-            del algo
+            algo = None
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out), flush=True)

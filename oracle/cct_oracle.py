@@ -140,7 +140,11 @@ _NB8 = ((0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1))   
 
 
 def external_contour_boxes(mask, min_vertices=50):
-    """Bounding boxes (min_x, max_x, min_y, max_y) of the external contours of a binary image whose
+    return [box for nvert, box in _external_contours(mask) if nvert > min_vertices]
+
+
+def _external_contours(mask):
+    """(vertex count, bounding box) of EVERY external contour -- see external_contour_boxes.  Bounding boxes (min_x, max_x, min_y, max_y) of the external contours of a binary image whose
     CHAIN_APPROX_SIMPLE polygon has more than `min_vertices` vertices (ssl_cct.py:630-636), in raster order of the
     contour's first pixel.  Pure-python restatement of the published border-following algorithm."""
     m = np.asarray(mask) != 0
@@ -179,10 +183,9 @@ def external_contour_boxes(mask, min_vertices=50):
             if not outer[y, x - 1]:
                 continue                   # first pixel borders an enclosed hole: the component is not external
             nvert = _traced_vertices(pad, y, x)
-            if nvert > min_vertices:
-                ys = [p[0] for p in comp]
-                xs = [p[1] for p in comp]
-                boxes.append((min(xs) - 1, max(xs) - 1, min(ys) - 1, max(ys) - 1))
+            ys = [p[0] for p in comp]
+            xs = [p[1] for p in comp]
+            boxes.append((nvert, (min(xs) - 1, max(xs) - 1, min(ys) - 1, max(ys) - 1)))
     return boxes
 
 
@@ -214,6 +217,19 @@ def _traced_vertices(pad, y0, x0):
     return sum(1 for i in range(len(dirs)) if dirs[i] != dirs[i - 1])
 
 
+def find_contours_stand_in(mask_np, mode=None, method=None):
+    """Stand-in for `cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)` (OpenCV is not installed): one int32
+    array [n_vertices, 1, 2] of (x, y) points per external contour found by `external_contour_boxes`' border following,
+    with the same vertex COUNT and the same bounding box as the traced polygon -- the two properties
+    CutOutDecoder.guided_cutout reads (ssl_cct.py:632-636: `c.shape[0] > 50`, min / max of x and y).  Used by
+    make_golden_cct.py to let the reference's own G-Cutout code run; what stays unpinned is exactly this function."""
+    out = []
+    for nvert, (min_w, max_w, min_h, max_h) in _external_contours(mask_np):
+        corners = np.array([[min_w, min_h], [max_w, min_h], [max_w, max_h], [min_w, max_h]], dtype=np.int32)
+        out.append(corners[np.arange(max(nvert, 1)) % 4].reshape(-1, 1, 2))
+    return out, None
+
+
 def cutout_mask(main_pred, erase, size, rnd=None, min_vertices=50):
     """CutOutDecoder.guided_cutout (ssl_cct.py:615-656): per sample, erase a random `erase`-sized window inside the
     bounding box of every (large enough) predicted object; nearest-resize to the latent size.  `rnd` = iterator of the
@@ -225,11 +241,14 @@ def cutout_mask(main_pred, erase, size, rnd=None, min_vertices=50):
         ones = np.ones(msk.shape, dtype=np.float32)
         for (min_w, max_w, min_h, max_h) in external_contour_boxes(msk.numpy(), min_vertices):
             bb_w, bb_h = max_w - min_w, max_h - min_h
-            uw = random.random() if rnd is None else next(rnd)
-            uh = random.random() if rnd is None else next(rnd)
+            nw, nh = int(bb_w * (1 - erase)), int(bb_h * (1 - erase))
+            # no injected draw: the reference's own stream, random.randint(0, n) (ssl_cct.py:637-638), recorded as the
+            # uniform u with floor(u * (n + 1)) = k so that a replay needs no knowledge of n
+            uw = (random.randint(0, nw) + 0.5) / (nw + 1) if rnd is None else next(rnd)
+            uh = (random.randint(0, nh) + 0.5) / (nh + 1) if rnd is None else next(rnd)
             draws += [uw, uh]
-            sw = int(uw * (int(bb_w * (1 - erase)) + 1))
-            sh = int(uh * (int(bb_h * (1 - erase)) + 1))
+            sw = int(uw * (nw + 1))
+            sh = int(uh * (nh + 1))
             ones[min_h + sh:min_h + sh + int(bb_h * erase), min_w + sw:min_w + sw + int(bb_w * erase)] = 0
         out.append(ones)
     m = torch.from_numpy(np.stack(out)).unsqueeze(1)

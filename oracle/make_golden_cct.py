@@ -29,8 +29,9 @@ BASE_CFG = dict(models={'model': 'pspnet'}, optimizers={'model': 'sgd'}, lrers={
                 criterions={'model': 'sseg_criterion'}, lr=0.00025, momentum=0.9, weight_decay=0.0005,
                 output_stride=16, backbone='resnet101', epochs=1, log_freq=1000)
 
-DECODERS = [("vat", dict(xi=1e-6, eps=2.0)), ("drop", dict(rate=0.5, spatial=True)), ("context", {}), ("object", {}),
+DECODERS_BASE = [("vat", dict(xi=1e-6, eps=2.0)), ("drop", dict(rate=0.5, spatial=True)), ("context", {}), ("object", {}),
             ("fd", {}), ("fn", dict(uniform=0.3))]
+DECODERS = list(DECODERS_BASE)
 
 MAIN_PROBES = ["backbone.conv1.weight", "backbone.layer4.2.conv2.weight", "psp.stages.0.1.weight",
                "psp.stages.3.2.weight", "psp.bottleneck.0.weight", "psp.bottleneck.1.bias",
@@ -43,15 +44,34 @@ def head(v):
     return dict(head=v[:64].clone(), sum=float(v.double().sum()), abssum=float(v.double().abs().sum()))
 
 
-def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspnet", gamma3=None, out=None, block=16):
-    """arch = 'pspnet' (the shipped script) or 'deeplabv2' (task/sseg/func.py:228: 2048-channel latent)."""
+def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspnet", gamma3=None, out=None, block=16,
+             with_cut=False, bias0_shift=0.0):
+    """arch = 'pspnet' (the shipped script) or 'deeplabv2' (task/sseg/func.py:228: 2048-channel latent).
+    with_cut: K = 7, the G-Cutout decoder included (BASELINE.json config 5).  The reference's own CutOutDecoder runs
+    (ssl_cct.py:597-650: erase-window draws, mask, nearest resize, decoder body) with `cv2.findContours` replaced by
+    cct_oracle.find_contours_stand_in; the fixture records the boxes that call returned and the random.randint draws, so
+    the GPU test pins everything of the decoder except the OpenCV contour search itself."""
+    global DECODERS
     ref = ref_shim.load_reference()
+    DECODERS = list(DECODERS_BASE)
+    cut_boxes, cut_calls = [], []
+    if with_cut:
+        DECODERS.insert(2, ("cut", dict(erase=0.4)))         # order of WrappedCCTModel (ssl_cct.py:440-470): vat, drop, cut, ...
+        cv2 = sys.modules["cv2"]
+        cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_SIMPLE = 0, 2
+
+        def find_contours(mask_np, mode, method):
+            contours, hier = CO.find_contours_stand_in(mask_np, mode, method)
+            cut_calls.append([tuple(int(v) for v in (c[:, 0, 0].min(), c[:, 0, 0].max(), c[:, 0, 1].min(), c[:, 0, 1].max()))
+                              for c in contours if c.shape[0] > 50])
+            return contours, hier
+        cv2.findContours = find_contours
     pixelssl = ref['pixelssl']
     from pixelssl.nn import optimizer as ropt, lrer as rlr
     batch = lbs + ubs
     args = ref_shim.make_args('ssl_cct', dict(BASE_CFG, models={'model': arch}, batch_size=batch, unlabeled_batch_size=ubs, im_size=size,
                                               ignore_unlabeled=False, cons_scale=30.0, cons_rampup_epochs=5,
-                                              ad_lr_scale=10.0, vat_dec_num=1, drop_dec_num=1, cut_dec_num=0,
+                                              ad_lr_scale=10.0, vat_dec_num=1, drop_dec_num=1, cut_dec_num=1 if with_cut else 0, cut_dec_erase=0.4,
                                               context_dec_num=1, object_dec_num=1, fd_dec_num=1, fn_dec_num=1))
     args.iters_per_epoch = max(4, iters + 2)
     task_func = ref['func'].task_func()(args)
@@ -62,6 +82,11 @@ def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspne
     state = TO.init_pspnet_state(seed=seed) if psp else TO.init_deeplabv2_state(seed=seed)
     if gamma3 is not None:
         TO.condition_state(state, gamma3)
+    if bias0_shift:
+        # PSPNet's last layer feeds PixelShuffle(2): channels 0..3 are class 0.  Raising the background bias turns the
+        # all-foreground prediction of a fresh network into ragged blobs whose contours pass the `> 50 vertices` filter
+        assert psp
+        state["decoder.3.conv.bias"][0:4] += bias0_shift
     fwd = TO.pspnet_forward if psp else TO.deeplabv2_forward
     cin = 512 if psp else 2048
     main_probes = MAIN_PROBES if psp else ["backbone.conv1.weight", "backbone.layer4.2.conv2.weight", "backbone.layer3.11.bn2.weight",
@@ -80,6 +105,15 @@ def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspne
     torch.manual_seed(rng_seed); np.random.seed(rng_seed); random.seed(rng_seed)
     seen = record_meters(algo)
     algo._train(loader, 0)
+    if with_cut:
+        # ssl_cct.py:627-630 tries the OpenCV-3 signature first, so every mask is searched twice: keep one of each pair,
+        # ubs masks per iteration
+        assert len(cut_calls) == 2 * ubs * iters, (len(cut_calls), ubs, iters)
+        assert all(cut_calls[2 * j] == cut_calls[2 * j + 1] for j in range(ubs * iters))
+        per_mask = cut_calls[::2]
+        cut_boxes = [per_mask[i * ubs:(i + 1) * ubs] for i in range(iters)]
+        print("G-Cutout boxes per iteration:", [[len(b) for b in it] for it in cut_boxes])
+        del cut_calls[:]
     ref_iters = per_iteration(seen, ('task_loss', 'cons_loss'), iters)
     meters = {k: float(algo.meters[k].avg) for k in ('task_loss', 'cons_loss')}
     ref_main = OrderedDict((k[len("model."):], v) for k, v in wrapped.main_model.state_dict().items())
@@ -111,6 +145,12 @@ def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspne
     o0 = tr2.cct_step(batches[0][0], batches[0][1], lbs, draws=outs[0]["draws"])
     check("replayed draws: cons", o0["cons_loss"], outs[0]["cons_loss"])
 
+    draws_fx = [list(o["draws"]) for o in outs]
+    if with_cut:
+        ci = [k for k, _ in DECODERS].index("cut")
+        for i in range(iters):
+            assert len(draws_fx[i][ci]) == 2 * sum(len(b) for b in cut_boxes[i]), "two draws per kept contour"
+            draws_fx[i][ci] = dict(u=list(draws_fx[i][ci]), boxes=cut_boxes[i])
     g0 = outs[0]
     fx = dict(kind="cct", arch=arch, in_channels=cin, size=size, lbs=lbs, ubs=ubs, weight_seed=seed, decoder_seeds=[seed + 100 + i for i in range(len(DECODERS))],
               gamma3=gamma3, ref_per_iter=ref_iters, main_updates=probe_update(ref_main, state, main_probes),
@@ -118,7 +158,7 @@ def case_cct(size=65, lbs=2, ubs=2, seed=71, iters=2, rng_seed=1234, arch="pspne
               decoders=DECODERS, data_seeds=[seed + 10 + i for i in range(iters)], block=block,
               max_iters=args.epochs * args.iters_per_epoch, rampup_iters=len(loader) * 5,
               meters=meters, per_iter=[dict(task_loss=o["task_loss"], cons_loss=o["cons_loss"]) for o in outs],
-              draws=[o["draws"] for o in outs],
+              draws=draws_fx, with_cut=bool(with_cut), bias0_shift=float(bias0_shift),
               grads0={k: head(g0["grads"][k]) for k in main_probes if k in g0["grads"]},
               ad_grads0=[{k: head(g[k]) for k in AD_PROBES} for g in g0["ad_grads"]],
               main_probes={k: head(ref_main[k]) for k in main_probes},

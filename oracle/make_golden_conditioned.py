@@ -34,6 +34,11 @@ def main(which):
     if "mt" in which:
         import make_golden as MG
         MG.case_mt(size=SIZE, lbs=2, ubs=2, seed=131, iters=ITERS, gamma3=GAMMA3, out="mt_cond_%d.pt" % SIZE, block=32)
+    if "mt513" in which:
+        # the workload bench.py times (BASELINE.json configs[1]): MT, 4 labeled + 4 unlabeled crops at 513 x 513, the
+        # shipped hyper-parameters, FOUR iterations of the reference's own SSLMT._train (ssl_mt.py:124-224)
+        import make_golden as MG
+        MG.case_mt(size=513, lbs=4, ubs=4, seed=191, iters=4, gamma3=GAMMA3, out="mt_cond_513.pt", block=32)
     if "psp" in which:
         import make_golden_psp as MP
         MP.case_suponly(size=SIZE, batch=4, seed=161, iters=ITERS, gamma3=GAMMA3, out="pspnet_suponly_cond_%d.pt" % SIZE, block=32)
@@ -50,6 +55,13 @@ def main(which):
         import make_golden_cct as MCC
         MCC.case_cct(size=SIZE, lbs=2, ubs=2, seed=181, iters=ITERS, rng_seed=2468, gamma3=GAMMA3, out="cct_cond_%d.pt" % SIZE,
                      block=32)
+
+
+    if "cctcut" in which:
+        # K = 7 with the G-Cutout decoder (BASELINE.json config 5); boxes of the contour search carried by the fixture
+        import make_golden_cct as MCC
+        MCC.case_cct(size=SIZE, lbs=2, ubs=2, seed=201, iters=ITERS, rng_seed=1357, gamma3=GAMMA3,
+                     out="cct_cut_cond_%d.pt" % SIZE, block=32, with_cut=True, bias0_shift=3.3)
 
 
 if __name__ == "__main__":

@@ -263,19 +263,29 @@ class CutOutDecoder(_AuxDecoder):
             fg = pre[0].numpy()
         else:
             fg = fg_mask_nearest(output, (H, W)).to(torch.uint8).cpu().numpy()    # D2H + sync, like the reference
+        # an injected draw is either the list of uniform draws (two per kept contour) or a dict {'u': [...], 'boxes':
+        # [[(min_w, max_w, min_h, max_h), ...] per sample]} that also replaces the contour search (the parity fixtures
+        # carry the boxes the reference's cv2.findContours call returned: tests/test_multistep.py)
         draws = self._take_draw()
+        boxes_in = None
+        if isinstance(draws, dict):
+            boxes_in, draws = draws.get('boxes'), draws.get('u')
         draws = iter(draws) if draws is not None else None
-        used = []
+        used, used_boxes = [], []
         out = np.ones((B, H, W), dtype=np.float32)
         for b in range(B):
-            for (min_w, max_w, min_h, max_h) in external_contour_boxes(fg[b], self.min_vertices):
+            boxes = boxes_in[b] if boxes_in is not None else external_contour_boxes(fg[b], self.min_vertices)
+            used_boxes.append([tuple(int(v) for v in bx) for bx in boxes])
+            for (min_w, max_w, min_h, max_h) in boxes:
                 bb_w, bb_h = max_w - min_w, max_h - min_h
-                uw = random.random() if draws is None else next(draws)
-                uh = random.random() if draws is None else next(draws)
+                nw, nh = int(bb_w * (1 - erase)), int(bb_h * (1 - erase))
+                # random.randint(0, n) of ssl_cct.py:637-638, kept as the uniform u with floor(u * (n + 1)) = k
+                uw = (random.randint(0, nw) + 0.5) / (nw + 1) if draws is None else next(draws)
+                uh = (random.randint(0, nh) + 0.5) / (nh + 1) if draws is None else next(draws)
                 used += [uw, uh]
-                sw = int(uw * (int(bb_w * (1 - erase)) + 1))      # random.randint(0, int(bb_w*(1-erase)))
-                sh = int(uh * (int(bb_h * (1 - erase)) + 1))
+                sw, sh = int(uw * (nw + 1)), int(uh * (nh + 1))
                 out[b, min_h + sh:min_h + sh + int(bb_h * erase), min_w + sw:min_w + sw + int(bb_w * erase)] = 0
+        self.last_boxes = used_boxes
         self.last_draw = used
         ys = np.minimum(np.floor(np.arange(resize[0], dtype=np.float32) * np.float32(H / resize[0])).astype(np.int64), H - 1)
         xs = np.minimum(np.floor(np.arange(resize[1], dtype=np.float32) * np.float32(W / resize[1])).astype(np.int64), W - 1)

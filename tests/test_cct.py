@@ -268,3 +268,37 @@ def test_cct_train_steps_vs_reference_fixture(fixture):
         assert abs(got["cons_loss"] - ref["cons_loss"]) < (2e-2 if i == 0 else 0.5) * abs(ref["cons_loss"])
     # post-step weights / later iterations: pinned on the conditioned six-iteration fixtures (tests/test_multistep.py:
     # losses 1e-3, weights within 5 % of the update); this ill-conditioned 65 x 65 fixture pins iteration 0 only
+
+
+def test_gcutout_fixture_replays_on_the_oracle():
+    """CPU: first iteration of the K = 7 fixture (G-Cutout included, reference run with the contour stand-in) on the
+    oracle with the recorded draws: same losses; the stand-in returns the vertex count and bounding box of every
+    external contour the restatement finds; the fixture exercises erase windows in every iteration."""
+    import torch_oracle as TO
+    import cct_oracle as CO
+    fx = torch.load(os.path.join(ROOT, "tests", "golden", "cct_cut_cond_129.pt"), weights_only=False)
+    assert fx["with_cut"] and fx["decoders"][2][0] == "cut"
+    assert all(sum(len(b) for b in it[2]["boxes"]) >= 1 for it in fx["draws"]), "every iteration cuts at least one box"
+    assert all(len(it[2]["u"]) == 2 * sum(len(b) for b in it[2]["boxes"]) for it in fx["draws"])
+    rng = np.random.RandomState(3)
+    blob = np.zeros((65, 65), dtype=np.uint8)
+    for _ in range(40):
+        cy, cx, r = rng.randint(5, 60), rng.randint(5, 60), rng.randint(2, 9)
+        yy, xx = np.ogrid[:65, :65]
+        blob[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 1
+    contours, _ = CO.find_contours_stand_in(blob)
+    got = [(c.shape[0], (int(c[:, 0, 0].min()), int(c[:, 0, 0].max()), int(c[:, 0, 1].min()), int(c[:, 0, 1].max()))) for c in contours]
+    assert got == [(max(n, 1), box) for n, box in CO._external_contours(blob)] and len(got) >= 2
+    assert CO.external_contour_boxes(blob, 10) == [box for n, box in got if n > 10]
+    # one oracle iteration with the recorded draws (the cut decoder's draw list is its 'u' part)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    state = TO.condition_state(TO.init_pspnet_state(seed=fx["weight_seed"]), fx["gamma3"])
+    state["decoder.3.conv.bias"][0:4] += fx["bias0_shift"]
+    decs = [(k, c, CO.init_decoder_state(s, in_channels=fx["in_channels"])) for (k, c), s in zip(fx["decoders"], fx["decoder_seeds"])]
+    tr = CO.CCTOracleTrainer(state, decs, dict(max_iters=fx["max_iters"], cons_scale=30.0, cons_rampup_iters=fx["rampup_iters"],
+                                               ad_lr_scale=10.0))
+    x, gt = TO.synthetic_batch(fx["lbs"] + fx["ubs"], fx["size"], fx["lbs"], seed=fx["data_seeds"][0], block=fx["block"])
+    draws = [d["u"] if isinstance(d, dict) else d for d in fx["draws"][0]]
+    out = tr.cct_step(x, gt, fx["lbs"], draws=draws)
+    for k in ("task_loss", "cons_loss"):
+        assert abs(out[k] - fx["ref_per_iter"][0][k]) <= 2e-5 * abs(fx["ref_per_iter"][0][k]) + 1e-9, (k, out[k])
