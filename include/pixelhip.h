@@ -309,6 +309,20 @@ int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, int C, int 
                              const float* dlogits, const float* dprob, const float* prob, void* dlow, void* workspace,
                              size_t ws_bytes, void* stream);
 
+/* The training seam without full-resolution planes: everything the reference computes between the low-resolution logits
+ * and their gradient -- F.interpolate (deeplab_v2.py:32), CommonSSEGCriterion on the labeled samples of the student and
+ * of the teacher (task/sseg/criterion.py:24-38, ssl_mt.py:166-176), nn.MSELoss between the two predictions
+ * (ssl_mt.py:179-184) and autograd's backward through all of them -- as one pass over the labels.
+ * s_low / t_low: NHWC [B][h][w][Cp] in the engine dtype (t_low NULL: student-only, SupOnly); gt: float class ids
+ * [n_ce][H][W]; ce_weight = d(loss)/d(per-sample CE), mse_weight = d(loss)/d(MSE mean).  Writes dlow [B][h][w][Cp] =
+ * d(loss)/d(s_low) and sums[2*B+1] (zeroed here): student CE per sample, teacher CE per sample, MSE mean over samples
+ * [mse_lo, mse_hi).  workspace: pxl_upsample_bwd_workspace().  PXL_ERR_UNSUPPORTED when a row does not fit the LDS
+ * staging (pxl_head_loss_lds_bytes() > 64 KiB) */
+size_t pxl_head_loss_lds_bytes(int w, int C, int W);
+int pxl_head_loss(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
+                  const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight,
+                  float mse_weight, void* dlow, void* workspace, size_t ws_bytes, float* sums, void* stream);
+
 /* CommonSSEGCriterion (task/sseg/criterion.py:24-38): loss[n] = mean over ALL HW pixels of CE with
  * ignore_index (ignored pixels add 0); gt holds class ids as float32. */
 int pxl_ce_fwd(int N, int C, int HW, const float* logits, const float* gt, int ignore_index, float* loss,
@@ -510,6 +524,19 @@ int pxl_net_tensor_shape(const pxl_net* net, int tensor, int* C, int* h, int* w)
 int pxl_net_backward(pxl_net* net, const float* params, const void* packed, const float* dlogits,
                      const float* dprob, const float* prob, float* grads, void* arena, size_t arena_bytes,
                      void* scratch, size_t scratch_bytes, int training, void* stream);
+
+/* Deferred head: pxl_net_forward with logits == NULL skips the up-sampling / soft-max op; pxl_net_head_loss evaluates the
+ * losses of one (teacher == NULL) or two forward passes on their low-resolution logits (pxl_head_loss) and writes
+ * d(loss)/d(low-res logits) into the student's gradient slot; pxl_net_backward_low is pxl_net_backward starting from
+ * that slot.  Together they stand in for deeplab_v2.py:32 + task/sseg/criterion.py:24-38 + ssl_mt.py:166-196 + the
+ * autograd backward through them when no plugin reads the full-resolution predictions. */
+int pxl_net_head_loss_supported(const pxl_net* net);
+int pxl_net_head_forward(pxl_net* net, const void* arena, float* logits, float* prob, void* stream);   /* the skipped op, on demand */
+int pxl_net_head_loss(pxl_net* net, const void* arena, const pxl_net* teacher, const void* t_arena, const float* gt,
+                      int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight, float mse_weight, void* scratch,
+                      size_t scratch_bytes, float* sums, void* stream);
+int pxl_net_backward_low(pxl_net* net, const float* params, const void* packed, float* grads, void* arena,
+                         size_t arena_bytes, void* scratch, size_t scratch_bytes, int training, void* stream);
 
 /* Seed the gradient of the latent tensor before pxl_net_backward (auxiliary decoders that consume the latent outside
  * this program, SSLCCT): dlatent NCHW fp32 [B,C,h,w]; consumed (and cleared) by the next backward */

@@ -123,6 +123,8 @@ SIGNATURES = {
     "pxl_upsample_softmax_fwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "pxl_upsample_bwd_workspace": (_Z, [_I, _I, _I, _I]),
     "pxl_upsample_softmax_bwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "pxl_head_loss_lds_bytes": (_Z, [_I, _I, _I]),
+    "pxl_head_loss": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _Z, _P, _P]),
     "pxl_ce_fwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P]),
     "pxl_ce_bwd": (_I, [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "pxl_ce_mse_bwd": (_I, [_I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
@@ -192,6 +194,10 @@ SIGNATURES = {
     "pxl_net_profile": (_I, [_P, _I]),
     "pxl_net_profile_read": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
     "pxl_net_profile_bytes": (_I, [_P, _I, C.POINTER(C.c_double)]),
+    "pxl_net_head_loss_supported": (_I, [_P]),
+    "pxl_net_head_forward": (_I, [_P, _P, _P, _P, _P]),
+    "pxl_net_head_loss": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _Z, _P, _P]),
+    "pxl_net_backward_low": (_I, [_P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
     "pxl_net_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
 }
 

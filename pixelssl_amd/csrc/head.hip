@@ -171,6 +171,152 @@ __global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(int B, int h, in
   }
 }
 
+
+// ---- training seam of the segmentation step without the full-resolution planes -------------------------------------
+// The reference materialises logits = upsample(low) [B][C][H][W] (deeplab_v2.py:32), softmax(logits)
+// (task/sseg/model.py:62), then the criterion (task/sseg/criterion.py:24-38), the consistency term (ssl_mt.py:179-184)
+// and autograd's backward read / write those planes again: at 8 x 21 x 513 x 513 that is 177 MB per plane and seven
+// launches between the last forward convolution and the first data gradient.  When no plugin reads the planes, everything
+// between the low-resolution logits and their gradient is a function of (student low-res logits, teacher low-res logits,
+// labels): this kernel evaluates it per full-resolution row in registers / LDS and never writes a plane.
+//   per pixel:  z_s = bilinear(s_low), z_t = bilinear(t_low)                           (same expression as the forward kernel)
+//               n <  n_ce          : CE(z_s, label), CE(z_t, label) with ignore_index, summed / (H*W) per sample
+//               mse_lo <= n < mse_hi: sum (z_s - z_t)^2
+//               G = ce_scale * (softmax(z_s) - onehot) [valid label]  +  mse_scale * (z_s - z_t)
+//   then the x-reduction of upsample_bwd_rows_kernel on G -> tmp[b][y][x0][c]; upsample_bwd_cols_kernel finishes d(low).
+// One block per (row y, sample b).  LDS: G [C][W+1], the column tables, and the two low-res rows of both networks.
+template <typename T>
+__global__ __launch_bounds__(256) void head_loss_rows_kernel(int C, int Cp, int h, int w, int H, int W, float sy, float sx,
+                                                             int align, const T* __restrict__ s_low,
+                                                             const T* __restrict__ t_low, const float* __restrict__ gt,
+                                                             int ignore_index, int n_ce, int mse_lo, int mse_hi,
+                                                             float ce_scale, float mse_scale, float inv_hw, float inv_mse_n,
+                                                             float* __restrict__ tmp, float* __restrict__ sums, int B) {
+  extern __shared__ float g[];   // [C][W+1] | ci0[W] ci1[W] cl1[W] | srow[2][w][C] | trow[2][w][C]
+  __shared__ float red[4];
+  const int y = blockIdx.x, b = blockIdx.y;
+  const int ld = W + 1;
+  int* ci0 = reinterpret_cast<int*>(g + (size_t)C * ld);
+  int* ci1 = ci0 + W;
+  float* cl1 = reinterpret_cast<float*>(ci1 + W);
+  float* srow = cl1 + W;
+  float* trow = srow + 2 * w * C;
+  int y0, y1;
+  float ly;
+  src_coord(y, sy, align, h, y0, y1, ly);
+  const bool has_t = t_low != nullptr;
+  for (int i = threadIdx.x; i < 2 * w * C; i += blockDim.x) {
+    const int c = i % C, xx = (i / C) % w, r = i / (C * w);
+    const size_t o = ((size_t)(b * h + (r ? y1 : y0)) * w + xx) * Cp + c;
+    srow[i] = to_f(s_low[o]);
+    if (has_t) trow[i] = to_f(t_low[o]);
+  }
+  __syncthreads();
+  const bool ce = b < n_ce;
+  const bool mse = has_t && b >= mse_lo && b < mse_hi;
+  float acc_s = 0.f, acc_t = 0.f, acc_m = 0.f;
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    int x0, x1;
+    float lx;
+    src_coord(x, sx, align, w, x0, x1, lx);
+    ci0[x] = x0; ci1[x] = x1; cl1[x] = lx;
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    const float* s00 = srow + x0 * C; const float* s01 = srow + x1 * C;
+    const float* s10 = srow + (w + x0) * C; const float* s11 = srow + (w + x1) * C;
+    const float* t00 = trow + x0 * C; const float* t01 = trow + x1 * C;
+    const float* t10 = trow + (w + x0) * C; const float* t11 = trow + (w + x1) * C;
+    int label = -1;
+    bool valid = false;
+    if (ce) {
+      label = (int)gt[((size_t)b * H + y) * W + x];
+      valid = !(label == ignore_index || label < 0 || label >= C);
+    }
+    float zs[MAXC], zt[MAXC];
+    float mxs = -INFINITY, mxt = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c < C) {
+        zs[c] = w00 * s00[c] + w01 * s01[c] + w10 * s10[c] + w11 * s11[c];
+        mxs = fmaxf(mxs, zs[c]);
+        if (has_t) {
+          zt[c] = w00 * t00[c] + w01 * t01[c] + w10 * t10[c] + w11 * t11[c];
+          mxt = fmaxf(mxt, zt[c]);
+        }
+      }
+    }
+    float es[MAXC];
+    float inv = 0.f;
+    if (valid) {
+      float sum = 0.f, pick = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) { es[c] = expf(zs[c] - mxs); sum += es[c]; if (c == label) pick = zs[c]; }
+      acc_s += (mxs + logf(sum)) - pick;
+      inv = ce_scale / sum;
+      if (has_t) {
+        float tsum = 0.f, tpick = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if (c < C) { tsum += expf(zt[c] - mxt); if (c == label) tpick = zt[c]; }
+        acc_t += (mxt + logf(tsum)) - tpick;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) {
+        float gv = valid ? __fmaf_rn(es[c], inv, c == label ? -ce_scale : 0.f) : 0.f;
+        if (mse) {
+          const float d = zs[c] - zt[c];
+          acc_m += d * d;
+          const float m = __fmul_rn(mse_scale, d);
+          gv = ce ? __fadd_rn(gv, m) : m;
+        }
+        g[c * ld + x] = gv;
+      }
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < w * C; o += blockDim.x) {
+    const int c = o % C, x0 = o / C;
+    const float xoff = align ? 0.f : 0.5f;
+    int xlo = (int)floorf(((float)(x0 - 1) + xoff) / sx - xoff) - 1;
+    int xhi = (int)ceilf(((float)(x0 + 1) + xoff) / sx - xoff) + 1;
+    if (xlo < 0) xlo = 0;
+    if (xhi > W - 1) xhi = W - 1;
+    float acc = 0.f;
+    for (int x = xlo; x <= xhi; ++x) {
+      const float l1 = cl1[x];
+      float wgt = 0.f;
+      if (ci0[x] == x0) wgt += 1.f - l1;
+      if (ci1[x] == x0) wgt += l1;
+      acc += wgt * g[c * ld + x];
+    }
+    tmp[(((size_t)b * H + y) * w + x0) * C + c] = acc;
+  }
+  // loss sums: one atomic per block and quantity (as ce_fwd_kernel / mse_fwd_kernel do)
+  float v = wave_sum(acc_s);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (ce) {
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sums + b, (red[0] + red[1] + red[2] + red[3]) * inv_hw);
+    __syncthreads();
+    if (has_t) {
+      v = wave_sum(acc_t);
+      if (lane == 0) red[wave] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) atomicAdd(sums + B + b, (red[0] + red[1] + red[2] + red[3]) * inv_hw);
+      __syncthreads();
+    }
+  }
+  if (mse) {
+    v = wave_sum(acc_m);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sums + 2 * B, (red[0] + red[1] + red[2] + red[3]) * inv_mse_n);
+  }
+}
+
 }  // namespace
 
 extern "C" int pxl_upsample_softmax_fwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners,
@@ -217,6 +363,63 @@ extern "C" int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, 
   PXL_REQUIRE(smem <= 64 * 1024, "upsample_softmax_bwd: row too wide for LDS staging (W=%d)", W);
   hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(H, B), dim3(256), smem, s, C, H, W, w, sx, align, dlogits, dprob,
                      prob, (float*)workspace);
+  PXL_LAUNCH_CHECK();
+  const long total = (long)B * h * w * Cp;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<float>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
+                       (const float*)workspace, (float*)dlow);
+  else
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
+                       (const float*)workspace, (bf16_t*)dlow);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+
+// LDS bytes of head_loss_rows_kernel; the fused seam runs when this fits the default 64 KiB dynamic limit
+extern "C" size_t pxl_head_loss_lds_bytes(int w, int C, int W) {
+  return (size_t)C * (W + 1) * sizeof(float) + (size_t)W * 3 * sizeof(float) + (size_t)4 * w * C * sizeof(float);
+}
+
+// Fused training seam (see head_loss_rows_kernel).  s_low / t_low: low-resolution logits NHWC [B][h][w][Cp] in the engine
+// dtype (t_low NULL: no teacher -> no teacher CE, no consistency term); gt: float class ids [n_ce][H][W]; ce_weight =
+// d(final loss)/d(per-sample CE) (1 / n_ce for torch.mean over the labeled samples), mse_weight = d(final loss)/d(MSE
+// mean) (ramp * cons_scale).  Outputs: dlow [B][h][w][Cp] (engine dtype) = d(final loss)/d(s_low); sums [2*B + 1]
+// fp32, zeroed here: per-sample student CE, per-sample teacher CE, the MSE mean over samples [mse_lo, mse_hi).
+// workspace: pxl_upsample_bwd_workspace(B, w, C, H) bytes.
+extern "C" int pxl_head_loss(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
+                             const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi,
+                             float ce_weight, float mse_weight, void* dlow, void* workspace, size_t ws_bytes, float* sums,
+                             void* stream) {
+  PXL_REQUIRE(s_low && dlow && workspace && sums, "head_loss: null argument");
+  PXL_REQUIRE(n_ce == 0 || gt != nullptr, "head_loss: labels missing");
+  PXL_REQUIRE(C >= 1 && C <= MAXC && C <= Cp, "head_loss: C=%d unsupported (max %d)", C, MAXC);
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "head_loss: bad dtype");
+  PXL_REQUIRE(n_ce >= 0 && n_ce <= B && 0 <= mse_lo && mse_lo <= mse_hi && mse_hi <= B, "head_loss: bad sample ranges");
+  PXL_REQUIRE(H >= 1 && W >= 1 && h >= 1 && w >= 1 && (!align_corners || (H > 1 && W > 1)), "head_loss: degenerate sizes");
+  if (ws_bytes < pxl_upsample_bwd_workspace(B, w, C, H)) return pxl_set_error(PXL_ERR_WORKSPACE, "head_loss: workspace too small");
+  const size_t smem = pxl_head_loss_lds_bytes(w, C, W);
+  if (smem > 64 * 1024) return pxl_set_error(PXL_ERR_UNSUPPORTED, "head_loss: row too wide for LDS staging (W=%d)", W);
+  const int align = align_corners ? 1 : 0;
+  const float sy = align ? (float)(h - 1) / (float)(H - 1) : (float)h / (float)H;
+  const float sx = align ? (float)(w - 1) / (float)(W - 1) : (float)w / (float)W;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PXL_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)(2 * B + 1) * sizeof(float), s));
+  const float hw = (float)H * (float)W;
+  const float ce_scale = ce_weight / hw;                                         // = g_ce[n] / HW of ce_bwd_kernel
+  const double mse_n = (double)(mse_hi - mse_lo) * C * (double)H * W;
+  const float mse_scale = mse_hi > mse_lo ? (float)(2.0 / mse_n) * mse_weight : 0.f;      // = g_mse * two_inv_n of mse_bwd_kernel
+  const float inv_mse_n = mse_hi > mse_lo ? (float)(1.0 / mse_n) : 0.f;
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(head_loss_rows_kernel<float>, dim3(H, B), dim3(256), smem, s, C, Cp, h, w, H, W, sy, sx, align,
+                       (const float*)s_low, (const float*)t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_scale, mse_scale,
+                       1.f / hw, inv_mse_n, (float*)workspace, sums, B);
+  else
+    hipLaunchKernelGGL(head_loss_rows_kernel<bf16_t>, dim3(H, B), dim3(256), smem, s, C, Cp, h, w, H, W, sy, sx, align,
+                       (const bf16_t*)s_low, (const bf16_t*)t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_scale, mse_scale,
+                       1.f / hw, inv_mse_n, (float*)workspace, sums, B);
   PXL_LAUNCH_CHECK();
   const long total = (long)B * h * w * Cp;
   int grid = (int)((total + 255) / 256);

@@ -40,6 +40,10 @@ int pxl_nhwc_to_nchw_parts(int dtype, const void* x, int nparts, float* const* d
 int pxl_residual_bwd_reduce(int dtype, int M, int C, const void* dout, const void* out, const void* y, const float* coef,
                             void* g, void* g2, float* sums, void* stream);
 int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_scale, const void* workspace);
+size_t pxl_head_loss_lds_bytes(int w, int C, int W);
+int pxl_head_loss(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
+                  const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight,
+                  float mse_weight, void* dlow, void* workspace, size_t ws_bytes, float* sums, void* stream);
 int pxl_conv_wgrad_dma_eligible(const pxl_conv_desc* d, const float* in_scale);
 }
 
@@ -841,7 +845,9 @@ pxl_bn_fin make_fin(const pxl_net* n, const BnInfo& b, const float* params, floa
 extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* packed, float* running,
                                const float* x, float* logits, float* prob, void* arena, size_t arena_bytes,
                                int training, void* stream) {
-  PXL_REQUIRE(n && n->planned && params && packed && (x || n->in_parts > 0) && logits && arena, "net_forward: bad argument (plan first)");
+  // logits == NULL: the HEAD op (up-sampling + soft-max to full resolution) is skipped -- the caller consumes the
+  // low-resolution logits in the arena directly (pxl_net_head_loss)
+  PXL_REQUIRE(n && n->planned && params && packed && (x || n->in_parts > 0) && arena, "net_forward: bad argument (plan first)");
   if (arena_bytes < n->arena_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_forward: arena too small (%zu < %zu)", arena_bytes, n->arena_bytes);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (training && n->stats_region_bytes)
@@ -1024,6 +1030,7 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
         break;
       }
       case PXL_OP_HEAD: {
+        if (logits == nullptr) break;
         const TensorInfo& low = n->tensors[d.in0];
         rc = pxl_upsample_softmax_fwd(dt, n->B, low.H, low.W, low.Cp, n->classes, n->Ho, n->Wo, d.stride, at(arena, low.off),
                                       logits, prob, stream);
@@ -1133,12 +1140,74 @@ extern "C" int pxl_net_seed_latent_grad(pxl_net* n, void* scratch, size_t scratc
   return rc;
 }
 
+namespace {
+int net_backward_impl(pxl_net* n, const float* params, const void* packed, const float* dlogits, const float* dprob,
+                      const float* prob, float* grads, void* arena, size_t arena_bytes, void* scratch, size_t scratch_bytes,
+                      int training, void* stream, bool from_low);
+}
+
 extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* packed, const float* dlogits,
                                 const float* dprob, const float* prob, float* grads, void* arena,
                                 size_t arena_bytes, void* scratch, size_t scratch_bytes, int training,
                                 void* stream) {
+  return net_backward_impl(n, params, packed, dlogits, dprob, prob, grads, arena, arena_bytes, scratch, scratch_bytes, training,
+                           stream, false);
+}
+
+// Backward pass that starts from d(loss)/d(low-resolution logits), already written into the gradient slot of the HEAD's
+// input tensor by pxl_net_head_loss: the HEAD op's own backward is skipped, everything else is pxl_net_backward.
+extern "C" int pxl_net_backward_low(pxl_net* n, const float* params, const void* packed, float* grads, void* arena,
+                                    size_t arena_bytes, void* scratch, size_t scratch_bytes, int training, void* stream) {
+  return net_backward_impl(n, params, packed, nullptr, nullptr, nullptr, grads, arena, arena_bytes, scratch, scratch_bytes,
+                           training, stream, true);
+}
+
+// Fused training seam on the low-resolution logits of one (student) or two (student + teacher) forward passes held in
+// their arenas: per-sample CE of both networks, the MSE consistency term and d(loss)/d(student low-res logits) into the
+// student's gradient slot (csrc/head.hip: pxl_head_loss).  `teacher` / `t_arena` NULL: no teacher terms.
+extern "C" int pxl_net_head_loss(pxl_net* n, const void* arena, const pxl_net* teacher, const void* t_arena, const float* gt,
+                                 int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight, float mse_weight,
+                                 void* scratch, size_t scratch_bytes, float* sums, void* stream) {
+  PXL_REQUIRE(n && n->planned && arena && scratch && sums && n->head_op >= 0, "net_head_loss: bad argument (plan first)");
+  if (scratch_bytes < n->scratch_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_head_loss: scratch too small");
+  const pxl_op& d = n->ops[n->head_op].d;
+  const TensorInfo& low = n->tensors[d.in0];
+  const void* t_low = nullptr;
+  if (teacher != nullptr && t_arena != nullptr) {
+    PXL_REQUIRE(teacher->planned && teacher->head_op >= 0, "net_head_loss: teacher is not planned");
+    const TensorInfo& tl = teacher->tensors[teacher->ops[teacher->head_op].d.in0];
+    PXL_REQUIRE(teacher->dtype == n->dtype && teacher->B == n->B && tl.H == low.H && tl.W == low.W && tl.Cp == low.Cp &&
+                teacher->Ho == n->Ho && teacher->Wo == n->Wo, "net_head_loss: student and teacher plans differ");
+    t_low = at(t_arena, tl.off);
+  }
+  return pxl_head_loss(n->dtype, n->B, low.H, low.W, low.Cp, n->classes, n->Ho, n->Wo, d.stride, at(arena, low.off), t_low, gt,
+                       ignore_index, n_ce, mse_lo, mse_hi, ce_weight, mse_weight, at(scratch, low.goff), at(scratch, n->up_ws_off),
+                       n->up_ws_bytes, sums, stream);
+}
+
+// The HEAD op alone (up-sampling + soft-max of the low-resolution logits held in `arena`): materialises the
+// full-resolution planes of a pass that ran with logits == NULL, for a consumer that wants them after all
+extern "C" int pxl_net_head_forward(pxl_net* n, const void* arena, float* logits, float* prob, void* stream) {
+  PXL_REQUIRE(n && n->planned && arena && logits && n->head_op >= 0, "net_head_forward: bad argument (plan first)");
+  const pxl_op& d = n->ops[n->head_op].d;
+  const TensorInfo& low = n->tensors[d.in0];
+  return pxl_upsample_softmax_fwd(n->dtype, n->B, low.H, low.W, low.Cp, n->classes, n->Ho, n->Wo, d.stride, at(arena, low.off),
+                                  logits, prob, stream);
+}
+
+// 1 when pxl_net_head_loss can run on this plan (the full-resolution row fits the kernel's LDS staging)
+extern "C" int pxl_net_head_loss_supported(const pxl_net* n) {
+  if (!n || !n->planned || n->head_op < 0) return 0;
+  const TensorInfo& low = n->tensors[n->ops[n->head_op].d.in0];
+  return n->classes <= 32 && pxl_head_loss_lds_bytes(low.W, n->classes, n->Wo) <= 64 * 1024 ? 1 : 0;
+}
+
+namespace {
+int net_backward_impl(pxl_net* n, const float* params, const void* packed, const float* dlogits, const float* dprob,
+                      const float* prob, float* grads, void* arena, size_t arena_bytes, void* scratch, size_t scratch_bytes,
+                      int training, void* stream, bool from_low) {
   PXL_REQUIRE(n && n->planned && params && packed && grads && arena && scratch, "net_backward: bad argument");
-  PXL_REQUIRE(dlogits || dprob, "net_backward: no incoming gradient");
+  PXL_REQUIRE(from_low || dlogits || dprob, "net_backward: no incoming gradient");
   PXL_REQUIRE(n->pack_dgrad, "net_backward: this network packs no data-gradient weights (pxl_net_set_pack_dgrad(net, 0))");
   if (arena_bytes < n->arena_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_backward: arena too small");
   if (scratch_bytes < n->scratch_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_backward: scratch too small (%zu < %zu)", scratch_bytes, n->scratch_bytes);
@@ -1264,6 +1333,7 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
     }
     switch (d.kind) {
       case PXL_OP_HEAD: {
+        if (from_low) { written[d.in0] = 1; break; }       // d(low) was written by pxl_net_head_loss
         const TensorInfo& low = n->tensors[d.in0];
         rc = pxl_upsample_softmax_bwd(dt, n->B, low.H, low.W, low.Cp, n->classes, n->Ho, n->Wo, d.stride, dlogits, dprob, prob,
                                       at(scratch, low.goff), at(scratch, n->up_ws_off), n->up_ws_bytes, stream);
@@ -1498,3 +1568,4 @@ extern "C" int pxl_net_backward(pxl_net* n, const float* params, const void* pac
   }
   return PXL_OK;
 }
+}  // namespace

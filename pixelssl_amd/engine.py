@@ -563,9 +563,9 @@ class SegNetCore(nn.Module):
                 check(lib().pxl_net_set_wgrad(pl.net, int(bool(enable))))
             self._wgrad_on = bool(enable)
 
-    def _forward_raw(self, x, arena, want_prob=None, parts=None):
+    def _forward_raw(self, x, arena, want_prob=None, parts=None, deferred=False):
         """`parts`: NCHW tensors whose channel concatenation is the input (gathered by the input op itself: no torch.cat
-        copy); `x` is then parts[0]."""
+        copy); `x` is then parts[0].  deferred: stop at the low-resolution logits (no full-resolution planes)."""
         if self.keep_arena:
             self._last_arena = arena
         if parts is not None and len(parts) > 1:
@@ -575,8 +575,8 @@ class SegNetCore(nn.Module):
         B = x.shape[0]
         H, W = self._cur.out_size
         want_prob = self.want_prob if want_prob is None else want_prob
-        logits = torch.empty(B, self.num_classes, H, W, device=x.device, dtype=torch.float32)
-        prob = torch.empty_like(logits) if want_prob else None
+        logits = None if deferred else torch.empty(B, self.num_classes, H, W, device=x.device, dtype=torch.float32)
+        prob = torch.empty_like(logits) if want_prob and not deferred else None
         training = self.training and not self.freeze_bn
         check(lib().pxl_net_forward(self._net, ptr(self._store.params), ptr(self._packed), ptr(self._store.running),
                                     ptr(x), ptr(logits), ptr(prob), ptr(arena), arena.numel(), int(training),
@@ -618,6 +618,39 @@ class SegNetCore(nn.Module):
             arena = self._cur.eval_arena
             logits, prob = self._forward_raw(x, arena, parts=parts)
         return logits, prob, (_LatentHandle(self, arena, self._cur) if self.has_latent else None)
+
+    def seam_supported(self, x):
+        """can forward_deferred + functional.head_losses run for this input (shape)?  Plans the shape, runs nothing."""
+        if not x.is_cuda or x.dim() != 4:
+            return False
+        B, _, H, W = x.shape
+        need_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list[:1])
+        self._plan(B, H, W, None, inference=not need_graph and not self.training)
+        return bool(lib().pxl_net_head_loss_supported(self._cur.net))
+
+    def forward_deferred(self, x):
+        """Forward pass up to the LOW-RESOLUTION logits: the up-sampling / soft-max op is not run and no full-resolution
+        plane is written.  -> DeferredHead, which pixelssl_amd.functional.head_losses consumes (criterion + consistency
+        term + their backward on the low-resolution maps, csrc/head.hip) and whose .backward() runs the executor's
+        backward from the gradient that call left behind.  A consumer that wants the planes after all calls
+        .materialize().  None when this plan cannot run the fused seam (the caller then uses forward())."""
+        if not x.is_cuda:
+            raise _lib.PixelHipError("SegNetCore runs on the GPU only (input is on %s); there is no CPU path" % x.device)
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        need_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list[:1])
+        self._plan(B, H, W, None, inference=not need_graph and not self.training)
+        if not lib().pxl_net_head_loss_supported(self._cur.net):
+            return None
+        self._ensure_packed()
+        if need_graph:
+            arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
+        else:
+            if self._cur.eval_arena is None:
+                self._cur.eval_arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
+            arena = self._cur.eval_arena
+        self._forward_raw(x, arena, deferred=True)
+        return DeferredHead(self, arena, self._cur, B, bool(self.training and not self.freeze_bn), need_graph)
 
     def forward_with_latent(self, x):
         """-> (logits, softmax, latent) where the latent (NCHW fp32) is part of the autograd graph: a gradient that
@@ -704,6 +737,41 @@ class _Plan:
                 self.net = ctypes.c_void_p()
         except Exception:
             pass
+
+
+class DeferredHead:
+    """A forward pass that stopped at the low-resolution logits (SegNetCore.forward_deferred)."""
+
+    def __init__(self, core, arena, plan, batch, bn_training, trainable):
+        self.core, self.arena, self.plan, self.batch = core, arena, plan, batch
+        self.bn_training, self.trainable = bn_training, trainable
+        self.has_grad = False           # functional.head_losses wrote d(loss)/d(low-res logits) into the plan's scratch
+
+    def materialize(self, want_prob=True):
+        """-> (logits, softmax) NCHW fp32 at full resolution, detached (what forward() would have returned)."""
+        core = self.core
+        H, W = self.plan.out_size
+        logits = torch.empty(self.batch, core.num_classes, H, W, device=core._device, dtype=torch.float32)
+        prob = torch.empty_like(logits) if want_prob else None
+        check(lib().pxl_net_head_forward(self.plan.net, ptr(self.arena), ptr(logits), ptr(prob), stream_ptr()))
+        return logits, prob
+
+    def backward(self):
+        """The executor's backward pass from the low-resolution gradient (parameter gradients accumulate into the flat
+        gradient buffer, exactly like the autograd path of forward())."""
+        if not (self.trainable and self.has_grad):
+            raise _lib.PixelHipError("DeferredHead.backward: no gradient to propagate (no-grad pass, or head_losses not called)")
+        core, pl = self.core, self.plan
+        core.ensure_grad_views()
+        s = core._store
+        if pl.wt_ready is not None:
+            torch.cuda.current_stream().wait_event(pl.wt_ready)
+        check(lib().pxl_net_backward_low(pl.net, ptr(s.params), ptr(pl.packed), ptr(s.grads), ptr(self.arena), self.arena.numel(),
+                                         ptr(pl.scratch), pl.scratch.numel(), int(self.bn_training), stream_ptr()))
+        hook = getattr(core, "_post_backward_hook", None)
+        if hook is not None and core._wgrad_on:
+            hook(core)
+        self.has_grad = False
 
 
 class _LatentHandle:

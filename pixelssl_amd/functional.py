@@ -119,6 +119,31 @@ def task_consistency(logits, gt, ce_values, target, lo, hi, ignore_index=255):
     return _TaskConsistency.apply(logits, gt, ce_values.detach(), target.detach(), int(lo), int(hi), int(ignore_index))
 
 
+def head_losses(s_head, t_head, gt, n_ce, mse_lo, mse_hi, ce_weight, mse_weight, ignore_index=255):
+    """The training seam on the low-resolution logits of deferred forward passes (engine.DeferredHead; csrc/head.hip:
+    pxl_head_loss): per-sample cross-entropy of the student and of the teacher on the first `n_ce` samples
+    (task/sseg/criterion.py:24-38), the MSE between their predictions over samples [mse_lo, mse_hi) (ssl_mt.py:179-184)
+    and d(loss)/d(student low-res logits) for loss = ce_weight * sum(CE_student) + mse_weight * MSE, left in the
+    student's executor for s_head.backward().  t_head None: student terms only.
+    -> (student CE [n_ce], teacher CE [n_ce] or None, MSE mean scalar), detached fp32 device tensors."""
+    _gpu(gt)
+    gt = gt.contiguous().float()
+    B = s_head.batch
+    if t_head is not None and (t_head.batch != B or t_head.plan.out_size != s_head.plan.out_size):
+        raise ValueError("head_losses: student and teacher passes differ in shape")
+    H, W = s_head.plan.out_size
+    if n_ce and gt.numel() != n_ce * H * W:
+        raise ValueError("head_losses: gt %s does not hold %d maps of %d x %d" % (tuple(gt.shape), n_ce, H, W))
+    sums = torch.empty(2 * B + 1, device=gt.device, dtype=torch.float32)
+    pl = s_head.plan
+    check(lib().pxl_net_head_loss(pl.net, ptr(s_head.arena), t_head.plan.net if t_head is not None else None,
+                                  ptr(t_head.arena) if t_head is not None else None, ptr(gt), int(ignore_index), int(n_ce),
+                                  int(mse_lo), int(mse_hi), float(ce_weight), float(mse_weight), ptr(pl.scratch),
+                                  pl.scratch.numel(), ptr(sums), stream_ptr()))
+    s_head.has_grad = True
+    return sums[:n_ce], (sums[B:B + n_ce] if t_head is not None else None), sums[2 * B]
+
+
 class MSELoss(torch.nn.Module):
     """Drop-in for the `nn.MSELoss()` the SSL algorithms instantiate."""
 

@@ -46,7 +46,40 @@ class _Resulter(dict):
         return list(dict.keys(self)) + ([] if dict.__contains__(self, 'sslcct_ad_inp') else ['sslcct_ad_inp'])
 
 
-class DeepLabV2(model_template.TaskModel):
+class _DeferredResulter(dict):
+    """resulter of a deferred forward pass: 'pred' / 'activated_pred' are materialised (detached) when first read."""
+
+    def __init__(self, head):
+        super().__init__()
+        self.head = head
+
+    def __missing__(self, key):
+        if key in ('pred', 'activated_pred'):
+            logits, prob = self.head.materialize()
+            self['pred'], self['activated_pred'] = (logits,), (prob,)
+            return self[key]
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return key in ('pred', 'activated_pred') or dict.__contains__(self, key)
+
+    def keys(self):
+        return list(dict.keys(self)) + [k for k in ('pred', 'activated_pred') if not dict.__contains__(self, k)]
+
+
+class _DeferredForward:
+    """Engine extension of the sseg task models (not in the reference): forward_deferred(inp) stops at the
+    low-resolution logits -> engine.DeferredHead (None when unsupported); SSL algorithms whose losses the fused seam
+    covers (SupOnly, MT) use it when nothing reads the full-resolution predictions."""
+
+    def forward_deferred(self, inp):
+        if not len(inp) == 1:
+            logger.log_err('Semantic segmentation models require only one input\n'
+                           'However, {0} inputs are given\n'.format(len(inp)))
+        return self.model.forward_deferred(inp[0])
+
+
+class DeepLabV2(model_template.TaskModel, _DeferredForward):
     def __init__(self, args):
         super().__init__(args)
         if args.backbone not in ('resnet50', 'resnet101', 'resnet101-coco'):
@@ -71,7 +104,7 @@ class DeepLabV2(model_template.TaskModel):
         return resulter, {}
 
 
-class PSPNet(model_template.TaskModel):
+class PSPNet(model_template.TaskModel, _DeferredForward):
     """task/sseg/model.py:83-125: PSPNet TaskModel with three parameter groups (backbone lr, psp / decoder lr x10);
     'sslcct_ad_inp' is the pyramid module's 512-channel output."""
 

@@ -2,6 +2,8 @@
 an export function named like the module, and a class with NAME / SUPPORTED_TASK_TYPES,
 build / train / validate / save_checkpoint / load_checkpoint and the public dicts
 models / optimizers / lrers / criterions / meters."""
+import torch
+
 from ..utils import logger
 
 
@@ -74,6 +76,24 @@ class _SSLBase:
             else:
                 self._enq_pool = None
         return self._enq_pool
+
+    @staticmethod
+    def _seam_fusable(task_models, criterion, inp, gt):
+        """True when the fused training seam (functional.head_losses on deferred forward passes) computes exactly what
+        the generic path would: sseg task models of this engine, the sseg criterion of this engine, one input / one
+        ground-truth tensor, gradients enabled, and a plan whose rows fit the kernel.  PXL_FUSE_SEAM=0 turns it off."""
+        import os
+        from ..sseg.criterion import CommonSSEGCriterion
+        if os.environ.get('PXL_FUSE_SEAM', '1') == '0' or not torch.is_grad_enabled():
+            return False
+        if type(criterion) is not CommonSSEGCriterion or len(inp) != 1 or len(gt) != 1 or not inp[0].is_cuda:
+            return False
+        for m in task_models:
+            tm = getattr(m, 'module', None)
+            core = getattr(tm, 'model', None)
+            if not hasattr(tm, 'forward_deferred') or not hasattr(core, 'seam_supported') or not core.seam_supported(inp[0]):
+                return False
+        return True
 
     @staticmethod
     def _single_component(name, *dicts):

@@ -84,6 +84,9 @@ class SSLMT(ssl_base._SSLBase):
 
         self.s_optimizer.zero_grad()
         l_gt = func.split_tensor_tuple(gt, 0, lbs)
+        if lbs > 0 and type(self.cons_criterion) is MSELoss and \
+                self._seam_fusable([self.s_model, self.t_model], self.s_criterion, s_inp, gt):
+            return self._train_step_fused_seam(s_inp, t_inp, l_gt, lbs, ramp, cur_step)
 
         def teacher_pass():
             with torch.no_grad():
@@ -161,6 +164,57 @@ class SSLMT(ssl_base._SSLBase):
             self.s_lrer.step()
         return dict(s_task_loss=s_task_loss.detach(), t_task_loss=t_task_loss.detach(),
                     cons_loss=cons_loss.detach()), s_resulter, t_resulter
+
+    def _train_step_fused_seam(self, s_inp, t_inp, l_gt, lbs, ramp, cur_step):
+        """The same iteration with the seam between the two forward passes and the backward pass fused
+        (functional.head_losses): both networks stop at their low-resolution logits, one kernel evaluates the student's
+        and the teacher's task loss, the consistency term and d(loss)/d(student logits) per full-resolution row, and the
+        executor's backward starts from that gradient.  No 8 x 21 x 513 x 513 plane (logits, soft-max, their gradients:
+        177 MB each) is written; the loss values and the weight update are those of the generic path (same per-pixel
+        expressions, tests/test_seam.py)."""
+        from .. import functional as PF
+        from ..sseg.model import _DeferredResulter
+        side = self._teacher_stream()
+
+        def teacher_pass():
+            with torch.no_grad():
+                return self.t_model.module.forward_deferred(t_inp)
+        fut = None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            dev = torch.cuda.current_device()
+
+            def on_side():
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(side):
+                    return teacher_pass()
+            pool = self._enqueue_worker()
+            if pool is not None:
+                fut = pool.submit(on_side)
+            else:
+                t_head = on_side()
+        s_head = self.s_model.module.forward_deferred(s_inp)
+        if side is not None:
+            if fut is not None:
+                t_head = fut.result()
+            main.wait_stream(side)
+            t_head.arena.record_stream(main)
+        else:
+            t_head = teacher_pass()
+        B = s_inp[0].shape[0]
+        lo, hi = (0, B) if self.args.cons_for_labeled else ((lbs, B) if self.args.unlabeled_batch_size > 0 else (0, 0))
+        w_cons = ramp * self.args.cons_scale
+        ce_s, ce_t, mse = PF.head_losses(s_head, t_head, l_gt[0], lbs, lo, hi, 1.0 / lbs, w_cons, self.args.ignore_index)
+        s_task_loss, t_task_loss = torch.mean(ce_s), torch.mean(ce_t)
+        cons_loss = w_cons * mse
+        s_head.backward()
+        self.s_optimizer.step()
+        self._update_ema_variables(self.s_model, self.t_model, self.args.ema_decay, cur_step)
+        if not self.args.is_epoch_lrer:
+            self.s_lrer.step()
+        return dict(s_task_loss=s_task_loss.detach(), t_task_loss=t_task_loss.detach(),
+                    cons_loss=cons_loss.detach()), _DeferredResulter(s_head), _DeferredResulter(t_head)
 
     def _train(self, data_loader, epoch):
         self.meters.reset()

@@ -46,6 +46,18 @@ class SSLNULL(ssl_base._SSLBase):
         """One iteration of ssl_null.py:97-136 on already-device-resident tuples; returns the loss tensor."""
         lbs = self.args.labeled_batch_size
         self.optimizer.zero_grad()
+        if lbs > 0 and self._seam_fusable([self.model], self.criterion, inp, gt):
+            # fused seam: forward to the low-resolution logits, criterion + its backward on them (no 21 x 513 x 513 planes)
+            from .. import functional as PF
+            from ..sseg.model import _DeferredResulter
+            head = self.model.module.forward_deferred(inp)
+            ce, _, _ = PF.head_losses(head, None, gt[0][:lbs], lbs, 0, 0, 1.0 / lbs, 0.0, self.args.ignore_index)
+            task_loss = torch.mean(ce)
+            head.backward()
+            self.optimizer.step()
+            if not self.args.is_epoch_lrer:
+                self.lrer.step()
+            return task_loss.detach(), _DeferredResulter(head)
         resulter, _ = self.model.forward(inp)
         self._need_pred(resulter, 'SSL_NULL')
         pred = tool.dict_value(resulter, 'pred')

@@ -28,8 +28,11 @@ LOSS_TOL = {"fp32": 1e-3, "bf16": 1e-2}
 WEIGHT_FRAC = {"fp32": 0.05, "bf16": 0.6}
 EPS32 = 1.1920929e-07
 # bf16 engine, CCT (seven decoders back-propagated through ~100 bf16 layers): bars on the direction of the six-step update
-CCT_BF16_MIN_COS = 0.3
-CCT_BF16_MEDIAN_COS = 0.7
+# (measured on the MI355X: worst probed tensor 0.67-0.75 -- conv1 and layer4.2.conv2, whose gradient arrives through
+# the bf16 latent of the unlabeled pass -- median 0.996-0.999, norm ratios 0.99-1.30; a no-op scores ratio 0)
+CCT_BF16_MIN_COS = 0.55
+CCT_BF16_MEDIAN_COS = 0.95
+CCT_BF16_RATIO = (0.8, 1.45)
 
 
 def _fx(name):
@@ -167,7 +170,7 @@ def test_suponly_six_iterations(dtype):
         _check_losses("suponly", i, {"task_loss": loss.item()}, fx["per_iter"][i], dtype)
     _check_weights("suponly " + dtype, core.state_dict(), fx["updates"], dtype)
     _check_update_direction("suponly " + dtype, core.state_dict(), _deeplab_state(fx["weight_seed"], fx["gamma3"]), fx["updates"],
-                            min_cos=0.99 if dtype == "fp32" else 0.7, ratio=(0.9, 1.1) if dtype == "fp32" else (0.6, 1.4))
+                            min_cos=0.99 if dtype == "fp32" else 0.85, ratio=(0.97, 1.03) if dtype == "fp32" else (0.9, 1.1))
 
 
 @pytest.mark.gpu
@@ -255,7 +258,7 @@ def test_mt_at_the_baseline_configuration(dtype):
     _check_weights("mt 513 student " + dtype, s_sd, fx["student_updates"], dtype)
     _check_weights("mt 513 teacher " + dtype, t_sd, fx["teacher_updates"], dtype)
     _check_update_direction("mt 513 student " + dtype, s_sd, s_init, fx["student_updates"],
-                            min_cos=0.99 if dtype == "fp32" else 0.7, ratio=(0.9, 1.1) if dtype == "fp32" else (0.6, 1.4))
+                            min_cos=0.99 if dtype == "fp32" else 0.85, ratio=(0.97, 1.03) if dtype == "fp32" else (0.9, 1.1))
 
 
 @pytest.mark.gpu
@@ -400,7 +403,7 @@ def test_cct_six_iterations(dtype):
         # algorithms (0.68-0.9 x the update vs 0.35): tools/diag_bf16_grad.py, profiles/r03_bf16_grad_diag.txt.
         init = TO.condition_state(TO.init_pspnet_state(seed=fx["weight_seed"]), fx["gamma3"])
         _check_update_direction("cct main bf16", main_sd, init, fx["main_updates"], min_cos=CCT_BF16_MIN_COS,
-                                ratio=(0.5, 1.5), median_cos=CCT_BF16_MEDIAN_COS, skip=("psp.stages.0.",))
+                                ratio=CCT_BF16_RATIO, median_cos=CCT_BF16_MEDIAN_COS, skip=("psp.stages.0.",))
 
 
 @pytest.mark.gpu
@@ -454,4 +457,4 @@ def test_cct_six_iterations_with_gcutout(dtype):
         _check_weights("cct+cut main fp32", main_sd, fx["main_updates"], dtype, frac=0.1)
     else:
         _check_update_direction("cct+cut main bf16", main_sd, init, fx["main_updates"], min_cos=CCT_BF16_MIN_COS,
-                                ratio=(0.5, 1.5), median_cos=CCT_BF16_MEDIAN_COS, skip=("psp.stages.0.",))
+                                ratio=CCT_BF16_RATIO, median_cos=CCT_BF16_MEDIAN_COS, skip=("psp.stages.0.",))

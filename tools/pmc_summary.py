@@ -5,7 +5,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
-for f in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True)):
+for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             name = re.sub(r"\(anonymous namespace\)::", "", row.get("Kernel_Name", ""))
