@@ -399,6 +399,9 @@ int pxl_dilate3_reflect(int B, int H, int W, const float* x, float* out, void* s
  * clip = -INFINITY: FDGT normalisation (ssl_gct.py:722-725); clip = 0.1: FlawmapHandler (:648-655). */
 int pxl_minmax_norm_persample(int B, long HW, const float* x, float clip_threshold, float* mm, float* out,
                               void* stream);
+/* GaussianNoiseLayer.forward (pixelssl/nn/module/gaussian_noise.py:18-40), in place on x [B][n] fp32: per-sample min-max
+ * normalise, add `noise`, clip to [0, 1], de-normalise; mm = [B][2] scratch */
+int pxl_gaussian_noise_apply(int B, long n, float* x, const float* noise, float* mm, void* stream);
 /* DCGTGenerator.forward (ssl_gct.py:668-689): l_fm / r_fm are updated IN PLACE (fm <= thr ? fm : 1) */
 int pxl_dcgt(int B, int C, long HW, const float* l_pred, const float* r_pred, float* l_fm, float* r_fm,
              float threshold, float* l_gt, float* r_gt, float* both_bad, void* stream);
@@ -417,10 +420,16 @@ int pxl_mse_persample_bwd(int B, long n, const float* a, const float* g, const f
 /* torch.optim.SGD(momentum, weight_decay) semantics, pixelssl/nn/optimizer.py:57-75 */
 int pxl_sgd_step(long n, float* p, const float* g, float* buf, float lr, float momentum, float weight_decay,
                  int first_step, void* stream);
+/* the full torch.optim.SGD update incl. dampening and nesterov (pixelssl/nn/optimizer.py:57-75 passes both through) */
+int pxl_sgd_step_general(long n, float* p, const float* g, float* buf, float lr, float momentum, float dampening,
+                         float weight_decay, int nesterov, int first_step, void* stream);
 /* torch.optim.Adam(lr, betas, eps) without weight decay over a flat buffer (ssl_adv.py:101-102, discriminator);
  * `step` counts from 1 (bias correction) */
 int pxl_adam_step(long n, float* p, const float* g, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                   float beta2, float eps, int step, void* stream);
+/* ... with torch.optim.Adam's L2 weight decay (g += wd * p; pixelssl/nn/optimizer.py:103-122 passes --weight-decay) */
+int pxl_adam_step_wd(long n, float* p, const float* g, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, void* stream);
 /* SSLMT._update_ema_variables, pixelssl/ssl_algorithm/ssl_mt.py:359-363 */
 int pxl_ema_update(long n, float* teacher, const float* student, float alpha, void* stream);
 int pxl_scale_inplace(long n, float* x, float a, void* stream);

@@ -69,6 +69,23 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T
   const ColGeom g = col_geom(C, EPC, cgmax);
   const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
   const int cc = blockIdx.x * g.cg + ccol;
+  // FIN: the first rows of both operands are requested BEFORE the finalize prologue (statistics loads + two barriers):
+  // the launch is latency-bound (a few rows per thread), so the two round trips overlap instead of adding up
+  const int m_begin = blockIdx.y * rows_per_group;
+  const int m_end = min(M, m_begin + rows_per_group);
+  const size_t col = (size_t)cc * EPC, step = (size_t)g.rl * C;
+  int m = m_begin + rlane;
+  constexpr int PF = FIN ? 4 : 0;
+  uint4 pa[PF > 0 ? PF : 1], pb[PF > 0 ? PF : 1];
+  if constexpr (FIN) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      if (m + k * g.rl < m_end) {
+        pa[k] = *reinterpret_cast<const uint4*>(y + (size_t)(m + k * g.rl) * C + col);
+        pb[k] = *reinterpret_cast<const uint4*>(res + (size_t)(m + k * g.rl) * C + col);
+      }
+    }
+  }
   float ys[EPC], yb[EPC], rs[EPC], rb[EPC];
   if constexpr (FIN) {
     __shared__ float lsum[256], lsc[128], lsh[128];
@@ -104,18 +121,21 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T
     for (int e = 0; e < EPC; ++e) v[e] = fmaxf(fy[e] * ys[e] + yb[e] + (fr[e] * rs[e] + rb[e]), 0.f);
     return Chunk<T>::pack(v);
   };
-  const int m_begin = blockIdx.y * rows_per_group;
-  const int m_end = min(M, m_begin + rows_per_group);
-  int m = m_begin + rlane;
+  if constexpr (FIN) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (m + k * g.rl < m_end) *reinterpret_cast<uint4*>(out + (size_t)(m + k * g.rl) * C + col) = one(pa[k], pb[k]);
+    m += PF * g.rl;
+  }
   for (; m + g.rl < m_end; m += 2 * g.rl) {
-    const size_t o0 = (size_t)m * C + cc * EPC, o1 = (size_t)(m + g.rl) * C + cc * EPC;
+    const size_t o0 = (size_t)m * C + col, o1 = o0 + step;
     const uint4 a0 = *reinterpret_cast<const uint4*>(y + o0), b0 = *reinterpret_cast<const uint4*>(res + o0);
     const uint4 a1 = *reinterpret_cast<const uint4*>(y + o1), b1 = *reinterpret_cast<const uint4*>(res + o1);
     *reinterpret_cast<uint4*>(out + o0) = one(a0, b0);
     *reinterpret_cast<uint4*>(out + o1) = one(a1, b1);
   }
   if (m < m_end) {
-    const size_t o0 = (size_t)m * C + cc * EPC;
+    const size_t o0 = (size_t)m * C + col;
     *reinterpret_cast<uint4*>(out + o0) = one(*reinterpret_cast<const uint4*>(y + o0), *reinterpret_cast<const uint4*>(res + o0));
   }
 }
@@ -130,6 +150,18 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(int M, int C, const T
   const ColGeom g = col_geom(C, EPC, cgmax);
   const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
   const int cc = blockIdx.x * g.cg + ccol;
+  const int m_begin = blockIdx.y * rows_per_group;
+  const int m_end = min(M, m_begin + rows_per_group);
+  const size_t col = (size_t)cc * EPC, step = (size_t)g.rl * C;
+  int m = m_begin + rlane;
+  // FIN: first rows requested before the finalize prologue (see residual_fwd_kernel)
+  constexpr int PF = FIN ? 4 : 0;
+  uint4 pa[PF > 0 ? PF : 1];
+  if constexpr (FIN) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (m + k * g.rl < m_end) pa[k] = *reinterpret_cast<const uint4*>(y + (size_t)(m + k * g.rl) * C + col);
+  }
   float sc[EPC], sh[EPC];
   if constexpr (FIN) {
     __shared__ float lsum[256], lsc[128], lsh[128];
@@ -151,18 +183,21 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(int M, int C, const T
     }
     return Chunk<T>::pack(f);
   };
-  const int m_begin = blockIdx.y * rows_per_group;
-  const int m_end = min(M, m_begin + rows_per_group);
-  int m = m_begin + rlane;
+  if constexpr (FIN) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (m + k * g.rl < m_end) *reinterpret_cast<uint4*>(z + (size_t)(m + k * g.rl) * C + col) = one(pa[k]);
+    m += PF * g.rl;
+  }
   for (; m + g.rl < m_end; m += 2 * g.rl) {
-    const size_t o0 = (size_t)m * C + cc * EPC, o1 = (size_t)(m + g.rl) * C + cc * EPC;
+    const size_t o0 = (size_t)m * C + col, o1 = o0 + step;
     const uint4 a0 = *reinterpret_cast<const uint4*>(y + o0);
     const uint4 a1 = *reinterpret_cast<const uint4*>(y + o1);
     *reinterpret_cast<uint4*>(z + o0) = one(a0);
     *reinterpret_cast<uint4*>(z + o1) = one(a1);
   }
   if (m < m_end) {
-    const size_t o0 = (size_t)m * C + cc * EPC;
+    const size_t o0 = (size_t)m * C + col;
     *reinterpret_cast<uint4*>(z + o0) = one(*reinterpret_cast<const uint4*>(y + o0));
   }
 }

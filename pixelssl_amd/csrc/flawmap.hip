@@ -151,6 +151,25 @@ __global__ void minmax_norm_kernel(long HW, const float* __restrict__ x, const f
     out[b * HW + i] = (x[b * HW + i] * keep - lo) / den;
 }
 
+// GaussianNoiseLayer.forward (pixelssl/nn/module/gaussian_noise.py:18-40), in place on x: per-sample min-max normalise to
+// [0, 1], add the noise, clip to [0, 1] (the reference's mask arithmetic), de-normalise.  Same operation order as the
+// reference's in-place chain: sub_(min).div_(range) ; add_(noise) ; clip ; mul_(range).add_(min).
+__global__ void gaussian_noise_kernel(long n, float* __restrict__ x, const float* __restrict__ noise,
+                                      const float* __restrict__ mm) {
+  const int b = blockIdx.y;
+  const float lo = mm[2 * b], hi = mm[2 * b + 1];
+  const float range = hi - lo + 1e-9f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = (x[b * n + i] - lo) / range;
+    v = v + noise[b * n + i];
+    const float ub = v > 1.f ? 1.f : 0.f;
+    v = v * (1.f - ub) + ub;
+    const float lb = v < 0.f ? 1.f : 0.f;
+    v = v * (1.f - lb);
+    x[b * n + i] = v * range + lo;
+  }
+}
+
 // DCGTGenerator: fm := fm <= thr ? fm : 1 (in place); mask_l = r_fm >= l_fm; gt_l = mask_l ? l_pred : r_pred
 __global__ void dcgt_kernel(int B, int C, long HW, const float* __restrict__ lp, const float* __restrict__ rp,
                             float* __restrict__ lf, float* __restrict__ rf, float thr, float* __restrict__ lgt,
@@ -280,6 +299,17 @@ extern "C" int pxl_minmax_norm_persample(int B, long HW, const float* x, float c
   const int gx = (int)((HW + 256 * 8 - 1) / (256 * 8));
   hipLaunchKernelGGL(minmax_kernel, dim3(gx, B), dim3(256), 0, s, HW, x, mm);
   hipLaunchKernelGGL(minmax_norm_kernel, dim3(gx, B), dim3(256), 0, s, HW, x, mm, clip_threshold, out);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_gaussian_noise_apply(int B, long n, float* x, const float* noise, float* mm, void* stream) {
+  PXL_REQUIRE(x && noise && mm && B > 0 && n > 0, "gaussian_noise_apply: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(minmax_init_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, B, mm);
+  const int gx = (int)((n + 256 * 8 - 1) / (256 * 8));
+  hipLaunchKernelGGL(minmax_kernel, dim3(gx, B), dim3(256), 0, s, n, x, mm);
+  hipLaunchKernelGGL(gaussian_noise_kernel, dim3(gx, B), dim3(256), 0, s, n, x, noise, mm);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

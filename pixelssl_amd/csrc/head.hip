@@ -6,6 +6,7 @@
 // engine dtype; full-res outputs NCHW fp32 [B][C][H][W] (what the plugin API hands to the SSL
 // algorithms).  HBM-bound: the forward writes 2*C*H*W floats per image; consecutive lanes walk x
 // so every channel-plane store is a coalesced 256-byte line.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -317,6 +318,214 @@ __global__ __launch_bounds__(256) void head_loss_rows_kernel(int C, int Cp, int 
   }
 }
 
+// ---- the same seam, cell-wise (large up-sampling factors: DeepLab's 33 x 33 -> 513 x 513) ----------------------------------
+// One WAVE per low-resolution cell (b, i, j) = the full-resolution pixels whose bilinear footprint is the four corners
+// (i, j) .. (i+1, j+1): 16 x 16 pixels at scale 16.  The corner values of both networks sit in LDS (broadcast reads); a
+// lane owns ONE pixel column of the cell (its x weight is a constant) and walks the rows, everything of a pixel stays in
+// registers; it accumulates A0 = sum (1 - ly) * G and A1 = sum ly * G (2 * C registers), the x weights and the sum over
+// the lanes are applied once per cell by a butterfly, and 4 * C fp32 atomics per cell go into dacc [B][h][w][C] (every
+// element receives at most four addends).  The row-wise kernel above spends its time in two barriers and an LDS image
+// of the row per 513 pixels; this one has no barrier in the pixel loop and ~8x the waves in flight.  Loss partial sums go
+// to part[cell][3] and are reduced in a fixed order by head_loss_finish_kernel (no contended atomics, deterministic
+// losses).  C is a template parameter: with a run-time channel count the accumulators spill.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void head_loss_cells_kernel(int Cp, int h, int w, int H, int W, float sy, float sx,
+                                                              int align, const T* __restrict__ s_low,
+                                                              const T* __restrict__ t_low, const float* __restrict__ gt,
+                                                              int ignore_index, int n_ce, int mse_lo, int mse_hi,
+                                                              float ce_scale, float mse_scale, float* __restrict__ dacc,
+                                                              float* __restrict__ part, int B) {
+  __shared__ float corner[4][2][4 * C];      // [wave][student | teacher][corner k = 2 * dy + dx][c]
+  __shared__ float tr[4][(2 * C + 1) * 65];    // [wave][A0 rows | A1 rows | lx][lane], pitch 65
+  __shared__ float lsum[4][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long cell = (long)blockIdx.x * 4 + wave;
+  const long ncell = (long)B * h * w;
+  float acc_s = 0.f, acc_t = 0.f, acc_m = 0.f;
+  int b = 0, i = 0, j = 0, i1 = 0, j1 = 0;
+  bool live = cell < ncell;
+  int ya = 0, yb = 0, xa = 0, xb = 0;
+  if (live) {
+    j = (int)(cell % w);
+    i = (int)((cell / w) % h);
+    b = (int)(cell / ((long)w * h));
+    i1 = i + (i < h - 1 ? 1 : 0);
+    j1 = j + (j < w - 1 ? 1 : 0);
+    // pixel range of the cell: floor(src) is monotone in the destination index
+    auto first_ge = [&](int target, float scale, int in_size, int out_size) {
+      int lo = 0, hi = out_size;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        int a0, a1; float l;
+        src_coord(mid, scale, align, in_size, a0, a1, l);
+        if (a0 >= target) hi = mid; else lo = mid + 1;
+      }
+      return lo;
+    };
+    ya = first_ge(i, sy, h, H); yb = first_ge(i + 1, sy, h, H);
+    xa = first_ge(j, sx, w, W); xb = first_ge(j + 1, sx, w, W);
+    live = yb > ya && xb > xa;
+  }
+  const bool has_t = t_low != nullptr;
+  if (live) {
+    for (int e = lane; e < 4 * C; e += 64) {
+      const int k = e / C, c = e - k * C;
+      const size_t o = ((size_t)(b * h + ((k >> 1) ? i1 : i)) * w + ((k & 1) ? j1 : j)) * Cp + c;
+      corner[wave][0][e] = to_f(s_low[o]);
+      if (has_t) corner[wave][1][e] = to_f(t_low[o]);
+    }
+  }
+  __syncthreads();
+  float A0[C], A1[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) A0[c] = A1[c] = 0.f;
+  float lx = 0.f;
+  if (live) {
+    const bool ce = b < n_ce;
+    const bool mse = has_t && b >= mse_lo && b < mse_hi;
+    const float ms = mse ? mse_scale : 0.f, msq = mse ? 1.f : 0.f;
+    // lane -> (row group, column): columns padded to a power of two <= 64 (the host guarantees xb - xa <= 64)
+    const int nx = xb - xa;
+    int nxp = 1;
+    while (nxp < nx) nxp <<= 1;
+    const int xl = lane & (nxp - 1), rg = lane / nxp, nrg = 64 / nxp;
+    const int x = xa + xl;
+    const bool col = xl < nx;
+    int a0, a1;
+    src_coord(col ? x : xa, sx, align, w, a0, a1, lx);
+    for (int y = ya + rg; y < yb && col; y += nrg) {
+      // the corner values are re-read from LDS (broadcast) for every pixel: hoisted out of the loop they would cost
+      // 8 * C registers -- the empty asm makes the offset opaque to that optimisation
+      int coff = 0;
+      asm volatile("" : "+v"(coff));
+      const float* cs = corner[wave][0] + coff;
+      const float* ct = corner[wave][1] + coff;
+      float ly;
+      src_coord(y, sy, align, h, a0, a1, ly);
+      const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+      int label = -1;
+      bool valid = false;
+      if (ce) {
+        label = (int)gt[((size_t)b * H + y) * W + x];
+        valid = !(label == ignore_index || label < 0 || label >= C);
+      }
+      // straight-line per-pixel code with scalar switches (ce / mse are uniform over the wave): conditional in-place
+      // updates of the channel arrays made the register allocator keep two copies of them
+      float zs[C], gm[C];
+      float mxs = -INFINITY, mxt = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        zs[c] = w00 * cs[c] + w01 * cs[C + c] + w10 * cs[2 * C + c] + w11 * cs[3 * C + c];
+        mxs = fmaxf(mxs, zs[c]);
+      }
+      float tsum = 0.f, tpick = 0.f;
+      if (has_t) {                                   // teacher: max, then exp-sum + the consistency part of G in one sweep
+        float zt[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          zt[c] = w00 * ct[c] + w01 * ct[C + c] + w10 * ct[2 * C + c] + w11 * ct[3 * C + c];
+          mxt = fmaxf(mxt, zt[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          tsum += expf(zt[c] - mxt);
+          if (c == label) tpick = zt[c];
+          const float d = zs[c] - zt[c];
+          acc_m += msq * (d * d);
+          gm[c] = __fmul_rn(ms, d);
+        }
+        if (valid) acc_t += (mxt + logf(tsum)) - tpick;
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) gm[c] = 0.f;
+      }
+      float sum = 0.f, pick = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) { if (c == label) pick = zs[c]; zs[c] = expf(zs[c] - mxs); sum += zs[c]; }
+      if (valid) acc_s += (mxs + logf(sum)) - pick;
+      const float inv = valid ? ce_scale / sum : 0.f;
+      const float hot = valid ? -ce_scale : 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float gce = __fmaf_rn(zs[c], inv, c == label ? hot : 0.f);      // 0 for an invalid / unlabeled pixel
+        const float gv = ce ? (mse ? __fadd_rn(gce, gm[c]) : gce) : gm[c];
+        A0[c] += (1.f - ly) * gv;
+        A1[c] += ly * gv;
+      }
+    }
+  }
+  // x weights + sum over the lanes through LDS (a register butterfly over 4 * C values needs more registers than the
+  // pixel loop): every lane parks its 2 * C sums and its x weight, then lane e < 4 * C forms corner value e =
+  // sum_lanes (dx ? lx : 1 - lx) * A_dy[c] in lane order (deterministic).  Row pitch 65: conflict-free column walks.
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      tr[wave][c * 65 + lane] = A0[c];
+      tr[wave][(C + c) * 65 + lane] = A1[c];
+    }
+    tr[wave][2 * C * 65 + lane] = lx;
+    acc_s = wave_sum(acc_s); acc_t = wave_sum(acc_t); acc_m = wave_sum(acc_m);
+  }
+  if (lane == 0) { lsum[wave][0] = acc_s; lsum[wave][1] = acc_t; lsum[wave][2] = acc_m; }
+  __syncthreads();
+  if (live) {
+    for (int e = lane; e < 4 * C; e += 64) {
+      const int k = e / C, c = e - k * C;
+      const float* row = tr[wave] + ((k >> 1) * C + c) * 65;
+      const float* lxs = tr[wave] + 2 * C * 65;
+      float v = 0.f;
+      for (int l = 0; l < 64; ++l) v += ((k & 1) ? lxs[l] : 1.f - lxs[l]) * row[l];
+      const size_t o = ((size_t)(b * h + ((k >> 1) ? i1 : i)) * w + ((k & 1) ? j1 : j)) * C + c;
+      atomicAdd(dacc + o, v);
+    }
+  }
+  if (threadIdx.x < 12) {        // per-cell loss partials (an empty / out-of-range cell writes zeros)
+    const int wv = threadIdx.x / 3, q = threadIdx.x - wv * 3;
+    part[((size_t)blockIdx.x * 4 + wv) * 3 + q] = lsum[wv][q];
+  }
+}
+
+// d(low) fp32 accumulator -> engine dtype NHWC with zeroed channel padding; blocks >= gridDim.x - B reduce the per-cell
+// loss partials of one sample each, in cell order (deterministic): sums[b], sums[B + b] (x 1/HW), sums[2B] += MSE mean
+template <typename T>
+__global__ __launch_bounds__(256) void head_loss_finish_kernel(int B, int h, int w, int C, int Cp, const float* __restrict__ dacc,
+                                                               T* __restrict__ dlow, const float* __restrict__ part,
+                                                               float inv_hw, float inv_mse_n, int n_ce, int has_t,
+                                                               float* __restrict__ sums) {
+  __shared__ float red[3][4];
+  const int nconv = gridDim.x - B;
+  if ((int)blockIdx.x < nconv) {
+    const long total = (long)B * h * w * Cp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)nconv * blockDim.x) {
+      const int c = (int)(i % Cp);
+      const long px = i / Cp;
+      dlow[i] = from_f<T>(c < C ? dacc[px * C + c] : 0.f);
+    }
+    return;
+  }
+  const int b = blockIdx.x - nconv;
+  const long per = (long)h * w;
+  float a[3] = {0.f, 0.f, 0.f};
+  for (long k = threadIdx.x; k < per; k += blockDim.x) {      // fixed assignment of cells to threads: deterministic
+    const float* p = part + ((long)b * per + k) * 3;
+    a[0] += p[0]; a[1] += p[1]; a[2] += p[2];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const float v = wave_sum(a[q]);
+    if (lane == 0) red[q][wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float s0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const float s1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const float s2 = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    if (b < n_ce) { sums[b] = s0 * inv_hw; if (has_t) sums[B + b] = s1 * inv_hw; }
+    atomicAdd(sums + 2 * B, s2 * inv_mse_n);            // B addends
+  }
+}
+
 }  // namespace
 
 extern "C" int pxl_upsample_softmax_fwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners,
@@ -408,6 +617,41 @@ extern "C" int pxl_head_loss(int dtype, int B, int h, int w, int Cp, int C, int 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   PXL_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)(2 * B + 1) * sizeof(float), s));
   const float hw = (float)H * (float)W;
+  // cell-wise kernel for large up-sampling factors (DeepLab: x16), row-wise kernel otherwise (PSPNet's head resizes a map
+  // of nearly the output size: a "cell" there is a pixel or two).  PXL_HEAD_LOSS_CELLS=0/1 forces either.
+  const char* fc_env = getenv("PXL_HEAD_LOSS_CELLS");          // (read per call: the tests cover both kernels)
+  const int force_cells = fc_env ? atoi(fc_env) : -1;
+  const long ncell = (long)B * h * w;
+  const size_t cells_ws = (size_t)ncell * C * sizeof(float) + (size_t)((ncell + 3) / 4 * 4) * 3 * sizeof(float);
+  const float xscale = w > 1 ? (float)(W - 1) / (float)(w - 1) : (float)W;     // widest cell ~ ceil(scale) + 1 pixels
+  const bool cells = (force_cells >= 0 ? force_cells != 0 : ((long)H * W >= 36L * h * w)) && cells_ws <= ws_bytes && C == 21 &&
+                     xscale <= 60.f;
+  if (cells) {
+    const double mse_n_ = (double)(mse_hi - mse_lo) * C * (double)H * W;
+    const float ce_scale_ = ce_weight / hw;
+    const float mse_scale_ = mse_hi > mse_lo ? (float)(2.0 / mse_n_) * mse_weight : 0.f;
+    const float inv_mse_n_ = mse_hi > mse_lo ? (float)(1.0 / mse_n_) : 0.f;
+    float* dacc = reinterpret_cast<float*>(workspace);
+    float* part = dacc + ncell * C;
+    PXL_CHECK_HIP(hipMemsetAsync(dacc, 0, (size_t)ncell * C * sizeof(float), s));
+    const int nblk = (int)((ncell + 3) / 4);
+    const int nconv = 64;
+    if (dtype == PXL_F32) {
+      hipLaunchKernelGGL((head_loss_cells_kernel<float, 21>), dim3(nblk), dim3(256), 0, s, Cp, h, w, H, W, sy, sx, align,
+                         (const float*)s_low, (const float*)t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_scale_, mse_scale_,
+                         dacc, part, B);
+      hipLaunchKernelGGL(head_loss_finish_kernel<float>, dim3(nconv + B), dim3(256), 0, s, B, h, w, C, Cp, dacc, (float*)dlow, part,
+                         1.f / hw, inv_mse_n_, n_ce, t_low != nullptr ? 1 : 0, sums);
+    } else {
+      hipLaunchKernelGGL((head_loss_cells_kernel<bf16_t, 21>), dim3(nblk), dim3(256), 0, s, Cp, h, w, H, W, sy, sx, align,
+                         (const bf16_t*)s_low, (const bf16_t*)t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_scale_, mse_scale_,
+                         dacc, part, B);
+      hipLaunchKernelGGL(head_loss_finish_kernel<bf16_t>, dim3(nconv + B), dim3(256), 0, s, B, h, w, C, Cp, dacc, (bf16_t*)dlow, part,
+                         1.f / hw, inv_mse_n_, n_ce, t_low != nullptr ? 1 : 0, sums);
+    }
+    PXL_LAUNCH_CHECK();
+    return PXL_OK;
+  }
   const float ce_scale = ce_weight / hw;                                         // = g_ce[n] / HW of ce_bwd_kernel
   const double mse_n = (double)(mse_hi - mse_lo) * C * (double)H * W;
   const float mse_scale = mse_hi > mse_lo ? (float)(2.0 / mse_n) * mse_weight : 0.f;      // = g_mse * two_inv_n of mse_bwd_kernel

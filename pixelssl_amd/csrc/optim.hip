@@ -20,6 +20,23 @@ __global__ __launch_bounds__(256) void sgd_kernel(long n, float* __restrict__ p,
   }
 }
 
+// the full torch.optim.SGD update (torch/optim/sgd.py _single_tensor_sgd): dampening scales the gradient entering the
+// momentum buffer (not on the first step, where the buffer is a copy of d), nesterov steps along d + momentum * buf
+__global__ __launch_bounds__(256) void sgd_general_kernel(long n, float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ buf, float lr, float momentum, float dampening,
+                                                          float wd, int nesterov, int first) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float pv = p[i];
+    float d = g[i] + wd * pv;
+    if (momentum != 0.f) {
+      const float b = first ? d : momentum * buf[i] + (1.f - dampening) * d;
+      buf[i] = b;
+      d = nesterov ? d + momentum * b : b;
+    }
+    p[i] = pv - lr * d;
+  }
+}
+
 __global__ __launch_bounds__(256) void ema_kernel(long n, float* __restrict__ t, const float* __restrict__ s,
                                                   float alpha) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -29,9 +46,9 @@ __global__ __launch_bounds__(256) void ema_kernel(long n, float* __restrict__ t,
 // torch.optim.Adam (no weight decay, no amsgrad): the FC discriminator / flaw detector optimizer (ssl_adv.py:101-102)
 __global__ __launch_bounds__(256) void adam_kernel(long n, float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, float step_size,
-                                                   float beta1, float beta2, float eps, float inv_sqrt_bc2) {
+                                                   float beta1, float beta2, float eps, float inv_sqrt_bc2, float wd) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float gi = g[i];
+    const float gi = wd != 0.f ? g[i] + wd * p[i] : g[i];        // L2 weight decay folded into the gradient (torch.optim.Adam)
     const float mi = beta1 * m[i] + (1.f - beta1) * gi;
     const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
     m[i] = mi;
@@ -62,6 +79,16 @@ extern "C" int pxl_sgd_step(long n, float* p, const float* g, float* buf, float 
   return PXL_OK;
 }
 
+extern "C" int pxl_sgd_step_general(long n, float* p, const float* g, float* buf, float lr, float momentum, float dampening,
+                                    float weight_decay, int nesterov, int first_step, void* stream) {
+  PXL_REQUIRE(p && g && buf && n > 0, "sgd_step_general: bad argument");
+  PXL_REQUIRE(!nesterov || (momentum > 0.f && dampening == 0.f), "sgd_step_general: nesterov needs momentum > 0 and dampening = 0");
+  hipLaunchKernelGGL(sgd_general_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, p, g, buf,
+                     lr, momentum, dampening, weight_decay, nesterov, first_step);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
 extern "C" int pxl_ema_update(long n, float* teacher, const float* student, float alpha, void* stream) {
   PXL_REQUIRE(teacher && student && n > 0, "ema_update: bad argument");
   hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n,
@@ -70,13 +97,21 @@ extern "C" int pxl_ema_update(long n, float* teacher, const float* student, floa
   return PXL_OK;
 }
 
+extern "C" int pxl_adam_step_wd(long n, float* p, const float* g, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int step, void* stream);
+
 extern "C" int pxl_adam_step(long n, float* p, const float* g, float* exp_avg, float* exp_avg_sq, float lr,
                              float beta1, float beta2, float eps, int step, void* stream) {
+  return pxl_adam_step_wd(n, p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, 0.f, step, stream);
+}
+
+extern "C" int pxl_adam_step_wd(long n, float* p, const float* g, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int step, void* stream) {
   PXL_REQUIRE(p && g && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_step: bad argument (step counts from 1)");
   // torch: denom = sqrt(v) / sqrt(1 - beta2^t) + eps ; p -= lr / (1 - beta1^t) * m / denom
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, p, g,
-                     exp_avg, exp_avg_sq, (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)));
+                     exp_avg, exp_avg_sq, (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), weight_decay);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

@@ -27,14 +27,15 @@ def add_parser_arguments(parser):
 
 
 def _segments(params):
-    """Group pixelhip-managed parameters into maximal contiguous (store, offset, length) runs."""
+    """Group pixelhip-managed parameters into maximal contiguous (store, offset, length) runs.  Parameters that do not
+    live in an engine model's flat store (any other torch TaskModel a plugin brings) are skipped here: the optimizers
+    update them through their per-tensor path (`_foreign`)."""
     runs = []
     items = []
     for p in params:
         ref = getattr(p, '_pxl_flat', None)
         if ref is None:
-            raise _lib.PixelHipError('FusedSGD only updates parameters owned by a pixelssl_amd engine model '
-                                     '(got a foreign tensor of shape %s)' % (tuple(p.shape),))
+            continue
         items.append(ref)
     items.sort(key=lambda r: (id(r[0]), r[1]))
     for store, off, n in items:
@@ -44,6 +45,28 @@ def _segments(params):
         else:
             runs.append([store, off, padded])
     return runs
+
+
+def _foreign(params):
+    return [p for p in params if getattr(p, '_pxl_flat', None) is None]
+
+
+def _sync_foreign_grads(groups):
+    """Multi-rank: mean of the per-rank gradients of every tensor that is NOT owned by an engine model (those are
+    exchanged by the executor, overlapped with the backward pass).  One all-reduce over the concatenated gradients."""
+    from .. import dist as pdist
+    if not pdist.is_distributed():
+        return
+    ps = [p for foreign in groups for p in foreign if p.grad is not None]
+    if not ps:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    pdist.allreduce_mean_(flat)
+    off = 0
+    for p in ps:
+        n = p.grad.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
 
 
 def _flat_view(store, buf, p):
@@ -68,6 +91,10 @@ class _FlatStateMixin:
         state = {}
         if self._steps_taken > 0:
             for idx, p in enumerate(self._param_list()):
+                if getattr(p, '_pxl_flat', None) is None:          # foreign tensor: its state is torch-style already
+                    if p in self.state and self.state[p]:
+                        state[idx] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in self.state[p].items()}
+                    continue
                 store = p._pxl_flat[0]
                 entry = {k: _flat_view(store, getattr(store, attr), p).detach().clone().contiguous()
                          for k, attr in self._STATE_KEYS}
@@ -96,6 +123,10 @@ class _FlatStateMixin:
                 entry = state.get(idx, state.get(str(idx)))
                 if not entry:
                     continue
+                if getattr(p, '_pxl_flat', None) is None:
+                    self.state[p] = {k: (v.to(p.device).clone() if torch.is_tensor(v) else v) for k, v in entry.items()}
+                    steps = max(steps, self._steps_of(entry))
+                    continue
                 store = p._pxl_flat[0]
                 for k, attr in self._STATE_KEYS:
                     if entry.get(k) is not None:
@@ -115,17 +146,21 @@ class _FlatStateMixin:
 
 
 class FusedSGD(_FlatStateMixin, Optimizer):
-    """torch.optim.SGD semantics (momentum, weight decay, no dampening/nesterov):
-    d = g + wd*p ; buf = m*buf + d ; p -= lr*buf   (buf starts at 0, identical to torch's first step)."""
+    """torch.optim.SGD semantics (momentum, dampening, nesterov, weight decay):
+    d = g + wd*p ; buf = m*buf + (1-dampening)*d (buf = d on the first step) ; p -= lr * (nesterov ? d + m*buf : buf).
+    Parameters of an engine model are updated by one fused launch per contiguous run of its flat buffer; any other
+    tensor (a torch TaskModel a plugin brings) by the same arithmetic through torch ops."""
 
     def __init__(self, params, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
-        if dampening not in (0, 0.0) or nesterov:
-            raise NotImplementedError('FusedSGD implements dampening=0, nesterov=False (what every shipped script uses)')
-        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
-        self._runs = []
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError('Nesterov momentum requires a momentum and zero dampening')       # torch.optim.SGD's check
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
+                                      nesterov=nesterov))
+        self._runs, self._foreign = [], []
         for group in self.param_groups:
             group['params'] = list(group['params'])
             self._runs.append(_segments(group['params']))
+            self._foreign.append(_foreign(group['params']))
         self._stores = {}
         for runs in self._runs:
             for store, _, _ in runs:
@@ -140,11 +175,33 @@ class FusedSGD(_FlatStateMixin, Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        first = self._steps_taken == 0
         self._steps_taken += 1
-        for group, runs in zip(self.param_groups, self._runs):
+        _sync_foreign_grads(self._foreign)
+        for group, runs, foreign in zip(self.param_groups, self._runs, self._foreign):
+            lr, mom, wd = float(group['lr']), float(group['momentum']), float(group['weight_decay'])
+            damp, nest = float(group.get('dampening', 0.0)), bool(group.get('nesterov', False))
             for store, off, n in runs:
-                ops.sgd_step(store.params[off:off + n], store.grads[off:off + n], store.momentum[off:off + n],
-                             float(group['lr']), float(group['momentum']), float(group['weight_decay']))
+                if damp == 0.0 and not nest:
+                    # (buf starts at zero, so m * 0 + d = d: the plain kernel needs no first-step flag)
+                    ops.sgd_step(store.params[off:off + n], store.grads[off:off + n], store.momentum[off:off + n], lr, mom, wd)
+                else:
+                    _lib.check(_lib.lib().pxl_sgd_step_general(n, _lib.ptr(store.params[off:off + n]), _lib.ptr(store.grads[off:off + n]),
+                                                               _lib.ptr(store.momentum[off:off + n]), lr, mom, damp, wd, int(nest),
+                                                               int(first), _lib.stream_ptr()))
+            for p in foreign:
+                if p.grad is None:
+                    continue
+                d = p.grad.add(p, alpha=wd) if wd != 0 else p.grad
+                if mom != 0:
+                    st = self.state[p]
+                    if 'momentum_buffer' not in st or st['momentum_buffer'] is None:
+                        buf = st['momentum_buffer'] = torch.clone(d).detach()
+                    else:
+                        buf = st['momentum_buffer']
+                        buf.mul_(mom).add_(d, alpha=1 - damp)
+                    d = d.add(buf, alpha=mom) if nest else buf
+                p.add_(d, alpha=-lr)
         for store in self._stores.values():
             store.touch()
         return loss
@@ -153,23 +210,26 @@ class FusedSGD(_FlatStateMixin, Optimizer):
         # gradients are views of one flat buffer: one memset, views stay attached
         for store in self._stores.values():
             store.grads.zero_()
+        for foreign in self._foreign:
+            for p in foreign:
+                if p.grad is not None:
+                    p.grad = None if set_to_none else p.grad.detach().zero_()
 
 
 class FusedAdam(_FlatStateMixin, Optimizer):
-    """torch.optim.Adam semantics (L2 weight decay folded into the gradient, no amsgrad) as one fused launch per
+    """torch.optim.Adam semantics (L2 weight decay folded into the gradient: g += wd * p; no amsgrad) as one fused launch per
     contiguous run of the flat parameter buffer: the discriminator optimizer of AdvSSL (ssl_adv.py:101-102, betas
     (0.9, 0.99)) and the `adam` factory."""
 
     _STATE_KEYS = (('exp_avg', 'exp_avg'), ('exp_avg_sq', 'exp_avg_sq'))
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        if weight_decay not in (0, 0.0):
-            raise NotImplementedError('FusedAdam implements weight_decay = 0 (what every shipped script uses)')
-        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0.0))
-        self._runs = []
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self._runs, self._foreign = [], []
         for group in self.param_groups:
             group['params'] = list(group['params'])
             self._runs.append(_segments(group['params']))
+            self._foreign.append(_foreign(group['params']))
         self._stores = {}
         for runs in self._runs:
             for store, _, _ in runs:
@@ -196,13 +256,28 @@ class FusedAdam(_FlatStateMixin, Optimizer):
         loss = closure() if closure is not None else None
         self._step += 1
         self._steps_taken = self._step
-        for group, runs in zip(self.param_groups, self._runs):
+        _sync_foreign_grads(self._foreign)
+        for group, runs, foreign in zip(self.param_groups, self._runs, self._foreign):
             b1, b2 = group['betas']
+            wd = float(group.get('weight_decay', 0.0))
             for store, off, n in runs:
-                _lib.check(_lib.lib().pxl_adam_step(n, _lib.ptr(store.params[off:off + n]), _lib.ptr(store.grads[off:off + n]),
-                                                    _lib.ptr(store.exp_avg[off:off + n]), _lib.ptr(store.exp_avg_sq[off:off + n]),
-                                                    float(group['lr']), float(b1), float(b2), float(group['eps']),
-                                                    self._step, _lib.stream_ptr()))
+                _lib.check(_lib.lib().pxl_adam_step_wd(n, _lib.ptr(store.params[off:off + n]), _lib.ptr(store.grads[off:off + n]),
+                                                       _lib.ptr(store.exp_avg[off:off + n]), _lib.ptr(store.exp_avg_sq[off:off + n]),
+                                                       float(group['lr']), float(b1), float(b2), float(group['eps']), wd,
+                                                       self._step, _lib.stream_ptr()))
+            for p in foreign:                  # torch.optim.Adam's single-tensor update
+                if p.grad is None:
+                    continue
+                g = p.grad.add(p, alpha=wd) if wd != 0 else p.grad
+                st = self.state[p]
+                if 'exp_avg' not in st:
+                    st['exp_avg'], st['exp_avg_sq'] = torch.zeros_like(p), torch.zeros_like(p)
+                st['step'] = torch.tensor(float(self._step))
+                st['exp_avg'].mul_(b1).add_(g, alpha=1 - b1)
+                st['exp_avg_sq'].mul_(b2).addcmul_(g, g, value=1 - b2)
+                bc1, bc2 = 1 - b1 ** self._step, 1 - b2 ** self._step
+                denom = (st['exp_avg_sq'].sqrt() / (bc2 ** 0.5)).add_(float(group['eps']))
+                p.addcdiv_(st['exp_avg'], denom, value=-float(group['lr']) / bc1)
         for store in self._stores.values():
             store.touch()
         return loss
@@ -210,6 +285,10 @@ class FusedAdam(_FlatStateMixin, Optimizer):
     def zero_grad(self, set_to_none=False):
         for store in self._stores.values():
             store.grads.zero_()
+        for foreign in self._foreign:
+            for p in foreign:
+                if p.grad is not None:
+                    p.grad = None if set_to_none else p.grad.detach().zero_()
 
 
 def sgd(args):

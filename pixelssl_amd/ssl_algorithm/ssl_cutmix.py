@@ -221,7 +221,18 @@ class SSLCUTMIX(ssl_base._SSLBase):
         return checkpoint['epoch']
 
     def _update_ema_variables(self, s_model, t_model, ema_decay, cur_step):
-        alpha = min(1 - 1 / (cur_step + 1), ema_decay)        # ssl_cutmix.py:432-436
-        s_core, t_core = s_model.module.model, t_model.module.model
-        ops.ema_update(t_core.flat.params, s_core.flat.params, alpha)
-        t_core.mark_params_changed()
+        """alpha = min(1 - 1/(step+1), decay); parameters only, BN buffers evolve by the teacher's own
+        forward (ssl_cutmix.py:432-436).  Engine task models: one fused launch over the flat parameter buffers; any other
+        TaskModel (a plugin's torch model): the reference's per-parameter walk."""
+        alpha = min(1 - 1 / (cur_step + 1), ema_decay)
+        s_core, t_core = getattr(s_model.module, 'model', None), getattr(t_model.module, 'model', None)
+        if hasattr(s_core, 'flat') and hasattr(t_core, 'flat') and s_core.flat.np == t_core.flat.np and \
+                len(list(s_model.parameters())) == len(s_core._param_list):
+            ops.ema_update(t_core.flat.params, s_core.flat.params, alpha)
+            t_core.mark_params_changed()
+            return
+        with torch.no_grad():
+            for t_param, s_param in zip(t_model.parameters(), s_model.parameters()):
+                t_param.mul_(alpha).add_(s_param.detach(), alpha=1 - alpha)
+        for core in (m for m in t_model.modules() if hasattr(m, 'mark_params_changed')):
+            core.mark_params_changed()

@@ -78,8 +78,13 @@ class SSLMT(ssl_base._SSLBase):
         """One iteration of ssl_mt.py:131-220 on device-resident tuples.
         Returns dict(s_task_loss, t_task_loss, cons_loss) of detached device scalars."""
         lbs = self.args.labeled_batch_size
-        s_inp = tuple(self.gaussian_noiser(i) if k == 0 else i for k, i in enumerate(inp))
-        t_inp = s_inp      # noise disabled => same tensor; the reference uploads the batch twice (ssl_mt.py:344-348)
+        if self.gaussian_noiser.enable:
+            # ssl_mt.py:340-348: the batch is uploaded twice and each copy of the first input gets its own noise draw
+            # (student first); the layer works in place, so it is handed copies
+            s_inp = tuple(self.gaussian_noiser(i.clone()) if k == 0 else i for k, i in enumerate(inp))
+            t_inp = tuple(self.gaussian_noiser(i.clone()) if k == 0 else i for k, i in enumerate(inp))
+        else:
+            s_inp = t_inp = tuple(inp)     # noise disabled => one tensor serves both passes
         ramp = func.sigmoid_rampup(cur_step, total_rampup_steps)
 
         self.s_optimizer.zero_grad()
@@ -288,8 +293,17 @@ class SSLMT(ssl_base._SSLBase):
 
     def _update_ema_variables(self, s_model, t_model, ema_decay, cur_step):
         """alpha = min(1 - 1/(step+1), decay); parameters only, BN buffers evolve by the teacher's own
-        forward (ssl_mt.py:359-363).  One fused launch over the flat parameter buffers."""
+        forward (ssl_mt.py:359-363).  Engine task models: one fused launch over the flat parameter buffers; any other
+        TaskModel (a plugin's torch model): the reference's per-parameter walk."""
         alpha = min(1 - 1 / (cur_step + 1), ema_decay)
-        s_core, t_core = s_model.module.model, t_model.module.model
-        ops.ema_update(t_core.flat.params, s_core.flat.params, alpha)
-        t_core.mark_params_changed()
+        s_core, t_core = getattr(s_model.module, 'model', None), getattr(t_model.module, 'model', None)
+        if hasattr(s_core, 'flat') and hasattr(t_core, 'flat') and s_core.flat.np == t_core.flat.np and \
+                len(list(s_model.parameters())) == len(s_core._param_list):
+            ops.ema_update(t_core.flat.params, s_core.flat.params, alpha)
+            t_core.mark_params_changed()
+            return
+        with torch.no_grad():
+            for t_param, s_param in zip(t_model.parameters(), s_model.parameters()):
+                t_param.mul_(alpha).add_(s_param.detach(), alpha=1 - alpha)
+        for core in (m for m in t_model.modules() if hasattr(m, 'mark_params_changed')):
+            core.mark_params_changed()

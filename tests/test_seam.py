@@ -48,6 +48,7 @@ def _torch_seam(s_low, t_low, gt, n_ce, lo, hi, w_ce, w_mse, size, align, ignore
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["auto", "rows"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [
     dict(B=3, C=21, h=9, w=9, H=129, W=129, align=True, n_ce=2, lo=2, hi=3, teacher=True),
@@ -55,9 +56,17 @@ def _torch_seam(s_low, t_low, gt, n_ce, lo, hi, w_ce, w_mse, size, align, ignore
     dict(B=2, C=21, h=9, w=9, H=129, W=129, align=True, n_ce=2, lo=0, hi=0, teacher=False),    # SupOnly
     dict(B=3, C=7, h=8, w=8, H=50, W=61, align=False, n_ce=1, lo=1, hi=3, teacher=True),       # align_corners=False, odd sizes
     dict(B=2, C=21, h=33, w=33, H=513, W=513, align=True, n_ce=1, lo=1, hi=2, teacher=True),   # the BASELINE geometry
+    dict(B=2, C=21, h=9, w=7, H=65, W=67, align=True, n_ce=2, lo=0, hi=2, teacher=True),       # scale 8 x 11: cells 11 wide (padded to 16 lanes)
+    dict(B=1, C=21, h=6, w=6, H=70, W=45, align=False, n_ce=1, lo=0, hi=1, teacher=True),      # align_corners=False on the cell kernel
 ])
-def test_head_loss_kernel_vs_torch(dtype, case):
+def test_head_loss_kernel_vs_torch(dtype, case, kernel, monkeypatch):
+    """kernel = auto: the cell-wise kernel where it applies (21 classes, up-sampling factor >= 6), else the row-wise one;
+    kernel = rows: the row-wise kernel everywhere (PXL_HEAD_LOSS_CELLS=0)."""
     from pixelssl_amd._lib import lib, check, ptr, stream_ptr, dtype_code
+    if kernel == "rows":
+        monkeypatch.setenv("PXL_HEAD_LOSS_CELLS", "0")
+    else:
+        monkeypatch.delenv("PXL_HEAD_LOSS_CELLS", raising=False)
     c = argparse.Namespace(**case)
     g = torch.Generator().manual_seed(11 + c.h * c.W)
     Cp = 32
@@ -92,7 +101,7 @@ def test_head_loss_kernel_vs_torch(dtype, case):
     got = dlow.float().cpu()
     assert (got[..., c.C:] == 0).all(), "padded channels of the gradient must be zero"
     r = rel(got[..., :c.C].permute(0, 3, 1, 2), grad)
-    print("head_loss %s %s: d(low) rel err %.2e" % (dtype, case, r))
+    print("head_loss [%s] %s %s: d(low) rel err %.2e" % (kernel, dtype, case, r))
     assert r < (2e-5 if dtype == torch.float32 else 4e-3)       # bf16: the OUTPUT is rounded to bf16
 
 
@@ -106,6 +115,16 @@ def _mt_algo(dtype, size, lbs, ubs, cons_for_labeled=False):
                            im_size=size, gaussian_noise_std=None, cons_for_labeled=cons_for_labeled, cons_scale=1.0,
                            cons_rampup_epochs=3, ema_decay=0.99)
     return a, P, popt, plr
+
+
+def _condition(core):
+    """bottleneck-output BN gammas x 0.1 (torch_oracle.condition_state): without it a freshly initialised trunk amplifies
+    a 1-ulp difference of the first iteration into a percent-level difference of the second one"""
+    with torch.no_grad():
+        for name, prm in core.named_parameters():
+            if name.endswith("bn3.weight"):
+                prm.mul_(0.1)
+    core.mark_params_changed()
 
 
 class _Shallow:
@@ -147,6 +166,8 @@ def test_mt_step_fused_seam_equals_generic_path(dtype, cons_for_labeled, monkeyp
         gen = torch.Generator().manual_seed(3)
         s_core.reset_parameters(gen)
         t_core.reset_parameters(gen)
+        _condition(s_core)
+        _condition(t_core)
         algo.s_model.train()
         algo.t_model.train()
         losses = []
@@ -158,16 +179,17 @@ def test_mt_step_fused_seam_equals_generic_path(dtype, cons_for_labeled, monkeyp
                          {k: v.detach().float().cpu().clone() for k, v in t_core.state_dict().items()},
                          type(s_res).__name__)
     assert results["1"][3] == "_DeferredResulter" and results["0"][3] != "_DeferredResulter", "the switch selects the path"
-    tol = 2e-5 if dtype == "fp32" else 2e-3
-    for lf, lg in zip(results["1"][0], results["0"][0]):
+    for i, (lf, lg) in enumerate(zip(results["1"][0], results["0"][0])):
+        print("mt %s iteration %d fused %s generic %s" % (dtype, i, lf, lg))
+        tol = (2e-6 if i == 0 else 2e-4) if dtype == "fp32" else (1e-4 if i == 0 else 5e-3)
         for k in lg:
-            assert abs(lf[k] - lg[k]) <= tol * abs(lg[k]) + 1e-8, (k, lf, lg)
+            assert abs(lf[k] - lg[k]) <= tol * abs(lg[k]) + 1e-8, (i, k, lf, lg)
     for which in (1, 2):
         for k, v in results["0"][which].items():
             if "num_batches" in k:
                 continue
             r = rel(results["1"][which][k], v)
-            assert r < (1e-5 if dtype == "fp32" else 2e-3), (which, k, r)
+            assert r < (2e-5 if dtype == "fp32" else 2e-3), (which, k, r)
 
 
 @pytest.mark.gpu
@@ -182,6 +204,7 @@ def test_suponly_step_fused_seam_equals_generic_path(monkeypatch):
                                                 {"model": plr.polynomiallr(a)}, {"model": P.sseg.criterion.sseg_criterion()}, None)
         core = algo.model.module.model
         core.reset_parameters(torch.Generator().manual_seed(3))
+        _condition(core)
         algo.model.train()
         losses = []
         for i in range(2):
@@ -189,13 +212,14 @@ def test_suponly_step_fused_seam_equals_generic_path(monkeypatch):
             loss, res = algo.train_step((x.to(DEV),), (gt.to(DEV),))
             losses.append(loss.item())
         results[mode] = (losses, {k: v.detach().float().cpu().clone() for k, v in core.state_dict().items()}, res)
-    for lf, lg in zip(results["1"][0], results["0"][0]):
-        assert abs(lf - lg) <= 2e-5 * abs(lg)
+    for i, (lf, lg) in enumerate(zip(results["1"][0], results["0"][0])):
+        print("suponly iteration %d fused %.8f generic %.8f" % (i, lf, lg))
+        assert abs(lf - lg) <= (2e-6 if i == 0 else 2e-4) * abs(lg)
     for k, v in results["0"][1].items():
         if "num_batches" not in k:
-            assert rel(results["1"][1][k], v) < 1e-5, k
+            assert rel(results["1"][1][k], v) < 2e-5, k
     # the deferred resulter hands out the planes of the LAST forward pass on demand: same values as the generic path's
     pf, pg = results["1"][2]["pred"][0], results["0"][2]["pred"][0]
-    assert pf.shape == pg.shape and rel(pf, pg.detach()) < 1e-5
+    assert pf.shape == pg.shape and rel(pf, pg.detach()) < 2e-4
     af = results["1"][2]["activated_pred"][0]
     assert torch.allclose(af.sum(1), torch.ones_like(af.sum(1)), atol=1e-5)

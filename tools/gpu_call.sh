@@ -5,7 +5,7 @@
 #   gpurun --timeout 900 -- 'tools/gpu_call.sh TAG STAGE [STAGE ...]'
 #
 # stages (run in order; a stage never aborts the following ones):
-#   t=<pytest args>            python -m pytest <args> -m gpu -q            (e.g. t=tests/test_multistep.py::test_mt_at)
+#   t=<pytest args>[@<-k expr>] python -m pytest <args> -m gpu -q [-k "<expr>"]   (e.g. t=tests/test_seam.py@mt+or+suponly)
 #   all                        the whole GPU suite, -x
 #   smoke                      __graft_entry__.smoke()
 #   bench[=<bench.py args>]    python bench.py <args>                      -> bench_<n>.json   (default: driver defaults)
@@ -44,7 +44,9 @@ for st in "$@"; do
   arg="${arg//+/ }"
   t0=$(date +%s)
   case $kind in
-    t) timeout 1500 python -m pytest $arg -m gpu -q -s --tb=short -p no:cacheprovider > $OUT/t_$n.log 2>&1; rc=$?
+    t) files="${arg%%@*}"; kexpr=""; [ "$arg" != "$files" ] && kexpr="${arg#*@}"
+       if [ -n "$kexpr" ]; then timeout 1500 python -m pytest $files -m gpu -q -s --tb=short -p no:cacheprovider -k "$kexpr" > $OUT/t_$n.log 2>&1; rc=$?
+       else timeout 1500 python -m pytest $files -m gpu -q -s --tb=short -p no:cacheprovider > $OUT/t_$n.log 2>&1; rc=$?; fi
        grep -E "passed|failed|error|^FAILED|^ERROR" $OUT/t_$n.log | tail -8;;
     all) timeout 2400 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider > $OUT/test_all.log 2>&1; rc=$?
        grep -E "passed|failed|^FAILED|^ERROR" $OUT/test_all.log | tail -8;;
