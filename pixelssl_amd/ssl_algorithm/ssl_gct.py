@@ -305,8 +305,8 @@ def _define_sslgct():
                     if a.dc_rampup_epochs < 0 or a.dc_ssl_scale < 0 or a.dc_threshold < 0 or a.mu < 0 or a.nu < 0:
                         logger.log_err('The dynamic consistency constraint needs dc_rampup_epochs, dc_ssl_scale, '
                                        'dc_threshold, mu and nu to be set\n')
-            if a.ssl_mode != MODE_GCT:
-                raise NotImplementedError("SSL_GCT on the MI355X engine implements ssl_mode 'gct' (what every script uses)")
+            if a.ssl_mode not in (MODE_GCT, MODE_DC, MODE_FC):
+                logger.log_err('Unknown ssl_mode of SSL_GCT: {0} (gct / dc / fc)\n'.format(a.ssl_mode))
 
         def _build(self, model_funcs, optimizer_funcs, lrer_funcs, criterion_funcs, task_func):
             a = self.args
@@ -355,9 +355,20 @@ def _define_sslgct():
             flawmap = tool.dict_value(self.fd_model.forward(inp, activated_pred[0])[0], 'flawmap')
             task_loss = torch.mean(criterion.forward(func.split_tensor_tuple(pred, 0, lbs), func.split_tensor_tuple(gt, 0, lbs),
                                                      func.split_tensor_tuple(inp, 0, lbs)))
-            # flaw correction: MSE of the flaw map against zeros, masked by both_bad (ssl_gct.py:429-439)
-            fc_ssl_loss = a.fc_ssl_scale * _MaskedSqMean.apply(flawmap, fc_mask)
-            dc_ssl_loss = dc_rampup_scale * a.dc_ssl_scale * torch.mean(self.dc_criterion.forward(activated_pred[0], dc_gt))
+            # flaw correction: MSE of the flaw map against zeros (ssl_gct.py:429-442), masked by both_bad in 'gct' mode,
+            # unmasked in 'fc' mode, off in 'dc' mode
+            if a.ssl_mode in (MODE_GCT, MODE_FC):
+                mask = fc_mask if a.ssl_mode == MODE_GCT else torch.ones_like(flawmap)
+                fc_ssl_loss = a.fc_ssl_scale * _MaskedSqMean.apply(flawmap, mask)
+            else:
+                fc_ssl_loss = torch.zeros((), device=flawmap.device)
+            # dynamic consistency (ssl_gct.py:445-458): off in 'fc' mode
+            if a.ssl_mode in (MODE_GCT, MODE_DC):
+                if dc_gt is None:
+                    logger.log_err('The dynamic consistency constraint is enabled, but no pseudo ground truth is given.\n')
+                dc_ssl_loss = dc_rampup_scale * a.dc_ssl_scale * torch.mean(self.dc_criterion.forward(activated_pred[0], dc_gt))
+            else:
+                dc_ssl_loss = torch.zeros((), device=flawmap.device)
             # (the reference also builds an FDGT map of the full batch here, used only for visualisation: skipped)
             return task_loss + fc_ssl_loss + dc_ssl_loss, dict(task=task_loss.detach(), fc=fc_ssl_loss.detach(),
                                                                dc=dc_ssl_loss.detach())
@@ -400,11 +411,13 @@ def _define_sslgct():
             fd_core.set_wgrad(True)
             l_flawmap = tool.dict_value(self.fd_model.forward(inp, l_prob[0])[0], 'flawmap')
             r_flawmap = tool.dict_value(self.fd_model.forward(inp, r_prob[0])[0], 'flawmap')
-            with torch.no_grad():
-                l_handled = self.flawmap_handler.forward(l_flawmap)         # clamps l_flawmap / r_flawmap IN PLACE
-                r_handled = self.flawmap_handler.forward(r_flawmap)
-                l_dc_gt, r_dc_gt, l_fc_mask, r_fc_mask = self.dcgt_generator.forward(l_prob[0].detach(), r_prob[0].detach(),
-                                                                                    l_handled, r_handled)
+            l_dc_gt = r_dc_gt = l_fc_mask = r_fc_mask = None
+            if a.ssl_mode in (MODE_GCT, MODE_DC):          # ssl_gct.py:219-224 ('fc' mode: no handled maps, no in-place clamp)
+                with torch.no_grad():
+                    l_handled = self.flawmap_handler.forward(l_flawmap)         # clamps l_flawmap / r_flawmap IN PLACE
+                    r_handled = self.flawmap_handler.forward(r_flawmap)
+                    l_dc_gt, r_dc_gt, l_fc_mask, r_fc_mask = self.dcgt_generator.forward(l_prob[0].detach(), r_prob[0].detach(),
+                                                                                        l_handled, r_handled)
             # ---- step 1: task models; the flaw detector is frozen (requires_grad False in the reference).  Reference
             # order: [l: forward, losses, backward, step] then [r: ...]; the two are independent, so both forwards run
             # side by side, then the (ordered) detector passes and losses, then ONE backward over both graphs -- the

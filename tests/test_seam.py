@@ -24,6 +24,13 @@ def rel(a, b):
     return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
 
 
+def close(a, b, rtol):
+    """||a - b|| <= rtol * ||b|| + 1e-8 * sqrt(n): the absolute term covers tensors that ARE (numerically) zero -- a BN
+    beta after three tiny updates is ~1e-7, and the order of the fp32 atomics in its gradient moves it by 1e-10"""
+    d = (a.double() - b.double()).norm().item()
+    return d <= rtol * b.double().norm().item() + 1e-8 * (b.numel() ** 0.5)
+
+
 def _torch_seam(s_low, t_low, gt, n_ce, lo, hi, w_ce, w_mse, size, align, ignore=255):
     s_low = s_low.detach().clone().requires_grad_(True)
     zs = F.interpolate(s_low, size=size, mode="bilinear", align_corners=align)
@@ -181,15 +188,16 @@ def test_mt_step_fused_seam_equals_generic_path(dtype, cons_for_labeled, monkeyp
     assert results["1"][3] == "_DeferredResulter" and results["0"][3] != "_DeferredResulter", "the switch selects the path"
     for i, (lf, lg) in enumerate(zip(results["1"][0], results["0"][0])):
         print("mt %s iteration %d fused %s generic %s" % (dtype, i, lf, lg))
-        tol = (2e-6 if i == 0 else 2e-4) if dtype == "fp32" else (1e-4 if i == 0 else 5e-3)
+        # (bf16: BN statistics are fp32 atomics whose order moves sums by an ulp, which flips bf16 roundings downstream:
+        # two runs of the SAME path differ by ~2e-4 in a loss)
+        tol = (2e-6 if i == 0 else 2e-4) if dtype == "fp32" else (1e-3 if i == 0 else 5e-3)
         for k in lg:
             assert abs(lf[k] - lg[k]) <= tol * abs(lg[k]) + 1e-8, (i, k, lf, lg)
     for which in (1, 2):
         for k, v in results["0"][which].items():
             if "num_batches" in k:
                 continue
-            r = rel(results["1"][which][k], v)
-            assert r < (2e-5 if dtype == "fp32" else 2e-3), (which, k, r)
+            assert close(results["1"][which][k], v, 2e-5 if dtype == "fp32" else 2e-3), (which, k, rel(results["1"][which][k], v))
 
 
 @pytest.mark.gpu
@@ -217,7 +225,7 @@ def test_suponly_step_fused_seam_equals_generic_path(monkeypatch):
         assert abs(lf - lg) <= (2e-6 if i == 0 else 2e-4) * abs(lg)
     for k, v in results["0"][1].items():
         if "num_batches" not in k:
-            assert rel(results["1"][1][k], v) < 2e-5, k
+            assert close(results["1"][1][k], v, 2e-5), (k, rel(results["1"][1][k], v))
     # the deferred resulter hands out the planes of the LAST forward pass on demand: same values as the generic path's
     pf, pg = results["1"][2]["pred"][0], results["0"][2]["pred"][0]
     assert pf.shape == pg.shape and rel(pf, pg.detach()) < 2e-4
