@@ -85,6 +85,17 @@ int pxl_conv_igemm(const pxl_conv_desc* desc, const void* in, const void* w, voi
                    const float* in_scale, const float* in_shift, const float* bias,
                    const void* addend, float* stats, void* workspace, size_t ws_bytes, void* stream);
 
+/* Forward convolution whose input is relu?(bn(y)) of the previous convolution's RAW output y, applied to the input tiles
+ * as they land in LDS ("BN-apply on load"): one launch instead of pxl_bn_finalize + pxl_bn_apply_fwd + pxl_conv_igemm and no
+ * materialised activation tensor.  bin (struct below): the INPUT BatchNorm -- statistics [nrep][2*Cin] (or the running
+ * statistics when training == 0), affine parameters; workgroup 0 writes bin->coef [4*Cin] and updates the running
+ * statistics exactly as pxl_bn_finalize does.  Cin <= 512, Cin % 64 == 0.  Bit-identical to the three-launch path (the
+ * transformed tile is rounded to bf16 like the materialised tensor).  Replaces SynchronizedBatchNorm2d + nn.ReLU + the
+ * next nn.Conv2d of a Bottleneck (resnet.py:33-41).  PXL_ERR_UNSUPPORTED: use the three launches. */
+struct pxl_bn_fin;
+int pxl_conv_dma_bnin(const pxl_conv_desc* desc, const void* y, const void* w, void* out, const float* bias, float* stats,
+                      const struct pxl_bn_fin* bin, int bin_relu, void* stream);
+
 /* Data gradient with the BatchNorm-backward reduction of its OUTPUT fused into the epilogue (LDS-DMA kernel only):
  * din = dgrad(dy) (+ addend) and bn_sums[0..C) += sum_m gd, bn_sums[C..2C) += sum_m gd * xhat over the tensor just
  * written, gd = din * (bn_relu ? scale*bn_y + shift > 0 : 1), xhat = (bn_y - mean) * rstd from bn_coef [4C]; C =

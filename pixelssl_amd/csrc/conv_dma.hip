@@ -53,6 +53,12 @@ struct DmaArgs {
   // coefficients (what pxl_bn_finalize does), so no finalize launch and no replica reduction in the consumers
   pxl_bn_fin fin;    // fin.coef == nullptr: off
   unsigned* fin_counter;
+  // BNIN kernels: the A operand is the RAW output y of the previous convolution and relu?(bn(y)) is applied to the tile
+  // after it has landed in LDS (no materialised activation tensor, no pxl_bn_apply_fwd launch); `bin` describes that
+  // BatchNorm -- every workgroup derives (scale, shift) of all Cin channels from its statistics in the prologue, workgroup 0
+  // also writes bin.coef and updates the running statistics (what pxl_bn_finalize does)
+  pxl_bn_fin bin;
+  int bin_relu;
   unsigned in_bytes, w_bytes;
   int taps[64];      // (dy << 16) | (dx & 0xffff)
 };
@@ -120,6 +126,41 @@ __device__ __forceinline__ void wait_chunk(u32x4 (&fa)[TMI], u32x4 (&fw)[TNI], f
                  : "n"(N));
   }
 }
+template <int OFF> __device__ __forceinline__ void lds_write128(unsigned addr, u32x4 v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+// BN-on-load: the LA pieces a lane has DMA'd itself + the 4 coefficient vectors, all LDS reads waited for at once
+template <int LA> __device__ __forceinline__ void wait_xform(u32x4 (&d)[LA], u32x4 (&c)[4]) {
+  if constexpr (LA == 2)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+  else if constexpr (LA == 3)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+  else if constexpr (LA == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+  else if constexpr (LA == 5)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+  else {
+    static_assert(LA == 6, "wait_xform: unsupported tile height");
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]),
+                   "+v"(c[3]));
+  }
+}
+template <int I, int N> struct XformLoad {
+  static __device__ __forceinline__ void run(u32x4 (&d)[N], unsigned addr) {
+    d[I] = lds_read128<I * 4096>(addr);
+    if constexpr (I + 1 < N) XformLoad<I + 1, N>::run(d, addr);
+  }
+};
+template <int I, int N> struct XformStore {
+  static __device__ __forceinline__ void run(const u32x4 (&d)[N], unsigned addr) {
+    lds_write128<I * 4096>(addr, d[I]);
+    if constexpr (I + 1 < N) XformStore<I + 1, N>::run(d, addr);
+  }
+};
+
 template <int I, int N, int STRIDE, int BASE> struct FragLoad {
   static __device__ __forceinline__ void run(u32x4 (&f)[N], unsigned addr) {
     f[I] = lds_read128<BASE + I * STRIDE>(addr);
@@ -130,7 +171,7 @@ template <int I, int N, int STRIDE, int BASE> struct FragLoad {
 // BM x BN output tile (pixels x channels), 4 waves as WM x WN, NST LDS stages, GATHER = taps / padding logic
 // ABL: timing ablations for tools/conv_bench.py (results are garbage): 1 = no DMA in the loop, 2 = no MFMA,
 // 4 = no fragment reads, 8 = no barrier.  0 in every product instantiation.
-template <int BM, int BN, int WM, int WN, int NST, bool GATHER, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int NST, bool GATHER, int ABL = 0, bool BNIN = false>
 __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   constexpr int TMI = BM / WM / 32;          // 32-pixel tiles per wave
   constexpr int TNI = BN / WN / 32;          // 32-channel tiles per wave
@@ -226,10 +267,17 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
       }
     }
   };
+  unsigned vm = 0;                 // BNIN: 8 bits per ring stage, bit q = piece q of this lane was in range (not zero-filled)
   auto issue = [&](int stage) {
     unsigned char* sa = smem + stage * SB + wave * 1024;
 #pragma unroll
     for (int q = 0; q < LA; ++q) dma16(r_in, sa + q * 4096, voffA[q], kcb);
+    if constexpr (BNIN) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int q = 0; q < LA; ++q) bits |= (voffA[q] != OOB ? 1u : 0u) << q;
+      vm = (vm & ~(0xffu << (8 * stage))) | (bits << (8 * stage));
+    }
     unsigned char* sb = smem + stage * SB + BM * 128 + wave * 1024;
 #pragma unroll
     for (int q = 0; q < LB; ++q) dma16(r_w, sb + q * 4096, voffB[q], kwb);
@@ -267,6 +315,43 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) issue(s);
 
+  // ---- BNIN: (scale, shift) of every input channel -> LDS table behind the ring (the tiles of the prologue are in flight)
+  unsigned ckc = 0;                                   // channel offset of the tile being consumed
+  const unsigned tab0 = lds0 + NST * SB;              // [Cin] scale, [Cin] shift (fp32)
+  const int lchunk = (lane & 7) ^ ((wave * 4 + ((lane >> 3) >> 1)) & 7);     // the lane's (q-independent) source chunk
+  if constexpr (BNIN) {
+    float* tab = reinterpret_cast<float*>(smem + NST * SB);
+    const pxl_bn_fin& f = p.bin;
+    const int C = p.Cin;
+    for (int c = tid; c < C; c += 256) {
+      float mean, var;
+      if (f.training) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < f.nrep; ++r) { s1 += f.stats[(size_t)r * 2 * C + c]; s2 += f.stats[(size_t)r * 2 * C + C + c]; }
+        mean = s1 / f.count;
+        var = s2 / f.count - mean * mean;
+        if (var < 0.f) var = 0.f;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && f.running_mean != nullptr) {
+          const float unbiased = f.count > 1.f ? var * f.count / (f.count - 1.f) : var;
+          f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean;
+          f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
+        }
+      } else {
+        mean = f.running_mean[c];
+        var = f.running_var[c];
+      }
+      const float rstd = f.clamp_var ? rsqrtf(fmaxf(var, f.eps)) : rsqrtf(var + f.eps);
+      const float ga = f.gamma ? f.gamma[c] : 1.f, be = f.beta ? f.beta[c] : 0.f;
+      const float scale = ga * rstd, shift = be - mean * scale;
+      tab[c] = scale;
+      tab[C + c] = shift;
+      if (blockIdx.x == 0 && blockIdx.y == 0) {
+        f.coef[c] = mean; f.coef[C + c] = rstd; f.coef[2 * C + c] = scale; f.coef[3 * C + c] = shift;
+      }
+    }
+    __syncthreads();
+    ckc = ((unsigned)ks_begin * 64u) % (unsigned)C;
+  }
   // retire every scalar (kernel-argument) load the compiler still counts as outstanding: its own
   // `s_waitcnt lgkmcnt(0)` at the first use would otherwise land inside the loop and drain the LDS reads
   __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -274,6 +359,43 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   int st_l = NST - 1;         // stage being filled
   for (int ks = 0; ks < nk_here; ++ks) {
     wait_vmcnt<(NST - 2) * (LA + LB)>();      // this wave's share of tile ks has landed
+    if constexpr (BNIN) {
+      // relu?(scale * y + shift) on the pieces THIS lane has DMA'd (visible to the issuing wave after its vmcnt wait, no
+      // barrier needed), in place, rounded to bf16 like the materialised tensor was; zero-filled pieces (padding taps,
+      // rows past M) stay zero.  All LDS traffic is inline asm: see the note on the fragment reads.
+      const unsigned pa = lds0 + st_c * SB + wave * 1024 + lane * 16;
+      const unsigned tb = tab0 + (ckc + (unsigned)lchunk * 8u) * 4u;
+      const unsigned tb2 = tb + (unsigned)p.Cin * 4u;
+      u32x4 cf[4], dd[LA];
+      cf[0] = lds_read128<0>(tb);  cf[1] = lds_read128<16>(tb);
+      cf[2] = lds_read128<0>(tb2); cf[3] = lds_read128<16>(tb2);
+      XformLoad<0, LA>::run(dd, pa);
+      wait_xform<LA>(dd, cf);
+      const unsigned bits = (vm >> (8 * st_c)) & 0xffu;
+      float sc[8], sh[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[e] = __uint_as_float(cf[0][e]); sc[4 + e] = __uint_as_float(cf[1][e]);
+        sh[e] = __uint_as_float(cf[2][e]); sh[4 + e] = __uint_as_float(cf[3][e]);
+      }
+#pragma unroll
+      for (int q = 0; q < LA; ++q) {
+        float f[8];
+        Chunk<bf16_t>::unpack(make_uint4(dd[q][0], dd[q][1], dd[q][2], dd[q][3]), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = f[e] * sc[e] + sh[e];
+          f[e] = p.bin_relu ? fmaxf(v, 0.f) : v;
+        }
+        const uint4 r = Chunk<bf16_t>::pack(f);
+        const bool real = (bits >> q) & 1u;
+        dd[q] = real ? u32x4{r.x, r.y, r.z, r.w} : dd[q];
+      }
+      XformStore<0, LA>::run(dd, pa);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ckc += 64;
+      if (ckc == (unsigned)p.Cin) ckc = 0;
+    }
     if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();   // ... everyone's has; stage st_l is no longer being read
     if constexpr (!(ABL & 1)) issue(st_l);
     // all 4*(TMI+TNI) fragment reads of the step are issued up front (LDS returns in order), the MFMAs of
@@ -508,6 +630,7 @@ int launch_abl(const DmaArgs& a, hipStream_t stream) {
   p.ws = nullptr;
   p.nk_per = p.nk;
   p.fin.coef = nullptr;
+  p.bin.coef = nullptr;
   constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
   PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, 2, 2, NST, true, ABL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
@@ -539,19 +662,25 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
   splitk = cdiv(p.nk, p.nk_per);
   if (splitk > 1) PXL_CHECK_HIP(hipMemsetAsync(p.ws, 0, (size_t)p.M * p.Cout * sizeof(float), stream));
   else p.ws = nullptr;
-  constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
-  static bool raised[2] = {false, false};
-  if (!raised[gather ? 1 : 0]) {
-    if (gather) PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    else PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    raised[gather ? 1 : 0] = true;
+  const bool bnin = p.bin.coef != nullptr;
+  const size_t smem = (size_t)NST * (BM + BN) * 128 + (bnin ? (size_t)p.Cin * 8 : 0);
+  static bool raised[4] = {false, false, false, false};
+  const int vi = (gather ? 1 : 0) + (bnin ? 2 : 0);
+  const void* fn = vi == 0 ? reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, false>)
+                 : vi == 1 ? reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, true>)
+                 : vi == 2 ? reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, false, 0, true>)
+                           : reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, true, 0, true>);
+  if (!raised[vi]) {
+    PXL_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised[vi] = true;
   }
-  if (gather)
-    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, true>), dim3(grid, splitk), dim3(256), smem, stream, p);
-  else
-    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, false>), dim3(grid, splitk), dim3(256), smem, stream, p);
+  if (smem > 160 * 1024) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: tile + coefficient table exceed the LDS");
+  switch (vi) {
+    case 0: hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, false>), dim3(grid, splitk), dim3(256), smem, stream, p); break;
+    case 1: hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, true>), dim3(grid, splitk), dim3(256), smem, stream, p); break;
+    case 2: hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, false, 0, true>), dim3(grid, splitk), dim3(256), smem, stream, p); break;
+    default: hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, true, 0, true>), dim3(grid, splitk), dim3(256), smem, stream, p); break;
+  }
   PXL_LAUNCH_CHECK();
   if (splitk > 1)
     return pxl_splitk_finish(PXL_BF16, (long)p.M * p.Cout, p.Cout, p.Kreal, p.ws, p.bias, p.out, stream);
@@ -594,6 +723,7 @@ extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* 
   a.nk_per = 0;
   a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
+  a.bin.coef = nullptr; a.bin_relu = 0;
   const int sk = d->split_k;
   return conv_dma_launch(d, a, sk, ws_bytes, stream);
 }
@@ -613,6 +743,28 @@ extern "C" int pxl_conv_dma_finalize(const pxl_conv_desc* d, const void* in, con
   a.ws = nullptr; a.nk_per = 0;
   a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin = *fin; a.fin_counter = counter;
+  a.bin.coef = nullptr; a.bin_relu = 0;
+  return conv_dma_launch(d, a, 1, 0, stream);
+}
+
+// Forward convolution whose input is relu?(bn(y)) of the previous convolution's RAW output y, applied to the tiles as they
+// land in LDS: stands in for pxl_bn_finalize + pxl_bn_apply_fwd + pxl_conv_igemm (no materialised activation, one launch
+// instead of two or three).  `bin`: the input BatchNorm (statistics [nrep][2*Cin] or running statistics, affine
+// parameters, coef [4*Cin] written by workgroup 0, running statistics updated there); d->Cin == the BatchNorm's channel
+// count <= 512, a multiple of 64.  PXL_ERR_UNSUPPORTED when the LDS-DMA kernel cannot run the descriptor.
+extern "C" int pxl_conv_dma_bnin(const pxl_conv_desc* d, const void* y, const void* w, void* out, const float* bias,
+                                 float* stats, const pxl_bn_fin* bin, int bin_relu, void* stream) {
+  PXL_REQUIRE(d && y && w && out && bin && bin->coef && bin->count > 0.f, "conv_dma_bnin: bad argument");
+  PXL_REQUIRE(bin->training ? (bin->stats != nullptr && bin->nrep >= 1) : (bin->running_mean && bin->running_var),
+              "conv_dma_bnin: missing statistics");
+  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || d->div != 1 || d->Cin > 512 || (d->tile_cfg >= 0 && d->tile_cfg < 8))
+    return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_bnin: descriptor is not eligible for the BN-on-load kernel");
+  DmaArgs a;
+  a.in = y; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
+  a.ws = nullptr; a.nk_per = 0;
+  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
+  a.fin.coef = nullptr; a.fin_counter = nullptr;
+  a.bin = *bin; a.bin_relu = bin_relu;
   return conv_dma_launch(d, a, 1, 0, stream);
 }
 
@@ -631,6 +783,7 @@ extern "C" int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, c
   a.ws = nullptr; a.nk_per = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = bn_relu; a.bn_mask = nullptr;
+  a.bin.coef = nullptr; a.bin_relu = 0;
   pxl_conv_desc q = *d;
   q.stats_rep = 1;
   return conv_dma_launch(&q, a, 1, 0, stream);
@@ -651,6 +804,7 @@ extern "C" int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy,
   a.ws = nullptr; a.nk_per = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = 0; a.bn_mask = join_out;
+  a.bin.coef = nullptr; a.bin_relu = 0;
   pxl_conv_desc q = *d;
   q.stats_rep = 1;
   return conv_dma_launch(&q, a, 1, 0, stream);

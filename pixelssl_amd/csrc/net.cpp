@@ -26,6 +26,8 @@
 extern "C" {
 int pxl_conv_dma_finalize(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias, float* stats,
                           const pxl_bn_fin* fin, unsigned* counter, void* stream);
+int pxl_conv_dma_bnin(const pxl_conv_desc* d, const void* y, const void* w, void* out, const float* bias, float* stats,
+                      const pxl_bn_fin* bin, int bin_relu, void* stream);
 int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
                             const void* bn_y, const float* bn_coef, int bn_relu, float* bn_sums, void* stream);
 int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
@@ -88,6 +90,11 @@ struct BnInfo {
   bool fin_in_consumer = false;
   size_t cnt_off = 0;      // arena (inside the statistics region, zeroed with it): the last-block-done ticket counter
   bool fin_by_conv = false;   // this pass: the producing convolution's last workgroup finalized the BN
+  // BN-apply on load: the single convolution that consumes relu(bn(y)) reads the RAW y and applies the BatchNorm to its
+  // tiles in LDS (conv_dma.hip: pxl_conv_dma_bnin), finalizing it in its prologue -- no pxl_bn_apply_fwd launch on the
+  // forward chain.  z is then only needed by that convolution's weight gradient: networks that train materialise it on
+  // the side stream, off the critical path; no-grad networks (the MT teacher) never write it.
+  bool onload = false;
 };
 
 struct OpInfo {
@@ -163,6 +170,9 @@ struct pxl_net {
   std::vector<long> op_lo;         // per op: lowest flat offset (floats) its backward writes a gradient to, or -1
   bool bucket_ok = false;          // parameter offsets grow with the op index: suffixes of the op list = suffixes of the buffer
   int grad_buckets_last = 0;       // buckets issued by the last backward (tests / bench)
+  bool bn_onload = getenv("PXL_BN_ONLOAD") == nullptr || getenv("PXL_BN_ONLOAD")[0] != '0';
+  hipEvent_t z_join_ev = nullptr;
+  std::vector<hipEvent_t> z_ev;    // per op: the consumer convolution of an on-load BN has been issued (coef is final)
   bool wgrad_on = true;
   bool pack_dgrad = true;          // false: pxl_net_pack skips the transposed (data-gradient) weights (no-grad networks)
   int input_tensor = -1;
@@ -246,6 +256,7 @@ struct Timed {
 // or the raw tensor + the fused (scale, shift) prologue
 struct ConvIn { const void* ptr; const float* sc; const float* sh; };
 inline ConvIn conv_input(const pxl_net* n, const OpInfo& op, const void* arena) {
+  // (weight gradient / tuning view: the materialised activation of an on-load BN, like any other has_z BN)
   const pxl_op& d = op.d;
   const TensorInfo& tin = n->tensors[d.in0];
   const unsigned char* base = reinterpret_cast<const unsigned char*>(arena);
@@ -323,6 +334,8 @@ extern "C" void pxl_net_destroy(pxl_net* net) {
   for (auto e : net->pool) (void)hipEventDestroy(e);
   for (auto e : net->fork_ev) if (e) (void)hipEventDestroy(e);
   if (net->join_ev) (void)hipEventDestroy(net->join_ev);
+  if (net->z_join_ev) (void)hipEventDestroy(net->z_join_ev);
+  for (auto e : net->z_ev) if (e) (void)hipEventDestroy(e);
   if (net->side) (void)hipStreamDestroy(net->side);
   for (hipEvent_t e : {net->comm_main_ev, net->comm_side_ev, net->comm_done_ev}) if (e) (void)hipEventDestroy(e);
   if (net->comm_stream) (void)hipStreamDestroy(net->comm_stream);
@@ -565,6 +578,25 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
     b.has_z = true;
     b.z_off = arena;
     arena += tin.bytes;
+  }
+  // BN-apply on load (see BnInfo::onload): materialised BNs with exactly one consumer, a convolution the LDS-DMA kernel
+  // can run with its coefficient table in LDS
+  for (auto& b : n->bns) b.onload = false;
+  if (n->dtype == PXL_BF16 && n->bn_onload) {
+    std::vector<int> ncons(n->bns.size(), 0), conv_of(n->bns.size(), -1);
+    for (size_t i = 0; i < n->ops.size(); ++i) {
+      const pxl_op& d = n->ops[i].d;
+      if (d.bn_in0 >= 0) { ++ncons[d.bn_in0]; if (d.kind == PXL_OP_CONV) conv_of[d.bn_in0] = (int)i; }
+      if (d.bn_in1 >= 0) ncons[d.bn_in1] += 2;           // a second operand (join shortcut, HEAD latent): not on-load
+    }
+    for (size_t k = 0; k < n->bns.size(); ++k) {
+      BnInfo& b = n->bns[k];
+      if (!b.has_z || ncons[k] != 1 || conv_of[k] < 0) continue;
+      const OpInfo& oc = n->ops[conv_of[k]];
+      if (oc.patch || oc.ws_bytes != 0 || oc.fwd.Cin > 512 || oc.fwd.Cin != b.d.C) continue;
+      if (!pxl_conv_dma_eligible(&oc.fwd, nullptr, nullptr)) continue;
+      b.onload = true;
+    }
   }
   // forward finalize folded into its consumer: BNs that are materialised (z) or whose raw tensor feeds only one
   // residual join
@@ -853,6 +885,7 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
   if (training && n->stats_region_bytes)
     PXL_CHECK_HIP(hipMemsetAsync(at(arena, n->stats_region_off), 0, n->stats_region_bytes, s));
   const int dt = n->dtype;
+  bool z_on_side = false;          // activated tensors of on-load BNs are being written on the side stream
   for (size_t i = 0; i < n->ops.size(); ++i) {
     OpInfo& op = n->ops[i];
     const pxl_op& d = op.d;
@@ -886,7 +919,48 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
                                 tout.H, tout.W, op.patch_Kp, stream);
           if (rc != PXL_OK) return rc;
         }
-        {
+        // BN-apply on load: this convolution reads the raw output of its producer and finalizes + applies the BatchNorm
+        // itself; the activated tensor is written only where a weight gradient will read it, on the side stream
+        bool onload_done = false;
+        if (d.bn_in0 >= 0 && n->bns[d.bn_in0].onload && !n->bns[d.bn_in0].fin_by_conv) {
+          BnInfo& bi = n->bns[d.bn_in0];
+          const pxl_bn_fin bin = make_fin(n, bi, params, running, arena, training);
+          {
+            Timed t(n, s, 0, conv_flops(n, d, tout));
+            if (n->profile) n->prof_bytes[0] += conv_bytes(n, d, tin, tout, false);
+            rc = pxl_conv_dma_bnin(&op.fwd, at(arena, tin.off), at(packed, op.wf_off), at(arena, tout.off), bias, stats, &bin,
+                                   bi.relu, stream);
+          }
+          if (rc == PXL_OK) {
+            onload_done = true;
+            // networks that can run a backward pass (pack_dgrad) get z = relu(bn(y)) for this op's weight gradient -- whatever
+            // wgrad_on says now: it may be switched on between this pass and its backward
+            if (n->pack_dgrad) {
+              if (!n->side) {
+                PXL_CHECK_HIP(hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
+                if (!n->join_ev) PXL_CHECK_HIP(hipEventCreateWithFlags(&n->join_ev, hipEventDisableTiming));
+                if (n->fork_ev.empty()) n->fork_ev.assign(n->ops.size(), nullptr);
+                if (n->use_side < 0) { const char* e = getenv("PXL_SIDE_STREAM"); n->use_side = (e && e[0] == '0') ? 0 : 1; }
+              }
+              if (n->z_ev.empty()) n->z_ev.assign(n->ops.size(), nullptr);
+              if (!n->z_ev[i]) PXL_CHECK_HIP(hipEventCreateWithFlags(&n->z_ev[i], hipEventDisableTiming));
+              if (!n->z_join_ev) PXL_CHECK_HIP(hipEventCreateWithFlags(&n->z_join_ev, hipEventDisableTiming));
+              PXL_CHECK_HIP(hipEventRecord(n->z_ev[i], s));                  // coef is final once this convolution has run
+              PXL_CHECK_HIP(hipStreamWaitEvent(n->side, n->z_ev[i], 0));
+              rc = pxl_bn_apply_fwd(dt, (long)n->B * tin.H * tin.W, tin.Cp, at(arena, tin.off), fat(arena, bi.coef_off), bi.relu,
+                                    at(arena, bi.z_off), n->side);
+              if (rc != PXL_OK) return rc;
+              z_on_side = true;
+            }
+          } else if (rc == PXL_ERR_UNSUPPORTED) {     // (tile + coefficient table too large ...): materialise, then the plain path
+            rc = pxl_bn_finalize_apply_fwd(dt, (long)n->B * tin.H * tin.W, tin.Cp, at(arena, tin.off), &bin, bi.relu,
+                                           at(arena, bi.z_off), stream);
+            if (rc != PXL_OK) return rc;
+          } else {
+            return rc;
+          }
+        }
+        if (!onload_done) {
           Timed t(n, s, 0, conv_flops(n, d, tout));
           if (n->profile) n->prof_bytes[0] += conv_bytes(n, d, tin, tout, false);
           if (stats && n->conv_finalize && !(n->sync && n->world > 1) && n->dtype == PXL_BF16 && !op.ws_bytes &&
@@ -919,7 +993,9 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
             nrep = 1;
           }
           b.fin_nrep = nrep;
-          if (b.fin_in_consumer) {
+          if (b.onload) {
+            // finalized and applied by the convolution that consumes it (BN-apply on load)
+          } else if (b.fin_in_consumer) {
             if (b.has_z) {
               const pxl_bn_fin fin = make_fin(n, b, params, running, arena, training);
               rc = pxl_bn_finalize_apply_fwd(dt, (long)n->B * tout.H * tout.W, tout.Cp, at(arena, tout.off), &fin, b.relu,
@@ -1038,6 +1114,10 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
       }
     }
     if (rc != PXL_OK) return rc;
+  }
+  if (z_on_side) {                 // the arena is the caller's: nothing of this pass may still be running when it returns
+    PXL_CHECK_HIP(hipEventRecord(n->z_join_ev, n->side));
+    PXL_CHECK_HIP(hipStreamWaitEvent(s, n->z_join_ev, 0));
   }
   return PXL_OK;
 }

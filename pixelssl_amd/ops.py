@@ -49,6 +49,13 @@ def conv_dma_finalize(desc, x, w, out, stats, fin, counter, bias=None):
     return out
 
 
+def conv_dma_bnin(desc, y, w, out, bin_fin, relu=True, stats=None, bias=None):
+    """forward conv reading the RAW previous output y with relu?(bn(y)) applied on load; raises when not eligible"""
+    _require_cuda(y, w, out)
+    check(lib().pxl_conv_dma_bnin(desc, ptr(y), ptr(w), ptr(out), ptr(bias), ptr(stats), bin_fin, int(relu), stream_ptr()))
+    return out
+
+
 def conv_dgrad_bnreduce(desc, dy, wt, din, bn_y, bn_coef, bn_relu, bn_sums, addend=None):
     """data gradient + fused BN-backward reduction of its output (LDS-DMA kernel); raises when not eligible"""
     _require_cuda(dy, wt, din, bn_y, bn_coef, bn_sums)

@@ -204,6 +204,74 @@ def test_conv_with_last_block_bn_finalize(case, cfg):
         assert cnt[0].item() > 0
 
 
+BNIN_CASES = [
+    # name, B, Cin, Cout, H, W, k, stride, dil, pad
+    ("bnin_1x1", 2, 64, 256, 17, 17, 1, 1, 1, 0),
+    ("bnin_1x1_k256", 3, 256, 72, 9, 13, 1, 1, 1, 0),
+    ("bnin_1x1_k512_m8712", 8, 512, 128, 33, 33, 1, 1, 1, 0),
+    ("bnin_3x3", 2, 64, 64, 17, 17, 3, 1, 1, 1),
+    ("bnin_3x3_s2", 2, 128, 96, 17, 17, 3, 2, 1, 1),
+    ("bnin_3x3_d2", 2, 128, 128, 9, 9, 3, 1, 2, 2),
+    ("bnin_3x3_d4_wide", 1, 64, 288, 9, 9, 3, 1, 4, 4),
+    ("bnin_tiny_m", 1, 192, 40, 3, 5, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("cfg", [-1, 8, 9, 10, 11, 17, 18, 20, 21, 25, 26])
+@pytest.mark.parametrize("case", BNIN_CASES, ids=[c[0] for c in BNIN_CASES])
+def test_conv_with_bn_apply_on_load(case, cfg, training):
+    """pxl_conv_dma_bnin(y, BN) == pxl_bn_finalize + pxl_bn_apply_fwd + pxl_conv_igemm BIT FOR BIT (the tile transformed in
+    LDS is rounded to bf16 exactly like the materialised activation), padding taps stay zero (relu(shift) must not leak
+    into them), coef / running statistics as pxl_bn_finalize writes them, output statistics as pxl_conv_igemm's."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    name, B, Cin, Cout, H, W, k, s, d, p = case
+    if cfg >= 20 and _pitch(Cout) < 128:
+        pytest.skip("tall tiles are 128 channels wide")
+    g = torch.Generator().manual_seed(_seed(name) + 11)
+    y = qround(torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.4, dtype)
+    w = qround(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype)
+    gamma, beta = (torch.rand(Cin, generator=g) + 0.5).to(DEV), (torch.randn(Cin, generator=g) * 0.5 + 0.3).to(DEV)
+    Ho, Wo = (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
+    cip, cop = _pitch(Cin), _pitch(Cout)
+    taps = ops.fwd_taps(k, k, d, p)
+    yd = to_nhwc(y, cip, dtype)
+    wf, _ = pack_w(w, dtype, cip)
+    nrep, count = 4, float(B * H * W)
+    # statistics of y spread over the replicas (what the producing convolution's epilogue leaves behind)
+    yf = yd.float().reshape(-1, cip)
+    st = torch.zeros(nrep, 2 * Cin, device=DEV)
+    for r in range(nrep):
+        part = yf[r::nrep]
+        st[r, :Cin], st[r, Cin:] = part.sum(0), (part * part).sum(0)
+    desc = ops.conv_desc(dtype, B, H, W, cip, Ho, Wo, cop, Cout, taps, out_stride=s, tile_cfg=cfg, stats_rep=4)
+    rm_a, rv_a = torch.full((Cin,), 0.25, device=DEV), torch.full((Cin,), 1.5, device=DEV)
+    coef_a = ops.bn_finalize(st, count, gamma, beta, rm_a, rv_a, nrep=nrep, training=training)
+    z = ops.bn_apply_fwd(yd, coef_a, relu=True)
+    out_a = torch.full((B, Ho, Wo, cop), 3.0, device=DEV, dtype=dtype)
+    st_a = torch.zeros(4, 2 * Cout, device=DEV)
+    ops.conv_igemm(desc, z, wf, out_a, stats=st_a)
+    rm_b, rv_b = torch.full((Cin,), 0.25, device=DEV), torch.full((Cin,), 1.5, device=DEV)
+    coef_b = torch.full((4 * Cin,), float("nan"), device=DEV)
+    fin = ops.bn_fin(st, nrep, count, gamma, beta, rm_b, rv_b, coef_b, training=training)
+    out_b = torch.full((B, Ho, Wo, cop), 5.0, device=DEV, dtype=dtype)
+    st_b = torch.zeros(4, 2 * Cout, device=DEV)
+    ops.conv_dma_bnin(desc, yd, wf, out_b, fin, relu=True, stats=st_b)
+    torch.cuda.synchronize()
+    assert torch.equal(coef_a, coef_b), "coef written by workgroup 0 == pxl_bn_finalize"
+    assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+    assert torch.equal(out_a[..., :Cout], out_b[..., :Cout]), (name, cfg, rel_err(out_b.float().cpu(), out_a.float().cpu()))
+    assert rel_err(st_b.sum(0).cpu(), st_a.sum(0).cpu()) < 2e-6
+    # a non-ReLU BatchNorm in front (relu = 0) on one configuration
+    if cfg == -1:
+        z0 = ops.bn_apply_fwd(yd, coef_a, relu=False)
+        ops.conv_igemm(desc, z0, wf, out_a)
+        ops.conv_dma_bnin(desc, yd, wf, out_b, fin, relu=False)
+        torch.cuda.synchronize()
+        assert torch.equal(out_a[..., :Cout], out_b[..., :Cout])
+
+
 @pytest.mark.parametrize("cfg", [-1, 8, 10, 11, 18, 20, 21, 26])
 @pytest.mark.parametrize("shape", [(2, 128, 64, 17, 19, 3, 1, 1), (3, 64, 256, 9, 13, 1, 1, 0), (2, 192, 128, 12, 12, 3, 2, 2)])
 def test_conv_dgrad_with_fused_bn_backward_reduce(shape, cfg):

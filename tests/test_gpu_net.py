@@ -474,3 +474,41 @@ def test_full_size_properties_513():
     assert not torch.equal(w0, algo.s_model.module.model.flat.params)
     # EMA with alpha = 0 at step 0 copies the student into the teacher (ssl_mt.py:361)
     assert torch.equal(algo.t_model.module.model.flat.params, algo.s_model.module.model.flat.params)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layers", [(1, 1, 1, 1), (2, 2, 2, 2)])
+def test_bn_apply_on_load_equals_the_materialised_path(layers, monkeypatch):
+    """PXL_BN_ONLOAD (default on): conv2 / conv3 of every bottleneck read the RAW output of their producer and apply
+    relu(bn(.)) to the tiles in LDS.  Against the same network with materialised activations (PXL_BN_ONLOAD=0): logits
+    bit-identical in a training-mode forward (trainable and no-grad / teacher style), running statistics identical,
+    parameter gradients equal up to the order of the fp32 atomics of the weight gradients, eval-mode forward identical."""
+    import torch_oracle as TO
+    from pixelssl_amd.engine import DeepLabV2Core
+    from pixelssl_amd import functional as PF
+    x, gt = TO.synthetic_batch(3, 97, 3, seed=77, block=16)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PXL_BN_ONLOAD", mode)
+        core = DeepLabV2Core(backbone=layers, device="cuda", engine_dtype=torch.bfloat16)
+        core.reset_parameters(torch.Generator().manual_seed(5))
+        core.train()
+        logits, prob, _ = core(x.cuda())
+        PF.cross_entropy_per_sample(logits, gt.cuda(), 255).mean().backward()
+        grads = {k: p.grad.detach().float().cpu().clone() for k, p in core.named_parameters()}
+        run = {k: v.detach().float().cpu().clone() for k, v in core.named_buffers() if "running" in k}
+        with torch.no_grad():
+            l2, _, _ = core(x.cuda())                 # no-grad, train-mode BN: the MT teacher's pass
+        core.eval()
+        with torch.no_grad():
+            l3, _, _ = core(x.cuda())
+        out[mode] = (logits.detach().cpu(), grads, run, l2.cpu(), l3.cpu())
+    a, b = out["1"], out["0"]
+    assert torch.equal(a[0], b[0]), "training forward"
+    assert torch.equal(a[3], b[3]), "no-grad training-mode forward"
+    assert torch.equal(a[4], b[4]), "eval forward"
+    for k in b[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    for k in b[1]:
+        d = (a[1][k] - b[1][k]).norm().item()
+        assert d <= 1e-5 * b[1][k].norm().item() + 1e-7, (k, d)

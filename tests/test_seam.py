@@ -24,11 +24,11 @@ def rel(a, b):
     return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
 
 
-def close(a, b, rtol):
+def close(a, b, rtol, atol=1e-8):
     """||a - b|| <= rtol * ||b|| + 1e-8 * sqrt(n): the absolute term covers tensors that ARE (numerically) zero -- a BN
     beta after three tiny updates is ~1e-7, and the order of the fp32 atomics in its gradient moves it by 1e-10"""
     d = (a.double() - b.double()).norm().item()
-    return d <= rtol * b.double().norm().item() + 1e-8 * (b.numel() ** 0.5)
+    return d <= rtol * b.double().norm().item() + atol * (b.numel() ** 0.5)
 
 
 def _torch_seam(s_low, t_low, gt, n_ce, lo, hi, w_ce, w_mse, size, align, ignore=255):
@@ -197,7 +197,9 @@ def test_mt_step_fused_seam_equals_generic_path(dtype, cons_for_labeled, monkeyp
         for k, v in results["0"][which].items():
             if "num_batches" in k:
                 continue
-            assert close(results["1"][which][k], v, 2e-5 if dtype == "fp32" else 2e-3), (which, k, rel(results["1"][which][k], v))
+            # (bf16: gradients carry bf16 noise, a 1e-6 BN beta moves by 1e-7 between two runs of the SAME path)
+            assert close(results["1"][which][k], v, 2e-5 if dtype == "fp32" else 2e-3, 1e-8 if dtype == "fp32" else 5e-7), \
+                (which, k, rel(results["1"][which][k], v))
 
 
 @pytest.mark.gpu
