@@ -145,13 +145,36 @@ def clone_state(sd):
 # Forward pass (functional)
 # -----------------------------------------------------------------------------
 
+# Which variance formula the train-mode BatchNorm uses.  False: the single-device path of the reference (F.batch_norm,
+# (var + eps)^-1/2).  True: its MULTI-device path, taken whenever nn.DataParallel replicates the model over > 1 GPU
+# (sync_batchnorm/batchnorm.py:56-78 + _compute_mean_std :113-125): statistics summed over all replicas,
+# inv_std = clamp(biased var, eps)^-1/2, output = (x - mean) * (inv_std * weight) + bias.  The engine uses that formula on
+# every multi-rank run; tests/test_gpu_dist.py sets this switch to compare a 2-rank step with the oracle.
+SYNC_BN_MULTI_DEVICE = False
+
+
 def _bn(sd, prefix, x, train):
-    """Single-device path of _SynchronizedBatchNorm.forward
-    (pixelssl/nn/module/third_party/sync_batchnorm/batchnorm.py:48-53):
-    F.batch_norm with momentum 0.1, eps 1e-5, (var+eps)^-1/2, running var unbiased.
-    Running buffers in `sd` are updated in place when train=True."""
+    """_SynchronizedBatchNorm.forward (pixelssl/nn/module/third_party/sync_batchnorm/batchnorm.py:48-78).
+    Single-device / eval path: F.batch_norm with momentum 0.1, eps 1e-5, (var+eps)^-1/2, running var unbiased.
+    Multi-device training path (SYNC_BN_MULTI_DEVICE): the reference's own arithmetic on the whole batch
+    (_compute_mean_std, :113-125).  Running buffers in `sd` are updated in place when train=True."""
     if train and (prefix + ".num_batches_tracked") in sd:
         sd[prefix + ".num_batches_tracked"] += 1
+    if train and SYNC_BN_MULTI_DEVICE:
+        C = x.shape[1]
+        xv = x.reshape(x.shape[0], C, -1)
+        size = xv.shape[0] * xv.shape[2]
+        sum_ = xv.sum(dim=(0, 2))
+        ssum = (xv ** 2).sum(dim=(0, 2))
+        mean = sum_ / size
+        sumvar = ssum - sum_ * mean
+        unbias_var, bias_var = sumvar / (size - 1), sumvar / size
+        rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+        rm.copy_((1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean.detach())
+        rv.copy_((1 - BN_MOMENTUM) * rv + BN_MOMENTUM * unbias_var.detach())
+        inv_std = bias_var.clamp(BN_EPS) ** -0.5
+        out = (xv - mean.view(1, C, 1)) * (inv_std * sd[prefix + ".weight"]).view(1, C, 1) + sd[prefix + ".bias"].view(1, C, 1)
+        return out.view(x.shape)
     return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
                         sd[prefix + ".weight"], sd[prefix + ".bias"],
                         train, BN_MOMENTUM, BN_EPS)

@@ -91,6 +91,33 @@ class JointDatasetsWrapper(_SSLDatasetWrapper):
         raise IndexError(idx)
 
 
+class ShardedBatchSampler(Sampler):
+    """The labeled-only training loader of task_template/proxy.py:365-375 (DataLoader(shuffle=True, drop_last=True) over
+    batch_size = per-GPU batch x #GPUs) for one rank: ONE global permutation per epoch, cut into global batches of
+    batch_size x world_size, of which this rank takes its slice -- the union over the ranks is what the reference's
+    single process feeds nn.DataParallel.  All ranks must draw the same permutation: `rng` is a numpy RandomState seeded
+    identically everywhere (required when world_size > 1)."""
+
+    def __init__(self, num_samples, batch_size, rank=0, world_size=1, rng=None):
+        self.n, self.batch_size = int(num_samples), int(batch_size)
+        self.rank, self.world_size, self.rng = int(rank), int(world_size), rng
+        assert 0 <= self.rank < self.world_size
+        if self.world_size > 1 and rng is None:
+            raise ValueError('ShardedBatchSampler: world_size > 1 needs an explicit rng seeded identically on every rank '
+                             '(the global numpy state is not synchronised across processes)')
+        self._g = self.batch_size * self.world_size
+        assert self.n >= self._g > 0
+
+    def __len__(self):
+        return self.n // self._g
+
+    def __iter__(self):
+        perm = (self.rng or np.random).permutation(self.n)
+        b, r = self.batch_size, self.rank
+        for k in range(len(self)):
+            yield [int(i) for i in perm[k * self._g + r * b:k * self._g + (r + 1) * b]]
+
+
 class TwoStreamBatchSampler(Sampler):
     """Labeled-first mini-batches from two index streams; an epoch runs through the longer stream once and re-shuffles
     the shorter one as often as needed (nn/data.py:126-177).  `labeled_batch_size` / `unlabeled_batch_size` are PER
@@ -104,6 +131,9 @@ class TwoStreamBatchSampler(Sampler):
         self.unlabeled_batch_size = unlabeled_batch_size
         self.rank, self.world_size, self.rng = int(rank), int(world_size), rng
         assert 0 <= self.rank < self.world_size
+        if self.world_size > 1 and rng is None:
+            raise ValueError('TwoStreamBatchSampler: world_size > 1 needs an explicit rng seeded identically on every rank '
+                             '(the global numpy state is not synchronised across processes)')
         self._gl, self._gu = labeled_batch_size * self.world_size, unlabeled_batch_size * self.world_size
         assert len(self.labeled_idxs) >= self._gl > 0
         assert len(self.unlabeled_idxs) >= self._gu > 0

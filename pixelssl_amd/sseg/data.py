@@ -270,12 +270,19 @@ class DeviceNormalize:
 
 def make_train_loader(dataset, args, rank=0, world_size=1, rng=None):
     """The training DataLoader of task_template/proxy.py:365-375 for one rank: two-stream batches when the dataset has
-    unlabeled samples, plain shuffled batches otherwise; pinned memory; `num_workers` as given (per rank)."""
+    unlabeled samples, plain shuffled batches otherwise; pinned memory; `num_workers` as given (per rank).  With
+    world_size > 1 both kinds are sharded by rank and `rng` (a numpy RandomState seeded identically on every rank) is
+    REQUIRED: the ranks must draw the same permutations."""
     from ..nn import data as nndata
     unl = getattr(dataset, 'unlabeled_idxs', [])
     if len(unl) > 0 and args.unlabeled_batch_size > 0:
         sampler = nndata.TwoStreamBatchSampler(dataset.labeled_idxs, unl, args.labeled_batch_size, args.unlabeled_batch_size,
                                                rank=rank, world_size=world_size, rng=rng)
+        return torch.utils.data.DataLoader(dataset, batch_sampler=sampler, num_workers=args.num_workers, pin_memory=True)
+    if world_size > 1:
+        # one global permutation per epoch, this rank's slice of every global batch (the plain shuffled DataLoader below
+        # would give every rank the same samples with equal seeds and overlapping ones otherwise)
+        sampler = nndata.ShardedBatchSampler(len(dataset), args.batch_size, rank=rank, world_size=world_size, rng=rng)
         return torch.utils.data.DataLoader(dataset, batch_sampler=sampler, num_workers=args.num_workers, pin_memory=True)
     return torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers,
                                        pin_memory=True, drop_last=True)

@@ -90,6 +90,47 @@ def test_two_ranks_one_gpu_match_full_batch_step():
         _compare_with_full_batch(res, state, x, gt, rel)
     finally:                                   # (a failure must not leak the switch into the tests that follow)
         del os.environ["PXL_FORCE_CLAMP_VAR"]
+    _compare_with_oracle(res, state, x, gt, rel)
+
+
+def _compare_with_oracle(res, state, x, gt, rel):
+    """PARITY (not consistency): the two ranks' fp32 step against the CPU oracle of the full batch with the reference's
+    MULTI-device Sync-BN arithmetic (torch_oracle.SYNC_BN_MULTI_DEVICE: batchnorm.py:56-78,113-125, pinned against the
+    reference class in tests/test_oracle_golden.py) -- logits of both ranks, the averaged gradient of every parameter and
+    the running statistics."""
+    import torch_oracle as TO
+    TO.SYNC_BN_MULTI_DEVICE = True
+    try:
+        sd = TO.clone_state(state)
+        leaves = TO._param_leaves(sd)
+        torch.set_num_threads(min(8, os.cpu_count() or 1))
+        o_logits, _, _, _ = TO.deeplabv2_forward(TO._with_leaves(sd, leaves), x, train=True, layers=LAYERS)
+        TO.sseg_criterion(o_logits, gt).mean().backward()
+    finally:
+        TO.SYNC_BN_MULTI_DEVICE = False
+    from pixelssl_amd.engine import DeepLabV2Core
+    core = DeepLabV2Core(backbone=LAYERS, device="cuda:0", engine_dtype=torch.float32)      # (parameter -> flat offset map only)
+    r0, r1 = ({k: torch.from_numpy(v) for k, v in res[r][str(torch.float32)].items()} for r in (0, 1))
+    e_l = rel(torch.cat([r0["logits"], r1["logits"]]), o_logits.detach())
+    worst = (0.0, "")
+    num = den = 0.0
+    for name, prm in core.named_parameters():
+        _, off, n = prm._pxl_flat
+        og = leaves[name].grad
+        alloc = getattr(prm, "_pxl_alloc", None)
+        eg = core.flat._view(r0["grads"], tuple(prm.shape), n, off, alloc)
+        num += (eg.double() - og.double()).pow(2).sum().item()
+        den += og.double().pow(2).sum().item()
+        worst = max(worst, (rel(eg, og), name))
+    e_g = (num / den) ** 0.5
+    e_r = 0.0
+    for nm, shape, n, off, alloc in core.flat._r_entries:            # running means and variances (updated in place in `sd`)
+        e_r = max(e_r, rel(core.flat._view(r0["rmean"], shape, n, off, alloc), sd[nm]))
+    print("2-rank fp32 step vs the multi-device oracle: logits %.2e, all gradients %.2e (worst tensor %.2e %s), running statistics %.2e"
+          % (e_l, e_g, worst[0], worst[1], e_r))
+    # same bars as the single-device parity tests of this trunk (tests/test_gpu_net.py): 1e-3 on logits / running statistics;
+    # gradients 5e-3 over all parameters (a pre-activation within rounding of zero may take the other ReLU branch)
+    assert e_l < 1e-3 and e_r < 1e-3 and e_g < 5e-3, (e_l, e_g, e_r, worst)
 
 
 def _compare_with_full_batch(res, state, x, gt, rel):

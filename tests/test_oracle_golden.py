@@ -1,6 +1,7 @@
 """CPU: the oracle (oracle/torch_oracle.py) against the golden fixtures that
 oracle/make_golden.py produced by running the REAL reference."""
 import os
+import sys
 
 import pytest
 import torch
@@ -98,3 +99,48 @@ def test_schedules():
     assert abs(TO.sigmoid_rampup(0, 10) - 0.006737946999085467) < 1e-12
     assert TO.sigmoid_rampup(20, 10) == 1.0
     assert abs(TO.poly_lr(1.0, 1, 4, 0.9) - 0.7718895067235705) < 1e-12
+
+
+def test_oracle_multi_device_syncbn_formula_is_the_references():
+    """torch_oracle._bn with SYNC_BN_MULTI_DEVICE restates _SynchronizedBatchNorm's DataParallel path
+    (sync_batchnorm/batchnorm.py:56-78,113-125).  Pinned against the reference class itself when the reference tree is
+    present (its master / slave message passing driven by hand for two 'replicas' of one batch), and always against the
+    defining property: the two formulas differ exactly by clamp(var, eps) vs var + eps."""
+    import torch_oracle as TO
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 6, 5, 7, generator=g) * torch.tensor([1e-3, 0.1, 1, 3, 1e-4, 2]).view(1, 6, 1, 1) + 0.2
+    sd = {"b.weight": torch.rand(6, generator=g) + 0.5, "b.bias": torch.randn(6, generator=g),
+          "b.running_mean": torch.zeros(6), "b.running_var": torch.ones(6)}
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    TO.SYNC_BN_MULTI_DEVICE = True
+    try:
+        y_multi = TO._bn(sd, "b", x, True)
+    finally:
+        TO.SYNC_BN_MULTI_DEVICE = False
+    y_single = TO._bn(sd2, "b", x, True)
+    mean = x.mean(dim=(0, 2, 3))
+    var = x.var(dim=(0, 2, 3), unbiased=False)
+    want = (x - mean.view(1, 6, 1, 1)) * (var.clamp(1e-5) ** -0.5 * sd["b.weight"]).view(1, 6, 1, 1) + sd["b.bias"].view(1, 6, 1, 1)
+    assert torch.allclose(y_multi, want, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(sd["b.running_var"], sd2["b.running_var"], rtol=1e-5) and torch.allclose(sd["b.running_mean"], sd2["b.running_mean"], rtol=1e-5, atol=1e-7)
+    # low-variance channels (1e-3, 1e-4 scale: var << eps) are where the two formulas part: x 1/sqrt(eps) vs x 1/sqrt(var+eps)
+    d = (y_multi - y_single).abs().amax(dim=(0, 2, 3))
+    assert d[0] > 1e-3 and d[2] < 1e-4
+    import ref_shim
+    if not ref_shim.reference_available():
+        return
+    ref_shim.load_reference()
+    from pixelssl.nn.module.third_party.sync_batchnorm.batchnorm import SynchronizedBatchNorm2d, _ChildMessage
+    bn = SynchronizedBatchNorm2d(6)
+    with torch.no_grad():
+        bn.weight.copy_(sd2["b.weight"]); bn.bias.copy_(sd2["b.bias"])
+    # the master's reduction of two replicas' messages (each half of the batch), computed the way _data_parallel_master
+    # does after ReduceAddCoalesced: sums added, then _compute_mean_std
+    halves = [x[:2], x[2:]]
+    msgs = [(h.reshape(2, 6, -1).sum(dim=(0, 2)), (h.reshape(2, 6, -1) ** 2).sum(dim=(0, 2)), 2 * 35) for h in halves]
+    sum_, ssum, size = msgs[0][0] + msgs[1][0], msgs[0][1] + msgs[1][1], msgs[0][2] + msgs[1][2]
+    mean_r, inv_std_r = bn._compute_mean_std(sum_, ssum, size)
+    out_r = torch.cat([(h.reshape(2, 6, -1) - mean_r.view(1, 6, 1)) * (inv_std_r * bn.weight).view(1, 6, 1) + bn.bias.view(1, 6, 1)
+                       for h in halves]).view(x.shape)
+    assert torch.allclose(y_multi, out_r.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(sd["b.running_var"], bn.running_var, rtol=1e-5) and torch.allclose(sd["b.running_mean"], bn.running_mean, rtol=1e-5, atol=1e-7)
