@@ -91,10 +91,12 @@ int pxl_conv_igemm(const pxl_conv_desc* desc, const void* in, const void* w, voi
  * statistics when training == 0), affine parameters; workgroup 0 writes bin->coef [4*Cin] and updates the running
  * statistics exactly as pxl_bn_finalize does.  Cin <= 512, Cin % 64 == 0.  Bit-identical to the three-launch path (the
  * transformed tile is rounded to bf16 like the materialised tensor).  Replaces SynchronizedBatchNorm2d + nn.ReLU + the
- * next nn.Conv2d of a Bottleneck (resnet.py:33-41).  PXL_ERR_UNSUPPORTED: use the three launches. */
+ * next nn.Conv2d of a Bottleneck (resnet.py:33-41).  z (optional; 1x1 / stride-1 convolutions only): the activated tensor
+ * relu?(bn(y)), written on the way by the workgroups of output-channel tile 0 (what this convolution's weight gradient
+ * reads).  PXL_ERR_UNSUPPORTED: use the three launches. */
 struct pxl_bn_fin;
 int pxl_conv_dma_bnin(const pxl_conv_desc* desc, const void* y, const void* w, void* out, const float* bias, float* stats,
-                      const struct pxl_bn_fin* bin, int bin_relu, void* stream);
+                      const struct pxl_bn_fin* bin, int bin_relu, void* z, void* stream);
 
 /* Data gradient with the BatchNorm-backward reduction of its OUTPUT fused into the epilogue (LDS-DMA kernel only):
  * din = dgrad(dy) (+ addend) and bn_sums[0..C) += sum_m gd, bn_sums[C..2C) += sum_m gd * xhat over the tensor just

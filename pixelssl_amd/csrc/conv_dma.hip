@@ -59,6 +59,8 @@ struct DmaArgs {
   // also writes bin.coef and updates the running statistics (what pxl_bn_finalize does)
   pxl_bn_fin bin;
   int bin_relu;
+  void* bin_z;       // optional: the workgroups of output-channel tile 0 also write the activated tile to this tensor (the
+                     // weight gradient of this convolution reads it); only for convolutions without a gather (1x1, stride 1)
   unsigned in_bytes, w_bytes;
   int taps[64];      // (dy << 16) | (dx & 0xffff)
 };
@@ -392,6 +394,16 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
         dd[q] = real ? u32x4{r.x, r.y, r.z, r.w} : dd[q];
       }
       XformStore<0, LA>::run(dd, pa);
+      if constexpr (!GATHER) {
+        // materialise z = relu(bn(y)) for the weight gradient: one workgroup per pixel tile writes what it transformed (the
+        // same bytes, the same offsets as the source; zero-filled lanes are out of range for the store as well)
+        if (p.bin_z != nullptr && tn == 0) {
+          const __amdgpu_buffer_rsrc_t r_z = __builtin_amdgcn_make_buffer_rsrc(p.bin_z, 0, p.in_bytes, 0x00020000);
+#pragma unroll
+          for (int q = 0; q < LA; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128(dd[q], r_z, (int)voffA[q], (int)(ckc * 2u), 0);
+        }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       ckc += 64;
       if (ckc == (unsigned)p.Cin) ckc = 0;
@@ -630,7 +642,7 @@ int launch_abl(const DmaArgs& a, hipStream_t stream) {
   p.ws = nullptr;
   p.nk_per = p.nk;
   p.fin.coef = nullptr;
-  p.bin.coef = nullptr;
+  p.bin.coef = nullptr; p.bin_z = nullptr;
   constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
   PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, 2, 2, NST, true, ABL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
@@ -723,7 +735,7 @@ extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* 
   a.nk_per = 0;
   a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
-  a.bin.coef = nullptr; a.bin_relu = 0;
+  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr;
   const int sk = d->split_k;
   return conv_dma_launch(d, a, sk, ws_bytes, stream);
 }
@@ -743,7 +755,7 @@ extern "C" int pxl_conv_dma_finalize(const pxl_conv_desc* d, const void* in, con
   a.ws = nullptr; a.nk_per = 0;
   a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin = *fin; a.fin_counter = counter;
-  a.bin.coef = nullptr; a.bin_relu = 0;
+  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr;
   return conv_dma_launch(d, a, 1, 0, stream);
 }
 
@@ -751,9 +763,10 @@ extern "C" int pxl_conv_dma_finalize(const pxl_conv_desc* d, const void* in, con
 // land in LDS: stands in for pxl_bn_finalize + pxl_bn_apply_fwd + pxl_conv_igemm (no materialised activation, one launch
 // instead of two or three).  `bin`: the input BatchNorm (statistics [nrep][2*Cin] or running statistics, affine
 // parameters, coef [4*Cin] written by workgroup 0, running statistics updated there); d->Cin == the BatchNorm's channel
-// count <= 512, a multiple of 64.  PXL_ERR_UNSUPPORTED when the LDS-DMA kernel cannot run the descriptor.
+// count <= 512, a multiple of 64.  z (optional, 1x1 / stride-1 convolutions only): the activated tensor, written by the
+// workgroups of output-channel tile 0.  PXL_ERR_UNSUPPORTED when the LDS-DMA kernel cannot run the descriptor.
 extern "C" int pxl_conv_dma_bnin(const pxl_conv_desc* d, const void* y, const void* w, void* out, const float* bias,
-                                 float* stats, const pxl_bn_fin* bin, int bin_relu, void* stream) {
+                                 float* stats, const pxl_bn_fin* bin, int bin_relu, void* z, void* stream) {
   PXL_REQUIRE(d && y && w && out && bin && bin->coef && bin->count > 0.f, "conv_dma_bnin: bad argument");
   PXL_REQUIRE(bin->training ? (bin->stats != nullptr && bin->nrep >= 1) : (bin->running_mean && bin->running_var),
               "conv_dma_bnin: missing statistics");
@@ -764,7 +777,11 @@ extern "C" int pxl_conv_dma_bnin(const pxl_conv_desc* d, const void* y, const vo
   a.ws = nullptr; a.nk_per = 0;
   a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
-  a.bin = *bin; a.bin_relu = bin_relu;
+  a.bin = *bin; a.bin_relu = bin_relu; a.bin_z = z;
+  if (z != nullptr) {          // the activated tensor can only be written by a kernel that walks every input pixel exactly once per tile row
+    bool plain = d->ntaps == 1 && d->dy[0] == 0 && d->dx[0] == 0 && d->out_stride == 1 && d->Ho == d->Hi && d->Wo == d->Wi;
+    if (!plain) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_bnin: z output needs a 1x1 / stride-1 convolution");
+  }
   return conv_dma_launch(d, a, 1, 0, stream);
 }
 
@@ -783,7 +800,7 @@ extern "C" int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, c
   a.ws = nullptr; a.nk_per = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = bn_relu; a.bn_mask = nullptr;
-  a.bin.coef = nullptr; a.bin_relu = 0;
+  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr;
   pxl_conv_desc q = *d;
   q.stats_rep = 1;
   return conv_dma_launch(&q, a, 1, 0, stream);
@@ -804,7 +821,7 @@ extern "C" int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy,
   a.ws = nullptr; a.nk_per = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = 0; a.bn_mask = join_out;
-  a.bin.coef = nullptr; a.bin_relu = 0;
+  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr;
   pxl_conv_desc q = *d;
   q.stats_rep = 1;
   return conv_dma_launch(&q, a, 1, 0, stream);

@@ -27,7 +27,7 @@ extern "C" {
 int pxl_conv_dma_finalize(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias, float* stats,
                           const pxl_bn_fin* fin, unsigned* counter, void* stream);
 int pxl_conv_dma_bnin(const pxl_conv_desc* d, const void* y, const void* w, void* out, const float* bias, float* stats,
-                      const pxl_bn_fin* bin, int bin_relu, void* stream);
+                      const pxl_bn_fin* bin, int bin_relu, void* z, void* stream);
 int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
                             const void* bn_y, const float* bn_coef, int bn_relu, float* bn_sums, void* stream);
 int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
@@ -91,9 +91,9 @@ struct BnInfo {
   size_t cnt_off = 0;      // arena (inside the statistics region, zeroed with it): the last-block-done ticket counter
   bool fin_by_conv = false;   // this pass: the producing convolution's last workgroup finalized the BN
   // BN-apply on load: the single convolution that consumes relu(bn(y)) reads the RAW y and applies the BatchNorm to its
-  // tiles in LDS (conv_dma.hip: pxl_conv_dma_bnin), finalizing it in its prologue -- no pxl_bn_apply_fwd launch on the
-  // forward chain.  z is then only needed by that convolution's weight gradient: networks that train materialise it on
-  // the side stream, off the critical path; no-grad networks (the MT teacher) never write it.
+  // tiles in LDS (conv_dma.hip: pxl_conv_dma_bnin), finalizing it in its prologue -- no pxl_bn_apply_fwd launch.  z is
+  // then only needed by that convolution's weight gradient: networks that train have the convolution write it on the
+  // way (its workgroups of output-channel tile 0), no-grad networks (the MT teacher) never write it.
   bool onload = false;
 };
 
@@ -137,7 +137,8 @@ struct pxl_net {
   size_t up_ws_off = 0, up_ws_bytes = 0;                    // scratch: upsample backward workspace
   pxl_allreduce_fn sync = nullptr;
   void* sync_user = nullptr;
-  int world = 1;
+  int world = 1;                  // ranks sharing the BatchNorm statistics (pxl_net_set_sync); 1 = local statistics
+  int grad_world = 1;             // ranks averaging the gradients (pxl_net_set_grad_sync)
   int head_op = -1;
   // optional per-launch timing of the contraction kernels (bench.py roofline leg)
   bool profile = false;
@@ -171,8 +172,6 @@ struct pxl_net {
   bool bucket_ok = false;          // parameter offsets grow with the op index: suffixes of the op list = suffixes of the buffer
   int grad_buckets_last = 0;       // buckets issued by the last backward (tests / bench)
   bool bn_onload = getenv("PXL_BN_ONLOAD") == nullptr || getenv("PXL_BN_ONLOAD")[0] != '0';
-  hipEvent_t z_join_ev = nullptr;
-  std::vector<hipEvent_t> z_ev;    // per op: the consumer convolution of an on-load BN has been issued (coef is final)
   bool wgrad_on = true;
   bool pack_dgrad = true;          // false: pxl_net_pack skips the transposed (data-gradient) weights (no-grad networks)
   int input_tensor = -1;
@@ -334,8 +333,6 @@ extern "C" void pxl_net_destroy(pxl_net* net) {
   for (auto e : net->pool) (void)hipEventDestroy(e);
   for (auto e : net->fork_ev) if (e) (void)hipEventDestroy(e);
   if (net->join_ev) (void)hipEventDestroy(net->join_ev);
-  if (net->z_join_ev) (void)hipEventDestroy(net->z_join_ev);
-  for (auto e : net->z_ev) if (e) (void)hipEventDestroy(e);
   if (net->side) (void)hipStreamDestroy(net->side);
   for (hipEvent_t e : {net->comm_main_ev, net->comm_side_ev, net->comm_done_ev}) if (e) (void)hipEventDestroy(e);
   if (net->comm_stream) (void)hipStreamDestroy(net->comm_stream);
@@ -355,7 +352,7 @@ extern "C" int pxl_net_set_grad_sync(pxl_net* net, pxl_allreduce_fn fn, void* us
   PXL_REQUIRE(net && world_size >= 1 && bucket_floats >= 0 && total_floats >= 0, "net_set_grad_sync: bad argument");
   net->grad_sync = fn;
   net->grad_user = user;
-  net->world = world_size;
+  net->grad_world = world_size;      // (not `world`: a network may average gradients over ranks while its BatchNorms stay local)
   net->grad_bucket = bucket_floats;
   net->grad_total = total_floats;
   return PXL_OK;
@@ -595,6 +592,11 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
       const OpInfo& oc = n->ops[conv_of[k]];
       if (oc.patch || oc.ws_bytes != 0 || oc.fwd.Cin > 512 || oc.fwd.Cin != b.d.C) continue;
       if (!pxl_conv_dma_eligible(&oc.fwd, nullptr, nullptr)) continue;
+      // 1x1 / stride-1 consumers only (conv3 of a bottleneck).  Measured on the MI355X (profiles/r03_c_*): for a 3x3
+      // consumer every tap re-transforms the tile (9x the work of the materialising kernel) inside a K loop that is
+      // already latency-bound -- 59 vs 40 us per layer3 convolution in the step, more than the 12 us launch it removes
+      const pxl_conv_desc& f = oc.fwd;
+      if (!(f.ntaps == 1 && f.dy[0] == 0 && f.dx[0] == 0 && f.out_stride == 1 && f.Ho == f.Hi && f.Wo == f.Wi)) continue;
       b.onload = true;
     }
   }
@@ -885,7 +887,6 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
   if (training && n->stats_region_bytes)
     PXL_CHECK_HIP(hipMemsetAsync(at(arena, n->stats_region_off), 0, n->stats_region_bytes, s));
   const int dt = n->dtype;
-  bool z_on_side = false;          // activated tensors of on-load BNs are being written on the side stream
   for (size_t i = 0; i < n->ops.size(); ++i) {
     OpInfo& op = n->ops[i];
     const pxl_op& d = op.d;
@@ -928,30 +929,13 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
           {
             Timed t(n, s, 0, conv_flops(n, d, tout));
             if (n->profile) n->prof_bytes[0] += conv_bytes(n, d, tin, tout, false);
+            // networks that can run a backward pass (pack_dgrad) get z = relu(bn(y)) written on the way, for this op's
+            // weight gradient -- whatever wgrad_on says now: it may be switched on between this pass and its backward
             rc = pxl_conv_dma_bnin(&op.fwd, at(arena, tin.off), at(packed, op.wf_off), at(arena, tout.off), bias, stats, &bin,
-                                   bi.relu, stream);
+                                   bi.relu, n->pack_dgrad ? at(arena, bi.z_off) : nullptr, stream);
           }
           if (rc == PXL_OK) {
             onload_done = true;
-            // networks that can run a backward pass (pack_dgrad) get z = relu(bn(y)) for this op's weight gradient -- whatever
-            // wgrad_on says now: it may be switched on between this pass and its backward
-            if (n->pack_dgrad) {
-              if (!n->side) {
-                PXL_CHECK_HIP(hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
-                if (!n->join_ev) PXL_CHECK_HIP(hipEventCreateWithFlags(&n->join_ev, hipEventDisableTiming));
-                if (n->fork_ev.empty()) n->fork_ev.assign(n->ops.size(), nullptr);
-                if (n->use_side < 0) { const char* e = getenv("PXL_SIDE_STREAM"); n->use_side = (e && e[0] == '0') ? 0 : 1; }
-              }
-              if (n->z_ev.empty()) n->z_ev.assign(n->ops.size(), nullptr);
-              if (!n->z_ev[i]) PXL_CHECK_HIP(hipEventCreateWithFlags(&n->z_ev[i], hipEventDisableTiming));
-              if (!n->z_join_ev) PXL_CHECK_HIP(hipEventCreateWithFlags(&n->z_join_ev, hipEventDisableTiming));
-              PXL_CHECK_HIP(hipEventRecord(n->z_ev[i], s));                  // coef is final once this convolution has run
-              PXL_CHECK_HIP(hipStreamWaitEvent(n->side, n->z_ev[i], 0));
-              rc = pxl_bn_apply_fwd(dt, (long)n->B * tin.H * tin.W, tin.Cp, at(arena, tin.off), fat(arena, bi.coef_off), bi.relu,
-                                    at(arena, bi.z_off), n->side);
-              if (rc != PXL_OK) return rc;
-              z_on_side = true;
-            }
           } else if (rc == PXL_ERR_UNSUPPORTED) {     // (tile + coefficient table too large ...): materialise, then the plain path
             rc = pxl_bn_finalize_apply_fwd(dt, (long)n->B * tin.H * tin.W, tin.Cp, at(arena, tin.off), &bin, bi.relu,
                                            at(arena, bi.z_off), stream);
@@ -1114,10 +1098,6 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
       }
     }
     if (rc != PXL_OK) return rc;
-  }
-  if (z_on_side) {                 // the arena is the caller's: nothing of this pass may still be running when it returns
-    PXL_CHECK_HIP(hipEventRecord(n->z_join_ev, n->side));
-    PXL_CHECK_HIP(hipStreamWaitEvent(s, n->z_join_ev, 0));
   }
   return PXL_OK;
 }
@@ -1336,7 +1316,7 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
   bool forked = false;
   // ---- overlapped gradient exchange (multi-rank): flush [lo, hi) of the flat gradient buffer once every kernel writing
   // into it has been issued -- the communication stream waits for the main and the weight-gradient stream at that point
-  const bool bucketing = n->grad_sync && n->world > 1 && n->wgrad_on && n->grad_total > 0;
+  const bool bucketing = n->grad_sync && n->grad_world > 1 && n->wgrad_on && n->grad_total > 0;
   long grad_hi = n->grad_total;
   n->grad_buckets_last = 0;
   if (bucketing && !n->comm_stream) {
@@ -1359,7 +1339,7 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
       const int rc = n->grad_sync(n->grad_user, grads + o, (int)cnt, n->comm_stream);
       if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_backward: gradient all-reduce hook failed (%d)", rc);
     }
-    const int rc2 = pxl_scale_inplace(grad_hi - lo, grads + lo, 1.0f / (float)n->world, n->comm_stream);
+    const int rc2 = pxl_scale_inplace(grad_hi - lo, grads + lo, 1.0f / (float)n->grad_world, n->comm_stream);
     if (rc2 != PXL_OK) return rc2;
     grad_hi = lo;
     ++n->grad_buckets_last;

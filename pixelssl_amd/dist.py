@@ -1,12 +1,17 @@
 """One process per GPU: the replacement of the reference's single-process nn.DataParallel
 (pixelssl/nn/func.py:54-62) and thread-based Sync-BN (sync_batchnorm/comm.py).
 
-Three exchanges, all through torch.distributed ("nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU
-tests):
-  * gradients: ONE all-reduce (sum, then 1/world) of the model's flat fp32 gradient buffer after each
-    backward -- equal per-rank batches make the mean of rank means the global mean;
-  * Sync-BN statistics: all-reduce(sum) of the [sum, sumsq] (forward) / [sum dz, sum dz*xhat]
-    (backward) vectors the executor hands to the hook between a conv and its BN finalize;
+Three exchanges.  With the nccl backend every rank opens its own RCCL communicators from C (csrc/comm.cpp, one per
+engine network in rotation + one for gradients) and the executor issues `ncclAllReduce` itself; with gloo (CPU-launched
+tests) the same hooks call torch.distributed:
+  * gradients: the flat fp32 gradient buffer of a model is all-reduced (sum, then 1/world) in BUCKETS of contiguous
+    memory from INSIDE the backward pass, on a communication stream, as soon as every kernel writing into a bucket has
+    been issued (csrc/net.cpp: pxl_net_set_grad_sync; PXL_GRAD_BUCKET_MB, default 32) -- equal per-rank batches make the
+    mean of rank means the global mean; PXL_GRAD_OVERLAP=0 falls back to ONE all-reduce after the
+    backward; parameters that do not belong to an engine network are averaged by the optimizers (nn/optimizer.py);
+  * Sync-BN statistics: all-reduce(sum) of the [sum, sumsq] (forward) / [sum dz, sum dz*xhat] (backward) vectors
+    between a convolution's statistics epilogue and the BN finalize, one call per BatchNorm and direction
+    (~310 per MT step), with the reference's multi-device variance formula clamp(var, eps)^-1/2;
   * scalars for logging.
 No parameter broadcast per forward, no scatter/gather of activations (C1-C3 are gone).
 """
@@ -219,11 +224,13 @@ def attach(model):
                 cores.append(m)
     for m in cores:
         if not getattr(m, "_pxl_attached", False):
+            sync_bn = getattr(m, "sync_bn", True)     # False: local BatchNorm statistics (S4L's rotation classifier)
             if comms:                      # networks take the communicators in creation order (identical on all ranks)
                 m._pxl_comm = comms[_native["next"] % len(comms)]
                 _native["next"] += 1
-                m.set_sync_native(_native["hook"], m._pxl_comm, ws)
-            else:
+                if sync_bn:
+                    m.set_sync_native(_native["hook"], m._pxl_comm, ws)
+            elif sync_bn:
                 m.set_sync(_sync_stats_callback, ws)
             m._post_backward_hook = _post_backward
             if os.environ.get("PXL_GRAD_OVERLAP", "1") != "0":

@@ -390,6 +390,31 @@ class SegNetCore(nn.Module):
     def mark_params_changed(self):
         self._store.touch()
 
+    def load_pretrained_backbone(self, src, prefix="backbone"):
+        """ResNet._load_pretrained_model (task/sseg/module/backbone/resnet.py:145-156) for the trunk under `prefix`:
+        a FILE is loaded as a state dict of the trunk itself (strict, like the reference's `self.load_state_dict(
+        torch.load(path))`); anything else is treated as a model-zoo URL (torch.hub cache; `file://` works offline) whose
+        entries are FILTERED to the keys the trunk has -- a torchvision ResNet brings `fc.*`, which the dilated trunk
+        lacks -- and loaded on top of the current values.  -> the list of keys taken."""
+        own = OrderedDict((k[len(prefix) + 1:], v) for k, v in self.state_dict().items() if k.startswith(prefix + "."))
+        if os.path.isfile(src):
+            loaded = torch.load(src, map_location="cpu")
+            missing = [k for k in own if k not in loaded]
+            unexpected = [k for k in loaded if k not in own]
+            if missing or unexpected:      # torch's strict load_state_dict error, for the trunk
+                raise RuntimeError("Error(s) in loading state_dict for the backbone: missing %s, unexpected %s"
+                                   % (missing[:4], unexpected[:4]))
+            take = loaded
+        else:
+            loaded = torch.hub.load_state_dict_from_url(src, map_location="cpu")
+            take = OrderedDict((k, v) for k, v in loaded.items() if k in own)
+        bad = [k for k, v in take.items() if tuple(v.shape) != tuple(own[k].shape)]
+        if bad:
+            raise RuntimeError("pretrained backbone: shape mismatch for %s" % bad[:4])
+        self.load_state_dict(OrderedDict((prefix + "." + k, v) for k, v in take.items()), strict=False)
+        self.mark_params_changed()
+        return list(take.keys())
+
     def ensure_grad_views(self):
         """Re-attach .grad views (a foreign optimizer may have set them to None); returns True when
         the flat gradient buffer had to be treated as fresh (and was zeroed)."""
@@ -1091,6 +1116,9 @@ class RotationClassifierCore(SegNetCore):
         super().__init__(device, engine_dtype, 4)
         self.want_prob = False
         self.has_latent = False
+        # the reference's rotation classifier uses plain nn.BatchNorm2d (ssl_s4l.py:376-383): per-replica batch statistics,
+        # never synchronised across GPUs -- dist.attach() leaves the Sync-BN hook of this executor uninstalled
+        self.sync_bn = False
         c = in_channels
         pad32 = lambda v: (v + 31) // 32 * 32
         c1, c2 = pad32(c), pad32(2 * c)

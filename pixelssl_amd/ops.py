@@ -49,10 +49,12 @@ def conv_dma_finalize(desc, x, w, out, stats, fin, counter, bias=None):
     return out
 
 
-def conv_dma_bnin(desc, y, w, out, bin_fin, relu=True, stats=None, bias=None):
-    """forward conv reading the RAW previous output y with relu?(bn(y)) applied on load; raises when not eligible"""
+def conv_dma_bnin(desc, y, w, out, bin_fin, relu=True, stats=None, bias=None, z=None):
+    """forward conv reading the RAW previous output y with relu?(bn(y)) applied on load (z: also written out, 1x1 convs);
+    raises when not eligible"""
     _require_cuda(y, w, out)
-    check(lib().pxl_conv_dma_bnin(desc, ptr(y), ptr(w), ptr(out), ptr(bias), ptr(stats), bin_fin, int(relu), stream_ptr()))
+    check(lib().pxl_conv_dma_bnin(desc, ptr(y), ptr(w), ptr(out), ptr(bias), ptr(stats), bin_fin, int(relu), ptr(z),
+                                  stream_ptr()))
     return out
 
 

@@ -16,6 +16,10 @@ def add_parser_arguments(parser):
                         help='sseg - if true, the statistics in BatchNorm will not be updated')
     parser.add_argument('--engine-dtype', type=str, default='bf16',
                         help='sseg/amd - arithmetic of the HIP engine: bf16 (throughput) or fp32 (exact parity)')
+    parser.add_argument('--pretrained-backbone', type=str, default=None,
+                        help="sseg/amd - backbone weights: a state-dict file of the trunk, a model-zoo URL, or 'default' for "
+                             "the reference's URL of the chosen backbone (task/sseg/model.py:70-76); None = random init "
+                             "(the reference always downloads: this engine has to run without a network)")
 
 
 def deeplabv2():
@@ -44,6 +48,22 @@ class _Resulter(dict):
 
     def keys(self):
         return list(dict.keys(self)) + ([] if dict.__contains__(self, 'sslcct_ad_inp') else ['sslcct_ad_inp'])
+
+
+# task/sseg/model.py:70-76,88-93: the weights the reference downloads for each backbone name
+PRETRAINED_BACKBONE_URLS = {'resnet50': 'https://download.pytorch.org/models/resnet50-19c8e357.pth',
+                            'resnet101': 'https://download.pytorch.org/models/resnet101-5d3b4d8f.pth',
+                            'resnet101-coco': 'http://vllab1.ucmerced.edu/~whung/adv-semi-seg/resnet101COCO-41f33a49.pth'}
+
+
+def _maybe_load_pretrained(task_model, args):
+    src = getattr(args, 'pretrained_backbone', None)
+    if not src:
+        return
+    if src == 'default':
+        src = PRETRAINED_BACKBONE_URLS[args.backbone]
+    taken = task_model.model.load_pretrained_backbone(src)
+    logger.log_info('  pretrained backbone: {0} tensors from {1}\n'.format(len(taken), src))
 
 
 class _DeferredResulter(dict):
@@ -89,6 +109,7 @@ class DeepLabV2(model_template.TaskModel, _DeferredForward):
                                    num_classes=args.num_classes, device=pdist.local_device(),
                                    engine_dtype=torch.float32 if dtype in ('fp32', 'f32') else torch.bfloat16,
                                    freeze_bn=args.freeze_bn)
+        _maybe_load_pretrained(self, args)
         self.param_groups = [{'params': self.model.get_1x_lr_params(), 'lr': self.args.lr},
                              {'params': self.model.get_10x_lr_params(), 'lr': self.args.lr * 10}]
 
@@ -117,6 +138,7 @@ class PSPNet(model_template.TaskModel, _DeferredForward):
                                 num_classes=args.num_classes, device=pdist.local_device(),
                                 engine_dtype=torch.float32 if dtype in ('fp32', 'f32') else torch.bfloat16,
                                 freeze_bn=args.freeze_bn)
+        _maybe_load_pretrained(self, args)
         self.param_groups = [{'params': self.model.get_backbone_params(), 'lr': self.args.lr},
                              {'params': self.model.get_psp_params(), 'lr': self.args.lr * 10},
                              {'params': self.model.get_decoder_params(), 'lr': self.args.lr * 10}]

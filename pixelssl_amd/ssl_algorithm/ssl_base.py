@@ -68,6 +68,11 @@ class _SSLBase:
         from rank to rank (a torch.distributed group is not thread-safe; two RCCL communicators can dead-lock on it)."""
         import os
         from .. import dist as pdist
+        # the first iterations autotune (tile timings of one network must not be measured under the other network's
+        # kernels, and the tuner is entered from one thread only): the helper thread starts with the third call
+        self._enq_calls = getattr(self, '_enq_calls', 0) + 1
+        if self._enq_calls <= 2:
+            return None
         if not hasattr(self, '_enq_pool'):
             on = os.environ.get('PXL_ENQUEUE_THREAD', '1') != '0' and not pdist.is_distributed()
             if on:

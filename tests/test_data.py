@@ -66,7 +66,36 @@ def test_sampler_partitions_the_global_batch_across_ranks():
     seen = [i for g in one for i in g[4:]]
     assert len(set(seen)) == len(seen) == 30
     with pytest.raises(AssertionError):
-        TwoStreamBatchSampler(lab, unl, 6, 6, rank=0, world_size=2)                               # 12 labeled per global batch > 10
+        TwoStreamBatchSampler(lab, unl, 6, 6, rank=0, world_size=2, rng=np.random.RandomState(1))  # 12 labeled per global batch > 10
+    with pytest.raises(ValueError):          # multi-rank draws need a generator every rank seeds identically
+        TwoStreamBatchSampler(lab, unl, 2, 3, rank=0, world_size=2)
+
+
+def test_labeled_only_loader_is_sharded_by_rank():
+    """the labeled-only path of make_train_loader ignored rank / world_size.  Now: one global permutation per
+    epoch, disjoint per-rank slices whose union is the global batch; world_size > 1 without a shared rng is an error."""
+    import argparse
+    import torch
+    from pixelssl_amd.nn.data import ShardedBatchSampler
+    from pixelssl_amd.sseg.data import make_train_loader
+    one = list(ShardedBatchSampler(23, 4, rng=np.random.RandomState(7)))
+    parts = [list(ShardedBatchSampler(23, 2, rank=r, world_size=2, rng=np.random.RandomState(7))) for r in (0, 1)]
+    assert len(one) == len(parts[0]) == len(parts[1]) == 5
+    for g, a, b in zip(one, *parts):
+        assert a + b == g and len(set(g)) == 4
+    flat = [i for g in one for i in g]
+    assert len(set(flat)) == len(flat) == 20          # drop_last: 23 // 4 batches, no sample twice in an epoch
+    with pytest.raises(ValueError):
+        ShardedBatchSampler(23, 2, rank=0, world_size=2)
+
+    class DS(torch.utils.data.Dataset):
+        unlabeled_idxs, labeled_idxs = [], list(range(23))
+        def __len__(self): return 23
+        def __getitem__(self, i): return torch.tensor([i])
+    args = argparse.Namespace(batch_size=2, unlabeled_batch_size=0, labeled_batch_size=2, num_workers=0)
+    seen = [sorted(int(v) for batch in make_train_loader(DS(), args, rank=r, world_size=2, rng=np.random.RandomState(3)) for v in batch.view(-1))
+            for r in (0, 1)]
+    assert not set(seen[0]) & set(seen[1]) and len(seen[0]) == len(seen[1]) == 10
 
 
 @needs_reference

@@ -257,8 +257,15 @@ def test_conv_with_bn_apply_on_load(case, cfg, training):
     fin = ops.bn_fin(st, nrep, count, gamma, beta, rm_b, rv_b, coef_b, training=training)
     out_b = torch.full((B, Ho, Wo, cop), 5.0, device=DEV, dtype=dtype)
     st_b = torch.zeros(4, 2 * Cout, device=DEV)
-    ops.conv_dma_bnin(desc, yd, wf, out_b, fin, relu=True, stats=st_b)
+    plain = k == 1 and s == 1                  # 1x1 / stride 1: the kernel can also write the activated tensor on the way
+    z_b = torch.full_like(yd, 9.0) if plain else None
+    ops.conv_dma_bnin(desc, yd, wf, out_b, fin, relu=True, stats=st_b, z=z_b)
     torch.cuda.synchronize()
+    if plain:
+        assert torch.equal(z_b, z), "activated tensor written by the workgroups of output-channel tile 0"
+    else:
+        with pytest.raises(Exception):         # a gathering convolution cannot materialise z (each pixel is visited per tap)
+            ops.conv_dma_bnin(desc, yd, wf, out_b, fin, relu=True, z=torch.empty_like(yd))
     assert torch.equal(coef_a, coef_b), "coef written by workgroup 0 == pxl_bn_finalize"
     assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
     assert torch.equal(out_a[..., :Cout], out_b[..., :Cout]), (name, cfg, rel_err(out_b.float().cpu(), out_a.float().cpu()))
