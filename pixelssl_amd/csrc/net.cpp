@@ -791,6 +791,17 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
   PXL_CHECK_HIP(hipEventCreate(&b));
   const int reps = 3;
   int rc_all = PXL_OK;
+  // PXL_TUNE_CFGS="11,17,18": restrict the LDS-DMA tile candidates (experiments: the tuner times every launch ALONE, while
+  // in the step two or three streams share the CUs' LDS -- smaller footprints co-reside better); unset = all of them
+  std::vector<int> allow;
+  if (const char* e = getenv("PXL_TUNE_CFGS")) {
+    for (const char* q = e; *q;) { allow.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+  }
+  auto allowed = [&](int cfg) {
+    if (allow.empty() || cfg < 8) return true;
+    for (int a : allow) if (a == cfg) return true;
+    return false;
+  };
   for (auto& op : n->ops) {
     const pxl_op& d = op.d;
     if (d.kind != PXL_OP_CONV) continue;
@@ -808,6 +819,7 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
         if (!dma && (cfg & 3) == 3 && tout.Cp > 64) continue;
         if (dma && cfg >= 12 && cfg < 16) continue;          // 4-stage rings never won on the ResNet shapes
         if (dma && cfg >= 20 && tout.Cp < 128) continue;     // tall tiles are 128 channels wide
+        if (dma && !allowed(cfg)) continue;
         pxl_conv_desc q = op.fwd; q.tile_cfg = cfg;
         float t = time_launch([&]() { return pxl_conv_igemm(&q, cin.ptr, at(packed, op.wf_off), at(arena, tout.off),
                                                             sc, sh, bias, nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr,
@@ -825,6 +837,7 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
         if (!dma && (cfg & 3) == 3 && tin.Cp > 64) continue;
         if (dma && cfg >= 12 && cfg < 16) continue;
         if (dma && cfg >= 20 && tin.Cp < 128) continue;
+        if (dma && !allowed(cfg)) continue;
         pxl_conv_desc q = op.bwd; q.tile_cfg = cfg;
         float t = time_launch([&]() { return pxl_conv_igemm(&q, at(scratch, tout.goff), at(packed, op.wt_off), at(scratch, tin.goff),
                                                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream); },

@@ -60,7 +60,7 @@ for st in "$@"; do
        DB=$(find $OUT/prof_$n -name "*results.db" | head -1)
        if [ -n "$DB" ]; then
          python tools/prof_summary.py "$DB" $OUT/kernel_stats_$n.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 $Q $arg" | head -12
-         python tools/prof_summary.py --one-step "$DB" $OUT/step_breakdown_$n.txt "one step of: python bench.py --steps 5 --warmup 2 $Q $arg" | head -8
+         python tools/prof_summary.py --one-step "$DB" $OUT/step_breakdown_$n.txt "one step of: python bench.py --steps 5 --warmup 2 $Q $arg" | head -24
        fi
        rm -rf $OUT/prof_$n;;
     pmc) ctr="${arg%%@*}"; bargs="--steps 1 --warmup 1"; [ "$arg" != "$ctr" ] && bargs="${arg#*@}"

@@ -63,12 +63,32 @@ def one_step(db_path, out_txt=None, marker="sgd_kernel", per_step=2, header=""):
         small = [g for g in gaps if 0 <= g < 20000]
         lines.append("# stream %s: %d kernels, busy %.3f ms, gaps < 20 us: %d (sum %.3f ms)"
                      % (k, len(v), sum(r[2] - r[1] for r in v) / 1e6, len(small), sum(small) / 1e6))
+    # phase timeline of the step: per stream first start / last end (ms from the window start), and on every stream the
+    # start of a few marker kernels (the seam between forward and backward, the optimizer)
+    t0 = win[0][1]
+    for k, v in per.items():
+        lines.append("# stream %s: runs %.3f .. %.3f ms" % (k, (v[0][1] - t0) / 1e6, (v[-1][2] - t0) / 1e6))
+    for mk in ("head_loss", "upsample_softmax_fwd", "ce_mse_bwd", "upsample_bwd", "maxpool_bwd", "sgd_kernel", "ema_kernel", "pack_fwd", "stem_patches"):
+        hits = [r for r in win if mk in r[0]]
+        if hits:
+            lines.append("# marker %-22s: %s" % (mk, ", ".join("%.3f-%.3f ms (stream %s)" % ((r[1] - t0) / 1e6, (r[2] - t0) / 1e6, r[3]) for r in hits[:4])))
+    # utilisation over time: number of kernels in flight, sampled per 0.25 ms
+    step = 250000
+    nb = int((win[-1][2] - t0) // step) + 1
+    occ = [0.0] * nb
+    for r in win:
+        a, b = r[1] - t0, r[2] - t0
+        for i in range(int(a // step), min(nb - 1, int(b // step)) + 1):
+            lo, hi = max(a, i * step), min(b, (i + 1) * step)
+            if hi > lo:
+                occ[i] += (hi - lo) / step
+    lines.append("# kernels in flight per 0.25 ms bucket: " + " ".join("%.1f" % o for o in occ))
     lines.append("Name,Calls,TotalDurationNs,AverageNs,PercentageOfSum")
     for n, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
         lines.append('"%s",%d,%d,%.1f,%.2f' % (n, c, t, t / c, 100 * t / tot))
     if out_txt:
         open(out_txt, "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines[:40]))
+    print("\n".join(lines[:24]))
 
 
 if __name__ == "__main__":
