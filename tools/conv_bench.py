@@ -72,7 +72,7 @@ def main():
     totf = 0.0
     print("%-10s %5s %5s %2s %2s %2s %4s | %s" % ("shape", "Cin", "Cout", "k", "s", "d", "H", "mode:cfg TFLOP/s (us)"))
     for name, cin, cout, k, s, d, H, cnt in SHAPES:
-        if a.only and a.only not in name:
+        if a.only and not any(o in name for o in a.only.split(",")):       # comma list of substrings
             continue
         p = d * (k - 1) // 2 if k > 1 else 0
         if name == "stem7x7":

@@ -1,12 +1,12 @@
 #!/bin/bash
 # PMC passes over tools/conv_bench.py (separate rocprofv3 runs per counter group; --kernel-trace only).
-# usage: tools/pmc_conv.sh "<conv_bench args>"   -> gpurun_out/pmc/pass*.csv + summary
+# usage: tools/pmc_conv.sh <conv_bench args ...>   -> gpurun_out/pmc/pass*.csv + summary
 set -u
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT=$ROOT/gpurun_out/pmc
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="${1:---only l3.3x3 --cfgs 9,10 --modes fwd --iters 2}"
+ARGS="${*:---only l3.3x3 --cfgs 9,10 --modes fwd --iters 2}"
 i=0
 for pass in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
