@@ -68,7 +68,7 @@ for st in "$@"; do
        python tools/pmc_summary.py $OUT/pmc_$n > $OUT/pmc_$n.txt 2>&1; head -30 $OUT/pmc_$n.txt;;
     traffic) for c in FETCH_SIZE WRITE_SIZE; do
          (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$c -o p -- python $OLDPWD/bench.py --steps 1 --warmup 1 $Q > $OLDPWD/$OUT/pmc_$c.log 2>&1); done
-       python tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/traffic.json; rc=$?
+       python tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/traffic.json "tools/gpu_call.sh $TAG traffic"; rc=$?
        rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE;;
     py) timeout 1200 python $arg > $OUT/py_$n.log 2>&1; rc=$?; tail -25 $OUT/py_$n.log;;
     sh) timeout 1200 bash -c "$arg" > $OUT/sh_$n.log 2>&1; rc=$?; tail -25 $OUT/sh_$n.log;;

@@ -35,12 +35,12 @@ def per_kernel(d, tail=True):
     return acc
 
 
-def main(fetch_dir, write_dir, out):
+def main(fetch_dir, write_dir, out, how="tools/gpu_call.sh <tag> traffic"):
     fe, wr = per_kernel(fetch_dir), per_kernel(write_dir)
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace -- python bench.py --steps 1 --warmup 1 "
                      "--no-cpu-baseline --no-kernel-events --no-miou, MT 8x513x513 bf16, autotuned tiles; contraction kernels: "
                      "the last launches of the run only (the final training step)",
-           "measured": "two separate rocprofv3 --pmc passes of this command, tools/r02_call26.sh (round 2, final state)",
+           "measured": "two separate rocprofv3 --pmc passes of this command, " + how,
            "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads)",
            "kernels": {}}
     for k in sorted(set(fe) | set(wr), key=lambda k: -(2 * sum(fe.get(k, [0])) + sum(wr.get(k, [0])))):
@@ -56,4 +56,4 @@ def main(fetch_dir, write_dir, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
