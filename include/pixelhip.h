@@ -415,6 +415,10 @@ int pxl_minmax_norm_persample(int B, long HW, const float* x, float clip_thresho
 /* GaussianNoiseLayer.forward (pixelssl/nn/module/gaussian_noise.py:18-40), in place on x [B][n] fp32: per-sample min-max
  * normalise, add `noise`, clip to [0, 1], de-normalise; mm = [B][2] scratch */
 int pxl_gaussian_noise_apply(int B, long n, float* x, const float* noise, float* mm, void* stream);
+/* SSLS4L._batch_prehandle + _rotate_tensor (pixelssl/ssl_algorithm/ssl_s4l.py:296-355): src [B][C][N][N] (src_kind 0 = float32,
+ * 1 = int64, 2 = uint8) -> dst fp32 [2B][C][N][N] = the batch followed by one rotated copy per sample; angles = B HOST
+ * ints, 0 = copy, 1 = transpose + flip(W), 2 = flip(W) + flip(H), 3 = transpose + flip(H).  1 <= B <= 128. */
+int pxl_rotate_append(int src_kind, int B, int C, int N, const void* src, const int* angles, float* dst, void* stream);
 /* DCGTGenerator.forward (ssl_gct.py:668-689): l_fm / r_fm are updated IN PLACE (fm <= thr ? fm : 1) */
 int pxl_dcgt(int B, int C, long HW, const float* l_pred, const float* r_pred, float* l_fm, float* r_fm,
              float threshold, float* l_gt, float* r_gt, float* both_bad, void* stream);

@@ -92,13 +92,14 @@ def vat_perturb(sd, x, xi, eps, d0=None):
 
 
 def drop_perturb(x, rate, spatial=True, scale=None):
-    """DropOutDecoder (ssl_cct.py:584-592): nn.Dropout2d(p) in training mode; draw = the [B, C] keep-scale (0 or
-    1/(1-p))."""
+    """DropOutDecoder (ssl_cct.py:584-592): nn.Dropout2d(p) (spatial) or nn.Dropout(p) in training mode; draw = the keep-scale
+    (0 or 1/(1-p)): [B, C] for the spatial kind, x's shape for the element-wise kind."""
     if scale is None:
-        if not spatial:
-            raise NotImplementedError("element-wise dropout decoder (the shipped script uses spatial dropout)")
-        scale = F.dropout2d(torch.ones(x.shape[0], x.shape[1], 1, 1), rate, True).reshape(x.shape[0], x.shape[1])
-    return x * scale[:, :, None, None], scale
+        if spatial:
+            scale = F.dropout2d(torch.ones(x.shape[0], x.shape[1], 1, 1), rate, True).reshape(x.shape[0], x.shape[1])
+        else:
+            scale = F.dropout(torch.ones(x.shape), rate, True)
+    return x * (scale[:, :, None, None] if scale.dim() == 2 else scale), scale
 
 
 def fg_mask(main_pred, size):
@@ -140,13 +141,14 @@ _NB8 = ((0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1))   
 
 
 def external_contour_boxes(mask, min_vertices=50):
+    """Bounding boxes (min_x, max_x, min_y, max_y) of the external contours of a binary image whose CHAIN_APPROX_SIMPLE
+    polygon has more than `min_vertices` vertices (ssl_cct.py:630-636), in raster order of the contour's first pixel."""
     return [box for nvert, box in _external_contours(mask) if nvert > min_vertices]
 
 
 def _external_contours(mask):
-    """(vertex count, bounding box) of EVERY external contour -- see external_contour_boxes.  Bounding boxes (min_x, max_x, min_y, max_y) of the external contours of a binary image whose
-    CHAIN_APPROX_SIMPLE polygon has more than `min_vertices` vertices (ssl_cct.py:630-636), in raster order of the
-    contour's first pixel.  Pure-python restatement of the published border-following algorithm."""
+    """(vertex count, bounding box) of EVERY external contour.  Pure-python restatement of the published
+    border-following algorithm (see the header)."""
     m = np.asarray(mask) != 0
     H, W = m.shape
     pad = np.zeros((H + 2, W + 2), dtype=bool)

@@ -157,6 +157,7 @@ SIGNATURES = {
     "pxl_sgd_step_general": (_I, [_L, _P, _P, _P, _F, _F, _F, _F, _I, _I, _P]),
     "pxl_adam_step_wd": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _P]),
     "pxl_gaussian_noise_apply": (_I, [_I, _L, _P, _P, _P, _P]),
+    "pxl_rotate_append": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
     "pxl_adam_step": (_I, [_L, _P, _P, _P, _P, _F, _F, _F, _F, _I, _P]),
     "pxl_ema_update": (_I, [_L, _P, _P, _F, _P]),
     "pxl_scale_inplace": (_I, [_L, _P, _F, _P]),

@@ -219,19 +219,28 @@ class VATDecoder(_AuxDecoder):
 
 
 class DropOutDecoder(_AuxDecoder):
+    """ssl_cct.py:585-593: nn.Dropout2d (spatial_dropout, the shipped script: one Bernoulli(1 - p) per (sample, channel)) or
+    nn.Dropout (one per element) in front of the decoder body; kept values are scaled by 1 / (1 - p).  The draw is a scale
+    tensor -- [B, C] resp. [B, C, h, w] -- so that tests can inject the reference's."""
+
     def __init__(self, upscale, in_channels, num_classes, drop_rate=0.3, spatial_dropout=True, **kw):
         super().__init__(upscale, in_channels, num_classes, **kw)
-        if not spatial_dropout:
-            raise NotImplementedError('DropOutDecoder implements spatial dropout (nn.Dropout2d), what the shipped script uses')
         self.drop_rate = drop_rate
+        self.spatial_dropout = spatial_dropout
 
     def perturb(self, x, pred_of_main_decoder):
         scale = self._take_draw()
-        if scale is None:       # nn.Dropout2d: one Bernoulli(1-p) per (sample, channel), kept channels scaled by 1/(1-p)
-            keep = (torch.rand(x.shape[0], x.shape[1], device=x.device) >= self.drop_rate).float()
+        B, C, h, w = x.shape
+        if scale is None:
+            shape = (B, C) if self.spatial_dropout else (B, C, h, w)
+            keep = (torch.rand(shape, device=x.device) >= self.drop_rate).float()
             scale = keep / (1.0 - self.drop_rate)
         self.last_draw = scale
-        return perturb(x, cscale=scale.to(x.device))
+        scale = scale.to(x.device)
+        if scale.dim() == 2:
+            return perturb(x, cscale=scale)
+        # element-wise: the kernel's per-(sample, position) factor with every (sample, channel) plane as its own sample
+        return perturb(x.reshape(B * C, 1, h, w), mask=scale.reshape(B * C, h, w)).reshape(B, C, h, w)
 
 
 class CutOutDecoder(_AuxDecoder):

@@ -8,7 +8,7 @@ classifier at the base learning rate].
 
 Device mapping: the rotation classifier (2 x [conv 4x4 / s2 + BatchNorm + LeakyReLU], global pool, Linear) is one
 executor program (engine.RotationClassifierCore); its input gradient returns to autograd and reaches the task model's
-executor as part of d(pred).  The rotations are index permutations of device tensors (torch views + one copy)."""
+executor as part of d(pred).  The rotated copies of a batch are written by one tiled-transpose launch (csrc/rotate.hip)."""
 import os
 import time
 
@@ -252,7 +252,7 @@ class SSLS4L(ssl_base._SSLBase):
 
     def _batch_prehandle(self, inp, gt, is_train):
         """ssl_s4l.py:296-345: rotated copies behind the batch, the rotation classes as the last ground truth.  Same draw
-        from numpy's global stream; the copies are built with batched index ops on the device."""
+        from numpy's global stream; the copies are built by one kernel launch per tensor."""
         bs = inp[0].shape[0]
         rotation_angles = np.random.randint(low=1, high=4, size=bs)
         inp, gt = self._to_device(inp), self._to_device(gt)
@@ -268,16 +268,27 @@ class SSLS4L(ssl_base._SSLBase):
     # angle index of _rotate_tensor (ssl_s4l.py:347-355) -> quarter turns of torch.rot90 over (H, W): 1 = clockwise
     _QUARTER_TURNS = {0: 0, 1: -1, 2: 2, 3: 1}
 
+    _SRC_KIND = {torch.float32: 0, torch.int64: 1, torch.uint8: 2}
+
     def _with_rotated(self, t, angles):
-        """[bs, ...] -> [2 * bs, ...]: the batch followed by one rotated copy per sample (copies that share an angle are
-        produced by ONE rot90 over the sub-batch)."""
+        """[bs, C, N, N] -> fp32 [2 * bs, C, N, N]: the batch followed by one rotated copy per sample -- ONE launch of
+        csrc/rotate.hip (pxl_rotate_append: 32 x 32 tiles through LDS, unit-stride reads and writes for every angle)
+        instead of the reference's per-sample transposes / flips into a zero tensor (ssl_s4l.py:296-355)."""
+        import ctypes
+        from .._lib import lib, check, ptr, stream_ptr, PixelHipError
         bs = t.shape[0]
-        assert bs == len(angles) and t.shape[-1] == t.shape[-2], 'S4L rotates by quarter turns: square inputs'
+        if not (t.dim() == 4 and bs == len(angles) and t.shape[-1] == t.shape[-2]):
+            raise PixelHipError('SSL_S4L rotates [bs, C, N, N] tensors by quarter turns (square maps), got %s for %d angles'
+                                % (tuple(t.shape), len(angles)))
+        if not t.is_cuda:
+            raise PixelHipError('SSL_S4L builds the rotated copies on the GPU (csrc/rotate.hip); got a %s tensor' % t.device)
+        if t.dtype not in self._SRC_KIND:
+            t = t.float()
+        t = t.contiguous()
         out = torch.empty((2 * bs,) + tuple(t.shape[1:]), device=t.device, dtype=torch.float32)
-        out[:bs] = t
-        for a in sorted(set(int(v) for v in angles)):
-            idx = torch.as_tensor([i for i, v in enumerate(angles) if int(v) == a], device=t.device)
-            out[bs + idx] = torch.rot90(t[idx].float(), self._QUARTER_TURNS[a], (-2, -1))
+        host_angles = (ctypes.c_int * bs)(*[int(v) for v in angles])
+        check(lib().pxl_rotate_append(self._SRC_KIND[t.dtype], bs, t.shape[1], t.shape[2], ptr(t), host_angles, ptr(out),
+                                      stream_ptr()))
         return out
 
     def _rotate_tensor(self, tensor, angle_idx):

@@ -167,6 +167,7 @@ def test_every_auxiliary_decoder_matches_oracle(dtype, tol):
     tgt = torch.softmax(torch.randn(B, 21, size, size, generator=g), 1)
     # bf16: the finite-difference step of I-VAT must also be resolvable in the bf16 latent the engine reads (8 bits)
     cases = [("vat", dict(xi=0.5 if dtype == torch.float32 else 20.0, eps=2.0)), ("drop", dict(rate=0.5, spatial=True)), ("cut", dict(erase=0.4, min_vertices=4)),
+             ("drop", dict(rate=0.3, spatial=False)),       # nn.Dropout: one draw per element (DropOutDecoder(spatial_dropout=False))
              ("context", {}), ("object", {}), ("fd", {}), ("fn", dict(uniform=0.3))]
     for i, (kind, cfg) in enumerate(cases):
         state = CO.init_decoder_state(40 + i)

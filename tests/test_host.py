@@ -216,3 +216,45 @@ def test_attach_reaches_executors_kept_outside_the_module_registry(monkeypatch):
     n = len(wired)
     pdist.attach(model)                                                           # idempotent
     assert len(wired) == n
+
+
+def test_pretrained_backbone_file_and_model_zoo_url(tmp_path, monkeypatch):
+    """ResNet._load_pretrained_model (task/sseg/module/backbone/resnet.py:145-156) on the engine's trunk: a FILE is a strict
+    state dict of the trunk; a URL (here file://, through torch.hub's cache like model_zoo.load_url) is filtered to the keys
+    the dilated trunk has -- a torchvision ResNet also carries fc.* -- and everything outside the trunk keeps its values."""
+    import torch_oracle as TO
+    from pixelssl_amd.engine import DeepLabV2Core
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "hub"))
+    core = DeepLabV2Core(device="cpu", engine_dtype=torch.bfloat16)
+    before = {k: v.clone() for k, v in core.state_dict().items()}
+    donor = TO.init_deeplabv2_state(seed=77)
+    trunk = {k[len("backbone."):]: v + 0.25 for k, v in donor.items() if k.startswith("backbone.") and v.dtype.is_floating_point}
+    trunk.update({k[len("backbone."):]: v for k, v in donor.items() if k.startswith("backbone.") and not v.dtype.is_floating_point})
+    # (1) model-zoo style: torchvision names = the trunk's names + the classifier head the trunk does not have
+    zoo = dict(trunk)
+    zoo["fc.weight"], zoo["fc.bias"] = torch.randn(1000, 2048), torch.randn(1000)
+    f = tmp_path / "resnet101-synthetic.pth"
+    torch.save(zoo, f)
+    taken = core.load_pretrained_backbone("file://" + str(f))
+    assert "fc.weight" not in taken and len(taken) == len(trunk)
+    sd = core.state_dict()
+    for k, v in trunk.items():
+        assert torch.equal(sd["backbone." + k], v), k
+    for k, v in before.items():
+        if not k.startswith("backbone."):
+            assert torch.equal(sd[k], v), k                    # the ASPP head is untouched
+    # (2) a file path: strict -- the zoo file with fc.* is refused, the trunk-only file loads
+    with pytest.raises(RuntimeError, match="unexpected"):
+        core.load_pretrained_backbone(str(f))
+    g = tmp_path / "trunk.pth"
+    torch.save({k: v * 2 if v.dtype.is_floating_point else v for k, v in trunk.items()}, g)
+    core.load_pretrained_backbone(str(g))
+    assert torch.equal(core.state_dict()["backbone.layer3.5.conv2.weight"], trunk["layer3.5.conv2.weight"] * 2)
+    # (3) the task model's switch: --pretrained-backbone <file>
+    import argparse
+    from pixelssl_amd.sseg import model as SM
+    args = argparse.Namespace(backbone="resnet101", output_stride=16, num_classes=21, freeze_bn=False, engine_dtype="bf16",
+                              lr=0.001, pretrained_backbone=str(g))
+    tm = SM.DeepLabV2(args)
+    assert torch.equal(tm.model.state_dict()["backbone.conv1.weight"], trunk["conv1.weight"] * 2)
+    assert SM.PRETRAINED_BACKBONE_URLS["resnet101"].endswith("resnet101-5d3b4d8f.pth")

@@ -185,3 +185,37 @@ def test_ssls4l_train_steps_vs_reference(fixture, dtype):
         # (Linear + BN affine parameters of a 4-way classifier on 8 samples: bf16 is a sanity band)
         _check_weights("s4l rotation classifier " + dtype, algo.model.module.rotation_classifier.state_dict(), fx["rc_updates"],
                        dtype, frac=0.05 if dtype == "fp32" else 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [5, 32, 65, 513])
+@pytest.mark.parametrize("kind", ["f32", "i64", "u8"])
+def test_rotate_append_kernel_vs_oracle(kind, n):
+    """csrc/rotate.hip against the restated _batch_prehandle / _rotate_tensor (s4l_oracle.batch_prehandle, pinned against
+    the reference's method by make_golden_s4l.py): bit-exact, for images (fp32), label maps (int64, with the 255 ignore
+    value) and uint8 crops, at sizes below / at / above the 32 x 32 tile and at the BASELINE size 513."""
+    import s4l_oracle as SO
+    from pixelssl_amd.ssl_algorithm.ssl_s4l import SSLS4L
+    g = torch.Generator().manual_seed(n * 7 + len(kind))
+    bs, C = (6, 3) if n < 513 else (4, 3)
+    if kind == "f32":
+        t = torch.randn(bs, C, n, n, generator=g)
+    elif kind == "i64":
+        t = torch.randint(0, 21, (bs, 1, n, n), generator=g)
+        t[:, :, ::7, ::5] = 255
+    else:
+        t = torch.randint(0, 256, (bs, C, n, n), generator=g, dtype=torch.uint8)
+    angles = np.array([1, 2, 3, 0, 3, 1][:bs])
+    want, _, _ = SO.batch_prehandle(t.float(), t.float(), angles)
+    got = SSLS4L._with_rotated(SSLS4L, t.cuda(), angles)
+    assert got.dtype == torch.float32 and tuple(got.shape) == tuple(want.shape)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_rotate_append_rejects_what_it_cannot_do():
+    from pixelssl_amd._lib import PixelHipError
+    from pixelssl_amd.ssl_algorithm.ssl_s4l import SSLS4L
+    with pytest.raises(PixelHipError):
+        SSLS4L._with_rotated(SSLS4L, torch.zeros(2, 3, 8, 9), np.array([1, 2]))        # not square
+    with pytest.raises(PixelHipError):
+        SSLS4L._with_rotated(SSLS4L, torch.zeros(2, 3, 8, 8), np.array([1, 2]))        # no CPU fallback
