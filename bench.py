@@ -340,7 +340,9 @@ def main():
                "final_losses": loss_vals,
                # multi-rank: ranks on the C-driven RCCL communicators (0 = torch.distributed carries the exchanges) and the
                # gradient buckets all-reduced from inside the last backward pass (overlapped with it)
-               "rccl_ranks": pdist.rccl_ranks(), "grad_buckets": int(cores[0].grad_buckets())}
+               "rccl_ranks": pdist.rccl_ranks(), "grad_buckets": int(cores[0].grad_buckets()),
+               # networks whose Sync-BN statistics go through the peer-mapped one-shot exchange (csrc/peer.hip)
+               "peer_contexts": pdist.peer_contexts()}
         if elapsed_ev is not None:
             out["ms_per_step_with_kernel_events"] = round(1e3 * elapsed_ev / a.steps, 3)
         if kern:

@@ -616,6 +616,23 @@ int pxl_comm_allreduce_sum(pxl_comm* comm, float* buf, long n, void* stream);
  * Sync-BN statistics exchange a direct RCCL call from the executor (no host-language callback in the loop) */
 int pxl_comm_allreduce_hook(void* user, float* buf, int n, void* stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* One-shot all-reduce of small vectors over peer-mapped buffers (csrc/peer.hip): what replaces   */
+/* the per-BatchNorm master/slave exchange of sync_batchnorm/comm.py:59-137 for N > 1.            */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct pxl_peer pxl_peer;
+/* allocates this rank's exchange buffer (2 slot sets x world x slot_floats + flags); timeout_ms bounds every wait */
+int pxl_peer_create(int rank, int world, int slot_floats, int timeout_ms, pxl_peer** out);
+int pxl_peer_handle(pxl_peer* peer, void* handle64);           /* 64-byte HIP IPC handle of the buffer: gather over ranks */
+int pxl_peer_open(pxl_peer* peer, const void* handles);        /* [world][64] handles in rank order; maps every peer */
+void pxl_peer_destroy(pxl_peer* peer);
+/* in-place all-reduce(sum) of n floats at device pointer buf, enqueued on `stream`: one kernel per slot_floats floats.
+ * Every rank issues the same call sequence on a context; one context per concurrently running network. */
+int pxl_peer_allreduce_sum(pxl_peer* peer, float* buf, long n, void* stream);
+int pxl_peer_allreduce_hook(void* user, float* buf, int n, void* stream);      /* pxl_allreduce_fn signature */
+/* *status = 0, or k > 0: an exchange gave up waiting for rank k-1 (its result is invalid).  Synchronises the device. */
+int pxl_peer_status(pxl_peer* peer, int* status);
+
 /* Measurement aid (bench.py roofline leg): bracket every contraction launch of this net with HIP
  * events on the launch stream.  kind 0 = implicit-GEMM conv (forward + data gradient), 1 = weight
  * gradient.  read() synchronises on the recorded events, returns the summed kernel time, the number

@@ -168,6 +168,13 @@ SIGNATURES = {
     "pxl_comm_destroy": (None, [_P]),
     "pxl_comm_allreduce_sum": (_I, [_P, _P, _L, _P]),
     "pxl_comm_allreduce_hook": (_I, [_P, _P, _I, _P]),
+    "pxl_peer_create": (_I, [_I, _I, _I, _I, C.POINTER(_P)]),
+    "pxl_peer_handle": (_I, [_P, _P]),
+    "pxl_peer_open": (_I, [_P, _P]),
+    "pxl_peer_destroy": (None, [_P]),
+    "pxl_peer_allreduce_sum": (_I, [_P, _P, _L, _P]),
+    "pxl_peer_allreduce_hook": (_I, [_P, _P, _I, _P]),
+    "pxl_peer_status": (_I, [_P, C.POINTER(_I)]),
     "pxl_net_create": (_I, [_I, _I, C.POINTER(Op), _I, C.POINTER(BnDesc), _I, _I, C.POINTER(_P)]),
     "pxl_net_destroy": (None, [_P]),
     "pxl_net_plan": (_I, [_P, _I, _I, _I]),

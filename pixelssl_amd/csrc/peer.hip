@@ -1,0 +1,187 @@
+// One-shot all-reduce of SMALL vectors over peer-mapped buffers (Sync-BN statistics: 2*C floats, <= 16 KB).
+//   reference: the master/slave queue exchange of sync_batchnorm/comm.py:59-137 (one round trip per BatchNorm layer and
+//   pass); RCCL's ring / tree all-reduce costs 15-25 us per call at these sizes, and an MT step has ~310 of them on its
+//   critical path.
+// Every rank owns one exchange buffer in device memory that is mapped into every other rank's address space (HIP IPC,
+// dmabuf); xGMI is point-to-point, so a rank STORES its vector straight into its slot of every peer's buffer, publishes
+// an epoch flag behind a system-scope release, spins on the flags of its own buffer and adds the slots up in rank order
+// -- one kernel, one xGMI hop, no intermediate rank, and bit-identical sums on all ranks.  Two slot sets alternate by
+// epoch parity: a rank can only be one exchange ahead of the slowest rank (it needs that rank's flag of the current
+// exchange before it returns), so the set it overwrites next has been read by everyone.
+// A spin that exceeds the time-out (a peer died) raises the context's status word instead of hanging the GPU.
+#include <cstring>
+#include <new>
+
+#include "common.h"
+
+namespace {
+
+constexpr int MAXW = 16;
+constexpr int FLAG_STRIDE = 16;          // uint32 per flag: one 64-byte line each
+
+struct PeerArgs {
+  float* data[MAXW];                     // data area of every rank's buffer: [2][world][slot] floats
+  unsigned* flags[MAXW];                 // flag area of every rank's buffer: [2][world][FLAG_STRIDE]
+  unsigned* status;                      // local: != 0 after a time-out
+  int rank, world, slot;
+  long long timeout_ticks;               // of the 100 MHz wall clock
+};
+
+__device__ __forceinline__ float ld_sys(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a, float* __restrict__ buf, int n,
+                                                             unsigned epoch) {
+  const int tid = threadIdx.x;
+  const int par = epoch & 1u;
+  const size_t slot_off = ((size_t)par * a.world + a.rank) * a.slot;
+  // 1. my vector into my slot of every rank's buffer (my own included: the sum below reads every slot the same way)
+  for (int i = tid; i < n; i += 256) {
+    const float v = buf[i];
+    for (int r = 0; r < a.world; ++r) st_sys(a.data[r] + slot_off + i, v);
+  }
+  __threadfence_system();
+  __syncthreads();
+  // 2. publish: flag[par][my rank] of every buffer = epoch
+  if (tid < a.world)
+    __hip_atomic_store(a.flags[tid] + ((size_t)par * a.world + a.rank) * FLAG_STRIDE, epoch, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  // 3. wait for every rank's flag in MY buffer
+  if (tid < a.world) {
+    const unsigned* f = a.flags[a.rank] + ((size_t)par * a.world + tid) * FLAG_STRIDE;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > a.timeout_ticks) {
+        atomicExch(a.status, 1u + (unsigned)tid);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  // 4. sum in rank order (identical on every rank)
+  const float* mine = a.data[a.rank] + (size_t)par * a.world * a.slot;
+  for (int i = tid; i < n; i += 256) {
+    float acc = 0.f;
+    for (int q = 0; q < a.world; ++q) acc += ld_sys(mine + (size_t)q * a.slot + i);
+    buf[i] = acc;
+  }
+}
+
+}  // namespace
+
+struct pxl_peer {
+  int rank = 0, world = 1, slot = 0;
+  size_t bytes = 0, flag_off = 0, status_off = 0;
+  char* local = nullptr;
+  char* mapped[MAXW] = {};
+  bool opened = false;
+  unsigned epoch = 0;
+  long long timeout_ticks = 0;
+};
+
+extern "C" int pxl_peer_create(int rank, int world, int slot_floats, int timeout_ms, pxl_peer** out) {
+  PXL_REQUIRE(out && world >= 1 && world <= MAXW && rank >= 0 && rank < world && slot_floats > 0 && timeout_ms > 0,
+              "peer_create: bad argument (1 <= world <= %d)", MAXW);
+  pxl_peer* p = new (std::nothrow) pxl_peer();
+  PXL_REQUIRE(p != nullptr, "peer_create: out of host memory");
+  p->rank = rank; p->world = world; p->slot = (slot_floats + 63) / 64 * 64;
+  p->flag_off = (size_t)2 * world * p->slot * sizeof(float);
+  p->status_off = p->flag_off + (size_t)2 * world * FLAG_STRIDE * sizeof(unsigned);
+  p->bytes = p->status_off + 256;
+  p->timeout_ticks = (long long)timeout_ms * 100000LL;          // 100 MHz
+  void* mem = nullptr;
+  // uncached / fine-grained device memory: stores of a peer become visible while a kernel of this rank is running
+  hipError_t e = hipExtMallocWithFlags(&mem, p->bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipExtMallocWithFlags(&mem, p->bytes, hipDeviceMallocFinegrained);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    delete p;
+    return pxl_set_error(PXL_ERR_UNSUPPORTED, "peer_create: no fine-grained device memory (%s)", hipGetErrorString(e));
+  }
+  p->local = static_cast<char*>(mem);
+  e = hipMemset(p->local, 0, p->bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    (void)hipFree(p->local);
+    delete p;
+    return pxl_set_error(PXL_ERR_HIP, "peer_create: hipMemset failed: %s", hipGetErrorString(e));
+  }
+  p->mapped[rank] = p->local;
+  *out = p;
+  return PXL_OK;
+}
+
+extern "C" int pxl_peer_handle(pxl_peer* p, void* handle64) {
+  PXL_REQUIRE(p && handle64, "peer_handle: null argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+  hipIpcMemHandle_t h;
+  PXL_CHECK_HIP(hipIpcGetMemHandle(&h, p->local));
+  std::memcpy(handle64, &h, 64);
+  return PXL_OK;
+}
+
+// handles: [world][64] bytes, rank order (every rank's own entry is ignored)
+extern "C" int pxl_peer_open(pxl_peer* p, const void* handles) {
+  PXL_REQUIRE(p && handles && !p->opened, "peer_open: bad argument");
+  for (int r = 0; r < p->world; ++r) {
+    if (r == p->rank) continue;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, static_cast<const char*>(handles) + (size_t)r * 64, 64);
+    void* q = nullptr;
+    PXL_CHECK_HIP(hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess));
+    p->mapped[r] = static_cast<char*>(q);
+  }
+  p->opened = true;
+  return PXL_OK;
+}
+
+extern "C" void pxl_peer_destroy(pxl_peer* p) {
+  if (!p) return;
+  for (int r = 0; r < p->world; ++r)
+    if (r != p->rank && p->mapped[r]) (void)hipIpcCloseMemHandle(p->mapped[r]);
+  if (p->local) (void)hipFree(p->local);
+  delete p;
+}
+
+// in-place all-reduce(sum) of n floats at device pointer buf, enqueued on `stream`; vectors longer than the slot go in
+// several exchanges.  Every rank must issue the same sequence of calls on a context.
+extern "C" int pxl_peer_allreduce_sum(pxl_peer* p, float* buf, long n, void* stream) {
+  PXL_REQUIRE(p && buf && n > 0, "peer_allreduce_sum: bad argument");
+  PXL_REQUIRE(p->opened || p->world == 1, "peer_allreduce_sum: peer buffers not opened (pxl_peer_open)");
+  PeerArgs a;
+  for (int r = 0; r < MAXW; ++r) {
+    a.data[r] = r < p->world ? reinterpret_cast<float*>(p->mapped[r]) : nullptr;
+    a.flags[r] = r < p->world ? reinterpret_cast<unsigned*>(p->mapped[r] + p->flag_off) : nullptr;
+  }
+  a.status = reinterpret_cast<unsigned*>(p->local + p->status_off);
+  a.rank = p->rank; a.world = p->world; a.slot = p->slot; a.timeout_ticks = p->timeout_ticks;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  for (long off = 0; off < n; off += p->slot) {
+    const int m = (int)((n - off) < p->slot ? (n - off) : p->slot);
+    p->epoch += 1;
+    hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, s, a, buf + off, m, p->epoch);
+  }
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_peer_allreduce_hook(void* user, float* buf, int n, void* stream) {
+  return pxl_peer_allreduce_sum(reinterpret_cast<pxl_peer*>(user), buf, (long)n, stream) == PXL_OK ? 0 : 1;
+}
+
+// 0 = every exchange so far met its peers; k > 0 = an exchange gave up waiting for rank k-1 (synchronises the device)
+extern "C" int pxl_peer_status(pxl_peer* p, int* status) {
+  PXL_REQUIRE(p && status, "peer_status: null argument");
+  unsigned v = 0;
+  PXL_CHECK_HIP(hipMemcpy(&v, p->local + p->status_off, sizeof(v), hipMemcpyDeviceToHost));
+  *status = (int)v;
+  return PXL_OK;
+}

@@ -176,6 +176,85 @@ def native_comms():
     return comms
 
 
+_peer = {"ok": None, "ctxs": [], "hook": None}
+PEER_SLOT_FLOATS = 4096            # 2 * 2048 channels: the widest BatchNorm of the ResNet trunks in one exchange
+PEER_TIMEOUT_MS = int(os.environ.get("PXL_PEER_TIMEOUT_MS", "20000"))
+
+
+def _all_agree(flag, dev):
+    ok = torch.tensor([1.0 if flag else 0.0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return ok.item() >= 1
+
+
+def open_peer_context():
+    """One peer-mapped exchange context (csrc/peer.hip) or None.  COLLECTIVE: every rank calls it the same number of
+    times in the same order.  The buffers are shared through HIP IPC handles gathered with torch.distributed, and a context
+    is only handed out after 64 exchanges with known sums came out right on EVERY rank; PXL_PEER_SYNC=0 turns the path
+    off (the statistics then go through RCCL / torch.distributed)."""
+    if not is_distributed() or not torch.cuda.is_available() or os.environ.get("PXL_PEER_SYNC", "1") == "0":
+        return None
+    if _peer["ok"] is False:
+        return None
+    import ctypes
+    from . import _lib
+    h = _lib.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ws, rk = world_size(), rank()
+    ctx = ctypes.c_void_p()
+    good = h.pxl_peer_create(rk, ws, PEER_SLOT_FLOATS, PEER_TIMEOUT_MS, ctypes.byref(ctx)) == 0
+    handle = ctypes.create_string_buffer(64)
+    good = good and h.pxl_peer_handle(ctx, handle) == 0
+    gathered = [None] * ws
+    dist.all_gather_object(gathered, handle.raw if good else None)
+    good = good and all(g is not None for g in gathered)
+    if good:
+        good = h.pxl_peer_open(ctx, b"".join(gathered)) == 0
+    if _all_agree(good, dev):
+        # verified before anything depends on it: vectors of several lengths, every rank's contribution distinct
+        stream = torch.cuda.current_stream().cuda_stream
+        probe_ok = True
+        for k in range(64):
+            n = (64, 256, 1024, PEER_SLOT_FLOATS, PEER_SLOT_FLOATS + 192)[k % 5]
+            v = torch.arange(n, device=dev, dtype=torch.float32) * (rk + 1) + k
+            want = torch.arange(n, device=dev, dtype=torch.float32) * (ws * (ws + 1) / 2) + k * ws
+            probe_ok = probe_ok and h.pxl_peer_allreduce_sum(ctx, v.data_ptr(), n, stream) == 0
+            probe_ok = probe_ok and bool(torch.equal(v, want))
+        st = ctypes.c_int(0)
+        probe_ok = probe_ok and h.pxl_peer_status(ctx, ctypes.byref(st)) == 0 and st.value == 0
+        good = _all_agree(probe_ok, dev)
+    else:
+        good = False
+    if not good:
+        if ctx.value:
+            h.pxl_peer_destroy(ctx)
+        _peer["ok"] = False
+        return None
+    _peer["ok"] = True
+    _peer["ctxs"].append(ctx)
+    if _peer["hook"] is None:
+        _peer["hook"] = ctypes.cast(h.pxl_peer_allreduce_hook, _lib.ALLREDUCE_FN)
+    return ctx
+
+
+def peer_contexts():
+    """Number of peer-mapped exchange contexts in use (0 = Sync-BN goes through RCCL / torch.distributed)."""
+    return len(_peer["ctxs"])
+
+
+def check_peers():
+    """Raise if any peer-mapped exchange of this process timed out (its sums were invalid).  Synchronises the device:
+    call it at a checkpoint / epoch boundary, not per step."""
+    import ctypes
+    from . import _lib
+    for ctx in _peer["ctxs"]:
+        st = ctypes.c_int(0)
+        _lib.check(_lib.lib().pxl_peer_status(ctx, ctypes.byref(st)))
+        if st.value:
+            raise _lib.PixelHipError("peer-mapped Sync-BN exchange: rank %d gave up waiting for rank %d after %d ms"
+                                     % (rank(), st.value - 1, PEER_TIMEOUT_MS))
+
+
 def rccl_ranks():
     """Ranks of the C-driven RCCL communicators (0 = the exchanges go through torch.distributed)."""
     return world_size() if _native["comms"] else 0
@@ -205,9 +284,10 @@ def _post_backward(core):
 
 
 def attach(model):
-    """Wire every engine network inside `model` for multi-rank training (no-op on one rank): Sync-BN statistics and
-    the flat-gradient all-reduce go through the C-driven RCCL communicator when it is available (nccl backend), else
-    through torch.distributed (gloo in the CPU tests)."""
+    """Wire every engine network inside `model` for multi-rank training (no-op on one rank).  Sync-BN statistics: the
+    peer-mapped one-shot exchange (csrc/peer.hip, one context per network) when the ranks can map each other's device
+    memory, else the C-driven RCCL communicator (nccl backend), else torch.distributed (gloo in the CPU tests).  Flat-gradient
+    all-reduce: RCCL from C when available, else torch.distributed."""
     if not is_distributed():
         return model
     from .engine import SegNetCore
@@ -225,6 +305,12 @@ def attach(model):
     for m in cores:
         if not getattr(m, "_pxl_attached", False):
             sync_bn = getattr(m, "sync_bn", True)     # False: local BatchNorm statistics (S4L's rotation classifier)
+            # Sync-BN statistics: a peer-mapped one-shot exchange per network when the ranks can map each other's memory
+            peer = open_peer_context() if sync_bn else None
+            if peer is not None:
+                m._pxl_peer = peer
+                m.set_sync_native(_peer["hook"], peer, ws)
+                sync_bn = False                         # wired; the branches below only handle the gradient path
             if comms:                      # networks take the communicators in creation order (identical on all ranks)
                 m._pxl_comm = comms[_native["next"] % len(comms)]
                 _native["next"] += 1

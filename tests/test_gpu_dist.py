@@ -21,7 +21,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, peer="1"):
+    os.environ["PXL_PEER_SYNC"] = peer
     # 0.25 MB gradient buckets: the 8.9 M-parameter test trunk is exchanged in > 10 buckets issued from inside the backward
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), PXL_FORCE_DEVICE="0", PXL_DIST_BACKEND="gloo", PXL_AUTOTUNE="0",
@@ -44,6 +45,8 @@ def _worker(rank, world, port, q):
         core.load_state_dict(state)
         core.train()
         pdist.attach(core)
+        # Sync-BN statistics: the peer-mapped one-shot exchange (csrc/peer.hip, one context per network) unless switched off
+        assert (getattr(core, "_pxl_peer", None) is not None) == (peer == "1"), "peer-mapped exchange not in use"
         sl = slice(2 * rank, 2 * rank + 2)
         logits, _, _ = core(x[sl].cuda())
         loss = PF.cross_entropy_per_sample(logits, gt[sl].cuda(), 255).mean()
@@ -58,13 +61,93 @@ def _worker(rank, world, port, q):
         PF.cross_entropy_per_sample(logits2, gt[sl].cuda(), 255).mean().backward()
         torch.cuda.synchronize()
         out[str(dtype)]["grads2"] = core.flat.grads.detach().cpu().numpy().copy()
+    pdist.check_peers()                     # no exchange timed out
+    assert pdist.peer_contexts() == (2 if peer == "1" else 0)
     dist.barrier()
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_match_full_batch_step():
+def _peer_worker(rank, world, port, q):
+    """The exchange alone: random vectors of every length class against torch.distributed's sum (two ranks: a + b is exact in
+    either order, so the comparison is bitwise), two contexts interleaved on two streams, and the time per exchange."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), PXL_FORCE_DEVICE="0", PXL_DIST_BACKEND="gloo")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import ctypes
+    import torch.distributed as dist
+    from pixelssl_amd import dist as pdist, _lib
+    torch.cuda.set_device(0)
+    pdist.init_from_env()
+    h = _lib.lib()
+    a, b = pdist.open_peer_context(), pdist.open_peer_context()
+    assert a is not None and b is not None, "peer-mapped exchange unavailable: " + h.pxl_last_error().decode()
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)
+    s2 = torch.cuda.Stream()
+    bad = 0
+    for k in range(200):
+        n = (128, 512, 2048, 4096, 4096 + 320, 12)[k % 6]
+        v = torch.randn(n, device="cuda", generator=g)
+        w = torch.randn(n, device="cuda", generator=g)
+        rv, rw = v.clone(), w.clone()
+        dist.all_reduce(rv)
+        dist.all_reduce(rw)
+        s2.wait_stream(torch.cuda.current_stream())
+        _lib.check(h.pxl_peer_allreduce_sum(a, v.data_ptr(), n, torch.cuda.current_stream().cuda_stream))
+        with torch.cuda.stream(s2):
+            _lib.check(h.pxl_peer_allreduce_sum(b, w.data_ptr(), n, s2.cuda_stream))
+        torch.cuda.current_stream().wait_stream(s2)
+        bad += int(not torch.equal(v, rv)) + int(not torch.equal(w, rw))
+    pdist.check_peers()
+    # time per exchange, 2C = 2048 floats (a layer-3 BatchNorm), back to back on one stream
+    v = torch.randn(2048, device="cuda", generator=g)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dist.barrier()
+    for _ in range(20):
+        h.pxl_peer_allreduce_sum(a, v.data_ptr(), 2048, torch.cuda.current_stream().cuda_stream)
+    e0.record()
+    for _ in range(300):
+        h.pxl_peer_allreduce_sum(a, v.data_ptr(), 2048, torch.cuda.current_stream().cuda_stream)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 300 * 1e3
+    # the same through torch.distributed (gloo: device -> host -> socket -> device), what the two-rank tests used before
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(30):
+        dist.all_reduce(v)
+    t1.record()
+    torch.cuda.synchronize()
+    pdist.check_peers()
+    dist.barrier()
+    q.put((rank, dict(bad=bad, us_peer=us, us_gloo=t0.elapsed_time(t1) / 30 * 1e3)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_peer_mapped_exchange_two_processes_one_gpu():
+    """csrc/peer.hip between two PROCESSES that map each other's buffer through HIP IPC (both on cuda:0: the box has one GPU;
+    across GPUs the same stores travel over xGMI): 400 exchanges of 6 length classes on two contexts / two streams equal
+    torch.distributed's sums bitwise, nothing timed out; prints the time per exchange."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    print("peer-mapped exchange, 2 processes on one MI355X, 2048 floats: %.1f us per exchange (rank 0), %.1f us (rank 1); "
+          "torch.distributed/gloo: %.0f us" % (res[0]["us_peer"], res[1]["us_peer"], res[0]["us_gloo"]))
+    assert res[0]["bad"] == 0 and res[1]["bad"] == 0
+
+
+@pytest.mark.parametrize("peer", ["1", "0"])
+def test_two_ranks_one_gpu_match_full_batch_step(peer):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import torch_oracle as TO
     from pixelssl_amd import functional as PF
@@ -72,7 +155,7 @@ def test_two_ranks_one_gpu_match_full_batch_step():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, peer)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in procs)
