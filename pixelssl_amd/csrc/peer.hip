@@ -3,12 +3,14 @@
 //   pass); RCCL's ring / tree all-reduce costs 15-25 us per call at these sizes, and an MT step has ~310 of them on its
 //   critical path.
 // Every rank owns one exchange buffer in device memory that is mapped into every other rank's address space (HIP IPC,
-// dmabuf); xGMI is point-to-point, so a rank STORES its vector straight into its slot of every peer's buffer, publishes
-// an epoch flag behind a system-scope release, spins on the flags of its own buffer and adds the slots up in rank order
-// -- one kernel, one xGMI hop, no intermediate rank, and bit-identical sums on all ranks.  Two slot sets alternate by
-// epoch parity: a rank can only be one exchange ahead of the slowest rank (it needs that rank's flag of the current
-// exchange before it returns), so the set it overwrites next has been read by everyone.
-// A spin that exceeds the time-out (a peer died) raises the context's status word instead of hanging the GPU.
+// dmabuf); xGMI is point-to-point, so a rank STORES its vector straight into its slot of every peer's buffer and adds up
+// the slots of its own buffer in rank order -- one kernel, one xGMI hop, no intermediate rank, bit-identical sums on all
+// ranks.  Every element travels as ONE 8-byte word {value, epoch}: a reader spins on the word until it carries the
+// current epoch, so there is no separate flag, no fence and no ordering requirement between stores (the scheme of RCCL's
+// low-latency protocol).  Two slot sets alternate by epoch parity: a rank can only be one exchange ahead of the slowest
+// rank (it needs that rank's words of the current exchange before it returns), so the set it overwrites next has been
+// read by everyone.  A spin that exceeds the time-out (a peer died) raises the context's status word instead of hanging
+// the GPU.
 #include <cstring>
 #include <new>
 
@@ -17,57 +19,40 @@
 namespace {
 
 constexpr int MAXW = 16;
-constexpr int FLAG_STRIDE = 16;          // uint32 per flag: one 64-byte line each
 
 struct PeerArgs {
-  float* data[MAXW];                     // data area of every rank's buffer: [2][world][slot] floats
-  unsigned* flags[MAXW];                 // flag area of every rank's buffer: [2][world][FLAG_STRIDE]
+  unsigned long long* slots[MAXW];       // every rank's buffer: [2][world][slot] words {epoch << 32 | float bits}
   unsigned* status;                      // local: != 0 after a time-out
   int rank, world, slot;
   long long timeout_ticks;               // of the 100 MHz wall clock
 };
 
-__device__ __forceinline__ float ld_sys(const float* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ void st_sys(float* p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 __global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a, float* __restrict__ buf, int n,
                                                              unsigned epoch) {
-  const int tid = threadIdx.x;
   const int par = epoch & 1u;
-  const size_t slot_off = ((size_t)par * a.world + a.rank) * a.slot;
-  // 1. my vector into my slot of every rank's buffer (my own included: the sum below reads every slot the same way)
-  for (int i = tid; i < n; i += 256) {
-    const float v = buf[i];
-    for (int r = 0; r < a.world; ++r) st_sys(a.data[r] + slot_off + i, v);
-  }
-  __threadfence_system();
-  __syncthreads();
-  // 2. publish: flag[par][my rank] of every buffer = epoch
-  if (tid < a.world)
-    __hip_atomic_store(a.flags[tid] + ((size_t)par * a.world + a.rank) * FLAG_STRIDE, epoch, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-  // 3. wait for every rank's flag in MY buffer
-  if (tid < a.world) {
-    const unsigned* f = a.flags[a.rank] + ((size_t)par * a.world + tid) * FLAG_STRIDE;
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
-      __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > a.timeout_ticks) {
-        atomicExch(a.status, 1u + (unsigned)tid);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-  // 4. sum in rank order (identical on every rank)
-  const float* mine = a.data[a.rank] + (size_t)par * a.world * a.slot;
-  for (int i = tid; i < n; i += 256) {
+  const size_t set = (size_t)par * a.world * a.slot;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    // my element into my slot of every rank's buffer (my own included: the sum below reads every slot the same way)
+    const unsigned long long word = ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(buf[i]);
+    for (int r = 0; r < a.world; ++r)
+      __hip_atomic_store(a.slots[r] + set + (size_t)a.rank * a.slot + i, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // every rank's element from MY buffer, in rank order (identical on every rank)
+    const unsigned long long* mine = a.slots[a.rank] + set + i;
     float acc = 0.f;
-    for (int q = 0; q < a.world; ++q) acc += ld_sys(mine + (size_t)q * a.slot + i);
+    long long t0 = 0;
+    for (int q = 0; q < a.world; ++q) {
+      unsigned long long w = __hip_atomic_load(mine + (size_t)q * a.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      while ((unsigned)(w >> 32) != epoch) {
+        if (t0 == 0) t0 = wall_clock64();
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > a.timeout_ticks) {
+          atomicExch(a.status, 1u + (unsigned)q);
+          break;
+        }
+        w = __hip_atomic_load(mine + (size_t)q * a.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      acc += __uint_as_float((unsigned)w);
+    }
     buf[i] = acc;
   }
 }
@@ -76,7 +61,7 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a, f
 
 struct pxl_peer {
   int rank = 0, world = 1, slot = 0;
-  size_t bytes = 0, flag_off = 0, status_off = 0;
+  size_t bytes = 0, status_off = 0;
   char* local = nullptr;
   char* mapped[MAXW] = {};
   bool opened = false;
@@ -90,8 +75,7 @@ extern "C" int pxl_peer_create(int rank, int world, int slot_floats, int timeout
   pxl_peer* p = new (std::nothrow) pxl_peer();
   PXL_REQUIRE(p != nullptr, "peer_create: out of host memory");
   p->rank = rank; p->world = world; p->slot = (slot_floats + 63) / 64 * 64;
-  p->flag_off = (size_t)2 * world * p->slot * sizeof(float);
-  p->status_off = p->flag_off + (size_t)2 * world * FLAG_STRIDE * sizeof(unsigned);
+  p->status_off = (size_t)2 * world * p->slot * sizeof(unsigned long long);
   p->bytes = p->status_off + 256;
   p->timeout_ticks = (long long)timeout_ms * 100000LL;          // 100 MHz
   void* mem = nullptr;
@@ -157,17 +141,15 @@ extern "C" int pxl_peer_allreduce_sum(pxl_peer* p, float* buf, long n, void* str
   PXL_REQUIRE(p && buf && n > 0, "peer_allreduce_sum: bad argument");
   PXL_REQUIRE(p->opened || p->world == 1, "peer_allreduce_sum: peer buffers not opened (pxl_peer_open)");
   PeerArgs a;
-  for (int r = 0; r < MAXW; ++r) {
-    a.data[r] = r < p->world ? reinterpret_cast<float*>(p->mapped[r]) : nullptr;
-    a.flags[r] = r < p->world ? reinterpret_cast<unsigned*>(p->mapped[r] + p->flag_off) : nullptr;
-  }
+  for (int r = 0; r < MAXW; ++r) a.slots[r] = r < p->world ? reinterpret_cast<unsigned long long*>(p->mapped[r]) : nullptr;
   a.status = reinterpret_cast<unsigned*>(p->local + p->status_off);
   a.rank = p->rank; a.world = p->world; a.slot = p->slot; a.timeout_ticks = p->timeout_ticks;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   for (long off = 0; off < n; off += p->slot) {
     const int m = (int)((n - off) < p->slot ? (n - off) : p->slot);
     p->epoch += 1;
-    hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(256), 0, s, a, buf + off, m, p->epoch);
+    if (p->epoch == 0) p->epoch = 2;            // 0 is what the zero-filled buffer carries; keep the parity sequence
+    hipLaunchKernelGGL(peer_allreduce_kernel, dim3(m > 1024 ? 4 : 1), dim3(256), 0, s, a, buf + off, m, p->epoch);
   }
   PXL_LAUNCH_CHECK();
   return PXL_OK;

@@ -285,8 +285,8 @@ def test_bench_two_ranks_on_one_gpu_through_torchrun():
     """`bench.py --gpus 2` launched exactly like the driver does (torch.distributed.run, 127.0.0.1), with the gloo
     backend and both ranks on cuda:0 (RCCL refuses two ranks on one GPU): the full ResNet-101 MT step at 513 x 513,
     1 + 1 images per rank, Sync-BN statistics exchange, bucketed gradient exchange inside the backward pass, max-over-
-    ranks timing -- the multi-rank code path of the benchmark end to end, falling back from the C-driven RCCL
-    communicators to torch.distributed (rccl_ranks = 0) as it must when they cannot be opened."""
+    ranks timing -- the multi-rank code path of the benchmark end to end: statistics over the peer-mapped exchange, gradients
+    falling back from the C-driven RCCL communicators to torch.distributed (rccl_ranks = 0) as they must when those cannot be opened."""
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -300,4 +300,5 @@ def test_bench_two_ranks_on_one_gpu_through_torchrun():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 4 and d["config"]["sync_bn"] is True
     assert d["rccl_ranks"] == 0 and d["grad_buckets"] >= 5          # 176 MB of gradients in 32 MB buckets
+    assert d["peer_contexts"] == 2                                  # student + teacher: Sync-BN over the peer-mapped exchange
     assert d["value"] > 0 and all(v == v and abs(v) < 1e6 for v in d["final_losses"].values())
