@@ -451,7 +451,17 @@ class SegNetCore(nn.Module):
                                        len(pb.bns), pb.ntensors, ctypes.byref(pl.net)))
             check(lib().pxl_net_plan_out(pl.net, B, H, W, out_size[0], out_size[1]))
             dev = self._device
-            pl.packed = torch.empty(lib().pxl_net_packed_bytes(pl.net), device=dev, dtype=torch.uint8)
+            nbytes = lib().pxl_net_packed_bytes(pl.net)
+            if inference:
+                # the packed-weight layout depends on the layer program, not on the input shape: forward-only plans of all
+                # shapes (validation at native image sizes) read ONE copy, re-packed once per weight version
+                sh = getattr(self, "_eval_shared", None)
+                if sh is None or sh["packed"].numel() != nbytes:
+                    sh = dict(packed=torch.empty(nbytes, device=dev, dtype=torch.uint8), version=None)
+                    object.__setattr__(self, "_eval_shared", sh)
+                pl.shared, pl.packed = sh, sh["packed"]
+            else:
+                pl.packed = torch.empty(nbytes, device=dev, dtype=torch.uint8)
             pl.scratch = torch.empty(lib().pxl_net_scratch_bytes(pl.net), device=dev, dtype=torch.uint8)
             pl.arena_bytes = lib().pxl_net_arena_bytes(pl.net)
             if self._sync_cb is not None:
@@ -476,10 +486,13 @@ class SegNetCore(nn.Module):
         pl = self._cur
         v = self._store.version()
         trainable = bool(self._param_list) and self._param_list[0].requires_grad and not pl.inference
+        shared = getattr(pl, "shared", None)
         if pl.pack_dgrad != trainable:      # a no-grad network (the MT teacher) needs no transposed weight copies
             check(lib().pxl_net_set_pack_dgrad(pl.net, int(trainable)))
             pl.pack_dgrad = trainable
             pl.packed_version = None
+        if shared is not None and shared["version"] == v:
+            pl.packed_version = v           # another forward-only plan packed this weight version into the shared copy
         if pl.packed_version != v:
             # forward operands on this stream; the transposed data-gradient copies are first read by the backward pass, so
             # they are packed on a side stream next to the forward (event: pl.wt_ready)
@@ -497,6 +510,8 @@ class SegNetCore(nn.Module):
                     pl.wt_ready.record()
                 pl.wt_waiters = set()
             pl.packed_version = v
+            if shared is not None:
+                shared["version"] = v
         if not pl.tuned and self.autotune and not pl.inference:
             if pl.wt_ready is not None:
                 torch.cuda.current_stream().wait_event(pl.wt_ready)
@@ -749,6 +764,7 @@ class _Plan:
         self.net = ctypes.c_void_p()
         self.packed = self.scratch = self.eval_arena = None
         self.packed_version = None
+        self.shared = None           # forward-only plans: the record of the packed-weight copy they share
         self.pack_dgrad = True
         self.arena_bytes = 0
         self.tuned = False

@@ -127,6 +127,7 @@ class SSEGFunc(func_template.TaskFunc):
         source = (fcd_pred, task_gt, int(self.args.ignore_index), bool(is_real))
         p._pxl_fcd_source = source
         g._pxl_fcd_source = source
+        p._pxl_fcd_version, g._pxl_fcd_version = p._version, g._version        # an in-place edit of the pair voids the shortcut
         return p, g
 
     def ssladv_convert_task_gt_to_fcd_input(self, task_gt):

@@ -120,7 +120,8 @@ class FCDiscriminatorCriterion(nn.Module):
         if not pred.is_cuda:
             raise _lib.PixelHipError("FCDiscriminatorCriterion runs on the GPU only; there is no CPU path")
         src = getattr(pred, '_pxl_fcd_source', None)
-        if src is not None and getattr(gt, '_pxl_fcd_source', None) is src:
+        if (src is not None and getattr(gt, '_pxl_fcd_source', None) is src
+                and pred._version == pred._pxl_fcd_version and gt._version == gt._pxl_fcd_version):
             raw_pred, task_gt, ignore_index, is_real = src
             return _MaskedBCE.apply(raw_pred, task_gt, ignore_index, 1.0 if is_real else 0.0)
         return _PlainBCE.apply(pred, gt)

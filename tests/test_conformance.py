@@ -144,7 +144,8 @@ def test_task_templates_and_sseg_hooks_match_the_reference():
     assert r["model"].pspnet().__name__ == P.sseg.model.pspnet().__name__
     assert r["criterion"].sseg_criterion().__name__ == P.sseg.criterion.sseg_criterion().__name__
     rf, of = _flags(r["model"].add_parser_arguments), _flags(P.sseg.model.add_parser_arguments)
-    assert all(of[k] == v for k, v in rf.items()) and set(of) - set(rf) == {"engine_dtype"}     # the one added flag
+    assert all(of[k] == v for k, v in rf.items()) and set(of) - set(rf) == {"engine_dtype", "pretrained_backbone"}
+    # the two added flags: the engine's arithmetic, and where the backbone weights come from (the reference always downloads)
 
 
 @needs_reference

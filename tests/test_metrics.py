@@ -10,6 +10,8 @@ import argparse
 import os
 import sys
 
+from collections import OrderedDict
+
 import numpy as np
 import pytest
 import torch
@@ -193,11 +195,21 @@ def test_validate_suponly_and_mt_at_mixed_sizes_vs_oracle():
     assert torch.equal(core.state_dict()["backbone.bn1.running_mean"], before)           # eval mode: statistics untouched
     assert len(core._eval_plans) <= core.max_eval_plans and len(core._plans) == 0        # bounded, untuned inference plans
     assert all(pl.inference and not pl.pack_dgrad for pl in core._eval_plans.values())
+    # the forward-only plans of all image sizes read ONE packed copy of the weights (a new size allocates activations only)
+    assert len({pl.packed.data_ptr() for pl in core._eval_plans.values()}) == 1
     # training afterwards still works and uses a training plan
     algo.model.train()
     x, gt = TO.synthetic_batch(2, 65, 2, seed=5, block=16)
     loss, _ = algo.train_step((x.to(DEV),), (gt.to(DEV),))
     assert torch.isfinite(loss) and len(core._plans) == 1
+    # ... and the next validation sees the UPDATED weights through the shared copy (sizes whose plans are still cached included)
+    st2 = OrderedDict((k, v.detach().cpu().clone()) for k, v in core.state_dict().items())
+    short2 = _Loader(loader[-3:])
+    algo.validate(short2, 1)
+    torch.cuda.synchronize()
+    want2, _ = oracle(st2, short2)
+    got2 = algo.meters["task_confusion_matrix"].sum
+    assert got2.sum() == want2.sum() and np.abs(got2 - want2).sum() / 2 <= 5e-4 * want2.sum()
 
     # ---- Mean Teacher: student and teacher metrics + the validation consistency loss
     args = _args(labeled_batch_size=1, unlabeled_batch_size=1, ignore_unlabeled=False)
