@@ -260,6 +260,12 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
     torch.cuda.set_device(pdist.local_device())
     pdist.init_from_env("nccl")
+    # experiment switch: k streams created (and used once) before anything else shifts which hardware queue every later
+    # stream of the process lands on (HIP deals streams onto GPU_MAX_HW_QUEUES = 4 queues; streams that share one serialize)
+    _dummies = [torch.cuda.Stream() for _ in range(int(os.environ.get("PXL_DUMMY_STREAMS", "0")))]
+    for _s in _dummies:
+        with torch.cuda.stream(_s):
+            torch.zeros(1, device="cuda")
     dev = pdist.local_device()
 
     args = make_args(a, world)

@@ -617,6 +617,18 @@ int pxl_comm_allreduce_sum(pxl_comm* comm, float* buf, long n, void* stream);
 int pxl_comm_allreduce_hook(void* user, float* buf, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Hardware-queue-aware stream placement (csrc/streams.hip): the reference leaves concurrency to   */
+/* nn.DataParallel's threads; this engine overlaps ROLES on HIP streams, and two streams overlap   */
+/* only if they sit on different hardware queues -- the pool hands out streams proven to do so.    */
+/* ------------------------------------------------------------------------------------------ */
+#define PXL_STREAM_SIDE 0     /* a second network next to the main stream: MT teacher, GCT r model, AdvSSL discriminator update */
+#define PXL_STREAM_WGRAD 1    /* weight gradients next to the data-gradient chain */
+#define PXL_STREAM_AUX 2      /* weight packing, gradient-bucket exchange, a third chain */
+int pxl_stream_pool_init(void* main_stream, int* nqueues);      /* idempotent; PXL_STREAM_POOL=0 disables placement */
+void* pxl_stream_role(int role);                                /* NULL: placement off / not initialised / single queue */
+int pxl_stream_pool_probes(void);
+
+/* ------------------------------------------------------------------------------------------ */
 /* One-shot all-reduce of small vectors over peer-mapped buffers (csrc/peer.hip): what replaces   */
 /* the per-BatchNorm master/slave exchange of sync_batchnorm/comm.py:59-137 for N > 1.            */
 /* ------------------------------------------------------------------------------------------ */

@@ -168,6 +168,9 @@ SIGNATURES = {
     "pxl_comm_destroy": (None, [_P]),
     "pxl_comm_allreduce_sum": (_I, [_P, _P, _L, _P]),
     "pxl_comm_allreduce_hook": (_I, [_P, _P, _I, _P]),
+    "pxl_stream_pool_init": (_I, [_P, C.POINTER(_I)]),
+    "pxl_stream_role": (_P, [_I]),
+    "pxl_stream_pool_probes": (_I, []),
     "pxl_peer_create": (_I, [_I, _I, _I, _I, C.POINTER(_P)]),
     "pxl_peer_handle": (_I, [_P, _P]),
     "pxl_peer_open": (_I, [_P, _P]),

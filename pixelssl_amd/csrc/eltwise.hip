@@ -58,7 +58,13 @@ __device__ __forceinline__ void block_bn_finalize(const pxl_bn_fin& f, int C, in
 // Per-channel-affine element-wise kernels: column-group blocks (common.h: col_geom), the channel chunk is FIXED
 // per thread so the coefficients are loaded once into registers, two rows in flight per thread.  FIN: the BN finalize
 // of the operand(s) is folded into the prologue (yfin / rfin) instead of reading ready-made coefficients.
-template <typename T, bool FIN>
+// FIN kernels: request the first rows before the finalize prologue?  (PXL_ELT_PREFETCH; measured per workload)
+static bool elt_prefetch() {
+  static const bool on = [] { const char* e = getenv("PXL_ELT_PREFETCH"); return e != nullptr && e[0] == '1'; }();
+  return on;
+}
+
+template <typename T, bool FIN, int PFN = 0>
 __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T* __restrict__ y,
                                                            const float* __restrict__ ycoef,
                                                            const T* __restrict__ res,
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T
   const int m_end = min(M, m_begin + rows_per_group);
   const size_t col = (size_t)cc * EPC, step = (size_t)g.rl * C;
   int m = m_begin + rlane;
-  constexpr int PF = FIN ? 4 : 0;
+  constexpr int PF = FIN ? PFN : 0;
   uint4 pa[PF > 0 ? PF : 1], pb[PF > 0 ? PF : 1];
   if constexpr (FIN) {
 #pragma unroll
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T
 }
 
 // z = relu?(y*scale + shift): the activated tensor the LDS-DMA convolutions (conv_dma.hip, wgrad) read directly
-template <typename T, bool FIN>
+template <typename T, bool FIN, int PFN = 0>
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(int M, int C, const T* __restrict__ y,
                                                            const float* __restrict__ coef, int relu,
                                                            T* __restrict__ z, int rows_per_group, int cgmax,
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(int M, int C, const T
   const size_t col = (size_t)cc * EPC, step = (size_t)g.rl * C;
   int m = m_begin + rlane;
   // FIN: first rows requested before the finalize prologue (see residual_fwd_kernel)
-  constexpr int PF = FIN ? 4 : 0;
+  constexpr int PF = FIN ? PFN : 0;
   uint4 pa[PF > 0 ? PF : 1];
   if constexpr (FIN) {
 #pragma unroll
@@ -427,10 +433,10 @@ extern "C" int pxl_residual_finalize_fwd(int dtype, long M, int C, const void* y
   const dim3 grid(g.ncg, cdiv((int)M, rpg));
   const pxl_bn_fin rf = rfin ? *rfin : pxl_bn_fin{};
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL((residual_fwd_kernel<float, true>), grid, dim3(256), 0, s, (int)M, C, cp<float>(y), nullptr,
+    hipLaunchKernelGGL((elt_prefetch() ? residual_fwd_kernel<float, true, 4> : residual_fwd_kernel<float, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<float>(y), nullptr,
                        cp<float>(res), nullptr, mp<float>(out), rpg, cgmax, *yfin, rf, rfin ? 1 : 0);
   else
-    hipLaunchKernelGGL((residual_fwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, (int)M, C, cp<bf16_t>(y), nullptr,
+    hipLaunchKernelGGL((elt_prefetch() ? residual_fwd_kernel<bf16_t, true, 4> : residual_fwd_kernel<bf16_t, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<bf16_t>(y), nullptr,
                        cp<bf16_t>(res), nullptr, mp<bf16_t>(out), rpg, cgmax, *yfin, rf, rfin ? 1 : 0);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
@@ -470,10 +476,10 @@ extern "C" int pxl_bn_finalize_apply_fwd(int dtype, long M, int C, const void* y
   const int rpg = rows_per_group((int)M, g, pxl_tune_get(3));
   const dim3 grid(g.ncg, cdiv((int)M, rpg));
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL((bn_apply_fwd_kernel<float, true>), grid, dim3(256), 0, s, (int)M, C, cp<float>(y), nullptr, relu,
+    hipLaunchKernelGGL((elt_prefetch() ? bn_apply_fwd_kernel<float, true, 4> : bn_apply_fwd_kernel<float, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<float>(y), nullptr, relu,
                        mp<float>(z), rpg, cgmax, *fin);
   else
-    hipLaunchKernelGGL((bn_apply_fwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, (int)M, C, cp<bf16_t>(y), nullptr, relu,
+    hipLaunchKernelGGL((elt_prefetch() ? bn_apply_fwd_kernel<bf16_t, true, 4> : bn_apply_fwd_kernel<bf16_t, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<bf16_t>(y), nullptr, relu,
                        mp<bf16_t>(z), rpg, cgmax, *fin);
   PXL_LAUNCH_CHECK();
   return PXL_OK;

@@ -156,6 +156,7 @@ struct pxl_net {
   int in_chans[4] = {0, 0, 0, 0};
   int fork_every = getenv("PXL_FORK_EVERY") ? atoi(getenv("PXL_FORK_EVERY")) : 1;   // convolutions per fork event (>= 1)
   hipStream_t side = nullptr;
+  bool side_owned = true;       // false: the placement pool's weight-gradient stream (csrc/streams.hip)
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
   int use_side = -1;
@@ -167,6 +168,7 @@ struct pxl_net {
   long grad_bucket = 0;            // floats per bucket
   long grad_total = 0;             // floats in the flat gradient buffer
   hipStream_t comm_stream = nullptr;
+  bool comm_owned = true;
   hipEvent_t comm_main_ev = nullptr, comm_side_ev = nullptr, comm_done_ev = nullptr;
   std::vector<long> op_lo;         // per op: lowest flat offset (floats) its backward writes a gradient to, or -1
   bool bucket_ok = false;          // parameter offsets grow with the op index: suffixes of the op list = suffixes of the buffer
@@ -333,9 +335,9 @@ extern "C" void pxl_net_destroy(pxl_net* net) {
   for (auto e : net->pool) (void)hipEventDestroy(e);
   for (auto e : net->fork_ev) if (e) (void)hipEventDestroy(e);
   if (net->join_ev) (void)hipEventDestroy(net->join_ev);
-  if (net->side) (void)hipStreamDestroy(net->side);
+  if (net->side && net->side_owned) (void)hipStreamDestroy(net->side);
   for (hipEvent_t e : {net->comm_main_ev, net->comm_side_ev, net->comm_done_ev}) if (e) (void)hipEventDestroy(e);
-  if (net->comm_stream) (void)hipStreamDestroy(net->comm_stream);
+  if (net->comm_stream && net->comm_owned) (void)hipStreamDestroy(net->comm_stream);
   delete net;
 }
 
@@ -777,6 +779,25 @@ float time_launch(F&& fn, hipStream_t s, hipEvent_t a, hipEvent_t b, int reps) {
 }
 }  // namespace
 
+namespace {
+pxl_bn_fin make_fin(const pxl_net* n, const BnInfo& b, const float* params, float* running, void* arena, int training) {
+  pxl_bn_fin f;
+  f.stats = fat(arena, b.stats_off);
+  f.nrep = b.fin_nrep;
+  f.count = (float)b.M * n->world;
+  f.gamma = params + b.d.gamma_off;
+  f.beta = params + b.d.beta_off;
+  f.running_mean = running ? running + b.d.rmean_off : nullptr;
+  f.running_var = running ? running + b.d.rvar_off : nullptr;
+  f.momentum = b.d.momentum;
+  f.eps = b.d.eps;
+  f.training = training;
+  f.clamp_var = (n->world > 1 || n->force_clamp) ? 1 : 0;
+  f.coef = fat(arena, b.coef_off);
+  return f;
+}
+}  // namespace
+
 // "Measure, don't guess": time every tile configuration of every contraction on the planned shapes and
 // keep the fastest.  Results do not depend on the choice (same per-element reduction order for
 // forward/dgrad; wgrad differs only in fp32 atomic order).  Clobbers arena/scratch/grads contents.
@@ -815,15 +836,30 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
     {
       int best_cfg = -1; float best = 1e30f;
       const bool dma = pxl_conv_dma_eligible(&op.fwd, sc, nullptr) != 0;
+      const bool onload = dma && d.bn_in0 >= 0 && n->bns[d.bn_in0].onload && getenv("PXL_TUNE_ONLOAD_PLAIN") == nullptr;
       for (int cfg = dma ? 8 : 0; cfg < (dma ? 28 : 8); ++cfg) {
         if (!dma && (cfg & 3) == 3 && tout.Cp > 64) continue;
         if (dma && cfg >= 12 && cfg < 16) continue;          // 4-stage rings never won on the ResNet shapes
         if (dma && cfg >= 20 && tout.Cp < 128) continue;     // tall tiles are 128 channels wide
         if (dma && !allowed(cfg)) continue;
         pxl_conv_desc q = op.fwd; q.tile_cfg = cfg;
-        float t = time_launch([&]() { return pxl_conv_igemm(&q, cin.ptr, at(packed, op.wf_off), at(arena, tout.off),
-                                                            sc, sh, bias, nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr,
-                                                            op.ws_bytes, stream); }, s, a, b, reps);
+        float t;
+        if (onload) {
+          // the launch the forward pass will make: BatchNorm finalize + apply on load (its K loop carries the transform, so the
+          // best tile is not the plain kernel's); statistics of the zeroed arena, running statistics left alone
+          BnInfo& bi = n->bns[d.bn_in0];
+          bi.fin_nrep = STATS_REP;
+          const pxl_bn_fin bin = make_fin(n, bi, params, nullptr, arena, 1);
+          int rc1 = PXL_OK;
+          t = time_launch([&]() { rc1 = pxl_conv_dma_bnin(&q, at(arena, tin.off), at(packed, op.wf_off), at(arena, tout.off), bias,
+                                                          stats, &bin, bi.relu, n->pack_dgrad ? at(arena, bi.z_off) : nullptr, stream);
+                                  return rc1; }, s, a, b, reps);
+          if (t < 0 && rc1 == PXL_ERR_UNSUPPORTED) continue;        // this tile + the coefficient table do not fit
+        } else {
+          t = time_launch([&]() { return pxl_conv_igemm(&q, cin.ptr, at(packed, op.wf_off), at(arena, tout.off),
+                                                        sc, sh, bias, nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr,
+                                                        op.ws_bytes, stream); }, s, a, b, reps);
+        }
         if (t < 0) { rc_all = PXL_ERR_HIP; continue; }
         if (t < best) { best = t; best_cfg = cfg; }
       }
@@ -870,24 +906,6 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
   return PXL_OK;
 }
 
-namespace {
-pxl_bn_fin make_fin(const pxl_net* n, const BnInfo& b, const float* params, float* running, void* arena, int training) {
-  pxl_bn_fin f;
-  f.stats = fat(arena, b.stats_off);
-  f.nrep = b.fin_nrep;
-  f.count = (float)b.M * n->world;
-  f.gamma = params + b.d.gamma_off;
-  f.beta = params + b.d.beta_off;
-  f.running_mean = running ? running + b.d.rmean_off : nullptr;
-  f.running_var = running ? running + b.d.rvar_off : nullptr;
-  f.momentum = b.d.momentum;
-  f.eps = b.d.eps;
-  f.training = training;
-  f.clamp_var = (n->world > 1 || n->force_clamp) ? 1 : 0;
-  f.coef = fat(arena, b.coef_off);
-  return f;
-}
-}  // namespace
 
 extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* packed, float* running,
                                const float* x, float* logits, float* prob, void* arena, size_t arena_bytes,
@@ -1318,7 +1336,17 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
       // 18.9 -> 34.4 ms, GCT 45.7 -> 56.2 ms (bisected, gpurun_out/r02_22)
       int lo = 0, hi = 0;
       const char* pe = getenv("PXL_SIDE_PRIO");
-      if (pe != nullptr && pe[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+      // the process-wide weight-gradient stream of the placement pool (csrc/streams.hip): a hardware queue of its own,
+      // shared by every plan -- a stream created here would land on whatever queue the creation order gives it
+      hipStream_t placed = reinterpret_cast<hipStream_t>(pxl_stream_role(PXL_STREAM_WGRAD));
+      // a network whose passes run on the SIDE stream (GCT's r model, the AdvSSL discriminator) sends its weight gradients to
+      // the AUX queue: the two networks' backward passes may overlap, their weight gradients then do too
+      if (placed != nullptr && s == reinterpret_cast<hipStream_t>(pxl_stream_role(PXL_STREAM_SIDE)))
+        placed = reinterpret_cast<hipStream_t>(pxl_stream_role(PXL_STREAM_AUX));
+      if (placed != nullptr && placed != s) {
+        n->side = placed;
+        n->side_owned = false;
+      } else if (pe != nullptr && pe[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
         PXL_CHECK_HIP(hipStreamCreateWithPriority(&n->side, hipStreamNonBlocking, lo));
       else
         PXL_CHECK_HIP(hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
@@ -1333,7 +1361,13 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
   long grad_hi = n->grad_total;
   n->grad_buckets_last = 0;
   if (bucketing && !n->comm_stream) {
-    PXL_CHECK_HIP(hipStreamCreateWithFlags(&n->comm_stream, hipStreamNonBlocking));
+    hipStream_t placed = reinterpret_cast<hipStream_t>(pxl_stream_role(PXL_STREAM_AUX));
+    if (placed != nullptr && placed != s) {
+      n->comm_stream = placed;
+      n->comm_owned = false;
+    } else {
+      PXL_CHECK_HIP(hipStreamCreateWithFlags(&n->comm_stream, hipStreamNonBlocking));
+    }
     PXL_CHECK_HIP(hipEventCreateWithFlags(&n->comm_main_ev, hipEventDisableTiming));
     PXL_CHECK_HIP(hipEventCreateWithFlags(&n->comm_side_ev, hipEventDisableTiming));
     PXL_CHECK_HIP(hipEventCreateWithFlags(&n->comm_done_ev, hipEventDisableTiming));

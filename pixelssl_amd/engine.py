@@ -529,7 +529,8 @@ class SegNetCore(nn.Module):
     def _pack_stream(self):
         if not hasattr(self, "_pk_stream"):
             on = os.environ.get("PXL_PACK_STREAM", "1") != "0" and self._device.type == "cuda"
-            object.__setattr__(self, "_pk_stream", torch.cuda.Stream(device=self._device) if on else None)
+            from . import streams
+            object.__setattr__(self, "_pk_stream", streams.role_stream(streams.AUX, device=self._device) if on else None)
         return self._pk_stream
 
     def set_sync(self, callback, world_size):

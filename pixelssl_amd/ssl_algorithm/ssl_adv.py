@@ -13,7 +13,7 @@ from ..nn import func
 from ..nn.lrer import PolynomialLR
 from ..nn.optimizer import FusedAdam
 from ..nn.module import patch_replication_callback
-from .. import _lib, dist as pdist
+from .. import _lib, dist as pdist, streams
 from .._lib import check, lib, ptr, stream_ptr
 from ..engine import FCDiscriminatorCore
 from . import ssl_base
@@ -167,7 +167,7 @@ class SSLADV(ssl_base._SSLBase):
     def _side_stream(self):
         if not hasattr(self, '_d_stream'):
             on = os.environ.get('PXL_ADV_STREAMS', '1') != '0' and torch.cuda.is_available()
-            self._d_stream = torch.cuda.Stream() if on else None
+            self._d_stream = streams.role_stream(streams.SIDE) if on else None
         return self._d_stream
 
     def train_step(self, inp, gt):

@@ -27,7 +27,7 @@ from ..nn import func
 from ..nn.module import patch_replication_callback
 from ..functional import MSELoss
 from ..engine import AuxDecoderCore
-from .. import _lib
+from .. import _lib, streams
 from .. import dist as pdist
 from .._lib import check, lib, ptr, stream_ptr
 from . import ssl_base
@@ -362,7 +362,8 @@ class WrappedCCTModel(nn.Module):
     def _lanes(self, device):
         if not hasattr(self, '_lane_streams'):
             n = int(os.environ.get('PXL_CCT_STREAMS', '2')) if device.type == 'cuda' else 0
-            self._lane_streams = [torch.cuda.Stream(device=device) for _ in range(max(n, 0))]
+            # decoder lanes: dealt over the queues that are not the main stream's (AUX first: the labeled pass holds SIDE)
+            self._lane_streams = [streams.role_stream(streams.AUX, device=device, index=i) for i in range(max(n, 0))]
         return self._lane_streams
 
     def forward(self, inp, gt, is_unlabeled):
@@ -485,7 +486,7 @@ class SSLCCT(ssl_base._SSLBase):
     def _labeled_stream(self):
         if not hasattr(self, '_l_stream'):
             on = os.environ.get('PXL_CCT_SPLIT_BACKWARD', '1') != '0' and torch.cuda.is_available()
-            self._l_stream = torch.cuda.Stream() if on else None
+            self._l_stream = streams.role_stream(streams.SIDE) if on else None
         return self._l_stream
 
     def train_step(self, inp, gt, cur_step, total_rampup_steps):

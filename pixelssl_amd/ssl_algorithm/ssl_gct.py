@@ -18,7 +18,7 @@ import scipy.ndimage
 import torch
 import torch.nn as nn
 
-from .. import _lib
+from .. import _lib, streams
 from .._lib import check, lib, ptr, stream_ptr
 
 MODE_GCT, MODE_DC, MODE_FC = 'gct', 'dc', 'fc'
@@ -341,7 +341,7 @@ def _define_sslgct():
         def _side_stream(self):
             if not hasattr(self, '_r_stream'):
                 on = os.environ.get('PXL_GCT_STREAMS', '1') != '0' and torch.cuda.is_available()
-                self._r_stream = torch.cuda.Stream() if on else None
+                self._r_stream = streams.role_stream(streams.SIDE) if on else None
             return self._r_stream
 
         def _task_model_iter(self, mid, lbs, inp, gt, dc_gt, fc_mask, dc_rampup_scale, resulter=None):

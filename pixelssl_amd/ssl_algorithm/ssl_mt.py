@@ -10,7 +10,7 @@ from ..utils import REGRESSION, CLASSIFICATION, logger, cmd, tool
 from ..nn import func
 from ..nn.module import patch_replication_callback, GaussianNoiseLayer
 from ..functional import MSELoss
-from .. import ops
+from .. import ops, streams
 from . import ssl_base
 
 
@@ -71,7 +71,10 @@ class SSLMT(ssl_base._SSLBase):
             # PXL_TEACHER_PRIO=-1: high priority (the student waits for the teacher's logits before the consistency loss;
             # in the traces the teacher pass ends 0.5 ms after the student's when both have the same priority)
             prio = int(os.environ.get('PXL_TEACHER_PRIO', '0'))
-            self._t_stream = torch.cuda.Stream(priority=prio) if on else None
+            if prio != 0:
+                self._t_stream = torch.cuda.Stream(priority=prio) if on else None
+            else:           # the placement pool's stream for a second network: a hardware queue that is not the main stream's
+                self._t_stream = streams.role_stream(streams.SIDE) if on else None
         return self._t_stream
 
     def train_step(self, inp, gt, cur_step, total_rampup_steps):

@@ -31,6 +31,13 @@ def one_step(db_path, out_txt=None, marker="sgd_kernel", per_step=2, header=""):
     db = sqlite3.connect(db_path)
     rows = list(db.execute("select name, start, end, stream_id, queue_id from kernels order by start"))
     marks = [i for i, r in enumerate(rows) if marker in r[0]]
+    # marker launches per step: MT / SupOnly have two (one per lr group); algorithms with several optimizers (AdvSSL, GCT, CCT)
+    # have more -- derive it from the step count of the traced command line (--steps A --warmup B in the header)
+    m = re.search(r"--steps (\d+) --warmup (\d+)", header or "")
+    if m:
+        nsteps = int(m.group(1)) + int(m.group(2))
+        if nsteps > 0 and len(marks) % nsteps == 0 and len(marks) >= nsteps:
+            per_step = len(marks) // nsteps
     ends = marks[per_step - 1::per_step]
     a, b = ends[-3], ends[-2]
     win = rows[a + 1:b + 1]
