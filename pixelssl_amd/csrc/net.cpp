@@ -157,6 +157,9 @@ struct pxl_net {
   int fork_every = getenv("PXL_FORK_EVERY") ? atoi(getenv("PXL_FORK_EVERY")) : 1;   // convolutions per fork event (>= 1)
   hipStream_t side = nullptr;
   bool side_owned = true;       // false: the placement pool's weight-gradient stream (csrc/streams.hip)
+  hipStream_t side2 = nullptr;  // PXL_WGRAD_STREAMS=2: every other fork goes to a second placed stream (never owned)
+  hipEvent_t join_ev2 = nullptr;
+  int fork_count = 0;
   std::vector<hipEvent_t> fork_ev;
   hipEvent_t join_ev = nullptr;
   int use_side = -1;
@@ -335,6 +338,7 @@ extern "C" void pxl_net_destroy(pxl_net* net) {
   for (auto e : net->pool) (void)hipEventDestroy(e);
   for (auto e : net->fork_ev) if (e) (void)hipEventDestroy(e);
   if (net->join_ev) (void)hipEventDestroy(net->join_ev);
+  if (net->join_ev2) (void)hipEventDestroy(net->join_ev2);
   if (net->side && net->side_owned) (void)hipStreamDestroy(net->side);
   for (hipEvent_t e : {net->comm_main_ev, net->comm_side_ev, net->comm_done_ev}) if (e) (void)hipEventDestroy(e);
   if (net->comm_stream && net->comm_owned) (void)hipStreamDestroy(net->comm_stream);
@@ -1352,9 +1356,20 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
         PXL_CHECK_HIP(hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
       PXL_CHECK_HIP(hipEventCreateWithFlags(&n->join_ev, hipEventDisableTiming));
       n->fork_ev.assign(n->ops.size(), nullptr);
+      // a second weight-gradient stream: the SIDE queue is idle while a network that runs on the main stream goes backward
+      // (the MT teacher has finished), and weight gradients of different convolutions are independent
+      const char* w2 = getenv("PXL_WGRAD_STREAMS");
+      if (w2 != nullptr && w2[0] == '2' && !n->side_owned) {
+        hipStream_t cand = reinterpret_cast<hipStream_t>(pxl_stream_role(PXL_STREAM_SIDE));
+        if (cand == s) cand = reinterpret_cast<hipStream_t>(pxl_stream_role(PXL_STREAM_WGRAD));
+        if (cand != nullptr && cand != s && cand != n->side) {
+          n->side2 = cand;
+          PXL_CHECK_HIP(hipEventCreateWithFlags(&n->join_ev2, hipEventDisableTiming));
+        }
+      }
     }
   }
-  bool forked = false;
+  bool forked = false, forked2 = false;
   // ---- overlapped gradient exchange (multi-rank): flush [lo, hi) of the flat gradient buffer once every kernel writing
   // into it has been issued -- the communication stream waits for the main and the weight-gradient stream at that point
   const bool bucketing = n->grad_sync && n->grad_world > 1 && n->wgrad_on && n->grad_total > 0;
@@ -1401,9 +1416,9 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
     if (n->use_side) {                                     // fork: every queued dy is final on the main stream from here on
       if (!n->fork_ev[at_op]) PXL_CHECK_HIP(hipEventCreateWithFlags(&n->fork_ev[at_op], hipEventDisableTiming));
       PXL_CHECK_HIP(hipEventRecord(n->fork_ev[at_op], s));
-      PXL_CHECK_HIP(hipStreamWaitEvent(n->side, n->fork_ev[at_op], 0));
-      ws = n->side;
-      forked = true;
+      ws = (n->side2 != nullptr && !bucketing && (n->fork_count++ & 1)) ? n->side2 : n->side;
+      PXL_CHECK_HIP(hipStreamWaitEvent(ws, n->fork_ev[at_op], 0));
+      if (ws == n->side2) forked2 = true; else forked = true;
     }
     for (int k : pending_w) {
       OpInfo& opk = n->ops[k];
@@ -1672,6 +1687,10 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
   if (forked) {                                  // join: every weight gradient is complete before the caller goes on
     PXL_CHECK_HIP(hipEventRecord(n->join_ev, n->side));
     PXL_CHECK_HIP(hipStreamWaitEvent(s, n->join_ev, 0));
+  }
+  if (forked2) {
+    PXL_CHECK_HIP(hipEventRecord(n->join_ev2, n->side2));
+    PXL_CHECK_HIP(hipStreamWaitEvent(s, n->join_ev2, 0));
   }
   return PXL_OK;
 }
