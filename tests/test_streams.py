@@ -19,20 +19,29 @@ for s in extra:
 n = streams.init()
 roles = [streams.role_stream(r) for r in (streams.SIDE, streams.WGRAD, streams.AUX)]
 main = torch.cuda.current_stream()
+bufs = {}
+for st in [main] + roles:                       # one buffer per stream, touched once: the probe itself must not allocate
+    with torch.cuda.stream(st):
+        bufs[st.cuda_stream] = torch.zeros(8, device="cuda")
+        bufs[st.cuda_stream].add_(1)
+torch.cuda.synchronize()
 def overlaps(a, b):
-    # a spinning kernel on a, a tiny one on b: did the tiny one finish while a was still busy?
-    torch.cuda.synchronize()
-    ea, eb = torch.cuda.Event(), torch.cuda.Event()
-    with torch.cuda.stream(a):
-        torch.cuda._sleep(int(2.0e9 * 2e-3))          # ~2 ms
-        ea.record()
-    with torch.cuda.stream(b):
-        x = torch.zeros(8, device="cuda")
-        eb.record()
-    eb.synchronize()
-    free = not ea.query()
-    torch.cuda.synchronize()
-    return free
+    # a spinning kernel on a, a tiny one on b: did the tiny one finish while a was still busy?  (best of two tries)
+    for _ in range(2):
+        torch.cuda.synchronize()
+        ea, eb = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(int(2.0e9 * 5e-3))          # ~5 ms
+            ea.record()
+        with torch.cuda.stream(b):
+            bufs[b.cuda_stream].add_(1)
+            eb.record()
+        eb.synchronize()
+        free = not ea.query()
+        torch.cuda.synchronize()
+        if free:
+            return True
+    return False
 pairs = [(main, r) for r in roles] + [(roles[i], roles[j]) for i in range(3) for j in range(i + 1, 3)]
 print("RESULT", n, sum(int(overlaps(a, b)) for a, b in pairs), len(pairs), len({r.cuda_stream for r in roles}))
 """
