@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--cpu-warmup", type=int, default=3)
     p.add_argument("--cpu-budget-s", type=float, default=45.0, help="the CPU legs stop adding timed steps past this budget")
     p.add_argument("--no-miou", action="store_true")
+    p.add_argument("--no-seq-leg", action="store_true", help="skip the one-kernel-at-a-time roofline leg (stream overlap off, per-launch events)")
     p.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32_parity_mode leg (the engine mode that meets the 1e-3 parity bar)")
     p.add_argument("--fp32-steps", type=int, default=5)
     return p.parse_args()
@@ -209,6 +210,57 @@ def make_step(a, args, algo, batches):
             return algo.train_step(inp, gt, it, 5 * args.iters_per_epoch)[0]
         return algo.train_step(inp, gt)[0]
     return one_step
+
+
+def sequential_leg(a, world, batches, fence):
+    """Kernel quality without co-runners: the same workload on a second instance of the algorithm with every stream overlap
+    switched off (teacher, weight gradients, packing all on the main stream), per-launch HIP events around every contraction
+    launch -> TFLOP/s of the dominant kernel family when each launch has the GPU to itself.  The headline `roofline` figures
+    come from the overlapped step (two or three kernels share the CUs, so a launch's event pair also spans its co-runner);
+    this leg says what the kernels themselves reach."""
+    import torch
+    switches = ("PXL_TEACHER_STREAM", "PXL_SIDE_STREAM", "PXL_PACK_STREAM", "PXL_GCT_STREAMS", "PXL_ADV_STREAMS",
+                "PXL_CCT_STREAMS", "PXL_CCT_SPLIT_BACKWARD")
+    saved = {k: os.environ.get(k) for k in switches}
+    for k in switches:
+        os.environ[k] = "0"
+    try:
+        args = make_args(a, world)
+        algo, cores = build_algo(a, args)
+        step = make_step(a, args, algo, batches)
+        for it in range(2):
+            step(it)
+        for c in cores:
+            c.profile(True)
+        fence()
+        t0 = time.perf_counter()
+        n_steps = min(a.steps, 5)
+        for it in range(2, 2 + n_steps):
+            step(it)
+        fence()
+        dt = time.perf_counter() - t0
+        res = {}
+        for kind, name in ((0, "conv_dma/conv_igemm (fwd+dgrad)"), (1, "conv_wgrad_dma/conv_wgrad")):
+            ms = n = fl = 0.0
+            for c in cores:
+                m_, n_, f_ = c.profile_read(kind)
+                ms, n, fl = ms + m_, n + n_, fl + f_
+            if n:
+                res[name] = {"launches": int(n), "avg_us": round(1e3 * ms / n, 3), "total_ms_per_step": round(ms / n_steps, 3),
+                             "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                             "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[a.dtype], 4)}
+        for c in cores:
+            c.profile(False)
+        del algo, cores
+        torch.cuda.empty_cache()
+        return {"ms_per_step_with_kernel_events": round(1e3 * dt / n_steps, 3), "steps": n_steps, "kernels": res,
+                "note": "every stream overlap switched off: one kernel at a time, per-launch HIP events = the kernels' own durations"}
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def fp32_parity_leg(a, world, batches, fence):
@@ -383,12 +435,20 @@ def main():
         if world == 1 and not a.no_miou and a.algo in ("mt", "suponly") and a.size == 513:
             out["miou_vs_ref"] = miou_vs_oracle(cores[0], a)
     do_fp32 = a.dtype == "bf16" and not a.no_fp32_leg and world == 1      # (scaling runs stay the headline workload only)
-    if do_fp32:
+    do_seq = world == 1 and not a.no_kernel_events and not a.no_seq_leg
+    if do_fp32 or do_seq:
         del algo, one_step
         cores = None
         torch.cuda.empty_cache()
+    seq = sequential_leg(a, world, batches, fence) if do_seq else None
+    if do_fp32:
         leg = fp32_parity_leg(a, world, batches, fence)
     if rank == 0:
+        if seq is not None and "roofline" in out:
+            dom = out["roofline"]["kernel"]
+            out["roofline"]["one_kernel_at_a_time"] = dict(seq["kernels"].get(dom, {}), ms_per_step_with_kernel_events=seq["ms_per_step_with_kernel_events"],
+                                                           note=seq["note"])
+            out["kernels_one_at_a_time"] = seq["kernels"]
         if do_fp32:
             out["fp32_parity_mode"] = leg
         if world == 1 and not a.no_cpu_baseline:
