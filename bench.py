@@ -352,6 +352,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
+    pdist.check_peers()          # a peer-mapped statistics exchange that timed out would have produced invalid sums: fail loudly
 
     # ---- roofline leg: the SAME K steps once more with a HIP event pair around every contraction launch (recorded on
     # the launch stream).  Kept out of the timed region: ~850 event records per step cost ~13 % of the step time.

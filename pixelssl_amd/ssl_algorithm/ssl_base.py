@@ -31,6 +31,10 @@ class _SSLBase:
 
     def train(self, data_loader, epoch):
         self._train(data_loader, epoch)
+        # multi-rank: an epoch whose peer-mapped Sync-BN exchanges timed out trained on invalid statistics -- fail here, loudly
+        # (one device synchronisation per epoch; no-op on one rank)
+        from .. import dist as pdist
+        pdist.check_peers()
 
     def validate(self, data_loader, epoch):
         self._validate(data_loader, epoch)
