@@ -119,18 +119,30 @@ __global__ __launch_bounds__(256) void pack_t_batched_kernel(const float* __rest
   }
 }
 
-// x NCHW fp32 [B][C][H][W] -> NHWC [B][H][W][Cp] (zero padded channels)
+// x NCHW fp32 [B][C][H][W] (the channels optionally gathered from up to 4 tensors: concatenation along C on load, no torch.cat
+// copy) -> NHWC [B][H][W][Cp] (zero padded channels).  One thread per (pixel, 16-byte channel chunk), pixel fastest: a wave
+// reads 64 consecutive pixels of one channel plane per load (unit stride) and writes one 16-byte chunk per lane.  (The first
+// version ran one thread per PIXEL over all Cp channels: fine for the 3-channel image, 246 us for CCT's 512-channel latent
+// -- 17 blocks of 2-byte stores -- and 274 us for GCT's 24-channel flaw-detector input.)
+struct NchwParts { const float* src[4]; int chans[4]; int n; };
 template <typename T>
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C,
-                                    int H, int W, int Cp) {
-  const long total = (long)B * H * W;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long hw = i % ((long)H * W);
-    const long b = i / ((long)H * W);
-    for (int c = 0; c < Cp; ++c) {
-      const float v = c < C ? x[(b * C + c) * (long)H * W + hw] : 0.f;
-      y[i * Cp + c] = from_f<T>(v);
+__global__ __launch_bounds__(256) void nchw_parts_to_nhwc_kernel(const NchwParts ps, T* __restrict__ y, int B, long HW, int Cp) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int nch = Cp / EPC;
+  const long total = (long)B * HW * nch;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const long p = i % HW;
+    const long r = i / HW;
+    const int chunk = (int)(r % nch);
+    const long b = r / nch;
+    float v[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      int c = chunk * EPC + e, k = 0;
+      while (k < ps.n && c >= ps.chans[k]) { c -= ps.chans[k]; ++k; }
+      v[e] = k < ps.n ? ps.src[k][(b * ps.chans[k] + c) * HW + p] : 0.f;
     }
+    *reinterpret_cast<uint4*>(y + (b * HW + p) * Cp + chunk * EPC) = Chunk<T>::pack(v);
   }
 }
 
@@ -179,57 +191,30 @@ __global__ __launch_bounds__(256) void stem_patches_kernel(const float* __restri
 // flight -- were measured at 365-400 us against 134-146 us for this direct one, both networks running it at once; the
 // direct form stays.)
 
-// the same with the channels gathered from up to 4 NCHW tensors (concatenation along C on load: no torch.cat copy)
-struct NchwParts { const float* src[4]; int chans[4]; int n; };
-template <typename T>
-__global__ void nchw_parts_to_nhwc_kernel(const NchwParts ps, T* __restrict__ y, int B, int H, int W, int Cp) {
-  const long HW = (long)H * W, total = (long)B * HW;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long hw = i % HW, b = i / HW;
-    int c = 0;
-    for (int k = 0; k < ps.n; ++k)
-      for (int cc = 0; cc < ps.chans[k]; ++cc, ++c) y[i * Cp + c] = from_f<T>(ps.src[k][(b * ps.chans[k] + cc) * HW + hw]);
-    for (; c < Cp; ++c) y[i * Cp + c] = from_f<T>(0.f);
-  }
-}
-// NHWC gradient -> one NCHW fp32 tensor per part (NULL = that part needs none), 32 x 32 tiles through LDS
+// NHWC [B][H][W][Cp] (first C channels) -> NCHW fp32, one tensor per part (NULL = that part is not wanted).  One thread per
+// (pixel, 16-byte chunk), pixel fastest: every lane reads its chunk with one 16-byte load and the wave writes 64 consecutive
+// pixels of each channel plane (unit stride).
 struct NchwOutParts { float* dst[4]; int chans[4]; int n; };
 template <typename T>
-__global__ void nhwc_to_nchw_parts_kernel(const T* __restrict__ x, const NchwOutParts ps, int C, int HW, int Cp) {
-  __shared__ float tile[32][33];
-  const int b = blockIdx.z;
-  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int r = ty; r < 32; r += 8) {
-    const int p = p0 + r, c = c0 + tx;
-    tile[r][tx] = (p < HW && c < C) ? to_f(x[((long)b * HW + p) * Cp + c]) : 0.f;
-  }
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    int c = c0 + r;
-    const int p = p0 + tx;
-    if (c >= C || p >= HW) continue;
-    int k = 0;
-    while (k < ps.n && c >= ps.chans[k]) { c -= ps.chans[k]; ++k; }
-    if (k < ps.n && ps.dst[k] != nullptr) ps.dst[k][((long)b * ps.chans[k] + c) * HW + p] = tile[tx][r];
-  }
-}
-
-// NHWC [B][H][W][Cp] (first C channels) -> NCHW fp32, tiled through LDS (32 pixels x 32 channels)
-template <typename T>
-__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int C, int HW, int Cp) {
-  __shared__ float tile[32][33];
-  const int b = blockIdx.z;
-  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
-  for (int r = ty; r < 32; r += 8) {
-    const int p = p0 + r, c = c0 + tx;
-    tile[r][tx] = (p < HW && c < C) ? to_f(x[((long)b * HW + p) * Cp + c]) : 0.f;
-  }
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int c = c0 + r, p = p0 + tx;
-    if (c < C && p < HW) y[((long)b * C + c) * HW + p] = tile[tx][r];
+__global__ __launch_bounds__(256) void nhwc_to_nchw_parts_kernel(const T* __restrict__ x, const NchwOutParts ps, int B, int C, long HW,
+                                                                 int Cp) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int nch = (C + EPC - 1) / EPC;
+  const long total = (long)B * HW * nch;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const long p = i % HW;
+    const long r = i / HW;
+    const int chunk = (int)(r % nch);
+    const long b = r / nch;
+    float v[EPC];
+    Chunk<T>::unpack(*reinterpret_cast<const uint4*>(x + (b * HW + p) * Cp + chunk * EPC), v);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      int c = chunk * EPC + e, k = 0;
+      if (c >= C) break;
+      while (k < ps.n && c >= ps.chans[k]) { c -= ps.chans[k]; ++k; }
+      if (k < ps.n && ps.dst[k] != nullptr) ps.dst[k][(b * ps.chans[k] + c) * HW + p] = v[e];
+    }
   }
 }
 
@@ -317,19 +302,47 @@ extern "C" int pxl_pack_weights_batched(int dtype, const float* params, void* pa
   return PXL_OK;
 }
 
-extern "C" int pxl_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W, int Cp,
-                                void* stream) {
-  PXL_REQUIRE(x && y && Cp >= C, "nchw_to_nhwc: bad argument");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const long total = (long)B * H * W;
+namespace {
+int launch_to_nhwc(int dtype, const NchwParts& ps, void* y, int B, int H, int W, int Cp, hipStream_t s, const char* who) {
+  const long HW = (long)H * W;
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  if (Cp % epc != 0) return pxl_set_error(PXL_ERR_ARG, "%s: channel pitch %d is not a multiple of %d (16-byte chunks)", who, Cp, epc);
+  const long total = (long)B * HW * (Cp / epc);
+  const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, x, (float*)y, B, C, H, W, Cp);
+    hipLaunchKernelGGL(nchw_parts_to_nhwc_kernel<float>, dim3(grid), dim3(256), 0, s, ps, (float*)y, B, HW, Cp);
   else if (dtype == PXL_BF16)
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, x, (bf16_t*)y, B, C, H, W, Cp);
+    hipLaunchKernelGGL(nchw_parts_to_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, ps, (bf16_t*)y, B, HW, Cp);
   else
-    return pxl_set_error(PXL_ERR_ARG, "nchw_to_nhwc: bad dtype %d", dtype);
+    return pxl_set_error(PXL_ERR_ARG, "%s: bad dtype %d", who, dtype);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
+}
+int launch_to_nchw(int dtype, const void* x, const NchwOutParts& ps, int B, int C, int H, int W, int Cp, hipStream_t s,
+                   const char* who) {
+  const long HW = (long)H * W;
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  if (Cp % epc != 0) return pxl_set_error(PXL_ERR_ARG, "%s: channel pitch %d is not a multiple of %d (16-byte chunks)", who, Cp, epc);
+  const long total = (long)B * HW * ((C + epc - 1) / epc);
+  const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_parts_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ps, B, C, HW, Cp);
+  else if (dtype == PXL_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_parts_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ps, B, C, HW, Cp);
+  else
+    return pxl_set_error(PXL_ERR_ARG, "%s: bad dtype %d", who, dtype);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+}  // namespace
+
+extern "C" int pxl_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W, int Cp,
+                                void* stream) {
+  PXL_REQUIRE(x && y && Cp >= C && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad argument");
+  NchwParts ps;
+  ps.n = 1;
+  for (int k = 0; k < 4; ++k) { ps.src[k] = k == 0 ? x : nullptr; ps.chans[k] = k == 0 ? C : 0; }
+  return launch_to_nhwc(dtype, ps, y, B, H, W, Cp, reinterpret_cast<hipStream_t>(stream), "nchw_to_nhwc");
 }
 
 extern "C" int pxl_stem_patches(int dtype, const float* x, void* P, int B, int C, int H, int W, int kh, int kw, int stride,
@@ -353,7 +366,7 @@ extern "C" int pxl_stem_patches(int dtype, const float* x, void* P, int B, int C
 
 extern "C" int pxl_nchw_parts_to_nhwc(int dtype, int nparts, const float* const* srcs, const int* chans, void* y, int B,
                                      int H, int W, int Cp, void* stream) {
-  PXL_REQUIRE(srcs && chans && y && nparts >= 1 && nparts <= 4, "nchw_parts_to_nhwc: bad argument");
+  PXL_REQUIRE(srcs && chans && y && nparts >= 1 && nparts <= 4 && B > 0 && H > 0 && W > 0, "nchw_parts_to_nhwc: bad argument");
   NchwParts ps;
   ps.n = nparts;
   int C = 0;
@@ -363,21 +376,12 @@ extern "C" int pxl_nchw_parts_to_nhwc(int dtype, int nparts, const float* const*
     if (k < nparts) { PXL_REQUIRE(srcs[k] && chans[k] > 0, "nchw_parts_to_nhwc: empty part %d", k); C += chans[k]; }
   }
   PXL_REQUIRE(Cp >= C, "nchw_parts_to_nhwc: %d channels do not fit the pitch %d", C, Cp);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const long total = (long)B * H * W;
-  if (dtype == PXL_F32)
-    hipLaunchKernelGGL(nchw_parts_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, ps, (float*)y, B, H, W, Cp);
-  else if (dtype == PXL_BF16)
-    hipLaunchKernelGGL(nchw_parts_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, ps, (bf16_t*)y, B, H, W, Cp);
-  else
-    return pxl_set_error(PXL_ERR_ARG, "nchw_parts_to_nhwc: bad dtype %d", dtype);
-  PXL_LAUNCH_CHECK();
-  return PXL_OK;
+  return launch_to_nhwc(dtype, ps, y, B, H, W, Cp, reinterpret_cast<hipStream_t>(stream), "nchw_parts_to_nhwc");
 }
 
 extern "C" int pxl_nhwc_to_nchw_parts(int dtype, const void* x, int nparts, float* const* dsts, const int* chans, int B,
                                       int H, int W, int Cp, void* stream) {
-  PXL_REQUIRE(x && dsts && chans && nparts >= 1 && nparts <= 4, "nhwc_to_nchw_parts: bad argument");
+  PXL_REQUIRE(x && dsts && chans && nparts >= 1 && nparts <= 4 && B > 0 && H > 0 && W > 0, "nhwc_to_nchw_parts: bad argument");
   NchwOutParts ps;
   ps.n = nparts;
   int C = 0;
@@ -387,33 +391,16 @@ extern "C" int pxl_nhwc_to_nchw_parts(int dtype, const void* x, int nparts, floa
     if (k < nparts) { PXL_REQUIRE(chans[k] > 0, "nhwc_to_nchw_parts: empty part %d", k); C += chans[k]; }
   }
   PXL_REQUIRE(Cp >= C, "nhwc_to_nchw_parts: %d channels exceed the pitch %d", C, Cp);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int HW = H * W;
-  dim3 grid(cdiv(HW, 32), cdiv(C, 32), B);
-  if (dtype == PXL_F32)
-    hipLaunchKernelGGL(nhwc_to_nchw_parts_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ps, C, HW, Cp);
-  else if (dtype == PXL_BF16)
-    hipLaunchKernelGGL(nhwc_to_nchw_parts_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ps, C, HW, Cp);
-  else
-    return pxl_set_error(PXL_ERR_ARG, "nhwc_to_nchw_parts: bad dtype %d", dtype);
-  PXL_LAUNCH_CHECK();
-  return PXL_OK;
+  return launch_to_nchw(dtype, x, ps, B, C, H, W, Cp, reinterpret_cast<hipStream_t>(stream), "nhwc_to_nchw_parts");
 }
 
 extern "C" int pxl_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H, int W, int Cp,
                                 void* stream) {
-  PXL_REQUIRE(x && y && Cp >= C, "nhwc_to_nchw: bad argument");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int HW = H * W;
-  dim3 grid(cdiv(HW, 32), cdiv(C, 32), B);
-  if (dtype == PXL_F32)
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, (const float*)x, y, C, HW, Cp);
-  else if (dtype == PXL_BF16)
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, y, C, HW, Cp);
-  else
-    return pxl_set_error(PXL_ERR_ARG, "nhwc_to_nchw: bad dtype %d", dtype);
-  PXL_LAUNCH_CHECK();
-  return PXL_OK;
+  PXL_REQUIRE(x && y && Cp >= C && B > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad argument");
+  NchwOutParts ps;
+  ps.n = 1;
+  for (int k = 0; k < 4; ++k) { ps.dst[k] = k == 0 ? y : nullptr; ps.chans[k] = k == 0 ? C : 0; }
+  return launch_to_nchw(dtype, x, ps, B, C, H, W, Cp, reinterpret_cast<hipStream_t>(stream), "nhwc_to_nchw");
 }
 
 namespace {

@@ -835,3 +835,41 @@ def test_batched_pack_equals_per_tensor_pack(dtype):
                          Kp=it.Kp)
     torch.cuda.synchronize()
     assert torch.equal(packed, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, (3,), 8, 37, 41), (2, (3, 21), 32, 65, 65), (4, (512,), 512, 33, 33), (1, (21,), 32, 129, 129),
+                                   (2, (5, 1, 7, 2), 32, 9, 11)])
+def test_layout_kernels_chunk_per_thread(shape, dtype):
+    """NCHW (one tensor, or up to four concatenated along C on load) <-> NHWC with a channel pitch, against torch's permute: the
+    image (3 -> 8), GCT's flaw-detector input (3 + 21 -> 32), CCT's 512-channel latent, a head (21 -> 32), four ragged parts.
+    Bit-exact in both directions (bf16: round-to-nearest-even like torch's cast; padded channels are zero)."""
+    import ctypes
+    from pixelssl_amd import _lib
+    h = _lib.lib()
+    B, chans, Cp, H, W = shape
+    g = torch.Generator().manual_seed(sum(chans) + H)
+    parts = [torch.randn(B, c, H, W, generator=g).to(DEV) for c in chans]
+    C = sum(chans)
+    y = torch.full((B, H, W, Cp), 7.0, device=DEV, dtype=dtype)
+    srcs = (ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+    cs = (ctypes.c_int * len(parts))(*chans)
+    code = _lib.dtype_code(dtype)
+    _lib.check(h.pxl_nchw_parts_to_nhwc(code, len(parts), srcs, cs, y.data_ptr(), B, H, W, Cp, _lib.stream_ptr()))
+    want = torch.zeros(B, H, W, Cp, device=DEV, dtype=dtype)
+    want[..., :C] = torch.cat(parts, 1).permute(0, 2, 3, 1).to(dtype)
+    assert torch.equal(y, want)
+    if len(parts) == 1:
+        assert torch.equal(_ops().nchw_to_nhwc(dtype, parts[0], Cp), want)
+    # and back: one NCHW fp32 tensor per part (the second part, when there is one, is not wanted -> untouched)
+    outs = [torch.full((B, c, H, W), -3.0, device=DEV) for c in chans]
+    dsts = (ctypes.c_void_p * len(parts))(*[None if (k == 1 and len(parts) > 1) else o.data_ptr() for k, o in enumerate(outs)])
+    _lib.check(h.pxl_nhwc_to_nchw_parts(code, y.data_ptr(), len(parts), dsts, cs, B, H, W, Cp, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    for k, (o, p) in enumerate(zip(outs, parts)):
+        if k == 1 and len(parts) > 1:
+            assert bool((o == -3.0).all())
+        else:
+            assert torch.equal(o, p.to(dtype).float())
+    if len(parts) == 1:
+        assert torch.equal(_ops().nhwc_to_nchw(y, C), parts[0].to(dtype).float())
