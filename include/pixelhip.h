@@ -297,7 +297,8 @@ int pxl_fg_mask_nearest(int B, int C, int H, int W, const float* pred, int h, in
 int pxl_chan_mean(int B, int C, long HW, const float* x, float* att, void* stream);
 int pxl_fdrop_mask(int B, long HW, const float* att, float u, float* mask, void* stream);
 /* out[b] = scale * x[b] / (||x[b]||_2 + 1e-8)   (_l2_normalize, ssl_cct.py:577-581; scale = eps gives r_adv) */
-int pxl_l2_normalize_persample(int B, long n, const float* x, float scale, float* out, void* stream);
+int pxl_l2_normalize_persample(int B, long n, const float* x, float scale, float* norm2 /* B floats of scratch */, float* out,
+                               void* stream);
 /* out = (a - b) * scale: d KL(softmax(pred_hat) || pred) / d pred_hat with scale = 1/B (batchmean) */
 int pxl_sub_scale(long n, const float* a, const float* b, float scale, float* out, void* stream);
 /* HOST routine (no GPU): what G-Cutout's cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) + the `> 50 points`

@@ -118,7 +118,7 @@ SIGNATURES = {
     "pxl_fg_mask_nearest": (_I, [_I, _I, _I, _I, _P, _I, _I, _I, _P, _P]),
     "pxl_chan_mean": (_I, [_I, _I, _L, _P, _P, _P]),
     "pxl_fdrop_mask": (_I, [_I, _L, _P, _F, _P, _P]),
-    "pxl_l2_normalize_persample": (_I, [_I, _L, _P, _F, _P, _P]),
+    "pxl_l2_normalize_persample": (_I, [_I, _L, _P, _F, _P, _P, _P]),
     "pxl_sub_scale": (_I, [_L, _P, _P, _F, _P, _P]),
     "pxl_external_contour_boxes_host": (_I, [_P, _I, _I, _I, _P, _I, C.POINTER(_I)]),
     "pxl_upsample_softmax_fwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),

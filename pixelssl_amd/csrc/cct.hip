@@ -73,17 +73,27 @@ __global__ __launch_bounds__(256) void fdrop_mask_kernel(int HW, const float* __
   for (int p = threadIdx.x; p < HW; p += 256) mask[(size_t)blockIdx.x * HW + p] = a[p] < thr ? 1.f : 0.f;
 }
 
-// one block per sample: out[b] = scale * x[b] / (||x[b]||_2 + 1e-8)
-__global__ __launch_bounds__(256) void l2_normalize_kernel(long n, const float* __restrict__ x, float scale, float* __restrict__ out) {
+// out[b] = scale * x[b] / (||x[b]||_2 + 1e-8) in two passes over many blocks: squared-norm partials -> norm2[b] (fp32
+// atomics, caller-provided, zeroed here), then the scaling.  (One block per sample took 552 us for I-VAT's 4 x 512 x 33 x 33
+// direction: 4 blocks on 256 CUs.)
+__global__ __launch_bounds__(256) void l2_zero_kernel(int B, float* __restrict__ norm2) {
+  if (threadIdx.x < B) norm2[threadIdx.x] = 0.f;
+}
+__global__ __launch_bounds__(256) void l2_norm2_kernel(long n, const float* __restrict__ x, float* __restrict__ norm2) {
   __shared__ float red[4];
-  const float* a = x + (size_t)blockIdx.x * n;
+  const float* a = x + (size_t)blockIdx.y * n;
   float s = 0.f;
-  for (long i = threadIdx.x; i < n; i += 256) s += a[i] * a[i];
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) s += a[i] * a[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  const float inv = scale / (sqrtf(red[0] + red[1] + red[2] + red[3]) + 1e-8f);
-  for (long i = threadIdx.x; i < n; i += 256) out[(size_t)blockIdx.x * n + i] = a[i] * inv;
+  if (threadIdx.x == 0) atomicAdd(norm2 + blockIdx.y, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void l2_scale_kernel(long n, const float* __restrict__ x, const float* __restrict__ norm2, float scale,
+                                                       float* __restrict__ out) {
+  const float inv = scale / (sqrtf(norm2[blockIdx.y]) + 1e-8f);
+  const size_t base = (size_t)blockIdx.y * n;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) out[base + i] = x[base + i] * inv;
 }
 
 __global__ __launch_bounds__(256) void sub_scale_kernel(long n, const float* __restrict__ a, const float* __restrict__ b, float s,
@@ -127,10 +137,14 @@ extern "C" int pxl_fdrop_mask(int B, long HW, const float* att, float u, float* 
   return PXL_OK;
 }
 
-extern "C" int pxl_l2_normalize_persample(int B, long n, const float* x, float scale, float* out, void* stream) {
-  PXL_REQUIRE(x && out && B > 0 && n > 0, "l2_normalize_persample: bad argument");
+extern "C" int pxl_l2_normalize_persample(int B, long n, const float* x, float scale, float* norm2, float* out, void* stream) {
+  PXL_REQUIRE(x && out && norm2 && B > 0 && B <= 256 && n > 0, "l2_normalize_persample: bad argument (1 <= B <= 256, norm2 = B floats of scratch)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  l2_normalize_kernel<<<B, 256, 0, s>>>(n, x, scale, out);
+  int gx = (int)((n + 256 * 8 - 1) / (256 * 8));
+  if (gx > 512) gx = 512;
+  l2_zero_kernel<<<1, 256, 0, s>>>(B, norm2);
+  l2_norm2_kernel<<<dim3(gx, B), 256, 0, s>>>(n, x, norm2);
+  l2_scale_kernel<<<dim3(gx, B), 256, 0, s>>>(n, x, norm2, scale, out);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

@@ -122,7 +122,8 @@ def l2_normalize(d, scale=1.0):
     """scale * d / (||d_b||_2 + 1e-8) per sample (ssl_cct.py:577-581)"""
     d = _f32(d)
     out = torch.empty_like(d)
-    check(lib().pxl_l2_normalize_persample(d.shape[0], d[0].numel(), ptr(d), float(scale), ptr(out), stream_ptr()))
+    norm2 = torch.empty(d.shape[0], device=d.device, dtype=torch.float32)
+    check(lib().pxl_l2_normalize_persample(d.shape[0], d[0].numel(), ptr(d), float(scale), ptr(norm2), ptr(out), stream_ptr()))
     return out
 
 

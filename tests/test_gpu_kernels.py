@@ -873,3 +873,22 @@ def test_layout_kernels_chunk_per_thread(shape, dtype):
             assert torch.equal(o, p.to(dtype).float())
     if len(parts) == 1:
         assert torch.equal(_ops().nhwc_to_nchw(y, C), parts[0].to(dtype).float())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C,Cp", [(8 * 256 * 256, 64, 64), (4 * 264 * 264, 84, 96), (8 * 33 * 33, 21, 32), (5, 512, 512),
+                                    (2 * 17 * 17, 1, 8), (301, 2048, 2048)])
+def test_colsum_chunked(M, C, Cp, dtype):
+    """Bias gradients: out[c] += sum_m x[m][c] over 16-byte chunks, row lanes folded through LDS, one atomic per channel and block
+    -- the flaw detector's 64-channel rows, a decoder's 84 of 96, a head's 21 of 32, a pooled map of 5 rows, one channel, 2048."""
+    import ctypes
+    from pixelssl_amd import _lib
+    g = torch.Generator().manual_seed(M % 997 + C)
+    x = torch.randn(M, Cp, generator=g).to(DEV).to(dtype)
+    out = torch.full((Cp,), 0.5, device=DEV)
+    _lib.check(_lib.lib().pxl_colsum(_lib.dtype_code(dtype), M, Cp, C, x.data_ptr(), out.data_ptr(), _lib.stream_ptr()))
+    want = x.double().sum(0).cpu()
+    got = out.double().cpu()
+    scale = x.double().abs().sum(0).cpu().clamp_min(1.0)
+    assert float(((got[:C] - 0.5 - want[:C]).abs() / scale[:C]).max()) < 2e-6       # fp32 accumulation of M terms, accumulated onto `out`
+    assert bool((got[C:] == 0.5).all())                                             # padded channels are not touched

@@ -59,6 +59,8 @@ def test_argument_errors_are_reported_not_crashed():
     assert h.pxl_conv_dgrad_joinreduce(d2, 1, 1, 1, None, None, 1, 1, 1, None) == -1                         # no join output
     assert h.pxl_conv_dgrad_joinreduce(d2, 1, 1, 1, None, 1, 1, 1, 1, None) == -3 and b"not eligible" in h.pxl_last_error()
     assert h.pxl_confusion_matrix(0, 21, 100, None, None, None, None) == -1
+    assert h.pxl_colsum(1, 100, 20, 20, None, None, None) == -1          # (null pointers are caught before the pitch)
+    assert h.pxl_l2_normalize_persample(4, 100, None, 1.0, None, None, None) == -1 and b"scratch" in h.pxl_last_error()
     assert h.pxl_absdiff_chansum_dense(1, 21, 100, None, 1, 1.0, 1, None) == -1
 
 
