@@ -130,7 +130,14 @@ __global__ void minmax_kernel(long HW, const float* __restrict__ x, float* __res
   }
   hi = wave_max(hi);
   lo = -wave_max(-lo);
-  if ((threadIdx.x & 63) == 0) {
+  // one atomic pair per BLOCK: same-address atomics serialize at ~10 ns each, and with one pair per wave of ~130 blocks per
+  // sample the 16 result words took 74 us to settle
+  __shared__ float rlo[4], rhi[4];
+  if ((threadIdx.x & 63) == 0) { rlo[threadIdx.x >> 6] = lo; rhi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 1; w < nw; ++w) { lo = fminf(lo, rlo[w]); hi = fmaxf(hi, rhi[w]); }
     atomic_minf(mm + 2 * b, lo);
     atomic_maxf(mm + 2 * b + 1, hi);
   }
@@ -297,7 +304,7 @@ extern "C" int pxl_minmax_norm_persample(int B, long HW, const float* x, float c
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(minmax_init_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, B, mm);
   const int gx = (int)((HW + 256 * 8 - 1) / (256 * 8));
-  hipLaunchKernelGGL(minmax_kernel, dim3(gx, B), dim3(256), 0, s, HW, x, mm);
+  hipLaunchKernelGGL(minmax_kernel, dim3(gx > 32 ? 32 : gx, B), dim3(256), 0, s, HW, x, mm);
   hipLaunchKernelGGL(minmax_norm_kernel, dim3(gx, B), dim3(256), 0, s, HW, x, mm, clip_threshold, out);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
@@ -308,7 +315,7 @@ extern "C" int pxl_gaussian_noise_apply(int B, long n, float* x, const float* no
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(minmax_init_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, B, mm);
   const int gx = (int)((n + 256 * 8 - 1) / (256 * 8));
-  hipLaunchKernelGGL(minmax_kernel, dim3(gx, B), dim3(256), 0, s, n, x, mm);
+  hipLaunchKernelGGL(minmax_kernel, dim3(gx > 32 ? 32 : gx, B), dim3(256), 0, s, n, x, mm);
   hipLaunchKernelGGL(gaussian_noise_kernel, dim3(gx, B), dim3(256), 0, s, n, x, noise, mm);
   PXL_LAUNCH_CHECK();
   return PXL_OK;

@@ -43,13 +43,26 @@ __global__ __launch_bounds__(256) void upsample_softmax_fwd_kernel(int B, int h,
   const T* p01 = low + ((size_t)(b * h + y0) * w + x1) * Cp;
   const T* p10 = low + ((size_t)(b * h + y1) * w + x0) * Cp;
   const T* p11 = low + ((size_t)(b * h + y1) * w + x1) * Cp;
+  // the four corner vectors as 16-byte chunks (the pitch is a multiple of the chunk): 4 x ceil(C / EPC) loads per pixel instead
+  // of 4 x C element loads -- at the 264 -> 513 resize of CCT's decoders neighbouring pixels share almost no corner, and the
+  // element loads made this kernel 4 x slower than its writes
+  constexpr int EPC = Elem<T>::EPC;
   float v[MAXC];
   float mx = -INFINITY;
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    if (c < C) {
-      v[c] = w00 * to_f(p00[c]) + w01 * to_f(p01[c]) + w10 * to_f(p10[c]) + w11 * to_f(p11[c]);
-      mx = fmaxf(mx, v[c]);
+  for (int q = 0; q < MAXC / EPC; ++q) {
+    if (q * EPC < C) {
+      float a[EPC], bq[EPC], cq[EPC], d[EPC];
+      Chunk<T>::unpack(*reinterpret_cast<const uint4*>(p00 + q * EPC), a);
+      Chunk<T>::unpack(*reinterpret_cast<const uint4*>(p01 + q * EPC), bq);
+      Chunk<T>::unpack(*reinterpret_cast<const uint4*>(p10 + q * EPC), cq);
+      Chunk<T>::unpack(*reinterpret_cast<const uint4*>(p11 + q * EPC), d);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const int c = q * EPC + e;
+        v[c] = w00 * a[e] + w01 * bq[e] + w10 * cq[e] + w11 * d[e];
+        if (c < C) mx = fmaxf(mx, v[c]);
+      }
     }
   }
   const size_t plane = (size_t)H * W;
@@ -538,6 +551,10 @@ extern "C" int pxl_upsample_softmax_fwd(int dtype, int B, int h, int w, int Cp, 
   PXL_REQUIRE(low && logits, "upsample_softmax_fwd: null argument");
   PXL_REQUIRE(C >= 1 && C <= MAXC && C <= Cp, "upsample_softmax_fwd: C=%d unsupported (max %d)", C, MAXC);
   PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "upsample_softmax_fwd: bad dtype");
+  {
+    const int epc = dtype == PXL_F32 ? 4 : 8;             // the corner vectors are read as 16-byte chunks
+    PXL_REQUIRE(Cp % epc == 0 && (C + epc - 1) / epc * epc <= Cp, "upsample_softmax_fwd: pitch %d does not hold whole 16-byte chunks of %d channels", Cp, C);
+  }
   const int align = align_corners ? 1 : 0;
   const float sy = align ? (H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f) : (float)h / (float)H;
   const float sx = align ? (W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f) : (float)w / (float)W;
