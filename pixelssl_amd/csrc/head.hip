@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void upsample_softmax_fwd_kernel(int B, int h,
 
 // pass 1 (one block per full-res row): G = dlogits + softmax_bwd(dprob, prob) ; reduce along x onto
 // the w low-res columns:  tmp[b][y][x0][c] = sum_x wx(x,x0) * G[b][c][y][x]
-__global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(int C, int H, int W, int w, float sx, int align,
+__global__ __launch_bounds__(320) void upsample_bwd_rows_kernel(int C, int H, int W, int w, float sx, int align,
                                                                 const float* __restrict__ dlogits,
                                                                 const float* __restrict__ dprob,
                                                                 const float* __restrict__ prob,
@@ -592,7 +592,9 @@ extern "C" int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t smem = (size_t)C * (W + 1) * sizeof(float) + (size_t)W * 3 * sizeof(float);
   PXL_REQUIRE(smem <= 64 * 1024, "upsample_softmax_bwd: row too wide for LDS staging (W=%d)", W);
-  hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(H, B), dim3(256), smem, s, C, H, W, w, sx, align, dlogits, dprob,
+  // threads per row: W = 513 in two even passes (320 + 193) instead of 256 + 256 + 1
+  const int rows_threads = (W > 256 && W <= 640) ? 320 : 256;
+  hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(H, B), dim3(rows_threads), smem, s, C, H, W, w, sx, align, dlogits, dprob,
                      prob, (float*)workspace);
   PXL_LAUNCH_CHECK();
   const long total = (long)B * h * w * Cp;
