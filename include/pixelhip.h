@@ -221,7 +221,10 @@ int pxl_bn_bwd_apply(int dtype, int M, int C, const void* dz, const void* y, con
  * [all-reduce bn (2*nb floats) for Sync-BN] -> coef -> apply.  Backward: bwd_reduce -> fold (+ dgamma/dbeta from the
  * LOCAL sums) -> [all-reduce] -> bwd_apply.  sums / bsums: [B][2][C] fp32, bn: [2*nb], coef: [B][4][C]. */
 int pxl_ibn_stats(int dtype, int B, int HW, int C, const void* y, float* sums, void* stream);
+/* the same onto CALLER-ZEROED sums (the executor zeroes the sums of all IBNorm layers of a pass with one memset) */
+int pxl_ibn_stats_acc(int dtype, int B, int HW, int C, const void* y, float* sums, void* stream);
 int pxl_ibn_fold(int B, int C, int nb, const float* sums, float* bn, float* dgamma, float* dbeta, void* stream);
+/* bn = the folded (and, multi-rank, all-reduced) batch sums of the BN half; NULL: folded from `sums` inside the kernel */
 int pxl_ibn_coef(int B, int C, int nb, int HW, float count_bn, const float* sums, const float* bn, const float* gamma,
                  const float* beta, float* running_mean, float* running_var, float momentum, float eps, int training,
                  int clamp_var, float* coef, void* stream);
@@ -229,6 +232,8 @@ int pxl_ibn_apply_fwd(int dtype, int B, int HW, int C, const void* y, const floa
                       void* stream);
 int pxl_ibn_bwd_reduce(int dtype, int B, int HW, int C, const void* dout, const void* y, const float* coef, float slope,
                        float* bsums, void* stream);
+int pxl_ibn_bwd_reduce_acc(int dtype, int B, int HW, int C, const void* dout, const void* y, const float* coef, float slope,
+                           float* bsums, void* stream);       /* onto caller-zeroed sums */
 int pxl_ibn_bwd_apply(int dtype, int B, int HW, int C, int nb, const void* dout, const void* y, const float* coef,
                       const float* bsums, const float* bn, float count_bn, int training, float slope, void* dy,
                       void* stream);

@@ -93,10 +93,12 @@ SIGNATURES = {
     "pxl_bn_param_grad": (_I, [_I, _P, _P, _P, _P]),
     "pxl_bn_bwd_apply_fused": (_I, [_I, _I, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P]),
     "pxl_ibn_stats": (_I, [_I, _I, _I, _I, _P, _P, _P]),
+    "pxl_ibn_stats_acc": (_I, [_I, _I, _I, _I, _P, _P, _P]),
     "pxl_ibn_fold": (_I, [_I, _I, _I, _P, _P, _P, _P, _P]),
     "pxl_ibn_coef": (_I, [_I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P]),
     "pxl_ibn_apply_fwd": (_I, [_I, _I, _I, _I, _P, _P, _F, _P, _P]),
     "pxl_ibn_bwd_reduce": (_I, [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P]),
+    "pxl_ibn_bwd_reduce_acc": (_I, [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P]),
     "pxl_ibn_bwd_apply": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _I, _F, _P, _P]),
     "pxl_residual_fwd": (_I, [_I, _L, _I, _P, _P, _P, _P, _P, _P]),
     "pxl_leaky_fwd": (_I, [_I, _L, _P, _F, _P, _P]),

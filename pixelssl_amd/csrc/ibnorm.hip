@@ -91,8 +91,14 @@ __global__ void ibn_coef_kernel(int B, int C, int nb, float hw, float count_bn, 
   bool clamp = false;
   if (c < nb) {
     if (training) {
-      mean = bn[c] / count_bn;
-      var = fmaxf(bn[nb + c] / count_bn - mean * mean, 0.f);
+      float s1, s2;
+      if (bn != nullptr) { s1 = bn[c]; s2 = bn[nb + c]; }
+      else {                      // single rank: the fold over the samples (ibn_fold_kernel) in place, same order
+        s1 = s2 = 0.f;
+        for (int q = 0; q < B; ++q) { s1 += sums[((size_t)q * 2) * C + c]; s2 += sums[((size_t)q * 2 + 1) * C + c]; }
+      }
+      mean = s1 / count_bn;
+      var = fmaxf(s2 / count_bn - mean * mean, 0.f);
       if (b == 0 && rmean != nullptr) {
         const float unbiased = count_bn > 1.f ? var * count_bn / (count_bn - 1.f) : var;
         rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
@@ -204,10 +210,18 @@ inline bool ok_dtype(int dtype) { return dtype == PXL_F32 || dtype == PXL_BF16; 
   const dim3 grid(g.ncg, cdiv(HW, rpg), B);                     \
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
+static int ibn_stats_impl(int dtype, int B, int HW, int C, const void* y, float* sums, int zero, void* stream);
 extern "C" int pxl_ibn_stats(int dtype, int B, int HW, int C, const void* y, float* sums, void* stream) {
+  return ibn_stats_impl(dtype, B, HW, C, y, sums, 1, stream);
+}
+// the same onto CALLER-ZEROED sums (the executor zeroes the sums of all IBNorm layers of a pass with one memset)
+extern "C" int pxl_ibn_stats_acc(int dtype, int B, int HW, int C, const void* y, float* sums, void* stream) {
+  return ibn_stats_impl(dtype, B, HW, C, y, sums, 0, stream);
+}
+static int ibn_stats_impl(int dtype, int B, int HW, int C, const void* y, float* sums, int zero, void* stream) {
   PXL_REQUIRE(y && sums && B > 0 && HW > 0 && ok_dtype(dtype), "ibn_stats: bad argument");
   IBN_GEOM(1024)
-  PXL_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)B * 2 * C * sizeof(float), s));
+  if (zero) PXL_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)B * 2 * C * sizeof(float), s));
   if (dtype == PXL_F32)
     hipLaunchKernelGGL((ibn_reduce_kernel<float, 0>), grid, dim3(256), 0, s, HW, C, (const float*)y, nullptr, nullptr, 0.f, sums, rpg);
   else
@@ -227,7 +241,7 @@ extern "C" int pxl_ibn_fold(int B, int C, int nb, const float* sums, float* bn, 
 extern "C" int pxl_ibn_coef(int B, int C, int nb, int HW, float count_bn, const float* sums, const float* bn,
                             const float* gamma, const float* beta, float* rmean, float* rvar, float momentum, float eps,
                             int training, int clamp_var, float* coef, void* stream) {
-  PXL_REQUIRE(sums && bn && gamma && beta && coef && B > 0, "ibn_coef: bad argument");
+  PXL_REQUIRE(sums && gamma && beta && coef && B > 0, "ibn_coef: bad argument");      // bn NULL: batch sums folded from `sums` here
   PXL_REQUIRE(training || (rmean && rvar), "ibn_coef: eval mode needs running statistics");
   hipLaunchKernelGGL(ibn_coef_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), B, C, nb,
                      (float)HW, count_bn, sums, bn, gamma, beta, rmean, rvar, momentum, eps, training, clamp_var, coef);
@@ -247,11 +261,21 @@ extern "C" int pxl_ibn_apply_fwd(int dtype, int B, int HW, int C, const void* y,
   return PXL_OK;
 }
 
+static int ibn_bwd_reduce_impl(int dtype, int B, int HW, int C, const void* dout, const void* y, const float* coef, float slope,
+                               float* bsums, int zero, void* stream);
 extern "C" int pxl_ibn_bwd_reduce(int dtype, int B, int HW, int C, const void* dout, const void* y, const float* coef,
                                   float slope, float* bsums, void* stream) {
+  return ibn_bwd_reduce_impl(dtype, B, HW, C, dout, y, coef, slope, bsums, 1, stream);
+}
+extern "C" int pxl_ibn_bwd_reduce_acc(int dtype, int B, int HW, int C, const void* dout, const void* y, const float* coef,
+                                      float slope, float* bsums, void* stream) {
+  return ibn_bwd_reduce_impl(dtype, B, HW, C, dout, y, coef, slope, bsums, 0, stream);
+}
+static int ibn_bwd_reduce_impl(int dtype, int B, int HW, int C, const void* dout, const void* y, const float* coef, float slope,
+                               float* bsums, int zero, void* stream) {
   PXL_REQUIRE(dout && y && coef && bsums && B > 0 && ok_dtype(dtype), "ibn_bwd_reduce: bad argument");
   IBN_GEOM(1024)
-  PXL_CHECK_HIP(hipMemsetAsync(bsums, 0, (size_t)B * 2 * C * sizeof(float), s));
+  if (zero) PXL_CHECK_HIP(hipMemsetAsync(bsums, 0, (size_t)B * 2 * C * sizeof(float), s));
   if (dtype == PXL_F32)
     hipLaunchKernelGGL((ibn_reduce_kernel<float, 1>), grid, dim3(256), 0, s, HW, C, (const float*)y, (const float*)dout, coef, slope, bsums, rpg);
   else

@@ -134,6 +134,8 @@ struct pxl_net {
   size_t packed_bytes = 0, arena_bytes = 0, scratch_bytes = 0;
   size_t stats_region_off = 0, stats_region_bytes = 0;      // arena: all BN forward sums
   size_t bsum_region_off = 0, bsum_region_bytes = 0;        // scratch: all BN backward sums
+  size_t ibn_region_off = 0, ibn_region_bytes = 0;          // arena: per-sample sums of every IBNorm layer (forward)
+  size_t ibn_bregion_off = 0, ibn_bregion_bytes = 0;        // scratch: the same for the backward pass
   size_t up_ws_off = 0, up_ws_bytes = 0;                    // scratch: upsample backward workspace
   pxl_allreduce_fn sync = nullptr;
   void* sync_user = nullptr;
@@ -518,11 +520,9 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
         const int nb = n->bns[d.bn_out].d.C;
         PXL_REQUIRE(nb >= 1 && nb <= tin.C, "net_plan: IBNorm op %zu: BN half %d of %d channels", i, nb, tin.C);
         plan_tensor(d.out, tin.H, tin.W, tin.C);
-        const size_t per = align_up((size_t)B * 2 * tin.Cp * 4);
-        op.ibn_sums = arena; arena += per;
+        // (ibn_sums / ibn_bsums: one contiguous region per pass, planned after this loop -> one memset instead of one per layer)
         op.ibn_bn = arena; arena += align_up(2 * (size_t)nb * 4);
         op.ibn_coef = arena; arena += align_up((size_t)B * 4 * tin.Cp * 4);
-        op.ibn_bsums = scratch; scratch += per;
         op.ibn_bbn = scratch; scratch += align_up(2 * (size_t)nb * 4);
         break;
       }
@@ -715,6 +715,19 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
       if (lo >= 0) { if (lo <= prev) n->bucket_ok = false; prev = lo; }
     }
   }
+  // per-sample sums of the IBNorm layers: contiguous, zeroed by ONE memset per pass (GCT's flaw detector has seven such
+  // layers and runs four passes per step: 56 memset launches on the critical stream became 8)
+  n->ibn_region_off = arena;
+  n->ibn_bregion_off = scratch;
+  for (auto& op : n->ops) {
+    if (op.d.kind != PXL_OP_IBN) continue;
+    const TensorInfo& tin = n->tensors[op.d.in0];
+    const size_t per = align_up((size_t)B * 2 * tin.Cp * 4);
+    op.ibn_sums = arena; arena += per;
+    op.ibn_bsums = scratch; scratch += per;
+  }
+  n->ibn_region_bytes = arena - n->ibn_region_off;
+  n->ibn_bregion_bytes = scratch - n->ibn_bregion_off;
   n->arena_bytes = arena;
   n->scratch_bytes = scratch;
   n->packed_bytes = packed;
@@ -921,6 +934,8 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (training && n->stats_region_bytes)
     PXL_CHECK_HIP(hipMemsetAsync(at(arena, n->stats_region_off), 0, n->stats_region_bytes, s));
+  if (n->ibn_region_bytes)      // (instance statistics are computed in eval mode too)
+    PXL_CHECK_HIP(hipMemsetAsync(at(arena, n->ibn_region_off), 0, n->ibn_region_bytes, s));
   const int dt = n->dtype;
   for (size_t i = 0; i < n->ops.size(); ++i) {
     OpInfo& op = n->ops[i];
@@ -1080,15 +1095,19 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
         const BnInfo& b = n->bns[d.bn_out];
         const int nb = b.d.C, HW = tin.H * tin.W;
         const int train = training ? 1 : 0;
-        rc = pxl_ibn_stats(dt, n->B, HW, tin.Cp, at(arena, tin.off), fat(arena, op.ibn_sums), stream);
+        rc = pxl_ibn_stats_acc(dt, n->B, HW, tin.Cp, at(arena, tin.off), fat(arena, op.ibn_sums), stream);
         if (rc != PXL_OK) return rc;
-        rc = pxl_ibn_fold(n->B, tin.Cp, nb, fat(arena, op.ibn_sums), fat(arena, op.ibn_bn), nullptr, nullptr, stream);
-        if (rc != PXL_OK) return rc;
-        if (train && n->sync && n->world > 1) {
+        // multi-rank: batch sums of the BN half folded over the samples, exchanged, then the coefficients; one rank: the
+        // coefficient kernel folds them itself (one launch less per layer)
+        const bool exchange = train && n->sync && n->world > 1;
+        if (exchange) {
+          rc = pxl_ibn_fold(n->B, tin.Cp, nb, fat(arena, op.ibn_sums), fat(arena, op.ibn_bn), nullptr, nullptr, stream);
+          if (rc != PXL_OK) return rc;
           rc = n->sync(n->sync_user, fat(arena, op.ibn_bn), 2 * nb, stream);
           if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_forward: SyncBN all-reduce hook failed (%d)", rc);
         }
-        rc = pxl_ibn_coef(n->B, tin.Cp, nb, HW, (float)n->B * HW * n->world, fat(arena, op.ibn_sums), fat(arena, op.ibn_bn),
+        rc = pxl_ibn_coef(n->B, tin.Cp, nb, HW, (float)n->B * HW * n->world, fat(arena, op.ibn_sums),
+                          exchange ? fat(arena, op.ibn_bn) : nullptr,
                           params + b.d.gamma_off, params + b.d.beta_off, running ? running + b.d.rmean_off : nullptr,
                           running ? running + b.d.rvar_off : nullptr, b.d.momentum, b.d.eps, train,
                           (n->world > 1 || n->force_clamp) ? 1 : 0, fat(arena, op.ibn_coef), stream);
@@ -1310,6 +1329,8 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
   const int dt = n->dtype;
   if (n->bsum_region_bytes)
     PXL_CHECK_HIP(hipMemsetAsync(at(scratch, n->bsum_region_off), 0, n->bsum_region_bytes, s));
+  if (n->ibn_bregion_bytes)
+    PXL_CHECK_HIP(hipMemsetAsync(at(scratch, n->ibn_bregion_off), 0, n->ibn_bregion_bytes, s));
   std::vector<char> written(n->tensors.size(), 0);
   std::vector<char> reduced(n->bns.size(), 0);        // BN-backward sums already produced by a fused launch
   // where the gradient of a tensor currently lives: its own buffer, or -- after a fused residual join -- the buffer of
@@ -1518,8 +1539,8 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
         if (written[d.in0]) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net_backward: IBNorm input consumed twice");
         const BnInfo& b = n->bns[d.bn_out];
         const int nb = b.d.C, HW = tin.H * tin.W;
-        rc = pxl_ibn_bwd_reduce(dt, n->B, HW, tin.Cp, at(scratch, tout.goff), at(arena, tin.off), fat(arena, op.ibn_coef),
-                                d.slope, fat(scratch, op.ibn_bsums), stream);
+        rc = pxl_ibn_bwd_reduce_acc(dt, n->B, HW, tin.Cp, at(scratch, tout.goff), at(arena, tin.off), fat(arena, op.ibn_coef),
+                                    d.slope, fat(scratch, op.ibn_bsums), stream);
         if (rc != PXL_OK) return rc;
         // BN half: fold over the samples; affine gradients from the LOCAL sums, batch-mean terms from the all-reduced
         rc = pxl_ibn_fold(n->B, tin.Cp, nb, fat(scratch, op.ibn_bsums), fat(scratch, op.ibn_bbn),
