@@ -25,8 +25,10 @@ def rel(a, b):
 
 
 def close(a, b, rtol, atol=1e-8):
-    """||a - b|| <= rtol * ||b|| + 1e-8 * sqrt(n): the absolute term covers tensors that ARE (numerically) zero -- a BN
-    beta after three tiny updates is ~1e-7, and the order of the fp32 atomics in its gradient moves it by 1e-10"""
+    """||a - b|| <= rtol * ||b|| + atol * sqrt(n): the absolute term covers tensors that ARE (numerically) zero -- a BN beta
+    after three tiny updates is ~1e-6 and its gradient is a cancelling sum over every pixel, which the two paths (and two runs
+    of the same path: fp32 atomics) add up in different orders: measured 2.6e-7 in norm on 256 elements, i.e. 1.6e-8 per
+    element; the fp32 floor is 5e-8 per element"""
     d = (a.double() - b.double()).norm().item()
     return d <= rtol * b.double().norm().item() + atol * (b.numel() ** 0.5)
 
@@ -198,7 +200,7 @@ def test_mt_step_fused_seam_equals_generic_path(dtype, cons_for_labeled, monkeyp
             if "num_batches" in k:
                 continue
             # (bf16: gradients carry bf16 noise, a 1e-6 BN beta moves by 1e-7 between two runs of the SAME path)
-            assert close(results["1"][which][k], v, 2e-5 if dtype == "fp32" else 2e-3, 1e-8 if dtype == "fp32" else 5e-7), \
+            assert close(results["1"][which][k], v, 2e-5 if dtype == "fp32" else 2e-3, 5e-8 if dtype == "fp32" else 5e-7), \
                 (which, k, rel(results["1"][which][k], v))
 
 
