@@ -196,7 +196,13 @@ def test_pspnet_suponly_six_iterations(dtype):
         loss, _ = algo.train_step((x.to(DEV),), (gt.to(DEV),))
         print("pspnet %s iter %d: %.6f (reference %.6f)" % (dtype, i, loss.item(), fx["per_iter"][i]["task_loss"]))
         _check_losses("pspnet suponly", i, {"task_loss": loss.item()}, fx["per_iter"][i], dtype)
-    _check_weights("pspnet suponly " + dtype, core.state_dict(), fx["updates"], dtype)
+    # bf16: PSPNet's six-step distance is larger than DeepLab's (measured 0.53 of the update on conv1 against 0.33; run-to-run
+    # spread of a few hundredths): a 0.80 bar, plus the direction criterion that a no-op fails
+    _check_weights("pspnet suponly " + dtype, core.state_dict(), fx["updates"], dtype, frac=None if dtype == "fp32" else 0.8)
+    _check_update_direction("pspnet suponly " + dtype, core.state_dict(),
+                            TO.condition_state(TO.init_pspnet_state(seed=fx["weight_seed"]), fx["gamma3"]), fx["updates"],
+                            min_cos=0.99 if dtype == "fp32" else 0.7, ratio=(0.97, 1.03) if dtype == "fp32" else (0.8, 1.25))
+    # (bf16, three runs on the MI355X: distance 0.50 ... 0.54, worst cosine 0.85 ... 0.88, norm ratios 0.91 ... 1.06)
 
 
 @pytest.mark.gpu
