@@ -62,8 +62,14 @@ struct DmaArgs {
   void* bin_z;       // optional: the workgroups of output-channel tile 0 also write the activated tile to this tensor (the
                      // weight gradient of this convolution reads it); only for convolutions without a gather (1x1, stride 1)
   unsigned in_bytes, w_bytes;
+  unsigned* trace;   // TRACE kernels (tools/cbench): [workgroup][TRACE_WORDS] cycle stamps of wave 0, else unused
   int taps[64];      // (dy << 16) | (dx & 0xffff)
 };
+
+// timeline probe (tools/cbench.cpp; never on the product path): per workgroup, words 0..63 = s_memtime stamps of wave 0
+// (0 entry, 1 prologue issued, 2 + k = end of K step k (first 56), then loop drained / tile staged / stores done),
+// 64 = number of stamps, 65 = HW_ID, 66 = XCC_ID, 67/68 = s_memrealtime (100 MHz) at entry, 69/70 at exit, 71 = nk
+constexpr int TRACE_WORDS = 72;
 
 constexpr unsigned OOB = 0x80000000u;
 
@@ -173,7 +179,7 @@ template <int I, int N, int STRIDE, int BASE> struct FragLoad {
 // BM x BN output tile (pixels x channels), 4 waves as WM x WN, NST LDS stages, GATHER = taps / padding logic
 // ABL: timing ablations for tools/conv_bench.py (results are garbage): 1 = no DMA in the loop, 2 = no MFMA,
 // 4 = no fragment reads, 8 = no barrier.  0 in every product instantiation.
-template <int BM, int BN, int WM, int WN, int NST, bool GATHER, int ABL = 0, bool BNIN = false>
+template <int BM, int BN, int WM, int WN, int NST, bool GATHER, int ABL = 0, bool BNIN = false, bool TRACE = false>
 __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   constexpr int TMI = BM / WM / 32;          // 32-pixel tiles per wave
   constexpr int TNI = BN / WN / 32;          // 32-channel tiles per wave
@@ -193,6 +199,21 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+
+  unsigned tsv = 0;      // TRACE: lane i = stamp i
+  int tsi = 0;
+  unsigned long long rt0 = 0;
+  auto stamp = [&]() {
+    if constexpr (TRACE) {
+      if (tsi < 64) {
+        const unsigned now = (unsigned)__builtin_readcyclecounter();
+        tsv = lane == tsi ? now : tsv;
+      }
+      ++tsi;
+    }
+  };
+  if constexpr (TRACE) rt0 = wall_clock64();
+  stamp();
 
   const int ntiles = p.tiles_m * p.tiles_n;
   const int tile = xcd_remap(blockIdx.x, ntiles);
@@ -357,6 +378,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
   // retire every scalar (kernel-argument) load the compiler still counts as outstanding: its own
   // `s_waitcnt lgkmcnt(0)` at the first use would otherwise land inside the loop and drain the LDS reads
   __builtin_amdgcn_s_waitcnt(0xc07f);
+  stamp();
   int st_c = 0;               // stage being multiplied
   int st_l = NST - 1;         // stage being filled
   for (int ks = 0; ks < nk_here; ++ks) {
@@ -445,9 +467,11 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
     }
     st_c = st_c + 1 == NST ? 0 : st_c + 1;
     st_l = st_l + 1 == NST ? 0 : st_l + 1;
+    if constexpr (TRACE) { if (ks < 56) stamp(); }
   }
   wait_vmcnt<0>();                 // the tail DMAs (tiles past nk) must not land in the staging area
   __builtin_amdgcn_s_barrier();
+  stamp();
 
   if constexpr (ABL & 16) return;
   if (p.ws != nullptr) {
@@ -483,6 +507,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
       }
     }
   __syncthreads();
+  stamp();
 
   // ---- epilogue 2: coalesced read-back, bias / addend / statistics, 16-byte stores
   const int ec = tid % TPR;                  // 8-channel chunk of this thread
@@ -632,6 +657,23 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const DmaArgs p) {
       }
     }
   }
+  if constexpr (TRACE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile's stores have been performed
+    stamp();
+    if (wave == 0 && p.trace != nullptr) {
+      unsigned* t = p.trace + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * TRACE_WORDS;
+      t[lane] = tsv;
+      if (lane == 0) {
+        const unsigned long long rt1 = wall_clock64();
+        t[64] = (unsigned)tsi;
+        t[65] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+        t[66] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+        t[67] = (unsigned)rt0; t[68] = (unsigned)(rt0 >> 32);
+        t[69] = (unsigned)rt1; t[70] = (unsigned)(rt1 >> 32);
+        t[71] = (unsigned)nk_here;
+      }
+    }
+  }
 }
 
 template <int BM, int BN, int NST, int ABL>
@@ -642,7 +684,7 @@ int launch_abl(const DmaArgs& a, hipStream_t stream) {
   p.ws = nullptr;
   p.nk_per = p.nk;
   p.fin.coef = nullptr;
-  p.bin.coef = nullptr; p.bin_z = nullptr;
+  p.bin.coef = nullptr; p.bin_z = nullptr; p.trace = nullptr;
   constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
   PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, 2, 2, NST, true, ABL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
@@ -687,6 +729,16 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
     raised[vi] = true;
   }
   if (smem > 156 * 1024) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: tile + coefficient table exceed the LDS");
+  if (p.trace != nullptr) {          // timeline probe (tools/cbench): the same kernel with cycle stamps
+    if (bnin) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: no trace build of the BN-on-load kernel");
+    const void* tf = gather ? reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, true, 0, false, true>)
+                            : reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, false, 0, false, true>);
+    PXL_CHECK_HIP(hipFuncSetAttribute(tf, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    if (gather) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, true, 0, false, true>), dim3(grid, splitk), dim3(256), smem, stream, p);
+    else hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, false, 0, false, true>), dim3(grid, splitk), dim3(256), smem, stream, p);
+    PXL_LAUNCH_CHECK();
+    return PXL_OK;
+  }
   switch (vi) {
     case 0: hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, false>), dim3(grid, splitk), dim3(256), smem, stream, p); break;
     case 1: hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, true>), dim3(grid, splitk), dim3(256), smem, stream, p); break;
@@ -735,9 +787,25 @@ extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* 
   a.nk_per = 0;
   a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
-  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr;
+  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
   const int sk = d->split_k;
   return conv_dma_launch(d, a, sk, ws_bytes, stream);
+}
+
+// Timeline probe of pxl_conv_dma (tools/cbench.cpp, not on the product path): the same launch built with cycle stamps;
+// trace = [workgroups][72] uint32 (layout: TRACE_WORDS above).  Plain operands only (no split-K, no BN-on-load).
+extern "C" int pxl_conv_dma_trace(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
+                                  float* stats, unsigned* trace, void* stream) {
+  PXL_REQUIRE(d && in && w && out && trace, "conv_dma_trace: null argument");
+  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || (d->tile_cfg >= 0 && d->tile_cfg < 8))
+    return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_trace: descriptor is not eligible for the LDS-DMA kernel");
+  DmaArgs a;
+  a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
+  a.ws = nullptr; a.nk_per = 0;
+  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
+  a.fin.coef = nullptr; a.fin_counter = nullptr;
+  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = trace;
+  return conv_dma_launch(d, a, 1, 0, stream);
 }
 
 // Forward convolution with batch statistics AND the BatchNorm finalize: `stats` ([stats_rep][2*Kreal], caller-zeroed)
@@ -755,7 +823,7 @@ extern "C" int pxl_conv_dma_finalize(const pxl_conv_desc* d, const void* in, con
   a.ws = nullptr; a.nk_per = 0;
   a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin = *fin; a.fin_counter = counter;
-  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr;
+  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
   return conv_dma_launch(d, a, 1, 0, stream);
 }
 
@@ -777,7 +845,7 @@ extern "C" int pxl_conv_dma_bnin(const pxl_conv_desc* d, const void* y, const vo
   a.ws = nullptr; a.nk_per = 0;
   a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
-  a.bin = *bin; a.bin_relu = bin_relu; a.bin_z = z;
+  a.bin = *bin; a.bin_relu = bin_relu; a.bin_z = z; a.trace = nullptr;
   if (z != nullptr) {          // the activated tensor can only be written by a kernel that walks every input pixel exactly once per tile row
     bool plain = d->ntaps == 1 && d->dy[0] == 0 && d->dx[0] == 0 && d->out_stride == 1 && d->Ho == d->Hi && d->Wo == d->Wi;
     if (!plain) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_bnin: z output needs a 1x1 / stride-1 convolution");
@@ -800,7 +868,7 @@ extern "C" int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, c
   a.ws = nullptr; a.nk_per = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = bn_relu; a.bn_mask = nullptr;
-  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr;
+  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
   pxl_conv_desc q = *d;
   q.stats_rep = 1;
   return conv_dma_launch(&q, a, 1, 0, stream);
@@ -821,7 +889,7 @@ extern "C" int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy,
   a.ws = nullptr; a.nk_per = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = 0; a.bn_mask = join_out;
-  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr;
+  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
   pxl_conv_desc q = *d;
   q.stats_rep = 1;
   return conv_dma_launch(&q, a, 1, 0, stream);

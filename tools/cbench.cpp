@@ -1,0 +1,447 @@
+// tools/cbench -- torch-free micro-benchmark and timeline probe for the contraction kernels of libpixelhip.
+//
+// Tuning aid, not part of the product path.  Every ResNet-101 / DeepLab-v2 convolution shape at the BASELINE batch
+// (8 x 513 x 513 -> 129 / 65 / 33 feature maps) ALONE on the GPU, per tile configuration, through the C-ABI
+// (pxl_conv_igemm); plus
+//   --dual            the same launch on two streams at once (what the MT step does with student || teacher)
+//   --trace S:CFG[:M] cycle-stamp timeline of one launch (pxl_conv_dma_trace): launch skew, prologue, first tile,
+//                     K-step cadence, drain, epilogue; CU census (which CUs ran how many workgroups)
+//   --floor           what the chip does with NO arithmetic: an empty launch of the same grid / LDS footprint, and the
+//                     tile stream of a 1x1 convolution (same DMA instructions, ring depth 2 .. 6) without MFMAs
+//
+// build: hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude tools/cbench.cpp -o tools/cbench -Lpixelssl_amd -lpixelhip \
+//        -Wl,-rpath,'$ORIGIN/../pixelssl_amd'
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pixelhip.h"
+
+extern "C" int pxl_conv_dma_trace(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
+                                  float* stats, unsigned* trace, void* stream);
+
+#define CK(e)                                                                                         \
+  do {                                                                                                \
+    hipError_t _e = (e);                                                                              \
+    if (_e != hipSuccess) { fprintf(stderr, "%s failed: %s (%s:%d)\n", #e, hipGetErrorString(_e), __FILE__, __LINE__); exit(2); } \
+  } while (0)
+
+struct Shape { const char* name; int cin, cout, k, s, d, H, cnt; };
+static const Shape SHAPES[] = {
+    {"l1.1x1a", 64, 64, 1, 1, 1, 129, 1},     {"l1.3x3", 64, 64, 3, 1, 1, 129, 3},      {"l1.1x1b", 64, 256, 1, 1, 1, 129, 4},
+    {"l1.1x1c", 256, 64, 1, 1, 1, 129, 2},    {"l2.1x1a", 256, 128, 1, 1, 1, 129, 1},   {"l2.3x3s2", 128, 128, 3, 2, 1, 129, 1},
+    {"l2.1x1b", 128, 512, 1, 1, 1, 65, 4},    {"l2.ds", 256, 512, 1, 2, 1, 129, 1},     {"l2.1x1c", 512, 128, 1, 1, 1, 65, 3},
+    {"l2.3x3", 128, 128, 3, 1, 1, 65, 3},     {"l3.1x1a", 512, 256, 1, 1, 1, 65, 1},    {"l3.3x3s2", 256, 256, 3, 2, 1, 65, 1},
+    {"l3.1x1b", 256, 1024, 1, 1, 1, 33, 23},  {"l3.ds", 512, 1024, 1, 2, 1, 65, 1},     {"l3.1x1c", 1024, 256, 1, 1, 1, 33, 22},
+    {"l3.3x3", 256, 256, 3, 1, 1, 33, 22},    {"l4.1x1a", 1024, 512, 1, 1, 1, 33, 1},   {"l4.3x3d2", 512, 512, 3, 1, 2, 33, 1},
+    {"l4.1x1b", 512, 2048, 1, 1, 1, 33, 3},   {"l4.ds", 1024, 2048, 1, 1, 1, 33, 1},    {"l4.1x1c", 2048, 512, 1, 1, 1, 33, 2},
+    {"l4.3x3d4", 512, 512, 3, 1, 4, 33, 1},
+};
+
+static int pitch(int c) { return c <= 8 ? 8 : (c + 31) / 32 * 32; }
+
+static uint16_t f2bf(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+static void* dev_random_bf16(size_t n, float scale, unsigned seed) {
+  std::vector<uint16_t> h(n);
+  unsigned s = seed * 2654435761u + 12345u;
+  for (size_t i = 0; i < n; ++i) {
+    s = s * 1664525u + 1013904223u;
+    const float u = ((s >> 8) & 0xffff) / 65536.f + ((s >> 24) & 0xff) / 256.f - 1.0f;      // roughly triangular in (-1, 1)
+    h[i] = f2bf(u * scale);
+  }
+  void* d; CK(hipMalloc(&d, n * 2)); CK(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice));
+  return d;
+}
+
+struct Problem {
+  pxl_conv_desc fwd, bwd;
+  void *x, *y, *wf, *wt; float* stats;
+  size_t nx, ny; double flops; int M;
+};
+
+static Problem make_problem(const Shape& sh, int B, unsigned seed) {
+  Problem p; memset(&p, 0, sizeof(p));
+  const int pad = sh.k > 1 ? sh.d * (sh.k - 1) / 2 : 0;
+  const int Ho = (sh.H + 2 * pad - sh.d * (sh.k - 1) - 1) / sh.s + 1;
+  const int cip = pitch(sh.cin), cop = pitch(sh.cout);
+  pxl_conv_desc f; memset(&f, 0, sizeof(f));
+  f.dtype = PXL_BF16; f.B = B; f.Hi = sh.H; f.Wi = sh.H; f.Cin = cip; f.Ho = Ho; f.Wo = Ho; f.Cout = cop; f.Kreal = sh.cout;
+  f.ntaps = sh.k * sh.k; f.out_stride = sh.s; f.div = 1; f.relu_in = 0; f.tile_cfg = -1; f.stats_rep = 4; f.split_k = 1;
+  for (int r = 0; r < sh.k; ++r)
+    for (int c = 0; c < sh.k; ++c) { f.dy[r * sh.k + c] = (int16_t)(r * sh.d - pad); f.dx[r * sh.k + c] = (int16_t)(c * sh.d - pad); }
+  p.fwd = f;
+  pxl_conv_desc b = f;
+  b.Hi = Ho; b.Wi = Ho; b.Cin = cop; b.Ho = sh.H; b.Wo = sh.H; b.Cout = cip; b.Kreal = sh.cin; b.out_stride = 1; b.div = sh.s; b.stats_rep = 1;
+  for (int t = 0; t < f.ntaps; ++t) { b.dy[t] = (int16_t)(-f.dy[t]); b.dx[t] = (int16_t)(-f.dx[t]); }
+  p.bwd = b;
+  p.nx = (size_t)B * sh.H * sh.H * cip; p.ny = (size_t)B * Ho * Ho * cop;
+  p.x = dev_random_bf16(p.nx, 1.0f, seed + 1);
+  p.y = dev_random_bf16(p.ny, 1.0f, seed + 2);
+  p.wf = dev_random_bf16((size_t)sh.cout * f.ntaps * cip, 0.05f, seed + 3);
+  p.wt = dev_random_bf16((size_t)sh.cin * f.ntaps * cop, 0.05f, seed + 4);
+  CK(hipMalloc((void**)&p.stats, 4 * 2 * (size_t)cop * sizeof(float)));
+  CK(hipMemset(p.stats, 0, 4 * 2 * (size_t)cop * sizeof(float)));
+  p.flops = 2.0 * B * Ho * Ho * (double)sh.cout * sh.k * sh.k * sh.cin;
+  p.M = B * Ho * Ho;
+  return p;
+}
+static void free_problem(Problem& p) { (void)hipFree(p.x); (void)hipFree(p.y); (void)hipFree(p.wf); (void)hipFree(p.wt); (void)hipFree(p.stats); }
+
+static int launch(const Problem& p, bool dgrad, int cfg, hipStream_t s) {
+  if (!dgrad) { pxl_conv_desc q = p.fwd; q.tile_cfg = cfg;
+    return pxl_conv_igemm(&q, p.x, p.wf, p.y, nullptr, nullptr, nullptr, nullptr, p.stats, nullptr, 0, s); }
+  pxl_conv_desc q = p.bwd; q.tile_cfg = cfg;
+  return pxl_conv_igemm(&q, p.y, p.wt, p.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s);
+}
+
+// best-of-3 average time (us) of `iters` back-to-back launches
+static double time_single(const Problem& p, bool dgrad, int cfg, int iters, hipStream_t s, hipEvent_t a, hipEvent_t b) {
+  if (launch(p, dgrad, cfg, s) != PXL_OK) return -1.0;
+  CK(hipStreamSynchronize(s));
+  double best = 1e30;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) if (launch(p, dgrad, cfg, s) != PXL_OK) return -1.0;
+    CK(hipEventRecord(b, s));
+    CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    best = std::min(best, (double)ms * 1e3 / iters);
+  }
+  return best;
+}
+
+// two streams, two operand sets, `iters` launches each: wall time per PAIR of launches (us)
+static double time_dual(const Problem& p0, const Problem& p1, bool dgrad, int cfg, int iters, hipStream_t s0, hipStream_t s1) {
+  hipEvent_t a, b0, b1; CK(hipEventCreate(&a)); CK(hipEventCreate(&b0)); CK(hipEventCreate(&b1));
+  launch(p0, dgrad, cfg, s0); launch(p1, dgrad, cfg, s1);
+  CK(hipDeviceSynchronize());
+  double best = 1e30;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(a, s0));
+    CK(hipStreamWaitEvent(s1, a, 0));
+    for (int i = 0; i < iters; ++i) { launch(p0, dgrad, cfg, s0); launch(p1, dgrad, cfg, s1); }
+    CK(hipEventRecord(b0, s0)); CK(hipEventRecord(b1, s1));
+    CK(hipEventSynchronize(b0)); CK(hipEventSynchronize(b1));
+    float m0, m1; CK(hipEventElapsedTime(&m0, a, b0)); CK(hipEventElapsedTime(&m1, a, b1));
+    best = std::min(best, (double)std::max(m0, m1) * 1e3 / iters);
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b0); (void)hipEventDestroy(b1);
+  return best;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// timeline analysis
+// ---------------------------------------------------------------------------------------------------------------------
+static double pct(std::vector<double> v, double q) {
+  if (v.empty()) return 0.0;
+  std::sort(v.begin(), v.end());
+  const size_t i = std::min(v.size() - 1, (size_t)(q * (v.size() - 1) + 0.5));
+  return v[i];
+}
+static void row(const char* what, const std::vector<double>& v, double ns_per_cyc) {
+  printf("    %-34s med %8.0f cyc (%6.2f us)   p90 %8.0f   max %8.0f\n", what, pct(v, 0.5), pct(v, 0.5) * ns_per_cyc * 1e-3, pct(v, 0.9),
+         pct(v, 1.0));
+}
+
+struct TraceSet { std::vector<unsigned> w; int nwg; };
+
+static void analyze(const TraceSet& t, const char* title, const TraceSet* other) {
+  const int W = 72;
+  unsigned long long rmin = ~0ull, rmax = 0;
+  std::vector<double> pro, first, steps, drain, stage, store, total, skew, mhz;
+  std::map<unsigned, int> cu_count;
+  for (int g = 0; g < t.nwg; ++g) {
+    const unsigned* r = &t.w[(size_t)g * W];
+    const int ns = (int)r[64]; const int nk = (int)r[71];
+    if (ns < 5) continue;
+    const unsigned long long r0 = r[67] | ((unsigned long long)r[68] << 32), r1 = r[69] | ((unsigned long long)r[70] << 32);
+    rmin = std::min(rmin, r0); rmax = std::max(rmax, r1);
+  }
+  for (int g = 0; g < t.nwg; ++g) {
+    const unsigned* r = &t.w[(size_t)g * W];
+    const int ns = std::min((int)r[64], 64); const int nk = (int)r[71];
+    if (ns < 5) continue;
+    const int nkst = std::min(nk, 56);                           // stamped K steps
+    auto d = [&](int i, int j) { return (double)(unsigned)(r[j] - r[i]); };
+    pro.push_back(d(0, 1));
+    first.push_back(d(1, 2));
+    if (nkst > 1) steps.push_back(d(2, 1 + nkst) / (nkst - 1));
+    if (2 + nkst < ns) drain.push_back(d(1 + nkst, 2 + nkst));
+    if (3 + nkst < ns) stage.push_back(d(2 + nkst, 3 + nkst));
+    if (4 + nkst < ns) store.push_back(d(3 + nkst, 4 + nkst));
+    total.push_back(d(0, ns - 1));
+    const unsigned long long r0 = r[67] | ((unsigned long long)r[68] << 32), r1 = r[69] | ((unsigned long long)r[70] << 32);
+    skew.push_back((double)(r0 - rmin) * 10.0);                  // ns
+    if (r1 > r0 + 50) mhz.push_back(d(0, ns - 1) / ((double)(r1 - r0) * 10.0) * 1e3);
+    const unsigned key = (r[66] & 0xf) << 16 | ((r[65] >> 8) & 0xff);      // xcc, (se, sh, cu)
+    cu_count[key]++;
+  }
+  const double clk = pct(mhz, 0.5);                               // MHz (cycles per us)
+  const double nspc = clk > 0 ? 1e3 / clk : 0.42;
+  printf("  -- %s: %d workgroups, s_memtime clock ~%.0f MHz, first entry -> last exit %.2f us\n", title, t.nwg, clk,
+         (double)(rmax - rmin) * 0.01);
+  printf("    %-34s med %8.2f us   p90 %8.2f   max %8.2f\n", "entry skew (vs first workgroup)", pct(skew, 0.5) * 1e-3, pct(skew, 0.9) * 1e-3,
+         pct(skew, 1.0) * 1e-3);
+  row("prologue (args, addresses, issue)", pro, nspc);
+  row("first K step (first tiles land)", first, nspc);
+  row("K step, steady state (per step)", steps, nspc);
+  row("drain + barrier", drain, nspc);
+  row("accumulators -> staged tile", stage, nspc);
+  row("read-back, stores, statistics", store, nspc);
+  row("workgroup total", total, nspc);
+  std::map<int, int> hist;
+  for (auto& kv : cu_count) hist[kv.second]++;
+  printf("    CUs used %zu; workgroups per CU:", cu_count.size());
+  for (auto& kv : hist) printf(" %dx:%d", kv.first, kv.second);
+  printf("\n");
+  if (other) {
+    std::map<unsigned, int> oc;
+    for (int g = 0; g < other->nwg; ++g) {
+      const unsigned* r = &other->w[(size_t)g * W];
+      if (r[64] < 5) continue;
+      oc[(r[66] & 0xf) << 16 | ((r[65] >> 8) & 0xff)]++;
+    }
+    int both = 0, only_a = 0, only_b = 0;
+    for (auto& kv : cu_count) (oc.count(kv.first) ? both : only_a)++;
+    for (auto& kv : oc) if (!cu_count.count(kv.first)) only_b++;
+    printf("    co-running launch: CUs shared %d, only this %d, only other %d\n", both, only_a, only_b);
+  }
+}
+
+static TraceSet run_trace(const Problem& p, int cfg, hipStream_t s, int* grid_out) {
+  // grid is not known here: allocate for the smallest tile (64 x 64)
+  const int maxwg = ((p.M + 63) / 64) * ((p.fwd.Cout + 63) / 64) + 8;
+  unsigned* d; CK(hipMalloc((void**)&d, (size_t)maxwg * 72 * 4)); CK(hipMemset(d, 0, (size_t)maxwg * 72 * 4));
+  pxl_conv_desc q = p.fwd; q.tile_cfg = cfg;
+  const int rc = pxl_conv_dma_trace(&q, p.x, p.wf, p.y, nullptr, p.stats, d, s);
+  TraceSet t; t.nwg = 0;
+  if (rc != PXL_OK) { printf("  trace launch failed: %s\n", pxl_last_error()); (void)hipFree(d); return t; }
+  CK(hipStreamSynchronize(s));
+  t.w.resize((size_t)maxwg * 72);
+  CK(hipMemcpy(t.w.data(), d, t.w.size() * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  int n = 0;
+  for (int g = 0; g < maxwg; ++g) if (t.w[(size_t)g * 72 + 64] >= 5) n = g + 1;
+  t.nwg = n;
+  if (grid_out) *grid_out = n;
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// floor kernels: no arithmetic
+// ---------------------------------------------------------------------------------------------------------------------
+struct BigArgs { const void* a; const void* w; unsigned* sink; int K2, tiles_n, nk, pad; int filler[100]; };   // ~ the size of the conv's kernarg
+
+__global__ __launch_bounds__(256) void null_kernel(const BigArgs p) {
+  extern __shared__ unsigned char smem[];
+  if (p.sink && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) p.sink[0] = smem[0] + p.filler[3];
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+// the tile stream of a 1x1 convolution: workgroup (tm, tn) pulls rows [tm*BM, +BM) of A and [tn*BN, +BN) of W, 128 bytes
+// of every row per step, through an NST-deep LDS ring by `buffer_load ... lds` -- and does nothing with them
+template <int BM, int BN, int NST>
+__global__ __launch_bounds__(256) void stream_kernel(const BigArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int LA = BM / 32, LB = BN / 32, SB = (BM + BN) * 128;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, 0x7fffffff, 0x00020000);
+  unsigned va[LA], vb[LB];
+#pragma unroll
+  for (int q = 0; q < LA; ++q) va[q] = (unsigned)((tm * BM + (wave + 4 * q) * 8 + (lane >> 3)) * p.K2 + (lane & 7) * 16);
+#pragma unroll
+  for (int q = 0; q < LB; ++q) vb[q] = (unsigned)((tn * BN + (wave + 4 * q) * 8 + (lane >> 3)) * p.K2 + (lane & 7) * 16);
+  unsigned kb = 0;
+  auto issue = [&](int st) {
+    unsigned char* sa = smem + st * SB + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < LA; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(sa + q * 4096), 16, (int)va[q], (int)kb, 0, 0);
+    unsigned char* sb = smem + st * SB + BM * 128 + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < LB; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(sb + q * 4096), 16, (int)vb[q], (int)kb, 0, 0);
+    kb += 128;
+  };
+  for (int s = 0; s < NST - 1; ++s) issue(s);
+  int st = NST - 1;
+  for (int ks = 0; ks < p.nk; ++ks) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (LA + LB)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ks + NST - 1 < p.nk) issue(st);
+    st = st + 1 == NST ? 0 : st + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (p.sink && blockIdx.x == 0x7fffffff) p.sink[threadIdx.x] = smem[threadIdx.x];
+}
+
+template <typename F> static double time_kernel(F&& fn, int iters, hipStream_t s, hipEvent_t a, hipEvent_t b) {
+  fn(); CK(hipStreamSynchronize(s));
+  double best = 1e30;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) fn();
+    CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    best = std::min(best, (double)ms * 1e3 / iters);
+  }
+  return best;
+}
+
+template <int BM, int BN, int NST>
+static void floor_stream(const char* name, const Problem& p, int iters, hipStream_t s, hipEvent_t a, hipEvent_t b) {
+  BigArgs g; memset(&g, 0, sizeof(g));
+  g.a = p.x; g.w = p.wf; g.K2 = p.fwd.Cin * 2; g.nk = p.fwd.Cin / 64;
+  const int tiles_m = p.M / BM;       // whole tiles only (no ragged last tile: this is a bandwidth probe)
+  g.tiles_n = (p.fwd.Cout + BN - 1) / BN;
+  const int grid = tiles_m * g.tiles_n;
+  const size_t lds = (size_t)NST * (BM + BN) * 128;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_kernel<BM, BN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  const double t = time_kernel([&]() { hipLaunchKernelGGL((stream_kernel<BM, BN, NST>), dim3(grid), dim3(256), lds, s, g); }, iters, s, a, b);
+  const double bytes = (double)grid * g.nk * (BM + BN) * 128.0;
+  printf("  %-9s stream %3dx%3d ring %d: %4d wgs, %6.1f KB LDS, %7.2f us, %6.2f TB/s LDS-side (%5.1f MB), unique %5.1f MB\n", name, BM, BN, NST, grid,
+         lds / 1024.0, t, bytes / t * 1e-6, bytes * 1e-6, ((double)p.M * g.K2 + (double)p.fwd.Cout * g.K2) * 1e-6);
+}
+
+int main(int argc, char** argv) {
+  std::string only, cfgs_s = "-1", modes = "fwd,dgrad", trace;
+  int iters = 20, B = 8; bool dual = false, do_floor = false;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    auto val = [&]() { return std::string(i + 1 < argc ? argv[++i] : ""); };
+    if (a == "--only") only = val();
+    else if (a == "--cfgs") cfgs_s = val();
+    else if (a == "--modes") modes = val();
+    else if (a == "--iters") iters = atoi(val().c_str());
+    else if (a == "--batch") B = atoi(val().c_str());
+    else if (a == "--dual") dual = true;
+    else if (a == "--floor") do_floor = true;
+    else if (a == "--trace") trace = val();
+    else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 64; }
+  }
+  std::vector<int> cfgs;
+  for (size_t p = 0; p < cfgs_s.size();) { cfgs.push_back(atoi(cfgs_s.c_str() + p)); p = cfgs_s.find(',', p); if (p == std::string::npos) break; ++p; }
+  auto wanted = [&](const char* n) {
+    if (only.empty()) return true;
+    for (size_t p = 0; p < only.size();) {
+      size_t e = only.find(',', p); if (e == std::string::npos) e = only.size();
+      if (strstr(n, only.substr(p, e - p).c_str())) return true;
+      p = e + 1;
+    }
+    return false;
+  };
+  hipStream_t s0, s1; CK(hipStreamCreate(&s0)); CK(hipStreamCreate(&s1));
+  hipEvent_t ea, eb; CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+  printf("# cbench on %s (%d CUs), batch %d, %d launches per timing, best of 3\n", prop.name, prop.multiProcessorCount, B, iters);
+
+  if (!trace.empty()) {
+    // S:CFG[:dual]
+    const size_t c1 = trace.find(':');
+    const std::string sn = trace.substr(0, c1);
+    const size_t c2 = trace.find(':', c1 + 1);
+    const int cfg = atoi(trace.substr(c1 + 1, c2 == std::string::npos ? std::string::npos : c2 - c1 - 1).c_str());
+    const bool tdual = c2 != std::string::npos;
+    for (const Shape& sh : SHAPES) {
+      if (sn != sh.name) continue;
+      Problem p0 = make_problem(sh, B, 1), p1 = make_problem(sh, B, 2);
+      for (int w = 0; w < 3; ++w) launch(p0, false, cfg, s0);
+      CK(hipDeviceSynchronize());
+      printf("trace %s cfg %d (forward, statistics on)\n", sh.name, cfg);
+      TraceSet t = run_trace(p0, cfg, s0, nullptr);
+      analyze(t, "alone", nullptr);
+      TraceSet t2 = run_trace(p0, cfg, s0, nullptr);
+      analyze(t2, "alone (repeat)", nullptr);
+      if (tdual) {
+        // both launches enqueued before either runs: hold the streams behind an event recorded after a long-ish kernel
+        const int maxwg = ((p0.M + 63) / 64) * ((p0.fwd.Cout + 63) / 64) + 8;
+        unsigned *d0, *d1; CK(hipMalloc((void**)&d0, (size_t)maxwg * 288)); CK(hipMalloc((void**)&d1, (size_t)maxwg * 288));
+        CK(hipMemset(d0, 0, (size_t)maxwg * 288)); CK(hipMemset(d1, 0, (size_t)maxwg * 288));
+        pxl_conv_desc q = p0.fwd; q.tile_cfg = cfg;
+        for (int rep = 0; rep < 4; ++rep) { launch(p0, false, cfg, s0); launch(p1, false, cfg, s1); }     // both queues busy
+        pxl_conv_dma_trace(&q, p0.x, p0.wf, p0.y, nullptr, p0.stats, d0, s0);
+        pxl_conv_dma_trace(&q, p1.x, p1.wf, p1.y, nullptr, p1.stats, d1, s1);
+        CK(hipDeviceSynchronize());
+        TraceSet a, b; a.w.resize((size_t)maxwg * 72); b.w.resize((size_t)maxwg * 72);
+        CK(hipMemcpy(a.w.data(), d0, a.w.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.w.data(), d1, b.w.size() * 4, hipMemcpyDeviceToHost));
+        a.nwg = b.nwg = 0;
+        for (int g = 0; g < maxwg; ++g) { if (a.w[(size_t)g * 72 + 64] >= 5) a.nwg = g + 1; if (b.w[(size_t)g * 72 + 64] >= 5) b.nwg = g + 1; }
+        unsigned long long a0 = ~0ull, a1 = 0, b0 = ~0ull, b1 = 0;
+        for (int g = 0; g < a.nwg; ++g) { const unsigned* r = &a.w[(size_t)g * 72]; a0 = std::min(a0, r[67] | ((unsigned long long)r[68] << 32)); a1 = std::max(a1, r[69] | ((unsigned long long)r[70] << 32)); }
+        for (int g = 0; g < b.nwg; ++g) { const unsigned* r = &b.w[(size_t)g * 72]; b0 = std::min(b0, r[67] | ((unsigned long long)r[68] << 32)); b1 = std::max(b1, r[69] | ((unsigned long long)r[70] << 32)); }
+        printf("  two streams: launch A runs %.2f .. %.2f us, launch B %.2f .. %.2f us (common clock, 0 = earlier start)\n", 0.01 * (double)(a0 - std::min(a0, b0)),
+               0.01 * (double)(a1 - std::min(a0, b0)), 0.01 * (double)(b0 - std::min(a0, b0)), 0.01 * (double)(b1 - std::min(a0, b0)));
+        analyze(a, "stream A (co-running)", &b);
+        analyze(b, "stream B (co-running)", &a);
+        (void)hipFree(d0); (void)hipFree(d1);
+      }
+      free_problem(p0); free_problem(p1);
+    }
+    return 0;
+  }
+
+  if (do_floor) {
+    BigArgs g; memset(&g, 0, sizeof(g));
+    for (int grid : {137, 274, 548, 1096}) {
+      for (size_t lds : {(size_t)0, (size_t)48 * 1024, (size_t)72 * 1024, (size_t)144 * 1024}) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&null_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const double t = time_kernel([&]() { hipLaunchKernelGGL(null_kernel, dim3(grid), dim3(256), lds, s0, g); }, 50, s0, ea, eb);
+        printf("  empty launch: %4d wgs x 256 threads, %5.0f KB LDS, %zu-byte arguments: %6.2f us back to back\n", grid, lds / 1024.0, sizeof(BigArgs), t);
+      }
+    }
+    for (const Shape& sh : SHAPES) {
+      if (sh.k != 1 || sh.s != 1 || !wanted(sh.name)) continue;
+      Problem p = make_problem(sh, B, 1);
+      floor_stream<64, 128, 2>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<64, 128, 3>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<64, 128, 4>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<64, 128, 6>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<128, 128, 2>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<128, 128, 4>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<128, 64, 2>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<128, 64, 4>(sh.name, p, iters, s0, ea, eb);
+      free_problem(p);
+    }
+    return 0;
+  }
+
+  std::map<std::string, double> tot; double totf = 0.0;
+  printf("%-9s %5s %5s %1s %1s %1s %4s %6s |", "shape", "Cin", "Cout", "k", "s", "d", "H", "M");
+  printf(" mode:cfg us (TFLOP/s)%s\n", dual ? " [pair on two streams: us per pair]" : "");
+  for (const Shape& sh : SHAPES) {
+    if (!wanted(sh.name)) continue;
+    Problem p0 = make_problem(sh, B, 1), p1;
+    if (dual) p1 = make_problem(sh, B, 2);
+    printf("%-9s %5d %5d %1d %1d %1d %4d %6d |", sh.name, sh.cin, sh.cout, sh.k, sh.s, sh.d, sh.H, p0.M);
+    for (const char* mode : {"fwd", "dgrad"}) {
+      if (modes.find(mode) == std::string::npos) continue;
+      const bool dg = mode[0] == 'd';
+      double best = 1e30;
+      for (int cfg : cfgs) {
+        const double t = time_single(p0, dg, cfg, iters, s0, ea, eb);
+        if (t < 0) { printf(" %s:%d ERR", mode, cfg); continue; }
+        printf(" %s:%d %6.1f (%5.0f)", mode, cfg, t, p0.flops / t * 1e-6);
+        if (dual) { const double t2 = time_dual(p0, p1, dg, cfg, iters, s0, s1); printf(" [%6.1f]", t2); }
+        best = std::min(best, t);
+      }
+      if (best < 1e29) tot[mode] += best * sh.cnt;
+    }
+    totf += p0.flops * sh.cnt;
+    printf("\n"); fflush(stdout);
+    free_problem(p0); if (dual) free_problem(p1);
+  }
+  for (auto& kv : tot) printf("sum over net (%s, best cfg per shape x count): %.3f ms -> %.1f TFLOP/s\n", kv.first.c_str(), kv.second * 1e-3, totf / kv.second * 1e-6);
+  return 0;
+}
