@@ -95,6 +95,12 @@ int pxl_conv_igemm(const pxl_conv_desc* desc, const void* in, const void* w, voi
  * relu?(bn(y)), written on the way by the workgroups of output-channel tile 0 (what this convolution's weight gradient
  * reads).  PXL_ERR_UNSUPPORTED: use the three launches. */
 struct pxl_bn_fin;
+/* Diagnostics (tools/cbench.cpp; never on the product path): the LDS-DMA launch of pxl_conv_igemm built with cycle stamps.
+ * trace = [workgroups][72] uint32: words 0..63 s_memtime stamps of wave 0 (kernel entry, prologue issued, end of each of the
+ * first 52 K steps, loop drained, tile staged, read-back passes, statistics, everything acknowledged), 64 = stamp count,
+ * 65 = HW_ID, 66 = XCC_ID, 67..70 = s_memrealtime at entry / exit, 71 = K steps.  Plain bf16 operands only. */
+int pxl_conv_dma_trace(const pxl_conv_desc* desc, const void* in, const void* w, void* out, const float* bias,
+                       float* stats, unsigned* trace, void* stream);
 int pxl_conv_dma_bnin(const pxl_conv_desc* desc, const void* y, const void* w, void* out, const float* bias, float* stats,
                       const struct pxl_bn_fin* bin, int bin_relu, void* z, void* stream);
 

@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libpixelhip.so")
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "pixelhip.h")]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_dma_kernel.h"),
+           os.path.join(os.path.dirname(HERE), "include", "pixelhip.h")]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",

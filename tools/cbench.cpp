@@ -140,6 +140,43 @@ static double time_dual(const Problem& p0, const Problem& p1, bool dgrad, int cf
   return best;
 }
 
+static float bf2f_h(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+// max |a - b| / max |b| of the tensor a launch writes (forward: y, data gradient: x) against the generic register-staged
+// kernel (tile_cfg 1: independent code path), and of the statistics (forward)
+static void check_cfg(Problem& p, bool dgrad, int cfg, hipStream_t s) {
+  void* dst = dgrad ? p.x : p.y;
+  const size_t n = dgrad ? p.nx : p.ny;
+  const int C2 = 4 * 2 * p.fwd.Cout;
+  std::vector<uint16_t> ref(n), got(n);
+  std::vector<float> sref(C2), sgot(C2);
+  // the data gradient overwrites x (its output) -- and x is not an input of the data gradient, so running twice is fine
+  CK(hipMemsetAsync(p.stats, 0, C2 * sizeof(float), s));
+  if (launch(p, dgrad, 1, s) != PXL_OK) { printf(" chk:%d REF-ERR(%s)", cfg, pxl_last_error()); return; }
+  CK(hipStreamSynchronize(s));
+  CK(hipMemcpy(ref.data(), dst, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(sref.data(), p.stats, C2 * 4, hipMemcpyDeviceToHost));
+  CK(hipMemsetAsync(dst, 0xff, n * 2, s)); CK(hipMemsetAsync(p.stats, 0, C2 * sizeof(float), s));
+  if (launch(p, dgrad, cfg, s) != PXL_OK) { printf(" chk:%d ERR(%s)", cfg, pxl_last_error()); return; }
+  CK(hipStreamSynchronize(s));
+  CK(hipMemcpy(got.data(), dst, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(sgot.data(), p.stats, C2 * 4, hipMemcpyDeviceToHost));
+  double mx = 0, md = 0; size_t bad = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const double a = bf2f_h(got[i]), b = bf2f_h(ref[i]);
+    if (!(a == a)) { ++bad; continue; }
+    mx = std::max(mx, std::fabs(b)); md = std::max(md, std::fabs(a - b));
+  }
+  // statistics: fold the replicas
+  double smx = 0, smd = 0;
+  if (!dgrad) {
+    const int C = p.fwd.Kreal;
+    for (int w = 0; w < 2; ++w) for (int c = 0; c < C; ++c) {
+      double a = 0, b = 0;
+      for (int r = 0; r < 4; ++r) { a += sgot[(size_t)r * 2 * C + w * C + c]; b += sref[(size_t)r * 2 * C + w * C + c]; }
+      smx = std::max(smx, std::fabs(b)); smd = std::max(smd, std::fabs(a - b));
+    }
+  }
+  printf(" chk:%d %.1e/%.1e%s", cfg, mx > 0 ? md / mx : md, smx > 0 ? smd / smx : smd, bad ? " NAN!" : "");
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // timeline analysis
 // ---------------------------------------------------------------------------------------------------------------------
@@ -159,7 +196,7 @@ struct TraceSet { std::vector<unsigned> w; int nwg; };
 static void analyze(const TraceSet& t, const char* title, const TraceSet* other) {
   const int W = 72;
   unsigned long long rmin = ~0ull, rmax = 0;
-  std::vector<double> pro, first, steps, drain, stage, store, total, skew, mhz;
+  std::vector<double> pro, first, steps, drain, stage, pass0, pass1, store, statb, statv, ackv, total, skew, mhz;
   std::map<unsigned, int> cu_count;
   for (int g = 0; g < t.nwg; ++g) {
     const unsigned* r = &t.w[(size_t)g * W];
@@ -172,14 +209,19 @@ static void analyze(const TraceSet& t, const char* title, const TraceSet* other)
     const unsigned* r = &t.w[(size_t)g * W];
     const int ns = std::min((int)r[64], 64); const int nk = (int)r[71];
     if (ns < 5) continue;
-    const int nkst = std::min(nk, 56);                           // stamped K steps
+    const int nkst = std::min(nk, 52);                           // stamped K steps
     auto d = [&](int i, int j) { return (double)(unsigned)(r[j] - r[i]); };
     pro.push_back(d(0, 1));
     first.push_back(d(1, 2));
     if (nkst > 1) steps.push_back(d(2, 1 + nkst) / (nkst - 1));
     if (2 + nkst < ns) drain.push_back(d(1 + nkst, 2 + nkst));
     if (3 + nkst < ns) stage.push_back(d(2 + nkst, 3 + nkst));
-    if (4 + nkst < ns) store.push_back(d(3 + nkst, 4 + nkst));
+    if (4 + nkst < ns) pass0.push_back(d(3 + nkst, 4 + nkst));
+    if (5 + nkst < ns) pass1.push_back(d(4 + nkst, 5 + nkst));
+    if (6 + nkst < ns) store.push_back(d(5 + nkst, 6 + nkst));
+    if (7 + nkst < ns) statb.push_back(d(6 + nkst, 7 + nkst));
+    if (8 + nkst < ns) statv.push_back(d(7 + nkst, 8 + nkst));
+    if (9 + nkst < ns) ackv.push_back(d(8 + nkst, 9 + nkst));
     total.push_back(d(0, ns - 1));
     const unsigned long long r0 = r[67] | ((unsigned long long)r[68] << 32), r1 = r[69] | ((unsigned long long)r[70] << 32);
     skew.push_back((double)(r0 - rmin) * 10.0);                  // ns
@@ -198,8 +240,34 @@ static void analyze(const TraceSet& t, const char* title, const TraceSet* other)
   row("K step, steady state (per step)", steps, nspc);
   row("drain + barrier", drain, nspc);
   row("accumulators -> staged tile", stage, nspc);
-  row("read-back, stores, statistics", store, nspc);
+  row("read-back pass 0 (dispatch + loads)", pass0, nspc);
+  row("read-back pass 1", pass1, nspc);
+  row("remaining passes (stores issued)", store, nspc);
+  row("statistics parked + barrier", statb, nspc);
+  row("statistics summed, atomics issued", statv, nspc);
+  row("stores / atomics acknowledged", ackv, nspc);
   row("workgroup total", total, nspc);
+  // first-round workgroups (entered within 1 us of the launch) against the rest: cold vs warm instruction / scalar caches
+  {
+    std::vector<double> e_pro, l_pro, e_store, l_store, e_stat, l_stat, e_stage, l_stage;
+    size_t k = 0;
+    for (int g = 0; g < t.nwg; ++g) {
+      const unsigned* r = &t.w[(size_t)g * W];
+      const int ns = std::min((int)r[64], 64); const int nk = (int)r[71];
+      if (ns < 5) continue;
+      const int nkst = std::min(nk, 52);
+      auto d = [&](int i, int j) { return (double)(unsigned)(r[j] - r[i]); };
+      const bool early = skew[k++] < 1000.0;
+      (early ? e_pro : l_pro).push_back(d(0, 1));
+      if (3 + nkst < ns) (early ? e_stage : l_stage).push_back(d(2 + nkst, 3 + nkst));
+      if (6 + nkst < ns) (early ? e_store : l_store).push_back(d(3 + nkst, 6 + nkst));
+      if (8 + nkst < ns) (early ? e_stat : l_stat).push_back(d(6 + nkst, 8 + nkst));
+    }
+    if (!l_pro.empty())
+      printf("    first round (%zu wgs) vs later (%zu): prologue %.0f / %.0f, staging %.0f / %.0f, passes %.0f / %.0f, statistics %.0f / %.0f cyc (medians)\n",
+             e_pro.size(), l_pro.size(), pct(e_pro, 0.5), pct(l_pro, 0.5), pct(e_stage, 0.5), pct(l_stage, 0.5), pct(e_store, 0.5), pct(l_store, 0.5),
+             pct(e_stat, 0.5), pct(l_stat, 0.5));
+  }
   std::map<int, int> hist;
   for (auto& kv : cu_count) hist[kv.second]++;
   printf("    CUs used %zu; workgroups per CU:", cu_count.size());
@@ -249,38 +317,50 @@ __global__ __launch_bounds__(256) void null_kernel(const BigArgs p) {
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
-// the tile stream of a 1x1 convolution: workgroup (tm, tn) pulls rows [tm*BM, +BM) of A and [tn*BN, +BN) of W, 128 bytes
-// of every row per step, through an NST-deep LDS ring by `buffer_load ... lds` -- and does nothing with them
-template <int BM, int BN, int NST>
+// the tile stream of a 1x1 convolution: workgroup (tm, tn) pulls rows [tm*BM, +BM) of A and [tn*BN, +BN) of W, RB bytes
+// of every row per step, through an NST-deep LDS ring by `buffer_load ... lds` -- and does nothing with them.
+// MODE bits: 1 = XCD-aware tile order (conv_dma's), 2 = every workgroup starts at its own K offset and wraps (no two
+// neighbours hammer the same 128-byte column of their rows at the same time), 4 = every workgroup reads tile (0, 0)
+// (L2-hot: the DMA issue / L1 -> LDS rate alone)
+__device__ __forceinline__ int xcd_remap_h(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+template <int BM, int BN, int NST, int RB, int MODE>
 __global__ __launch_bounds__(256) void stream_kernel(const BigArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  constexpr int LA = BM / 32, LB = BN / 32, SB = (BM + BN) * 128;
+  constexpr int RPI = 1024 / RB;                       // rows per DMA instruction
+  constexpr int LA = BM * RB / 4096, LB = BN * RB / 4096, SB = (BM + BN) * RB;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x % p.tiles_n;
+  const int tile = (MODE & 1) ? xcd_remap_h(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
+  if (MODE & 4) tm = tn = 0;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.a), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, 0x7fffffff, 0x00020000);
   unsigned va[LA], vb[LB];
 #pragma unroll
-  for (int q = 0; q < LA; ++q) va[q] = (unsigned)((tm * BM + (wave + 4 * q) * 8 + (lane >> 3)) * p.K2 + (lane & 7) * 16);
+  for (int q = 0; q < LA; ++q) va[q] = (unsigned)((tm * BM + (wave + 4 * q) * RPI + lane / (RB / 16)) * p.K2 + (lane % (RB / 16)) * 16);
 #pragma unroll
-  for (int q = 0; q < LB; ++q) vb[q] = (unsigned)((tn * BN + (wave + 4 * q) * 8 + (lane >> 3)) * p.K2 + (lane & 7) * 16);
-  unsigned kb = 0;
+  for (int q = 0; q < LB; ++q) vb[q] = (unsigned)((tn * BN + (wave + 4 * q) * RPI + lane / (RB / 16)) * p.K2 + (lane % (RB / 16)) * 16);
+  const int nk = p.K2 / RB;
+  unsigned kb = (MODE & 2) ? (unsigned)(((tm * 5 + tn * 3) % nk) * RB) : 0u;
   auto issue = [&](int st) {
     unsigned char* sa = smem + st * SB + wave * 1024;
 #pragma unroll
     for (int q = 0; q < LA; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(sa + q * 4096), 16, (int)va[q], (int)kb, 0, 0);
-    unsigned char* sb = smem + st * SB + BM * 128 + wave * 1024;
+    unsigned char* sb = smem + st * SB + BM * RB + wave * 1024;
 #pragma unroll
     for (int q = 0; q < LB; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(sb + q * 4096), 16, (int)vb[q], (int)kb, 0, 0);
-    kb += 128;
+    kb += RB;
+    if (kb == (unsigned)p.K2) kb = 0;
   };
   for (int s = 0; s < NST - 1; ++s) issue(s);
   int st = NST - 1;
-  for (int ks = 0; ks < p.nk; ++ks) {
+  for (int ks = 0; ks < nk; ++ks) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (LA + LB)) : "memory");
     __builtin_amdgcn_s_barrier();
-    if (ks + NST - 1 < p.nk) issue(st);
+    if (ks + NST - 1 < nk) issue(st);
     st = st + 1 == NST ? 0 : st + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -300,24 +380,64 @@ template <typename F> static double time_kernel(F&& fn, int iters, hipStream_t s
   return best;
 }
 
-template <int BM, int BN, int NST>
+// store burst: every workgroup writes ROWS x 256-byte row segments (16 lanes x 16 B per row, 16 rows per pass of 256 threads) of a
+// [M][pitch] bf16 tensor -- the epilogue's store pattern -- and nothing else.  AUX = cache-policy bits of the buffer store
+// (0 default, 1 sc0, 2 nt, 16 sc1, 17 sc0 sc1 = write-through, 3 = sc0 nt ...)
+template <int ROWS, int AUX>
+__global__ __launch_bounds__(256) void store_kernel(unsigned char* out, int pitch_bytes, int tiles_n, unsigned total_bytes, unsigned* stamps) {
+  const int tile = xcd_remap_h(blockIdx.x, gridDim.x);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int er = threadIdx.x >> 4, ec = threadIdx.x & 15;
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(out, 0, total_bytes, 0x00020000);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = {threadIdx.x, blockIdx.x, 3u, 4u};
+  const unsigned t0 = (unsigned)__builtin_readcyclecounter();
+#pragma unroll
+  for (int ps = 0; ps < ROWS / 16; ++ps) {
+    const unsigned off = (unsigned)((tm * ROWS + ps * 16 + er) * pitch_bytes + tn * 256 + ec * 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, AUX);
+  }
+  const unsigned t1 = (unsigned)__builtin_readcyclecounter();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned t2 = (unsigned)__builtin_readcyclecounter();
+  if (threadIdx.x == 0 && stamps) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = t2 - t0; }
+}
+template <int ROWS, int AUX>
+static void store_probe(int M, int N, int iters, hipStream_t s, hipEvent_t a, hipEvent_t b) {
+  const int tiles_m = M / ROWS, tiles_n = N / 128, grid = tiles_m * tiles_n;
+  const size_t bytes = (size_t)M * N * 2;
+  unsigned char* out; CK(hipMalloc((void**)&out, bytes));
+  unsigned* st; CK(hipMalloc((void**)&st, (size_t)grid * 8));
+  const double t = time_kernel([&]() { hipLaunchKernelGGL((store_kernel<ROWS, AUX>), dim3(grid), dim3(256), 0, s, out, N * 2, tiles_n, (unsigned)bytes, st); }, iters, s, a, b);
+  std::vector<unsigned> h((size_t)grid * 2); CK(hipMemcpy(h.data(), st, h.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<double> iss, ack; for (int g = 0; g < grid; ++g) { iss.push_back(h[2 * g]); ack.push_back(h[2 * g + 1]); }
+  const double wr = (double)grid * ROWS * 256;
+  printf("  store burst M %6d N %4d tile %3dx128 aux %2d: %4d wgs, %7.2f us per launch = %5.2f TB/s written; per workgroup issue med %5.0f cyc, acknowledged med %5.0f p90 %5.0f\n",
+         M, N, ROWS, AUX, grid, t, wr / t * 1e-6, pct(iss, 0.5), pct(ack, 0.5), pct(ack, 0.9));
+  (void)hipFree(out); (void)hipFree(st);
+}
+
+template <int BM, int BN, int NST, int RB, int MODE>
 static void floor_stream(const char* name, const Problem& p, int iters, hipStream_t s, hipEvent_t a, hipEvent_t b) {
   BigArgs g; memset(&g, 0, sizeof(g));
-  g.a = p.x; g.w = p.wf; g.K2 = p.fwd.Cin * 2; g.nk = p.fwd.Cin / 64;
+  g.a = p.x; g.w = p.wf; g.K2 = p.fwd.Cin * 2; g.nk = g.K2 / RB;
+  if (g.K2 % RB != 0) return;
   const int tiles_m = p.M / BM;       // whole tiles only (no ragged last tile: this is a bandwidth probe)
   g.tiles_n = (p.fwd.Cout + BN - 1) / BN;
   const int grid = tiles_m * g.tiles_n;
-  const size_t lds = (size_t)NST * (BM + BN) * 128;
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_kernel<BM, BN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  const double t = time_kernel([&]() { hipLaunchKernelGGL((stream_kernel<BM, BN, NST>), dim3(grid), dim3(256), lds, s, g); }, iters, s, a, b);
-  const double bytes = (double)grid * g.nk * (BM + BN) * 128.0;
-  printf("  %-9s stream %3dx%3d ring %d: %4d wgs, %6.1f KB LDS, %7.2f us, %6.2f TB/s LDS-side (%5.1f MB), unique %5.1f MB\n", name, BM, BN, NST, grid,
-         lds / 1024.0, t, bytes / t * 1e-6, bytes * 1e-6, ((double)p.M * g.K2 + (double)p.fwd.Cout * g.K2) * 1e-6);
+  const size_t lds = (size_t)NST * (BM + BN) * RB;
+  if (lds > 160 * 1024) return;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_kernel<BM, BN, NST, RB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  const double t = time_kernel([&]() { hipLaunchKernelGGL((stream_kernel<BM, BN, NST, RB, MODE>), dim3(grid), dim3(256), lds, s, g); }, iters, s, a, b);
+  const double bytes = (double)grid * g.nk * (BM + BN) * RB;
+  printf("  %-9s stream %3dx%3d ring %d rowbytes %d mode %d%s%s%s: %4d wgs, %5.0f KB LDS, %7.2f us, %6.2f TB/s into LDS = %4.1f B/clk/CU @2.1GHz\n", name, BM, BN,
+         NST, RB, MODE, (MODE & 1) ? " xcd" : "", (MODE & 2) ? " krot" : "", (MODE & 4) ? " hot" : "", grid, lds / 1024.0, t, bytes / t * 1e-6,
+         bytes / t * 1e-6 * 1e12 / 256.0 / 2.1e9);
 }
 
 int main(int argc, char** argv) {
   std::string only, cfgs_s = "-1", modes = "fwd,dgrad", trace;
-  int iters = 20, B = 8; bool dual = false, do_floor = false;
+  int iters = 20, B = 8; bool dual = false, do_floor = false, check = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&]() { return std::string(i + 1 < argc ? argv[++i] : ""); };
@@ -328,6 +448,7 @@ int main(int argc, char** argv) {
     else if (a == "--batch") B = atoi(val().c_str());
     else if (a == "--dual") dual = true;
     else if (a == "--floor") do_floor = true;
+    else if (a == "--check") check = true;
     else if (a == "--trace") trace = val();
     else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 64; }
   }
@@ -401,17 +522,33 @@ int main(int argc, char** argv) {
         printf("  empty launch: %4d wgs x 256 threads, %5.0f KB LDS, %zu-byte arguments: %6.2f us back to back\n", grid, lds / 1024.0, sizeof(BigArgs), t);
       }
     }
+    if (wanted("store")) {
+      store_probe<64, 0>(8704, 256, iters, s0, ea, eb);  store_probe<64, 0>(8704, 1024, iters, s0, ea, eb);  store_probe<64, 0>(8704, 2048, iters, s0, ea, eb);
+      store_probe<64, 0>(133120, 256, iters, s0, ea, eb);
+      store_probe<128, 0>(8704, 256, iters, s0, ea, eb); store_probe<128, 0>(8704, 1024, iters, s0, ea, eb);
+      store_probe<64, 2>(8704, 256, iters, s0, ea, eb);  store_probe<64, 2>(8704, 1024, iters, s0, ea, eb);  store_probe<64, 2>(133120, 256, iters, s0, ea, eb);
+      store_probe<64, 17>(8704, 256, iters, s0, ea, eb); store_probe<64, 17>(8704, 1024, iters, s0, ea, eb);
+      store_probe<64, 16>(8704, 256, iters, s0, ea, eb); store_probe<64, 16>(8704, 1024, iters, s0, ea, eb);
+      store_probe<64, 1>(8704, 256, iters, s0, ea, eb);  store_probe<64, 1>(8704, 1024, iters, s0, ea, eb);
+      store_probe<64, 3>(8704, 1024, iters, s0, ea, eb); store_probe<64, 19>(8704, 1024, iters, s0, ea, eb);
+    }
     for (const Shape& sh : SHAPES) {
       if (sh.k != 1 || sh.s != 1 || !wanted(sh.name)) continue;
       Problem p = make_problem(sh, B, 1);
-      floor_stream<64, 128, 2>(sh.name, p, iters, s0, ea, eb);
-      floor_stream<64, 128, 3>(sh.name, p, iters, s0, ea, eb);
-      floor_stream<64, 128, 4>(sh.name, p, iters, s0, ea, eb);
-      floor_stream<64, 128, 6>(sh.name, p, iters, s0, ea, eb);
-      floor_stream<128, 128, 2>(sh.name, p, iters, s0, ea, eb);
-      floor_stream<128, 128, 4>(sh.name, p, iters, s0, ea, eb);
-      floor_stream<128, 64, 2>(sh.name, p, iters, s0, ea, eb);
-      floor_stream<128, 64, 4>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<64, 128, 3, 128, 0>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<64, 128, 3, 128, 1>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<64, 128, 3, 128, 2>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<64, 128, 3, 128, 3>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<64, 128, 3, 128, 4>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<64, 128, 3, 256, 1>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<64, 128, 3, 256, 3>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<64, 128, 2, 256, 3>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<128, 128, 3, 128, 1>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<128, 128, 3, 128, 3>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<128, 128, 3, 128, 4>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<128, 128, 2, 256, 3>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<128, 64, 3, 128, 3>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<256, 128, 3, 128, 3>(sh.name, p, iters, s0, ea, eb);
       free_problem(p);
     }
     return 0;
@@ -433,6 +570,7 @@ int main(int argc, char** argv) {
         const double t = time_single(p0, dg, cfg, iters, s0, ea, eb);
         if (t < 0) { printf(" %s:%d ERR", mode, cfg); continue; }
         printf(" %s:%d %6.1f (%5.0f)", mode, cfg, t, p0.flops / t * 1e-6);
+        if (check) check_cfg(p0, dg, cfg, s0);
         if (dual) { const double t2 = time_dual(p0, p1, dg, cfg, iters, s0, s1); printf(" [%6.1f]", t2); }
         best = std::min(best, t);
       }
