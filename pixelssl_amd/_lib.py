@@ -71,6 +71,7 @@ SIGNATURES = {
     "pxl_version": (_I, []),
     "pxl_conv_igemm": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "pxl_conv_dma_bnin": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.POINTER(BnFin), _I, _P, _P]),
+    "pxl_conv_dma_trace": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "pxl_conv_dgrad_bnreduce": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "pxl_conv_dgrad_joinreduce": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pxl_conv_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _I, _I, _P]),
