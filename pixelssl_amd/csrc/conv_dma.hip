@@ -29,7 +29,9 @@ extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_sca
 // 20..27: tall tiles 96 / 160 / 192 / 256 (pixels) x 128 with ONE wave column (WM = 1, WN = 4): M = 8 * 33 * 33 = 8712 is
 // 68.06 tiles of 128 and 136.1 tiles of 64 -- every ResNet-101 stage-3/4 launch ends with a nearly empty last wave of
 // workgroups (274 on 256 CUs).  96-row tiles give 91 x N/128 workgroups (182 for N = 256: one wave at 1.17x the tile
-// traffic instead of two), 160 / 192 rows fit N = 512 / 2048 the same way.  20..23 = 3 stages, 24..27 = 2 stages
+// traffic instead of two), 160 / 192 rows fit N = 512 / 2048 the same way.  20..23 = 3 stages, 24..27 = 2 stages;
+// 28..35: 8-wave workgroups (two waves per SIMD): 28 = 64x128, 29 = 128x64, 30 / 31 = 128x128 as 2x4 / 4x2 waves (2 stages),
+// 32 = 64x128, 33 = 128x128 (3 stages), 34 = 256x128, 35 = 128x256 (2 stages)
 namespace { int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes, void* stream); }
 
 extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
@@ -181,6 +183,8 @@ int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes,
   if (cfg >= 16 && cfg <= 19) return pxl_dma_launch_b(cfg, a, gather, sk, ws_bytes, s);
   if (cfg >= 20 && cfg <= 23) return pxl_dma_launch_c(cfg, a, gather, sk, ws_bytes, s);
   if (cfg >= 24 && cfg <= 27) return pxl_dma_launch_d(cfg, a, gather, sk, ws_bytes, s);
+  if (cfg >= 28 && cfg <= 31) return pxl_dma_launch_e(cfg, a, gather, sk, ws_bytes, s);
+  if (cfg >= 32 && cfg <= 35) return pxl_dma_launch_f(cfg, a, gather, sk, ws_bytes, s);
   switch (cfg) {
     case 12: return launch_dma<128, 128, 2, 2, 4>(a, gather, sk, ws_bytes, s);
     case 13: return launch_dma<128, 64, 2, 2, 4>(a, gather, sk, ws_bytes, s);

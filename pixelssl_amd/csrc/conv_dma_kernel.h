@@ -141,7 +141,9 @@ template <int OFF> __device__ __forceinline__ void lds_write128(unsigned addr, u
 }
 // BN-on-load: the LA pieces a lane has DMA'd itself + the 4 coefficient vectors, all LDS reads waited for at once
 template <int LA> __device__ __forceinline__ void wait_xform(u32x4 (&d)[LA], u32x4 (&c)[4]) {
-  if constexpr (LA == 2)
+  if constexpr (LA == 1)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+  else if constexpr (LA == 2)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
   else if constexpr (LA == 3)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
@@ -158,16 +160,16 @@ template <int LA> __device__ __forceinline__ void wait_xform(u32x4 (&d)[LA], u32
                    "+v"(c[3]));
   }
 }
-template <int I, int N> struct XformLoad {
+template <int I, int N, int STRIDE> struct XformLoad {
   static __device__ __forceinline__ void run(u32x4 (&d)[N], unsigned addr) {
-    d[I] = lds_read128<I * 4096>(addr);
-    if constexpr (I + 1 < N) XformLoad<I + 1, N>::run(d, addr);
+    d[I] = lds_read128<I * STRIDE>(addr);
+    if constexpr (I + 1 < N) XformLoad<I + 1, N, STRIDE>::run(d, addr);
   }
 };
-template <int I, int N> struct XformStore {
+template <int I, int N, int STRIDE> struct XformStore {
   static __device__ __forceinline__ void run(const u32x4 (&d)[N], unsigned addr) {
-    lds_write128<I * 4096>(addr, d[I]);
-    if constexpr (I + 1 < N) XformStore<I + 1, N>::run(d, addr);
+    lds_write128<I * STRIDE>(addr, d[I]);
+    if constexpr (I + 1 < N) XformStore<I + 1, N, STRIDE>::run(d, addr);
   }
 };
 
@@ -331,26 +333,35 @@ template <size_t BYTES> __device__ __forceinline__ void kernarg_touch() {
 #undef PXL_KT
 }
 
-// BM x BN output tile (pixels x channels), 4 waves as WM x WN, NST LDS stages, GATHER = taps / padding logic
+// BM x BN output tile (pixels x channels), 4 or 8 waves as WM x WN, NST LDS stages, GATHER = taps / padding logic.
+// Eight waves (two per SIMD) exist for the DMA issue rate: a `buffer_load ... lds` costs its wave 100-180 cycles of issue
+// (MI355X_MICROARCH.md), four waves x 6 pieces per K step of a 64 x 128 tile is the ~800 cycles per step that
+// tools/cbench --trace measures, and tools/cbench --floor shows a CU reaching ~40 B/clk only with more waves issuing.
 // ABL: timing ablations for tools/conv_bench.py (results are garbage): 1 = no DMA in the loop, 2 = no MFMA,
 // 4 = no fragment reads, 8 = no barrier.  0 in every product instantiation.
 // workgroups (= waves per SIMD) the register allocation must leave room for: small tiles live on co-residency (a CU with 3-4
 // workgroups in flight keeps ~38 B/clk of DMA going, one alone ~28: tools/cbench --floor)
 constexpr int dma_occupancy(int acc_tiles) { return acc_tiles <= 2 ? 3 : 2; }
+// ... as waves per SIMD (the launch-bounds unit): 8-wave workgroups put two waves on every SIMD
+constexpr int dma_waves_per_simd(int nw, int acc_tiles) { return nw == 4 ? dma_occupancy(acc_tiles) : (acc_tiles <= 1 ? 4 : 2); }
 
-template <int BM, int BN, int WM, int WN, int NST, bool GATHER, int ABL = 0, bool BNIN = false, bool TRACE = false>
-__global__ __launch_bounds__(256, dma_occupancy((BM / WM / 32) * (BN / WN / 32))) void conv_dma_kernel(const DmaArgs p) {
+template <int BM, int BN, int WM, int WN, int NST, bool GATHER, int ABL = 0, bool BNIN = false, bool TRACE = false, int EM = -1>
+__global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM / 32) * (BN / WN / 32))) void conv_dma_kernel(const DmaArgs p) {
   constexpr int TMI = BM / WM / 32;          // 32-pixel tiles per wave
   constexpr int TNI = BN / WN / 32;          // 32-channel tiles per wave
-  constexpr int LA = BM / 32, LB = BN / 32;  // DMA instructions per wave per K step
+  constexpr int NW = WM * WN;                // waves: 4, or 8 = two per SIMD (half the DMA instructions per wave and step)
+  constexpr int NT = NW * 64;
+  constexpr int LA = BM / (8 * NW), LB = BN / (8 * NW);  // DMA instructions per wave per K step
   constexpr int SB = (BM + BN) * 128;        // bytes per stage
   constexpr int TP = BN * 2 + 16;            // epilogue staging row pitch (bank-conflict-free ds_write_b64)
   constexpr int TPR = BN / 8;                // threads per output row on the read-back pass
-  constexpr int RPP = 256 / TPR;             // rows per pass
+  constexpr int RPP = NT / TPR;              // rows per pass
   constexpr int NPASS = BM / RPP;
-  static_assert(WM * WN == 4 && TMI >= 1 && TNI >= 1 && ((TMI <= 2 && TNI <= 2) || (TNI == 1 && TMI <= 6)), "tile");
+  static_assert((NW == 4 || NW == 8) && LA >= 1 && LB >= 1 && TMI >= 1 && TNI >= 1 && ((TMI <= 2 && TNI <= 2) || (TNI == 1 && TMI <= 6)), "tile");
   static_assert(BM % RPP == 0, "epilogue rows per pass must divide the tile");
-  static_assert(NST * SB >= BM * TP + RPP * 2 * BN * 4, "epilogue staging + statistics partials must fit in the ring");
+  constexpr int RED_BYTES = RPP * 2 * BN * 4;                   // statistics partials [RPP rows][2][BN] fp32
+  constexpr bool RED_ALIAS = BM * TP + RED_BYTES > NST * SB;    // no room behind the staged tile: reuse it (one more barrier)
+  static_assert(NST * SB >= BM * TP && NST * SB >= RED_BYTES, "epilogue staging / statistics partials must fit in the ring");
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(256, dma_occupancy((BM / WM / 32) * (BN / WN / 32))
   const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
 #pragma unroll
   for (int q = 0; q < LA; ++q) {
-    const int row = (wave + 4 * q) * 8 + lrow;
+    const int row = (wave + NW * q) * 8 + lrow;
     const int chunk = lslot ^ ((row >> 1) & 7);
     const int m = m0 + row;
     const bool in = m < p.M;
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(256, dma_occupancy((BM / WM / 32) * (BN / WN / 32))
   }
 #pragma unroll
   for (int q = 0; q < LB; ++q) {
-    const int row = (wave + 4 * q) * 8 + lrow;
+    const int row = (wave + NW * q) * 8 + lrow;
     const int chunk = lslot ^ ((row >> 1) & 7);
     const int n = n0 + row;
     voffB[q] = n < p.Kreal ? (unsigned)(n * p.Ktot * 2 + chunk * 16) : OOB;
@@ -460,7 +471,7 @@ __global__ __launch_bounds__(256, dma_occupancy((BM / WM / 32) * (BN / WN / 32))
   auto issue = [&](int stage) {
     unsigned char* sa = smem + stage * SB + wave * 1024;
 #pragma unroll
-    for (int q = 0; q < LA; ++q) dma16(r_in, sa + q * 4096, voffA[q], kcb);
+    for (int q = 0; q < LA; ++q) dma16(r_in, sa + q * NW * 1024, voffA[q], kcb);
     if constexpr (BNIN) {
       unsigned bits = 0;
 #pragma unroll
@@ -469,7 +480,7 @@ __global__ __launch_bounds__(256, dma_occupancy((BM / WM / 32) * (BN / WN / 32))
     }
     unsigned char* sb = smem + stage * SB + BM * 128 + wave * 1024;
 #pragma unroll
-    for (int q = 0; q < LB; ++q) dma16(r_w, sb + q * 4096, voffB[q], kwb);
+    for (int q = 0; q < LB; ++q) dma16(r_w, sb + q * NW * 1024, voffB[q], kwb);
     kwb += 128;
     kcb += 128;
     if (kcb == cin_bytes) {      // block-uniform: next tap
@@ -512,7 +523,7 @@ __global__ __launch_bounds__(256, dma_occupancy((BM / WM / 32) * (BN / WN / 32))
     float* tab = reinterpret_cast<float*>(smem + NST * SB);
     const pxl_bn_fin& f = p.bin;
     const int C = p.Cin;
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += NT) {
       float mean, var;
       if (f.training) {
         float s1 = 0.f, s2 = 0.f;
@@ -559,7 +570,7 @@ __global__ __launch_bounds__(256, dma_occupancy((BM / WM / 32) * (BN / WN / 32))
       u32x4 cf[4], dd[LA];
       cf[0] = lds_read128<0>(tb);  cf[1] = lds_read128<16>(tb);
       cf[2] = lds_read128<0>(tb2); cf[3] = lds_read128<16>(tb2);
-      XformLoad<0, LA>::run(dd, pa);
+      XformLoad<0, LA, NW * 1024>::run(dd, pa);
       wait_xform<LA>(dd, cf);
       const unsigned bits = (vm >> (8 * st_c)) & 0xffu;
       float sc[8], sh[8];
@@ -581,7 +592,7 @@ __global__ __launch_bounds__(256, dma_occupancy((BM / WM / 32) * (BN / WN / 32))
         const bool real = (bits >> q) & 1u;
         dd[q] = real ? u32x4{r.x, r.y, r.z, r.w} : dd[q];
       }
-      XformStore<0, LA>::run(dd, pa);
+      XformStore<0, LA, NW * 1024>::run(dd, pa);
       if constexpr (!GATHER) {
         // materialise z = relu(bn(y)) for the weight gradient: one workgroup per pixel tile writes what it transformed (the
         // same bytes, the same offsets as the source; zero-filled lanes are out of range for the store as well)
@@ -640,7 +651,7 @@ __global__ __launch_bounds__(256, dma_occupancy((BM / WM / 32) * (BN / WN / 32))
   stamp();
 
   if constexpr (ABL & 16) return;
-  if (p.ws != nullptr) {
+  if (EM == -2 || (EM == -1 && p.ws != nullptr)) {
     // split-K: fp32 partial sums of this K slice -> workspace; bias / rounding happen in the finish kernel
 #pragma unroll
     for (int j = 0; j < TNI; ++j)
@@ -680,19 +691,18 @@ __global__ __launch_bounds__(256, dma_occupancy((BM / WM / 32) * (BN / WN / 32))
   const int er = tid / TPR;
   const int n = n0 + ec * 8;
   const bool ncol = n < p.Cout;
-  const bf16_t* __restrict__ gadd = reinterpret_cast<const bf16_t*>(p.addend);
-  const bool has_bias = p.bias != nullptr;
-  const bool has_add = gadd != nullptr;
-  const bool has_stats = p.stats != nullptr && !(ABL & 32);
-  const bf16_t* __restrict__ gbny = reinterpret_cast<const bf16_t*>(p.bn_y);
-  const bool has_bnr = has_stats && gbny != nullptr;
-  const bf16_t* __restrict__ gmask = reinterpret_cast<const bf16_t*>(p.bn_mask);
-  const bool has_mask = has_bnr && gmask != nullptr;
+  // EM >= 0: the operand combination is a compile-time constant of this instantiation (the host picks it, launch_dma below).
+  // The round-4 timeline probe measured the run-time dispatch between the read-back variants at ~3500 cycles per workgroup
+  // (a ten-way scalar branch into cold instruction-cache lines): 4100 -> 660 cycles for the passes once it was gone.
+  const bool has_bias = EM >= 0 ? bool(EM & 2) : p.bias != nullptr;
+  const bool has_add = EM >= 0 ? bool(EM & 1) : p.addend != nullptr;
+  const bool has_stats = EM >= 0 ? bool(EM & 4) : (p.stats != nullptr && !(ABL & 32));
+  const bool has_bnr = EM >= 0 ? bool(EM & 8) : (has_stats && p.bn_y != nullptr);
+  const bool has_mask = EM >= 0 ? bool(EM & 16) : (has_bnr && p.bn_mask != nullptr);
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-  // Read-back passes: one straight-line specialisation per operand combination (epi_passes above), selected by ONE uniform
-  // branch.  emode bits: 1 addend, 2 bias, 4 statistics, 8 BatchNorm-backward sums, 16 join mask, 32 ReLU mask of the BN.
+  // Read-back passes: one straight-line specialisation per operand combination (epi_passes above).  emode bits: 1 addend, 2 bias, 4 statistics, 8 BatchNorm-backward sums, 16 join mask, 32 ReLU mask of the BN.
   {
     EpiCtx c;
     c.T = T; c.er = er; c.ec = ec; c.m0 = m0; c.M = p.M; c.Cout = p.Cout; c.n = n; c.ncol = ncol;
@@ -704,26 +714,16 @@ __global__ __launch_bounds__(256, dma_occupancy((BM / WM / 32) * (BN / WN / 32))
     c.bias = p.bias; c.bn_coef = p.bn_coef; c.Kreal = p.Kreal;
     const int emode = (has_add ? 1 : 0) | (has_bias ? 2 : 0) | (has_stats ? 4 : 0) | (has_bnr ? 8 : 0) | (has_mask ? 16 : 0) |
                       ((has_bnr && !has_mask && p.bn_relu) ? 32 : 0);
-    switch (emode) {
-      case 0: epi_passes<0, NPASS, RPP, TP>(stamp, c, s1, s2); break;           // plain store (data gradient, inference forward)
-      case 1: epi_passes<1, NPASS, RPP, TP>(stamp, c, s1, s2); break;           // + addend (gradient accumulation)
-      case 2: epi_passes<2, NPASS, RPP, TP>(stamp, c, s1, s2); break;           // + bias (head convolutions)
-      case 4: epi_passes<4, NPASS, RPP, TP>(stamp, c, s1, s2); break;           // forward with batch statistics
-      case 12: epi_passes<12, NPASS, RPP, TP>(stamp, c, s1, s2); break;         // data gradient + BatchNorm-backward sums
-      case 13: epi_passes<13, NPASS, RPP, TP>(stamp, c, s1, s2); break;
-      case 44: epi_passes<44, NPASS, RPP, TP>(stamp, c, s1, s2); break;         // ... through the BN's ReLU
-      case 45: epi_passes<45, NPASS, RPP, TP>(stamp, c, s1, s2); break;
-      case 28: epi_passes<28, NPASS, RPP, TP>(stamp, c, s1, s2); break;         // ... of a residual join
-      case 29: epi_passes<29, NPASS, RPP, TP>(stamp, c, s1, s2); break;
-      default: epi_passes<-1, NPASS, RPP, TP>(stamp, c, s1, s2, emode); break;  // anything else: run-time flags
-    }
+    if constexpr (EM >= 0) epi_passes<EM, NPASS, RPP, TP>(stamp, c, s1, s2);
+    else epi_passes<-1, NPASS, RPP, TP>(stamp, c, s1, s2, emode);           // uncommon combinations: run-time flags
   }
   stamp();
   if (has_stats) {
     // reduce over the RPP threads that share a channel chunk (one per row of a pass), through LDS: every thread parks its
     // 16 partial sums, one thread per (sum, channel) adds the RPP rows.  (The round-3 form -- 32 cross-lane shuffles, each an
     // LDS permute with its own wait, then a 4-wave LDS pass -- took 1.0 us of a 12 us workgroup: tools/cbench --trace.)
-    float* red = reinterpret_cast<float*>(smem + BM * TP);     // [RPP rows][2][BN]
+    if constexpr (RED_ALIAS) __syncthreads();                  // every thread is done reading the staged tile
+    float* red = reinterpret_cast<float*>(smem + (RED_ALIAS ? 0 : BM * TP));     // [RPP rows][2][BN]
     {
       float* mine = red + er * 2 * BN + ec * 8;
       *reinterpret_cast<float4*>(mine) = make_float4(s1[0], s1[1], s1[2], s1[3]);
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256, dma_occupancy((BM / WM / 32) * (BN / WN / 32))
     const int is_last = __syncthreads_or(mine);
     if (is_last) {
       const int C = p.Kreal;
-      for (int c = tid; c < C; c += 256) {
+      for (int c = tid; c < C; c += NT) {
         float s1 = 0.f, s2 = 0.f;
         for (int r = 0; r < p.stats_rep; ++r) {
           s1 += __hip_atomic_load(p.stats + (size_t)r * 2 * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -823,6 +823,19 @@ int launch_abl(const DmaArgs& a, hipStream_t stream) {
 extern "C" int pxl_splitk_finish(int dtype, long total, int Cout, int Kreal, const float* ws, const float* bias, void* out,
                                  void* stream);
 
+template <int BM, int BN, int WM, int WN, int NST, bool GATHER, bool BNIN, bool TRACE, int EM>
+int launch_one(dim3 grid, dim3 block, size_t smem, hipStream_t stream, const DmaArgs& p) {
+  static bool raised = false;
+  if (!raised) {
+    PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, GATHER, 0, BNIN, TRACE, EM>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    raised = true;
+  }
+  hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, GATHER, 0, BNIN, TRACE, EM>), grid, block, smem, stream, p);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
 template <int BM, int BN, int WM, int WN, int NST>
 int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, hipStream_t stream) {
   DmaArgs p = a;
@@ -845,34 +858,45 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
   else p.ws = nullptr;
   const bool bnin = p.bin.coef != nullptr;
   const size_t smem = (size_t)NST * (BM + BN) * 128 + (bnin ? (size_t)p.Cin * 8 : 0);
-  static bool raised[4] = {false, false, false, false};
-  const int vi = (gather ? 1 : 0) + (bnin ? 2 : 0);
-  const void* fn = vi == 0 ? reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, false>)
-                 : vi == 1 ? reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, true>)
-                 : vi == 2 ? reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, false, 0, true>)
-                           : reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, true, 0, true>);
-  if (!raised[vi]) {
-    PXL_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    raised[vi] = true;
-  }
   if (smem > 156 * 1024) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: tile + coefficient table exceed the LDS");
-  if (p.trace != nullptr) {          // timeline probe (tools/cbench): the same kernel with cycle stamps
-    if (bnin) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: no trace build of the BN-on-load kernel");
-    const void* tf = gather ? reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, true, 0, false, true>)
-                            : reinterpret_cast<const void*>(&conv_dma_kernel<BM, BN, WM, WN, NST, false, 0, false, true>);
-    PXL_CHECK_HIP(hipFuncSetAttribute(tf, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    if (gather) hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, true, 0, false, true>), dim3(grid, splitk), dim3(256), smem, stream, p);
-    else hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, false, 0, false, true>), dim3(grid, splitk), dim3(256), smem, stream, p);
-    PXL_LAUNCH_CHECK();
-    return PXL_OK;
+  const dim3 g(grid, splitk), b(WM * WN * 64);
+  if (p.trace != nullptr) {          // timeline probe (tools/cbench): the forward-with-statistics kernel with cycle stamps
+    if (bnin || p.stats == nullptr || p.addend != nullptr || p.bias != nullptr)
+      return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: the trace build is the plain forward convolution with statistics");
+    return gather ? launch_one<BM, BN, WM, WN, NST, true, false, true, 4>(g, b, smem, stream, p)
+                  : launch_one<BM, BN, WM, WN, NST, false, false, true, 4>(g, b, smem, stream, p);
   }
-  switch (vi) {
-    case 0: hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, false>), dim3(grid, splitk), dim3(256), smem, stream, p); break;
-    case 1: hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, true>), dim3(grid, splitk), dim3(256), smem, stream, p); break;
-    case 2: hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, false, 0, true>), dim3(grid, splitk), dim3(256), smem, stream, p); break;
-    default: hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, true, 0, true>), dim3(grid, splitk), dim3(256), smem, stream, p); break;
+  // operand combination of the read-back passes (epi_passes): a compile-time constant of the kernel that is launched
+  const bool has_stats = p.stats != nullptr, has_bnr = has_stats && p.bn_y != nullptr, has_mask = has_bnr && p.bn_mask != nullptr;
+  int em = (p.addend ? 1 : 0) | (p.bias ? 2 : 0) | (has_stats ? 4 : 0) | (has_bnr ? 8 : 0) | (has_mask ? 16 : 0) |
+           ((has_bnr && !has_mask && p.bn_relu) ? 32 : 0);
+  if (splitk > 1) em = -2;
+  int rc;
+#define PXL_EM(E) case E: rc = gather ? launch_one<BM, BN, WM, WN, NST, true, false, false, E>(g, b, smem, stream, p) \
+                                       : launch_one<BM, BN, WM, WN, NST, false, false, false, E>(g, b, smem, stream, p); break;
+#define PXL_EM_BNIN(E) case E: rc = gather ? launch_one<BM, BN, WM, WN, NST, true, true, false, E>(g, b, smem, stream, p) \
+                                            : launch_one<BM, BN, WM, WN, NST, false, true, false, E>(g, b, smem, stream, p); break;
+  if (!bnin) {
+    switch (em) {
+      PXL_EM(-2)                       // split-K partial sums
+      PXL_EM(0) PXL_EM(1)              // plain store; + addend (gradient accumulation)
+      PXL_EM(4)                        // forward with batch statistics
+      PXL_EM(12) PXL_EM(13)            // data gradient + BatchNorm-backward sums (+ addend)
+      PXL_EM(44) PXL_EM(45)            // ... through the BN's ReLU
+      PXL_EM(28) PXL_EM(29)            // ... of a residual join
+      default: rc = gather ? launch_one<BM, BN, WM, WN, NST, true, false, false, -1>(g, b, smem, stream, p)
+                           : launch_one<BM, BN, WM, WN, NST, false, false, false, -1>(g, b, smem, stream, p);
+    }
+  } else {
+    switch (em) {
+      PXL_EM_BNIN(0) PXL_EM_BNIN(4)
+      default: rc = gather ? launch_one<BM, BN, WM, WN, NST, true, true, false, -1>(g, b, smem, stream, p)
+                           : launch_one<BM, BN, WM, WN, NST, false, true, false, -1>(g, b, smem, stream, p);
+    }
   }
-  PXL_LAUNCH_CHECK();
+#undef PXL_EM
+#undef PXL_EM_BNIN
+  if (rc != PXL_OK) return rc;
   if (splitk > 1)
     return pxl_splitk_finish(PXL_BF16, (long)p.M * p.Cout, p.Cout, p.Kreal, p.ws, p.bias, p.out, stream);
   return PXL_OK;
@@ -880,9 +904,11 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
 
 }  // namespace pxl_dma
 
-// The tile configurations are instantiated in four translation units (conv_dma_a .. d.hip) so that the build compiles them in
+// The tile configurations are instantiated in six translation units (conv_dma_a .. f.hip) so that the build compiles them in
 // parallel: each defines one dispatcher over its share of the configuration numbers.
 int pxl_dma_launch_a(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s);   // 8..11  (3-stage 2x2)
 int pxl_dma_launch_b(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s);   // 16..19 (2-stage 2x2)
 int pxl_dma_launch_c(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s);   // 20..23 (3-stage tall)
 int pxl_dma_launch_d(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s);   // 24..27 (2-stage tall)
+int pxl_dma_launch_e(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s);   // 28..31 (8 waves)
+int pxl_dma_launch_f(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s);   // 32..35 (8 waves)

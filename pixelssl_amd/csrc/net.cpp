@@ -854,10 +854,11 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
       int best_cfg = -1; float best = 1e30f;
       const bool dma = pxl_conv_dma_eligible(&op.fwd, sc, nullptr) != 0;
       const bool onload = dma && d.bn_in0 >= 0 && n->bns[d.bn_in0].onload && getenv("PXL_TUNE_ONLOAD_PLAIN") == nullptr;
-      for (int cfg = dma ? 8 : 0; cfg < (dma ? 28 : 8); ++cfg) {
+      for (int cfg = dma ? 8 : 0; cfg < (dma ? 36 : 8); ++cfg) {
         if (!dma && (cfg & 3) == 3 && tout.Cp > 64) continue;
         if (dma && cfg >= 12 && cfg < 16) continue;          // 4-stage rings never won on the ResNet shapes
-        if (dma && cfg >= 20 && tout.Cp < 128) continue;     // tall tiles are 128 channels wide
+        if (dma && cfg >= 20 && cfg != 29 && tout.Cp < 128) continue;     // tall / 8-wave tiles are 128 channels wide (29: 128 x 64)
+        if (dma && cfg == 35 && tout.Cp < 256) continue;
         if (dma && !allowed(cfg)) continue;
         pxl_conv_desc q = op.fwd; q.tile_cfg = cfg;
         float t;
@@ -886,10 +887,11 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
     if (d.need_dgrad && n->pack_dgrad) {
       int best_cfg = -1; float best = 1e30f;
       const bool dma = pxl_conv_dma_eligible(&op.bwd, nullptr, nullptr) != 0;
-      for (int cfg = dma ? 8 : 0; cfg < (dma ? 28 : 8); ++cfg) {
+      for (int cfg = dma ? 8 : 0; cfg < (dma ? 36 : 8); ++cfg) {
         if (!dma && (cfg & 3) == 3 && tin.Cp > 64) continue;
         if (dma && cfg >= 12 && cfg < 16) continue;
-        if (dma && cfg >= 20 && tin.Cp < 128) continue;
+        if (dma && cfg >= 20 && cfg != 29 && tin.Cp < 128) continue;
+        if (dma && cfg == 35 && tin.Cp < 256) continue;
         if (dma && !allowed(cfg)) continue;
         pxl_conv_desc q = op.bwd; q.tile_cfg = cfg;
         float t = time_launch([&]() { return pxl_conv_igemm(&q, at(scratch, tout.goff), at(packed, op.wt_off), at(scratch, tin.goff),

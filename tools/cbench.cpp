@@ -345,13 +345,23 @@ __global__ __launch_bounds__(256) void stream_kernel(const BigArgs p) {
   for (int q = 0; q < LB; ++q) vb[q] = (unsigned)((tn * BN + (wave + 4 * q) * RPI + lane / (RB / 16)) * p.K2 + (lane % (RB / 16)) * 16);
   const int nk = p.K2 / RB;
   unsigned kb = (MODE & 2) ? (unsigned)(((tm * 5 + tn * 3) % nk) * RB) : 0u;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 breg[LB];
+  // MODE 8: the B (weight) rows go to REGISTERS by plain 16-byte loads, 1 KB contiguous per wave-instruction (what a
+  // fragment-ordered weight pack would give), instead of through the LDS-DMA path: is the ~40 B/clk/CU ceiling the DMA's or the L1's?
+  unsigned wbase = (unsigned)((tn * (gridDim.x / p.tiles_n > 0 ? 1 : 1)) * BN * p.K2) + (unsigned)(wave * LB) * 1024u + (unsigned)lane * 16u;
   auto issue = [&](int st) {
     unsigned char* sa = smem + st * SB + wave * 1024;
 #pragma unroll
     for (int q = 0; q < LA; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(sa + q * 4096), 16, (int)va[q], (int)kb, 0, 0);
-    unsigned char* sb = smem + st * SB + BM * RB + wave * 1024;
+    if constexpr (MODE & 8) {
 #pragma unroll
-    for (int q = 0; q < LB; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(sb + q * 4096), 16, (int)vb[q], (int)kb, 0, 0);
+      for (int q = 0; q < LB; ++q) breg[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(wbase + q * 1024), (int)(kb * (BN / (RB / 16) / 8)), 0);
+    } else {
+      unsigned char* sb = smem + st * SB + BM * RB + wave * 1024;
+#pragma unroll
+      for (int q = 0; q < LB; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(sb + q * 4096), 16, (int)vb[q], (int)kb, 0, 0);
+    }
     kb += RB;
     if (kb == (unsigned)p.K2) kb = 0;
   };
@@ -360,10 +370,18 @@ __global__ __launch_bounds__(256) void stream_kernel(const BigArgs p) {
   for (int ks = 0; ks < nk; ++ks) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (LA + LB)) : "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (MODE & 8) {
+#pragma unroll
+      for (int q = 0; q < LB; ++q) asm volatile("" ::"v"(breg[q]));     // (consumes the previous step's registers: the compiler waits for them here)
+    }
     if (ks + NST - 1 < nk) issue(st);
     st = st + 1 == NST ? 0 : st + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (MODE & 8) {
+#pragma unroll
+    for (int q = 0; q < LB; ++q) asm volatile("" ::"v"(breg[q]));
+  }
   if (p.sink && blockIdx.x == 0x7fffffff) p.sink[threadIdx.x] = smem[threadIdx.x];
 }
 
@@ -431,7 +449,7 @@ static void floor_stream(const char* name, const Problem& p, int iters, hipStrea
   const double t = time_kernel([&]() { hipLaunchKernelGGL((stream_kernel<BM, BN, NST, RB, MODE>), dim3(grid), dim3(256), lds, s, g); }, iters, s, a, b);
   const double bytes = (double)grid * g.nk * (BM + BN) * RB;
   printf("  %-9s stream %3dx%3d ring %d rowbytes %d mode %d%s%s%s: %4d wgs, %5.0f KB LDS, %7.2f us, %6.2f TB/s into LDS = %4.1f B/clk/CU @2.1GHz\n", name, BM, BN,
-         NST, RB, MODE, (MODE & 1) ? " xcd" : "", (MODE & 2) ? " krot" : "", (MODE & 4) ? " hot" : "", grid, lds / 1024.0, t, bytes / t * 1e-6,
+         NST, RB, MODE, (MODE & 1) ? " xcd" : "", (MODE & 2) ? " krot" : "", (MODE & 4) ? " hot" : (MODE & 8) ? " Breg" : "", grid, lds / 1024.0, t, bytes / t * 1e-6,
          bytes / t * 1e-6 * 1e12 / 256.0 / 2.1e9);
 }
 
@@ -535,6 +553,11 @@ int main(int argc, char** argv) {
     for (const Shape& sh : SHAPES) {
       if (sh.k != 1 || sh.s != 1 || !wanted(sh.name)) continue;
       Problem p = make_problem(sh, B, 1);
+      floor_stream<64, 128, 3, 128, 9>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<64, 128, 2, 128, 9>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<128, 128, 2, 128, 9>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<128, 128, 2, 128, 1>(sh.name, p, iters, s0, ea, eb);
+      floor_stream<64, 128, 2, 128, 1>(sh.name, p, iters, s0, ea, eb);
       floor_stream<64, 128, 3, 128, 0>(sh.name, p, iters, s0, ea, eb);
       floor_stream<64, 128, 3, 128, 1>(sh.name, p, iters, s0, ea, eb);
       floor_stream<64, 128, 3, 128, 2>(sh.name, p, iters, s0, ea, eb);
