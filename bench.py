@@ -6,6 +6,7 @@ classes, bf16 engine (fp32 accumulate, fp32 BN statistics, fp32 master weights /
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N [--algo gct]        # no launcher: bench.py starts the N ranks itself (the line above)
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  A "step" is the full reference
 iteration (ssl_mt.py:131-220): student fwd + CE, teacher fwd (no-grad, train-mode BN), MSE
@@ -296,8 +297,26 @@ def fp32_parity_leg(a, world, batches, fence):
                     "losses / weights are within 1e-3 of the reference (parity tests); same workload, same timing protocol"}
 
 
+def respawn_under_launcher(a):
+    """`python bench.py --gpus N` with no launcher environment: start the N ranks ourselves (one process per GPU, the launch
+    line of the docstring) and pass their output through -- the command cannot silently measure ONE GPU.  The reference's
+    single command drives every visible GPU as well (pixelssl/nn/func.py:54-62: DataParallel over all of them)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        respawn_under_launcher(a)
     import torch
     import torch.distributed as dist
     import pixelssl_amd as P
@@ -308,8 +327,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world != a.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+        # (main() re-launches `--gpus N` under torch.distributed.run when no launcher environment is present, so this is a
+        # launcher that started a different number of ranks than the command line asks for: refuse, do not measure the wrong job)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or run `python bench.py --gpus %d` "
+                         "without a launcher: it spawns the ranks itself)" % (a.gpus, world, a.gpus, a.gpus))
+    if world > 1 and os.environ.get("PXL_FORCE_DEVICE") is None and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(pdist.local_device())
     pdist.init_from_env("nccl")
     # experiment switch: k streams created (and used once) before anything else shifts which hardware queue every later
@@ -402,6 +425,14 @@ def main():
                "rccl_ranks": pdist.rccl_ranks(), "grad_buckets": int(cores[0].grad_buckets()),
                # networks whose Sync-BN statistics go through the peer-mapped one-shot exchange (csrc/peer.hip)
                "peer_contexts": pdist.peer_contexts()}
+        # what the line claims about the job, checked before it is printed: N ranks, every one of them on the RCCL
+        # communicators (unless the run was explicitly put on another backend / onto one shared GPU for a test)
+        shared = os.environ.get("PXL_FORCE_DEVICE") is not None or os.environ.get("PXL_DIST_BACKEND") not in (None, "nccl")
+        assert out["n_gpus"] == a.gpus, "n_gpus %d != --gpus %d" % (out["n_gpus"], a.gpus)
+        if world > 1 and not shared:
+            assert out["rccl_ranks"] == world, "only %d of %d ranks are on the RCCL communicators" % (out["rccl_ranks"], world)
+        out["checked"] = {"n_gpus_equals_gpus_flag": True, "rccl_ranks_equals_world": bool(world == 1 or shared or out["rccl_ranks"] == world),
+                          "peer_exchange_active": bool(out["peer_contexts"] > 0) if world > 1 else None}
         if elapsed_ev is not None:
             out["ms_per_step_with_kernel_events"] = round(1e3 * elapsed_ev / a.steps, 3)
         if kern:

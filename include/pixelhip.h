@@ -606,6 +606,20 @@ int pxl_nhwc_to_nchw_parts(int dtype, const void* x, int nparts, float* const* d
 /* enable = 0: pxl_net_pack skips the transposed (data-gradient) weight copies -- networks that only run forward (the
  * Mean-Teacher teacher); pxl_net_backward then refuses to run */
 int pxl_net_set_pack_dgrad(pxl_net* net, int enable);
+/* Forward pass of TWO networks that run the same program (Mean Teacher's student || teacher -- ssl_mt.py:131-170 runs them one
+ * after the other --, GCT's l || r task models, ssl_gct.py:176-230) in lockstep on ONE stream, every convolution of the pair as
+ * ONE launch where the two match (same geometry, tile configuration and operand combination).  Per network the arguments,
+ * semantics and results are exactly those of pxl_net_forward (logits* NULL: the HEAD op is skipped); nothing is shared between
+ * the passes.  pxl_net_tune_pair selects the tile configuration of every paired launch by timing it (arenas are clobbered:
+ * warm-up only); pxl_net_pairs(n0) = convolutions the last paired pass issued as one launch. */
+int pxl_net_forward_pair(pxl_net* n0, pxl_net* n1, const float* params0, const float* params1, const void* packed0,
+                         const void* packed1, float* running0, float* running1, const float* x0, const float* x1,
+                         float* logits0, float* prob0, float* logits1, float* prob1, void* arena0, void* arena1,
+                         size_t arena_bytes0, size_t arena_bytes1, int training0, int training1, void* stream);
+int pxl_net_tune_pair(pxl_net* n0, pxl_net* n1, const float* params0, const float* params1, const void* packed0,
+                      const void* packed1, void* arena0, void* arena1, size_t arena_bytes0, size_t arena_bytes1, void* stream);
+int pxl_net_pairs(const pxl_net* n);
+
 /* enable = 0: backward skips every parameter gradient (a frozen discriminator only relays dL/dinput) */
 int pxl_net_set_wgrad(pxl_net* net, int enable);
 

@@ -64,5 +64,23 @@ def main(which):
                      out="cct_cut_cond_%d.pt" % SIZE, block=32, with_cut=True, bias0_shift=3.3)
 
 
+    # ---- BASELINE.json configs 3-5 (+ CutMix) at the BASELINE crop size: the reference's own _train loops at 513 x 513, the shipped
+    # hyper-parameters, 2 labeled + 2 unlabeled crops (what one GPU of the 4 / 8-GPU configs sees per step is 4 + 4; the CPU
+    # reference needs minutes per iteration at that size), TWO iterations -- iteration 1 runs on weights the engine itself updated
+    if "gct513" in which:
+        import make_golden_gct_train as MGT
+        MGT.main(size=513, lbs=2, ubs=2, seed=211, iters=2, gamma3=GAMMA3, out="gct_cond_513.pt", block=32)
+    if "adv513" in which:
+        import make_golden_adv as MA
+        MA.main(size=513, lbs=2, ubs=2, seed=221, iters=2, gamma3=GAMMA3, out="adv_cond_513.pt", block=32)
+    if "cutmix513" in which:
+        import make_golden_cutmix as MC
+        MC.main(size=513, lbs=2, ubs=2, seed=231, iters=2, gamma3=GAMMA3, out="cutmix_cond_513.pt", block=32)
+    if "cct513" in which:
+        import make_golden_cct as MCC
+        MCC.case_cct(size=513, lbs=2, ubs=2, seed=241, iters=2, rng_seed=9753, gamma3=GAMMA3, out="cct_cut_cond_513.pt", block=32,
+                     with_cut=True, bias0_shift=3.3)
+
+
 if __name__ == "__main__":
     main(sys.argv[1:] or ["suponly", "mt", "psp", "adv", "cutmix", "gct", "cct"])

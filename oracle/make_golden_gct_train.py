@@ -43,9 +43,12 @@ def main(size=129, lbs=2, ubs=2, seed=61, iters=2, gamma3=None, out=None, block=
     (fm ** 2).mean().backward()
     print("stand-alone flaw detector:")
     check("flawmap", fm, fm_ref)
+    # (weight gradients are fp32 sums over 3 * size^2 pixels: the oracle's conv backward and the reference's agree to the
+    # summation-order noise of that length -- 1e-4 at 129^2, 1e-3 at 513^2)
+    wtol = 1e-4 if size <= 129 else 2e-3
     check("d/d prob", prob2.grad, prob.grad, rtol=1e-4)
-    check("d/d conv1.weight", leaves["conv1.weight"].grad, ref_fd.conv1.weight.grad, rtol=1e-4)
-    check("d/d ibn3.bnorm.weight", leaves["ibn3.bnorm.weight"].grad, ref_fd.ibn3.bnorm.weight.grad, rtol=1e-4)
+    check("d/d conv1.weight", leaves["conv1.weight"].grad, ref_fd.conv1.weight.grad, rtol=wtol)
+    check("d/d ibn3.bnorm.weight", leaves["ibn3.bnorm.weight"].grad, ref_fd.ibn3.bnorm.weight.grad, rtol=wtol)
     check("running_var ibn1", run["ibn1.bnorm.running_var"], ref_fd.ibn1.bnorm.running_var)
     standalone = dict(seed=seed, flawmap=fm_ref.detach().clone(), dprob_head=prob.grad[:, :, :4, :8].clone(),
                       dprob_abssum=float(prob.grad.double().abs().sum()),

@@ -195,6 +195,9 @@ SIGNATURES = {
     "pxl_net_pack": (_I, [_P, _P, _P, _P]),
     "pxl_net_pack_parts": (_I, [_P, _P, _P, _I, _P]),
     "pxl_net_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P]),
+    "pxl_net_forward_pair": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _Z, _I, _I, _P]),
+    "pxl_net_tune_pair": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _Z, _P]),
+    "pxl_net_pairs": (_I, [_P]),
     "pxl_net_latent": (_I, [_P, _P, _P, _P]),
     "pxl_net_latent_shape": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "pxl_net_read_tensor": (_I, [_P, _P, _I, _I, _P, _P, _P]),

@@ -109,6 +109,41 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Kernel-argument prefetch for the large-argument contraction kernels.  hipcc fetches a 400-600 byte argument block in 3-4
+// DEPENDENT batches (tile index -> geometry -> pointers -> taps), each a cold scalar-cache miss of 0.4-0.5 us right after
+// the launch (tools/cbench --trace: 1.6-2.8 us between kernel entry and the first DMA).  This touches every 64-byte line in
+// the same round trip as the compiler's first batch: one s_load per line + the wait in a single statement (the destination
+// of an asm load is unprotected until its own wait: cdna_hip_programming.md 5.7 item 1).  Call it first thing in the kernel.
+template <size_t BYTES> __device__ __forceinline__ void kernarg_touch() {
+  static_assert(BYTES <= 768, "kernarg_touch: at most twelve 64-byte lines");
+  auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+  // every load lands in VCC (discarded; an SGPR picked by the allocator may still be the target of one of the compiler's
+  // own argument loads in flight, which forces a wait BEFORE this statement and the second round trip it is meant to avoid)
+#define PXL_KT(OFF) "s_load_dword vcc_lo, %0, " #OFF "\n\t"
+  if constexpr (BYTES > 704)
+    asm volatile(PXL_KT(0x0) PXL_KT(0x40) PXL_KT(0x80) PXL_KT(0xc0) PXL_KT(0x100) PXL_KT(0x140) PXL_KT(0x180) PXL_KT(0x1c0) PXL_KT(0x200)
+                 PXL_KT(0x240) PXL_KT(0x280) PXL_KT(0x2c0) "s_waitcnt lgkmcnt(0)" : : "s"(ka) : "vcc", "memory");
+  else if constexpr (BYTES > 640)
+    asm volatile(PXL_KT(0x0) PXL_KT(0x40) PXL_KT(0x80) PXL_KT(0xc0) PXL_KT(0x100) PXL_KT(0x140) PXL_KT(0x180) PXL_KT(0x1c0) PXL_KT(0x200)
+                 PXL_KT(0x240) PXL_KT(0x280) "s_waitcnt lgkmcnt(0)" : : "s"(ka) : "vcc", "memory");
+  else if constexpr (BYTES > 576)
+    asm volatile(PXL_KT(0x0) PXL_KT(0x40) PXL_KT(0x80) PXL_KT(0xc0) PXL_KT(0x100) PXL_KT(0x140) PXL_KT(0x180) PXL_KT(0x1c0) PXL_KT(0x200)
+                 PXL_KT(0x240) "s_waitcnt lgkmcnt(0)" : : "s"(ka) : "vcc", "memory");
+  else if constexpr (BYTES > 512)
+    asm volatile(PXL_KT(0x0) PXL_KT(0x40) PXL_KT(0x80) PXL_KT(0xc0) PXL_KT(0x100) PXL_KT(0x140) PXL_KT(0x180) PXL_KT(0x1c0) PXL_KT(0x200)
+                 "s_waitcnt lgkmcnt(0)" : : "s"(ka) : "vcc", "memory");
+  else if constexpr (BYTES > 448)
+    asm volatile(PXL_KT(0x0) PXL_KT(0x40) PXL_KT(0x80) PXL_KT(0xc0) PXL_KT(0x100) PXL_KT(0x140) PXL_KT(0x180) PXL_KT(0x1c0)
+                 "s_waitcnt lgkmcnt(0)" : : "s"(ka) : "vcc", "memory");
+  else if constexpr (BYTES > 384)
+    asm volatile(PXL_KT(0x0) PXL_KT(0x40) PXL_KT(0x80) PXL_KT(0xc0) PXL_KT(0x100) PXL_KT(0x140) PXL_KT(0x180)
+                 "s_waitcnt lgkmcnt(0)" : : "s"(ka) : "vcc", "memory");
+  else
+    asm volatile(PXL_KT(0x0) PXL_KT(0x40) PXL_KT(0x80) PXL_KT(0xc0) PXL_KT(0x100) PXL_KT(0x140)
+                 "s_waitcnt lgkmcnt(0)" : : "s"(ka) : "vcc", "memory");
+#undef PXL_KT
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // branch-free q = m / d, r = m % d for 0 <= m < 2^24 (pixel indices) using a float reciprocal

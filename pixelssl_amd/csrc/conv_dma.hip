@@ -1,6 +1,9 @@
 // LDS-DMA implicit-GEMM convolution for gfx950: C-ABI entry points and tile-configuration dispatch.  The kernel itself is
 // conv_dma_kernel.h; its tile configurations are instantiated in conv_dma_a .. d.hip (parallel compilation) and here (12..15,
 // the timing ablations).
+#include <cstring>
+#include <new>
+
 #include "conv_dma_kernel.h"
 
 using namespace pxl_dma;
@@ -151,45 +154,35 @@ extern "C" int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy,
 }
 
 namespace {
-int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes, void* stream) {
-  a.stats_rep = d->stats_rep >= 1 ? d->stats_rep : 1;
-  a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin;
-  a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.Kreal = d->Kreal;
-  a.ntaps = d->ntaps; a.so = d->out_stride;
-  a.div_shift = d->div == 2 ? 1 : 0;
-  a.M = d->B * d->Ho * d->Wo;
-  a.Ktot = d->ntaps * d->Cin;
-  a.nk = a.Ktot / 64;
-  a.tiles_m = a.tiles_n = 0;
-  a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->Cin * 2);
-  a.w_bytes = (unsigned)((size_t)d->Kreal * a.Ktot * 2);
-  for (int t = 0; t < 64; ++t)
-    a.taps[t] = t < d->ntaps ? (((int)d->dy[t]) << 16) | (((int)d->dx[t]) & 0xffff) : 0;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  // taps at offset (0,0) only and every output pixel inside the input: no bounds logic at all
-  bool gather = false;
-  for (int t = 0; t < d->ntaps; ++t) gather |= d->dy[t] != 0 || d->dx[t] != 0;
-  gather |= d->ntaps != 1;
-  gather |= d->div != 1;
-  gather |= (d->Ho - 1) * d->out_stride >= d->Hi || (d->Wo - 1) * d->out_stride >= d->Wi;
-  int cfg = d->tile_cfg;
-  if (cfg < 8) {
-    const long t128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 128);
-    if (a.Cout <= 64) cfg = 9;
-    else if (t128 >= 384) cfg = 8;
-    else cfg = 9;
-  }
-  if (cfg >= 8 && cfg <= 11) return pxl_dma_launch_a(cfg, a, gather, sk, ws_bytes, s);
-  if (cfg >= 16 && cfg <= 19) return pxl_dma_launch_b(cfg, a, gather, sk, ws_bytes, s);
-  if (cfg >= 20 && cfg <= 23) return pxl_dma_launch_c(cfg, a, gather, sk, ws_bytes, s);
-  if (cfg >= 24 && cfg <= 27) return pxl_dma_launch_d(cfg, a, gather, sk, ws_bytes, s);
-  if (cfg >= 28 && cfg <= 31) return pxl_dma_launch_e(cfg, a, gather, sk, ws_bytes, s);
-  if (cfg >= 32 && cfg <= 35) return pxl_dma_launch_f(cfg, a, gather, sk, ws_bytes, s);
+// (LDS bytes of a tile configuration: the coefficient table of a BN-on-load launch must fit next to the ring -- checked before
+// a launch is captured for pairing, where it could no longer fall back)
+size_t dma_cfg_ring_bytes(int cfg) {
+  static const int BMs[] = {128, 128, 64, 64};                     // 8..19: 128x128, 128x64, 64x128, 64x64
+  static const int BNs[] = {128, 64, 128, 64};
+  if (cfg >= 8 && cfg <= 19) { const int st = cfg < 12 ? 3 : (cfg < 16 ? 4 : 2); return (size_t)st * (BMs[cfg & 3] + BNs[cfg & 3]) * 128; }
+  if (cfg >= 20 && cfg <= 27) { static const int T[] = {96, 160, 192, 128}; return (size_t)(cfg < 24 ? 3 : 2) * (T[cfg & 3] + 128) * 128; }
   switch (cfg) {
-    case 12: return launch_dma<128, 128, 2, 2, 4>(a, gather, sk, ws_bytes, s);
-    case 13: return launch_dma<128, 64, 2, 2, 4>(a, gather, sk, ws_bytes, s);
-    case 14: return launch_dma<64, 128, 2, 2, 4>(a, gather, sk, ws_bytes, s);
-    case 15: return launch_dma<64, 64, 2, 2, 4>(a, gather, sk, ws_bytes, s);
+    case 28: case 29: return 2 * 192 * 128;
+    case 30: case 31: return 2 * 256 * 128;
+    case 32: return 3 * 192 * 128;
+    case 33: return 3 * 256 * 128;
+    case 34: case 35: return 2 * 384 * 128;
+    default: return 0;
+  }
+}
+
+int dma_dispatch(int cfg, const DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s, int groups) {
+  if (cfg >= 8 && cfg <= 11) return pxl_dma_launch_a(cfg, a, gather, sk, ws_bytes, s, groups);
+  if (cfg >= 16 && cfg <= 19) return pxl_dma_launch_b(cfg, a, gather, sk, ws_bytes, s, groups);
+  if (cfg >= 20 && cfg <= 23) return pxl_dma_launch_c(cfg, a, gather, sk, ws_bytes, s, groups);
+  if (cfg >= 24 && cfg <= 27) return pxl_dma_launch_d(cfg, a, gather, sk, ws_bytes, s, groups);
+  if (cfg >= 28 && cfg <= 31) return pxl_dma_launch_e(cfg, a, gather, sk, ws_bytes, s, groups);
+  if (cfg >= 32 && cfg <= 35) return pxl_dma_launch_f(cfg, a, gather, sk, ws_bytes, s, groups);
+  switch (cfg) {
+    case 12: return launch_dma<128, 128, 2, 2, 4>(a, gather, sk, ws_bytes, s, groups);
+    case 13: return launch_dma<128, 64, 2, 2, 4>(a, gather, sk, ws_bytes, s, groups);
+    case 14: return launch_dma<64, 128, 2, 2, 4>(a, gather, sk, ws_bytes, s, groups);
+    case 15: return launch_dma<64, 64, 2, 2, 4>(a, gather, sk, ws_bytes, s, groups);
     // timing ablations (garbage results): 64x128 3-stage gather kernel, 100 + ABL bits
     case 100: return launch_abl<64, 128, 3, 0>(a, s);
     case 101: return launch_abl<64, 128, 3, 1>(a, s);
@@ -206,4 +199,109 @@ int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes,
     default: return pxl_set_error(PXL_ERR_ARG, "conv_dma: unknown tile config %d", cfg);
   }
 }
+
+// ---- paired launches: the executor runs two networks with the same program in lockstep (pxl_net_forward_pair) and brackets
+// the convolution of each with pxl_dma_capture_begin / _end: inside the bracket a launch that CAN be one half of a pair is
+// recorded instead of issued; pxl_dma_launch_captured then issues both halves as ONE launch (gridDim.z = 2) when they
+// match, else one after the other.
+struct DmaCapture {
+  bool armed = false, held = false;
+  DmaArgs a; int cfg = 0; bool gather = false; int sk = 1; size_t ws_bytes = 0; hipStream_t stream = nullptr;
+};
+thread_local DmaCapture* tl_capture = nullptr;
+
+int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes, void* stream) {
+  a.stats_rep = d->stats_rep >= 1 ? d->stats_rep : 1;
+  a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.Kreal = d->Kreal;
+  a.ntaps = d->ntaps; a.so = d->out_stride;
+  a.div_shift = d->div == 2 ? 1 : 0;
+  a.M = d->B * d->Ho * d->Wo;
+  a.Ktot = d->ntaps * d->Cin;
+  a.nk = a.Ktot / 64;
+  a.tiles_m = a.tiles_n = 0;
+  a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->Cin * 2);
+  a.w_bytes = (unsigned)((size_t)d->Kreal * a.Ktot * 2);
+  std::memset(&a.g1, 0, sizeof(a.g1));
+  for (int t = 0; t < 64; ++t)
+    a.taps[t] = t < d->ntaps ? (((int)d->dy[t]) << 16) | (((int)d->dx[t]) & 0xffff) : 0;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // taps at offset (0,0) only and every output pixel inside the input: no bounds logic at all
+  bool gather = false;
+  for (int t = 0; t < d->ntaps; ++t) gather |= d->dy[t] != 0 || d->dx[t] != 0;
+  gather |= d->ntaps != 1;
+  gather |= d->div != 1;
+  gather |= (d->Ho - 1) * d->out_stride >= d->Hi || (d->Wo - 1) * d->out_stride >= d->Wi;
+  int cfg = d->tile_cfg;
+  if (cfg < 8) {
+    const long t128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 128);
+    if (a.Cout <= 64) cfg = 9;
+    else if (t128 >= 384) cfg = 8;
+    else cfg = 9;
+  }
+  DmaCapture* cap = tl_capture;
+  if (cap != nullptr && cap->armed && !cap->held && cfg >= 8 && cfg <= 35 && a.addend == nullptr && a.bn_y == nullptr &&
+      a.fin.coef == nullptr && a.trace == nullptr && (a.ws == nullptr || sk == 1 || a.stats != nullptr)) {
+    // would this launch split K on its own?  (launch_dma's rule: few tiles and a long reduction, only with a workspace and no
+    // statistics) -- those stay single launches
+    const bool may_split = a.ws != nullptr && a.stats == nullptr && sk != 1;
+    const size_t ring = dma_cfg_ring_bytes(cfg) + (a.bin.coef != nullptr ? (size_t)a.Cin * 8 : 0);
+    if (!may_split && ring > 0 && ring <= 156 * 1024) {
+      cap->a = a; cap->cfg = cfg; cap->gather = gather; cap->sk = 1; cap->ws_bytes = 0; cap->stream = s;
+      cap->a.ws = nullptr;
+      cap->held = true;
+      return PXL_OK;
+    }
+  }
+  return dma_dispatch(cfg, a, gather, sk, ws_bytes, s, 1);
+}
 }  // namespace
+
+// Capture bracket of the paired forward pass (csrc/net.cpp: pxl_net_forward_pair).  *slot receives an opaque record (heap,
+// released by pxl_dma_launch_captured); a bracket that captured nothing leaves it untouched.
+extern "C" void pxl_dma_capture_begin(void** slot) {
+  DmaCapture* c = new (std::nothrow) DmaCapture();
+  if (c != nullptr) c->armed = true;
+  *slot = c;
+  tl_capture = c;
+}
+extern "C" void pxl_dma_capture_end(void) {
+  if (tl_capture != nullptr) tl_capture->armed = false;
+  tl_capture = nullptr;
+}
+// Issue what two brackets recorded: ONE launch of both networks' convolution when both were recorded with the same tile
+// configuration / geometry / operand combination, else each on its own.  Frees the records.  -> 1 paired, 0 separate, < 0 error
+extern "C" int pxl_dma_launch_captured(void* slot0, void* slot1) {
+  DmaCapture* c0 = static_cast<DmaCapture*>(slot0);
+  DmaCapture* c1 = static_cast<DmaCapture*>(slot1);
+  int rc = PXL_OK, paired = 0;
+  const bool h0 = c0 != nullptr && c0->held, h1 = c1 != nullptr && c1->held;
+  if (h0 && h1) {
+    const DmaArgs &x = c0->a, &y = c1->a;
+    const bool same = c0->cfg == c1->cfg && c0->gather == c1->gather && c0->stream == c1->stream && x.B == y.B && x.Hi == y.Hi &&
+                      x.Wi == y.Wi && x.Cin == y.Cin && x.Ho == y.Ho && x.Wo == y.Wo && x.Cout == y.Cout && x.Kreal == y.Kreal &&
+                      x.ntaps == y.ntaps && x.so == y.so && x.div_shift == y.div_shift && x.stats_rep == y.stats_rep &&
+                      (x.bias != nullptr) == (y.bias != nullptr) && (x.stats != nullptr) == (y.stats != nullptr) &&
+                      (x.bin.coef != nullptr) == (y.bin.coef != nullptr) && x.bin_relu == y.bin_relu &&
+                      (x.bin_z != nullptr) == (y.bin_z != nullptr) && std::memcmp(x.taps, y.taps, sizeof(x.taps)) == 0 &&
+                      (x.bin.coef == nullptr || (x.bin.nrep == y.bin.nrep && x.bin.count == y.bin.count && x.bin.training == y.bin.training &&
+                                                 x.bin.momentum == y.bin.momentum && x.bin.eps == y.bin.eps && x.bin.clamp_var == y.bin.clamp_var &&
+                                                 (x.bin.running_mean != nullptr) == (y.bin.running_mean != nullptr) &&
+                                                 (x.bin.gamma != nullptr) == (y.bin.gamma != nullptr) && (x.bin.beta != nullptr) == (y.bin.beta != nullptr)));
+    if (same) {
+      DmaArgs p = x;
+      p.g1.in = y.in; p.g1.w = y.w; p.g1.out = y.out; p.g1.bias = y.bias; p.g1.stats = y.stats;
+      p.g1.bin_stats = y.bin.stats; p.g1.bin_gamma = y.bin.gamma; p.g1.bin_beta = y.bin.beta;
+      p.g1.bin_rmean = y.bin.running_mean; p.g1.bin_rvar = y.bin.running_var; p.g1.bin_coef = y.bin.coef; p.g1.bin_z = y.bin_z;
+      rc = dma_dispatch(c0->cfg, p, c0->gather, 1, 0, c0->stream, 2);
+      paired = 1;
+    }
+  }
+  if (!paired) {
+    if (h0) rc = dma_dispatch(c0->cfg, c0->a, c0->gather, 1, 0, c0->stream, 1);
+    if (h1 && rc == PXL_OK) rc = dma_dispatch(c1->cfg, c1->a, c1->gather, 1, 0, c1->stream, 1);
+  }
+  delete c0;
+  delete c1;
+  return rc != PXL_OK ? rc : paired;
+}

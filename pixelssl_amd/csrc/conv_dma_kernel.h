@@ -63,6 +63,15 @@ struct DmaArgs {
   void* bin_z;       // optional: the workgroups of output-channel tile 0 also write the activated tile to this tensor (the
                      // weight gradient of this convolution reads it); only for convolutions without a gather (1x1, stride 1)
   unsigned in_bytes, w_bytes;
+  // PAIRED launch (gridDim.z == 2): the same convolution of a SECOND network with the same geometry -- student || teacher
+  // of Mean Teacher, the l || r task models of GCT -- as workgroups blockIdx.z == 1 of ONE launch: twice the tiles per launch
+  // (M = 8712 per network leaves 256 CUs with 138 - 274 tiles), half the launches.  Forward launches only (no addend /
+  // BatchNorm-backward operands, no split-K, no in-kernel finalize).
+  struct Second {
+    const void* in; const void* w; void* out; const float* bias; float* stats;
+    const float* bin_stats; const float* bin_gamma; const float* bin_beta; float* bin_rmean; float* bin_rvar; float* bin_coef;
+    void* bin_z;
+  } g1;
   unsigned* trace;   // TRACE kernels (tools/cbench): [workgroup][TRACE_WORDS] cycle stamps of wave 0, else unused
   int taps[64];      // (dy << 16) | (dx & 0xffff)
 };
@@ -307,32 +316,6 @@ __device__ __forceinline__ void epi_passes(STAMP&& stamp, const EpiCtx& c, float
   }
 }
 
-// one s_load per 64-byte line of the kernel arguments + the wait, in a single statement (the destination registers of an
-// asm load are unprotected until its own wait: cdna_hip_programming.md 5.7 item 1)
-template <size_t BYTES> __device__ __forceinline__ void kernarg_touch() {
-  static_assert(BYTES <= 640, "kernarg_touch: at most ten 64-byte lines");
-  auto ka = __builtin_amdgcn_kernarg_segment_ptr();
-  // every load lands in VCC (discarded; an SGPR picked by the allocator may still be the target of one of the compiler's
-  // own argument loads in flight, which forces a wait BEFORE this statement and the second round trip it is meant to avoid)
-#define PXL_KT(OFF) "s_load_dword vcc_lo, %0, " #OFF "\n\t"
-  if constexpr (BYTES > 576)
-    asm volatile(PXL_KT(0x0) PXL_KT(0x40) PXL_KT(0x80) PXL_KT(0xc0) PXL_KT(0x100) PXL_KT(0x140) PXL_KT(0x180) PXL_KT(0x1c0) PXL_KT(0x200)
-                 PXL_KT(0x240) "s_waitcnt lgkmcnt(0)" : : "s"(ka) : "vcc", "memory");
-  else if constexpr (BYTES > 512)
-    asm volatile(PXL_KT(0x0) PXL_KT(0x40) PXL_KT(0x80) PXL_KT(0xc0) PXL_KT(0x100) PXL_KT(0x140) PXL_KT(0x180) PXL_KT(0x1c0) PXL_KT(0x200)
-                 "s_waitcnt lgkmcnt(0)" : : "s"(ka) : "vcc", "memory");
-  else if constexpr (BYTES > 448)
-    asm volatile(PXL_KT(0x0) PXL_KT(0x40) PXL_KT(0x80) PXL_KT(0xc0) PXL_KT(0x100) PXL_KT(0x140) PXL_KT(0x180) PXL_KT(0x1c0)
-                 "s_waitcnt lgkmcnt(0)" : : "s"(ka) : "vcc", "memory");
-  else if constexpr (BYTES > 384)
-    asm volatile(PXL_KT(0x0) PXL_KT(0x40) PXL_KT(0x80) PXL_KT(0xc0) PXL_KT(0x100) PXL_KT(0x140) PXL_KT(0x180)
-                 "s_waitcnt lgkmcnt(0)" : : "s"(ka) : "vcc", "memory");
-  else
-    asm volatile(PXL_KT(0x0) PXL_KT(0x40) PXL_KT(0x80) PXL_KT(0xc0) PXL_KT(0x100) PXL_KT(0x140)
-                 "s_waitcnt lgkmcnt(0)" : : "s"(ka) : "vcc", "memory");
-#undef PXL_KT
-}
-
 // BM x BN output tile (pixels x channels), 4 or 8 waves as WM x WN, NST LDS stages, GATHER = taps / padding logic.
 // Eight waves (two per SIMD) exist for the DMA issue rate: a `buffer_load ... lds` costs its wave 100-180 cycles of issue
 // (MI355X_MICROARCH.md), four waves x 6 pieces per K step of a 64 x 128 tile is the ~800 cycles per step that
@@ -396,8 +379,15 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
   const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+  // operand set of this workgroup's network (paired launches: blockIdx.z == 1 takes DmaArgs::g1; scalar selects)
+  const bool second = blockIdx.z != 0;
+  const void* const a_in = second ? p.g1.in : p.in;
+  const void* const a_w = second ? p.g1.w : p.w;
+  void* const a_out = second ? p.g1.out : p.out;
+  const float* const a_bias = second ? p.g1.bias : p.bias;
+  float* const a_stats = second ? p.g1.stats : p.stats;
+  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a_in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a_w), 0, p.w_bytes, 0x00020000);
 
   // ---- loader coordinates: DMA instruction g = wave + 4*q covers tile rows 8g .. 8g+7, lane -> (row, 16-byte slot)
   const int lrow = lane >> 3, lslot = lane & 7;
@@ -521,7 +511,11 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
   const int lchunk = (lane & 7) ^ ((wave * 4 + ((lane >> 3) >> 1)) & 7);     // the lane's (q-independent) source chunk
   if constexpr (BNIN) {
     float* tab = reinterpret_cast<float*>(smem + NST * SB);
-    const pxl_bn_fin& f = p.bin;
+    pxl_bn_fin f = p.bin;
+    if (second) {
+      f.stats = p.g1.bin_stats; f.gamma = p.g1.bin_gamma; f.beta = p.g1.bin_beta;
+      f.running_mean = p.g1.bin_rmean; f.running_var = p.g1.bin_rvar; f.coef = p.g1.bin_coef;
+    }
     const int C = p.Cin;
     for (int c = tid; c < C; c += NT) {
       float mean, var;
@@ -596,8 +590,9 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
       if constexpr (!GATHER) {
         // materialise z = relu(bn(y)) for the weight gradient: one workgroup per pixel tile writes what it transformed (the
         // same bytes, the same offsets as the source; zero-filled lanes are out of range for the store as well)
-        if (p.bin_z != nullptr && tn == 0) {
-          const __amdgpu_buffer_rsrc_t r_z = __builtin_amdgcn_make_buffer_rsrc(p.bin_z, 0, p.in_bytes, 0x00020000);
+        void* const a_z = second ? p.g1.bin_z : p.bin_z;
+        if (a_z != nullptr && tn == 0) {
+          const __amdgpu_buffer_rsrc_t r_z = __builtin_amdgcn_make_buffer_rsrc(a_z, 0, p.in_bytes, 0x00020000);
 #pragma unroll
           for (int q = 0; q < LA; ++q)
             __builtin_amdgcn_raw_buffer_store_b128(dd[q], r_z, (int)voffA[q], (int)(ckc * 2u), 0);
@@ -694,9 +689,9 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
   // EM >= 0: the operand combination is a compile-time constant of this instantiation (the host picks it, launch_dma below).
   // The round-4 timeline probe measured the run-time dispatch between the read-back variants at ~3500 cycles per workgroup
   // (a ten-way scalar branch into cold instruction-cache lines): 4100 -> 660 cycles for the passes once it was gone.
-  const bool has_bias = EM >= 0 ? bool(EM & 2) : p.bias != nullptr;
+  const bool has_bias = EM >= 0 ? bool(EM & 2) : a_bias != nullptr;
   const bool has_add = EM >= 0 ? bool(EM & 1) : p.addend != nullptr;
-  const bool has_stats = EM >= 0 ? bool(EM & 4) : (p.stats != nullptr && !(ABL & 32));
+  const bool has_stats = EM >= 0 ? bool(EM & 4) : (a_stats != nullptr && !(ABL & 32));
   const bool has_bnr = EM >= 0 ? bool(EM & 8) : (has_stats && p.bn_y != nullptr);
   const bool has_mask = EM >= 0 ? bool(EM & 16) : (has_bnr && p.bn_mask != nullptr);
   float s1[8], s2[8];
@@ -707,11 +702,11 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
     EpiCtx c;
     c.T = T; c.er = er; c.ec = ec; c.m0 = m0; c.M = p.M; c.Cout = p.Cout; c.n = n; c.ncol = ncol;
     const unsigned out_bytes = (unsigned)((size_t)p.M * p.Cout * 2);
-    c.r_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
+    c.r_out = __builtin_amdgcn_make_buffer_rsrc(a_out, 0, out_bytes, 0x00020000);
     c.r_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.addend), 0, out_bytes, 0x00020000);
     c.r_bny = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bn_y), 0, out_bytes, 0x00020000);
     c.r_msk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bn_mask), 0, out_bytes, 0x00020000);
-    c.bias = p.bias; c.bn_coef = p.bn_coef; c.Kreal = p.Kreal;
+    c.bias = a_bias; c.bn_coef = p.bn_coef; c.Kreal = p.Kreal;
     const int emode = (has_add ? 1 : 0) | (has_bias ? 2 : 0) | (has_stats ? 4 : 0) | (has_bnr ? 8 : 0) | (has_mask ? 16 : 0) |
                       ((has_bnr && !has_mask && p.bn_relu) ? 32 : 0);
     if constexpr (EM >= 0) epi_passes<EM, NPASS, RPP, TP>(stamp, c, s1, s2);
@@ -739,7 +734,7 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
       for (int r = 0; r < RPP; ++r) v += red[r * 2 * BN + tid];
       const int which = tid / BN, c = tid % BN;
       if (n0 + c < p.Kreal) {
-        float* rep = p.stats + (size_t)(tm % p.stats_rep) * 2 * p.Kreal;
+        float* rep = a_stats + (size_t)(tm % p.stats_rep) * 2 * p.Kreal;
         atomicAdd(rep + which * p.Kreal + n0 + c, v);
       }
     }
@@ -788,7 +783,7 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile's stores have been performed
     stamp();
     if (wave == 0 && p.trace != nullptr) {
-      unsigned* t = p.trace + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * TRACE_WORDS;
+      unsigned* t = p.trace + (size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * TRACE_WORDS;
       t[lane] = tsv;
       if (lane == 0) {
         const unsigned long long rt1 = wall_clock64();
@@ -837,7 +832,7 @@ int launch_one(dim3 grid, dim3 block, size_t smem, hipStream_t stream, const Dma
 }
 
 template <int BM, int BN, int WM, int WN, int NST>
-int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, hipStream_t stream) {
+int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, hipStream_t stream, int groups = 1) {
   DmaArgs p = a;
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.Cout, BN);
@@ -859,7 +854,9 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
   const bool bnin = p.bin.coef != nullptr;
   const size_t smem = (size_t)NST * (BM + BN) * 128 + (bnin ? (size_t)p.Cin * 8 : 0);
   if (smem > 156 * 1024) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: tile + coefficient table exceed the LDS");
-  const dim3 g(grid, splitk), b(WM * WN * 64);
+  if (groups == 2 && (splitk > 1 || p.addend || p.bn_y || p.fin.coef || p.trace))
+    return pxl_set_error(PXL_ERR_ARG, "conv_dma: a paired launch is a plain forward convolution (no split-K / addend / finalize)");
+  const dim3 g(grid, splitk, groups), b(WM * WN * 64);
   if (p.trace != nullptr) {          // timeline probe (tools/cbench): the forward-with-statistics kernel with cycle stamps
     if (bnin || p.stats == nullptr || p.addend != nullptr || p.bias != nullptr)
       return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: the trace build is the plain forward convolution with statistics");
@@ -906,9 +903,9 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
 
 // The tile configurations are instantiated in six translation units (conv_dma_a .. f.hip) so that the build compiles them in
 // parallel: each defines one dispatcher over its share of the configuration numbers.
-int pxl_dma_launch_a(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s);   // 8..11  (3-stage 2x2)
-int pxl_dma_launch_b(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s);   // 16..19 (2-stage 2x2)
-int pxl_dma_launch_c(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s);   // 20..23 (3-stage tall)
-int pxl_dma_launch_d(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s);   // 24..27 (2-stage tall)
-int pxl_dma_launch_e(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s);   // 28..31 (8 waves)
-int pxl_dma_launch_f(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s);   // 32..35 (8 waves)
+int pxl_dma_launch_a(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s, int groups);   // 8..11  (3-stage 2x2)
+int pxl_dma_launch_b(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s, int groups);   // 16..19 (2-stage 2x2)
+int pxl_dma_launch_c(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s, int groups);   // 20..23 (3-stage tall)
+int pxl_dma_launch_d(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s, int groups);   // 24..27 (2-stage tall)
+int pxl_dma_launch_e(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s, int groups);   // 28..31 (8 waves)
+int pxl_dma_launch_f(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s, int groups);   // 32..35 (8 waves)

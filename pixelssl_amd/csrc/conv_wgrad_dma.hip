@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const WDmaArgs p) {
   constexpr int RPK = 2 * (TN + TC);                    // transposing reads per k-chunk
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  kernarg_touch<sizeof(WDmaArgs)>();        // every argument line in one scalar-cache round trip (common.h)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

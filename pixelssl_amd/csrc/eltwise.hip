@@ -58,6 +58,9 @@ __device__ __forceinline__ void block_bn_finalize(const pxl_bn_fin& f, int C, in
 // Per-channel-affine element-wise kernels: column-group blocks (common.h: col_geom), the channel chunk is FIXED
 // per thread so the coefficients are loaded once into registers, two rows in flight per thread.  FIN: the BN finalize
 // of the operand(s) is folded into the prologue (yfin / rfin) instead of reading ready-made coefficients.
+// second operand set of a PAIRED launch (gridDim.z == 2: the same op of a second network, pxl_net_forward_pair)
+struct EltSecond { const void* y; const void* res; void* out; pxl_bn_fin yfin, rfin; };
+
 // FIN kernels: request the first rows before the finalize prologue?  (PXL_ELT_PREFETCH; measured per workload)
 static bool elt_prefetch() {
   static const bool on = [] { const char* e = getenv("PXL_ELT_PREFETCH"); return e != nullptr && e[0] == '1'; }();
@@ -65,13 +68,17 @@ static bool elt_prefetch() {
 }
 
 template <typename T, bool FIN, int PFN = 0>
-__global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T* __restrict__ y,
+__global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T* y,
                                                            const float* __restrict__ ycoef,
-                                                           const T* __restrict__ res,
+                                                           const T* res,
                                                            const float* __restrict__ rcoef,
-                                                           T* __restrict__ out, int rows_per_group, int cgmax,
-                                                           pxl_bn_fin yfin, pxl_bn_fin rfin, int has_rfin) {
+                                                           T* out, int rows_per_group, int cgmax,
+                                                           pxl_bn_fin yfin, pxl_bn_fin rfin, int has_rfin, EltSecond sec) {
   constexpr int EPC = Elem<T>::EPC;
+  if (blockIdx.z != 0) {        // paired launch (pxl_net_forward_pair): the same join of the second network
+    y = static_cast<const T*>(sec.y); res = static_cast<const T*>(sec.res); out = static_cast<T*>(sec.out);
+    yfin = sec.yfin; rfin = sec.rfin;
+  }
   const ColGeom g = col_geom(C, EPC, cgmax);
   const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
   const int cc = blockIdx.x * g.cg + ccol;
@@ -148,11 +155,12 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T
 
 // z = relu?(y*scale + shift): the activated tensor the LDS-DMA convolutions (conv_dma.hip, wgrad) read directly
 template <typename T, bool FIN, int PFN = 0>
-__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(int M, int C, const T* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(int M, int C, const T* y,
                                                            const float* __restrict__ coef, int relu,
-                                                           T* __restrict__ z, int rows_per_group, int cgmax,
-                                                           pxl_bn_fin fin) {
+                                                           T* z, int rows_per_group, int cgmax,
+                                                           pxl_bn_fin fin, EltSecond sec) {
   constexpr int EPC = Elem<T>::EPC;
+  if (blockIdx.z != 0) { y = static_cast<const T*>(sec.y); z = static_cast<T*>(sec.out); fin = sec.yfin; }
   const ColGeom g = col_geom(C, EPC, cgmax);
   const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
   const int cc = blockIdx.x * g.cg + ccol;
@@ -428,10 +436,10 @@ extern "C" int pxl_residual_fwd(int dtype, long M, int C, const void* y, const f
   const pxl_bn_fin none = {};
   if (dtype == PXL_F32)
     hipLaunchKernelGGL((residual_fwd_kernel<float, false>), grid, dim3(256), 0, s, (int)M, C,
-                       cp<float>(y), ycoef, cp<float>(res), rcoef, mp<float>(out), rpg, cgmax, none, none, 0);
+                       cp<float>(y), ycoef, cp<float>(res), rcoef, mp<float>(out), rpg, cgmax, none, none, 0, EltSecond{});
   else
     hipLaunchKernelGGL((residual_fwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, (int)M, C,
-                       cp<bf16_t>(y), ycoef, cp<bf16_t>(res), rcoef, mp<bf16_t>(out), rpg, cgmax, none, none, 0);
+                       cp<bf16_t>(y), ycoef, cp<bf16_t>(res), rcoef, mp<bf16_t>(out), rpg, cgmax, none, none, 0, EltSecond{});
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -442,6 +450,66 @@ inline bool fin_ok(const pxl_bn_fin* f) {
 }
 }  // namespace
 
+// ---- paired launches of the two finalize-folding kernels (pxl_net_forward_pair).  Inside a pxl_elt_pair_begin / _end
+// bracket the FIRST eligible call is held back; a second call of the same kind and shape is issued together with it as one
+// launch (gridDim.z = 2); anything else (or the end of the bracket) issues the held call on its own.
+namespace {
+struct EltHeld {
+  bool armed = false, held = false;
+  int kind = 0, dtype = 0, C = 0, relu = 0, has_rfin = 0; long M = 0; hipStream_t s = nullptr;
+  const void* y = nullptr; const void* res = nullptr; void* out = nullptr; pxl_bn_fin yfin{}, rfin{};
+};
+thread_local EltHeld tl_elt;
+
+int launch_residual_fin(int dtype, long M, int C, const void* y, const pxl_bn_fin& yfin, const void* res, const pxl_bn_fin& rf, int has_rfin,
+                        void* out, hipStream_t s, const EltSecond* sec) {
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  const int cgmax = 16;                         // 16 chunks x EPC <= 128 channels per block (LDS coefficient arrays)
+  const ColGeom g = col_geom(C, epc, cgmax);
+  const int rpg = rows_per_group((int)M, g, pxl_tune_get(2));
+  const dim3 grid(g.ncg, cdiv((int)M, rpg), sec ? 2 : 1);
+  const EltSecond e2 = sec ? *sec : EltSecond{};
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL((elt_prefetch() ? residual_fwd_kernel<float, true, 4> : residual_fwd_kernel<float, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<float>(y), nullptr,
+                       cp<float>(res), nullptr, mp<float>(out), rpg, cgmax, yfin, rf, has_rfin, e2);
+  else
+    hipLaunchKernelGGL((elt_prefetch() ? residual_fwd_kernel<bf16_t, true, 4> : residual_fwd_kernel<bf16_t, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<bf16_t>(y), nullptr,
+                       cp<bf16_t>(res), nullptr, mp<bf16_t>(out), rpg, cgmax, yfin, rf, has_rfin, e2);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+int launch_bn_fin_apply(int dtype, long M, int C, const void* y, const pxl_bn_fin& fin, int relu, void* z, hipStream_t s, const EltSecond* sec) {
+  const int epc = dtype == PXL_F32 ? 4 : 8;
+  const int cgmax = 16;
+  const ColGeom g = col_geom(C, epc, cgmax);
+  const int rpg = rows_per_group((int)M, g, pxl_tune_get(3));
+  const dim3 grid(g.ncg, cdiv((int)M, rpg), sec ? 2 : 1);
+  const EltSecond e2 = sec ? *sec : EltSecond{};
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL((elt_prefetch() ? bn_apply_fwd_kernel<float, true, 4> : bn_apply_fwd_kernel<float, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<float>(y), nullptr, relu,
+                       mp<float>(z), rpg, cgmax, fin, e2);
+  else
+    hipLaunchKernelGGL((elt_prefetch() ? bn_apply_fwd_kernel<bf16_t, true, 4> : bn_apply_fwd_kernel<bf16_t, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<bf16_t>(y), nullptr, relu,
+                       mp<bf16_t>(z), rpg, cgmax, fin, e2);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+int issue_held() {
+  EltHeld& h = tl_elt;
+  if (!h.held) return PXL_OK;
+  h.held = false;
+  return h.kind == 1 ? launch_residual_fin(h.dtype, h.M, h.C, h.y, h.yfin, h.res, h.rfin, h.has_rfin, h.out, h.s, nullptr)
+                     : launch_bn_fin_apply(h.dtype, h.M, h.C, h.y, h.yfin, h.relu, h.out, h.s, nullptr);
+}
+bool same_fin_shape(const pxl_bn_fin& a, const pxl_bn_fin& b) {
+  return a.nrep == b.nrep && a.count == b.count && a.momentum == b.momentum && a.eps == b.eps && a.training == b.training &&
+         a.clamp_var == b.clamp_var;
+}
+}  // namespace
+
+extern "C" void pxl_elt_pair_begin(void) { tl_elt.armed = true; tl_elt.held = false; }
+extern "C" int pxl_elt_pair_end(void) { tl_elt.armed = false; return issue_held(); }
+
 extern "C" int pxl_residual_finalize_fwd(int dtype, long M, int C, const void* y, const pxl_bn_fin* yfin, const void* res,
                                          const pxl_bn_fin* rfin, void* out, void* stream) {
   PXL_REQUIRE(y && res && out && fin_ok(yfin) && (rfin == nullptr || fin_ok(rfin)), "residual_finalize_fwd: bad argument");
@@ -449,19 +517,22 @@ extern "C" int pxl_residual_finalize_fwd(int dtype, long M, int C, const void* y
   const int epc = dtype == PXL_F32 ? 4 : 8;
   PXL_REQUIRE(C % epc == 0, "residual_finalize_fwd: C=%d must be a multiple of %d", C, epc);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int cgmax = 16;                         // 16 chunks x EPC <= 128 channels per block (LDS coefficient arrays)
-  const ColGeom g = col_geom(C, epc, cgmax);
-  const int rpg = rows_per_group((int)M, g, pxl_tune_get(2));
-  const dim3 grid(g.ncg, cdiv((int)M, rpg));
   const pxl_bn_fin rf = rfin ? *rfin : pxl_bn_fin{};
-  if (dtype == PXL_F32)
-    hipLaunchKernelGGL((elt_prefetch() ? residual_fwd_kernel<float, true, 4> : residual_fwd_kernel<float, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<float>(y), nullptr,
-                       cp<float>(res), nullptr, mp<float>(out), rpg, cgmax, *yfin, rf, rfin ? 1 : 0);
-  else
-    hipLaunchKernelGGL((elt_prefetch() ? residual_fwd_kernel<bf16_t, true, 4> : residual_fwd_kernel<bf16_t, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<bf16_t>(y), nullptr,
-                       cp<bf16_t>(res), nullptr, mp<bf16_t>(out), rpg, cgmax, *yfin, rf, rfin ? 1 : 0);
-  PXL_LAUNCH_CHECK();
-  return PXL_OK;
+  EltHeld& h = tl_elt;
+  if (h.armed) {
+    if (h.held && h.kind == 1 && h.dtype == dtype && h.M == M && h.C == C && h.s == s && h.has_rfin == (rfin ? 1 : 0) &&
+        same_fin_shape(h.yfin, *yfin) && (!rfin || same_fin_shape(h.rfin, rf))) {
+      h.held = false;
+      const EltSecond sec{y, res, out, *yfin, rf};
+      return launch_residual_fin(dtype, M, C, h.y, h.yfin, h.res, h.rfin, h.has_rfin, h.out, s, &sec);
+    }
+    const int rc = issue_held();
+    if (rc != PXL_OK) return rc;
+    h.held = true; h.kind = 1; h.dtype = dtype; h.M = M; h.C = C; h.s = s; h.has_rfin = rfin ? 1 : 0;
+    h.y = y; h.res = res; h.out = out; h.yfin = *yfin; h.rfin = rf;
+    return PXL_OK;
+  }
+  return launch_residual_fin(dtype, M, C, y, *yfin, res, rf, rfin ? 1 : 0, out, s, nullptr);
 }
 
 extern "C" int pxl_bn_apply_fwd(int dtype, long M, int C, const void* y, const float* coef, int relu, void* z,
@@ -478,10 +549,10 @@ extern "C" int pxl_bn_apply_fwd(int dtype, long M, int C, const void* y, const f
   const pxl_bn_fin none = {};
   if (dtype == PXL_F32)
     hipLaunchKernelGGL((bn_apply_fwd_kernel<float, false>), grid, dim3(256), 0, s, (int)M, C, cp<float>(y),
-                       coef, relu, mp<float>(z), rpg, cgmax, none);
+                       coef, relu, mp<float>(z), rpg, cgmax, none, EltSecond{});
   else
     hipLaunchKernelGGL((bn_apply_fwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, (int)M, C,
-                       cp<bf16_t>(y), coef, relu, mp<bf16_t>(z), rpg, cgmax, none);
+                       cp<bf16_t>(y), coef, relu, mp<bf16_t>(z), rpg, cgmax, none, EltSecond{});
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -493,18 +564,19 @@ extern "C" int pxl_bn_finalize_apply_fwd(int dtype, long M, int C, const void* y
   const int epc = dtype == PXL_F32 ? 4 : 8;
   PXL_REQUIRE(C % epc == 0, "bn_finalize_apply_fwd: C=%d must be a multiple of %d", C, epc);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int cgmax = 16;
-  const ColGeom g = col_geom(C, epc, cgmax);
-  const int rpg = rows_per_group((int)M, g, pxl_tune_get(3));
-  const dim3 grid(g.ncg, cdiv((int)M, rpg));
-  if (dtype == PXL_F32)
-    hipLaunchKernelGGL((elt_prefetch() ? bn_apply_fwd_kernel<float, true, 4> : bn_apply_fwd_kernel<float, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<float>(y), nullptr, relu,
-                       mp<float>(z), rpg, cgmax, *fin);
-  else
-    hipLaunchKernelGGL((elt_prefetch() ? bn_apply_fwd_kernel<bf16_t, true, 4> : bn_apply_fwd_kernel<bf16_t, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<bf16_t>(y), nullptr, relu,
-                       mp<bf16_t>(z), rpg, cgmax, *fin);
-  PXL_LAUNCH_CHECK();
-  return PXL_OK;
+  EltHeld& h = tl_elt;
+  if (h.armed) {
+    if (h.held && h.kind == 2 && h.dtype == dtype && h.M == M && h.C == C && h.s == s && h.relu == relu && same_fin_shape(h.yfin, *fin)) {
+      h.held = false;
+      const EltSecond sec{y, nullptr, z, *fin, pxl_bn_fin{}};
+      return launch_bn_fin_apply(dtype, M, C, h.y, h.yfin, relu, h.out, s, &sec);
+    }
+    const int rc = issue_held();
+    if (rc != PXL_OK) return rc;
+    h.held = true; h.kind = 2; h.dtype = dtype; h.M = M; h.C = C; h.s = s; h.relu = relu; h.y = y; h.out = z; h.yfin = *fin;
+    return PXL_OK;
+  }
+  return launch_bn_fin_apply(dtype, M, C, y, *fin, relu, z, s, nullptr);
 }
 
 extern "C" int pxl_leaky_fwd(int dtype, long n, const void* x, float slope, void* y, void* stream) {

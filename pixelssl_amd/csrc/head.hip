@@ -341,6 +341,14 @@ __global__ __launch_bounds__(256) void head_loss_rows_kernel(int C, int Cp, int 
 // of the row per 513 pixels; this one has no barrier in the pixel loop and ~8x the waves in flight.  Loss partial sums go
 // to part[cell][3] and are reduced in a fixed order by head_loss_finish_kernel (no contended atomics, deterministic
 // losses).  C is a template parameter: with a run-time channel count the accumulators spill.
+// fp32 engine (the parity mode): library expf / logf; bf16 engine: v_exp_f32 / v_log_f32 (~1e-6 relative)
+template <typename T> __device__ __forceinline__ float head_exp(float x) {
+  if constexpr (sizeof(T) == 4) return expf(x); else return __expf(x);
+}
+template <typename T> __device__ __forceinline__ float head_log(float x) {
+  if constexpr (sizeof(T) == 4) return logf(x); else return __logf(x);
+}
+
 template <typename T, int C>
 __global__ __launch_bounds__(256) void head_loss_cells_kernel(int Cp, int h, int w, int H, int W, float sy, float sx,
                                                               int align, const T* __restrict__ s_low,
@@ -441,13 +449,13 @@ __global__ __launch_bounds__(256) void head_loss_cells_kernel(int Cp, int h, int
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-          if (ce) tsum += __expf(zt[c] - mxt);          // (ce is uniform over the wave: unlabeled samples skip the exps)
+          if (ce) tsum += head_exp<T>(zt[c] - mxt);          // (ce is uniform over the wave: unlabeled samples skip the exps)
           if (c == label) tpick = zt[c];
           const float d = zs[c] - zt[c];
           acc_m += msq * (d * d);
           gm[c] = __fmul_rn(ms, d);
         }
-        if (valid) acc_t += (mxt + __logf(tsum)) - tpick;
+        if (valid) acc_t += (mxt + head_log<T>(tsum)) - tpick;
       } else {
 #pragma unroll
         for (int c = 0; c < C; ++c) gm[c] = 0.f;
@@ -458,9 +466,9 @@ __global__ __launch_bounds__(256) void head_loss_cells_kernel(int Cp, int h, int
       if (ce) {
         sum = 0.f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) { if (c == label) pick = zs[c]; zs[c] = __expf(zs[c] - mxs); sum += zs[c]; }
+        for (int c = 0; c < C; ++c) { if (c == label) pick = zs[c]; zs[c] = head_exp<T>(zs[c] - mxs); sum += zs[c]; }
       }
-      if (valid) acc_s += (mxs + __logf(sum)) - pick;
+      if (valid) acc_s += (mxs + head_log<T>(sum)) - pick;
       const float inv = valid ? ce_scale / sum : 0.f;
       const float hot = valid ? -ce_scale : 0.f;
 #pragma unroll
@@ -504,7 +512,8 @@ __global__ __launch_bounds__(256) void head_loss_cells_kernel(int Cp, int h, int
 }
 
 // d(low) fp32 accumulator -> engine dtype NHWC with zeroed channel padding; blocks >= gridDim.x - B reduce the per-cell
-// loss partials of one sample each, in cell order (deterministic): sums[b], sums[B + b] (x 1/HW), sums[2B] += MSE mean
+// loss partials of one sample each, in cell order (deterministic): sums[b], sums[B + b] (x 1/HW); the first of them also
+// sums[2B] = MSE mean over every sample
 template <typename T>
 __global__ __launch_bounds__(256) void head_loss_finish_kernel(int B, int h, int w, int C, int Cp, const float* __restrict__ dacc,
                                                                T* __restrict__ dlow, const float* __restrict__ part,
@@ -538,9 +547,22 @@ __global__ __launch_bounds__(256) void head_loss_finish_kernel(int B, int h, int
   if (threadIdx.x == 0) {
     const float s0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     const float s1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    const float s2 = red[2][0] + red[2][1] + red[2][2] + red[2][3];
     if (b < n_ce) { sums[b] = s0 * inv_hw; if (has_t) sums[B + b] = s1 * inv_hw; }
-    atomicAdd(sums + 2 * B, s2 * inv_mse_n);            // B addends
+  }
+  // the MSE mean: ONE block adds every sample's cell partials, sample by sample with the same per-sample reduction as above
+  // -> a fixed order, bit-identical from run to run (B contended atomicAdds used to decide the last bits)
+  if (b == 0) {
+    float total = 0.f;
+    for (int q = 0; q < B; ++q) {
+      float a2 = 0.f;
+      for (long k = threadIdx.x; k < per; k += blockDim.x) a2 += part[((long)q * per + k) * 3 + 2];
+      const float v = wave_sum(a2);
+      __syncthreads();
+      if (lane == 0) red[2][wave] = v;
+      __syncthreads();
+      total += red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    }
+    if (threadIdx.x == 0) sums[2 * B] = total * inv_mse_n;
   }
 }
 

@@ -101,6 +101,7 @@ struct OpInfo {
   pxl_op d;
   int ntaps = 0;
   pxl_conv_desc fwd;       // forward geometry (all groups)
+  int pair_cfg = -2;       // tile configuration of the PAIRED forward launch (pxl_net_tune_pair); -2 = not tuned: use fwd.tile_cfg
   pxl_conv_desc bwd;       // data-gradient geometry
   pxl_conv_desc grp[4];    // per-group forward geometry (wgrad)
   size_t wf_off = 0, wt_off = 0, bias_off = 0;   // packed buffer offsets
@@ -178,6 +179,7 @@ struct pxl_net {
   std::vector<long> op_lo;         // per op: lowest flat offset (floats) its backward writes a gradient to, or -1
   bool bucket_ok = false;          // parameter offsets grow with the op index: suffixes of the op list = suffixes of the buffer
   int grad_buckets_last = 0;       // buckets issued by the last backward (tests / bench)
+  int pairs_last = 0;              // convolutions the last paired forward issued as one launch for both networks
   bool bn_onload = getenv("PXL_BN_ONLOAD") == nullptr || getenv("PXL_BN_ONLOAD")[0] != '0';
   bool wgrad_on = true;
   bool pack_dgrad = true;          // false: pxl_net_pack skips the transposed (data-gradient) weights (no-grad networks)
@@ -926,23 +928,26 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
 }
 
 
-extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* packed, float* running,
-                               const float* x, float* logits, float* prob, void* arena, size_t arena_bytes,
-                               int training, void* stream) {
-  // logits == NULL: the HEAD op (up-sampling + soft-max to full resolution) is skipped -- the caller consumes the
-  // low-resolution logits in the arena directly (pxl_net_head_loss)
-  PXL_REQUIRE(n && n->planned && params && packed && (x || n->in_parts > 0) && arena, "net_forward: bad argument (plan first)");
-  if (arena_bytes < n->arena_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_forward: arena too small (%zu < %zu)", arena_bytes, n->arena_bytes);
+namespace {
+// everything one forward pass hands to its ops
+struct FwdCtx {
+  const float* params; const void* packed; float* running; const float* x; float* logits; float* prob; void* arena;
+  int training; void* stream;
+};
+
+// Forward of op i.  phase 0: the whole op.  CONV ops can run in two halves -- 1: everything up to and including the
+// convolution launch, 2: what follows it (Sync-BN exchange, finalize, activation) -- so that the paired pass
+// (pxl_net_forward_pair) can issue the convolution of two networks as ONE launch between the halves; *fin_flag carries
+// "the convolution finalized its BatchNorm itself" from half 1 to half 2.
+int forward_op(pxl_net* n, size_t i, const FwdCtx& c, int phase, bool* fin_flag) {
+  const float* params = c.params; const void* packed = c.packed; float* running = c.running; const float* x = c.x;
+  float* logits = c.logits; float* prob = c.prob; void* arena = c.arena; const int training = c.training; void* stream = c.stream;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (training && n->stats_region_bytes)
-    PXL_CHECK_HIP(hipMemsetAsync(at(arena, n->stats_region_off), 0, n->stats_region_bytes, s));
-  if (n->ibn_region_bytes)      // (instance statistics are computed in eval mode too)
-    PXL_CHECK_HIP(hipMemsetAsync(at(arena, n->ibn_region_off), 0, n->ibn_region_bytes, s));
   const int dt = n->dtype;
-  for (size_t i = 0; i < n->ops.size(); ++i) {
-    OpInfo& op = n->ops[i];
-    const pxl_op& d = op.d;
-    int rc = PXL_OK;
+  OpInfo& op = n->ops[i];
+  const pxl_op& d = op.d;
+  int rc = PXL_OK;
+  if (phase != 0 && d.kind != PXL_OP_CONV) return pxl_set_error(PXL_ERR_ARG, "net_forward: only convolutions run in halves");
     switch (d.kind) {
       case PXL_OP_INPUT: {
         const TensorInfo& t = n->tensors[d.out];
@@ -959,6 +964,7 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
         break;
       }
       case PXL_OP_CONV: {
+        if (phase != 2) {
         const TensorInfo& tin = n->tensors[d.in0];
         const TensorInfo& tout = n->tensors[d.out];
         const ConvIn cin = conv_input(n, op, arena);
@@ -1012,6 +1018,12 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
                                 nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr, op.ws_bytes, stream);
         }
         if (rc != PXL_OK) return rc;
+        *fin_flag = fin_by_conv;
+        }   // phase != 2
+        if (phase == 1) break;
+        {
+        const bool fin_by_conv = *fin_flag;
+        const TensorInfo& tout = n->tensors[d.out];
         if (d.bn_out >= 0) n->bns[d.bn_out].fin_by_conv = fin_by_conv;
         if (d.bn_out >= 0 && fin_by_conv) {
           BnInfo& b = n->bns[d.bn_out];
@@ -1048,6 +1060,7 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
                                     b.relu, at(arena, b.z_off), stream);
           }
         }
+        }   // post
         break;
       }
       case PXL_OP_MAXPOOL: {
@@ -1153,9 +1166,174 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
         break;
       }
     }
+  return rc;
+}
+}  // namespace
+
+extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* packed, float* running,
+                               const float* x, float* logits, float* prob, void* arena, size_t arena_bytes,
+                               int training, void* stream) {
+  // logits == NULL: the HEAD op (up-sampling + soft-max to full resolution) is skipped -- the caller consumes the
+  // low-resolution logits in the arena directly (pxl_net_head_loss)
+  PXL_REQUIRE(n && n->planned && params && packed && (x || n->in_parts > 0) && arena, "net_forward: bad argument (plan first)");
+  if (arena_bytes < n->arena_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_forward: arena too small (%zu < %zu)", arena_bytes, n->arena_bytes);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (training && n->stats_region_bytes)
+    PXL_CHECK_HIP(hipMemsetAsync(at(arena, n->stats_region_off), 0, n->stats_region_bytes, s));
+  if (n->ibn_region_bytes)      // (instance statistics are computed in eval mode too)
+    PXL_CHECK_HIP(hipMemsetAsync(at(arena, n->ibn_region_off), 0, n->ibn_region_bytes, s));
+  const FwdCtx ctx{params, packed, running, x, logits, prob, arena, training, stream};
+  for (size_t i = 0; i < n->ops.size(); ++i) {
+    bool fin = false;
+    const int rc = forward_op(n, i, ctx, 0, &fin);
     if (rc != PXL_OK) return rc;
   }
   return PXL_OK;
+}
+
+extern "C" void pxl_dma_capture_begin(void** slot);
+extern "C" void pxl_dma_capture_end(void);
+extern "C" int pxl_dma_launch_captured(void* slot0, void* slot1);
+extern "C" void pxl_elt_pair_begin(void);
+extern "C" int pxl_elt_pair_end(void);
+
+// Forward pass of TWO networks with the same program (Mean Teacher's student || teacher, GCT's l || r task models) in
+// lockstep on ONE stream: op by op, and every convolution of the pair as ONE launch (conv_dma.hip: gridDim.z = 2) where the
+// two launches match.  Per network the arguments and the results are those of pxl_net_forward; nothing is shared between the
+// two passes.  Why: at M = 8 x 33 x 33 a ResNet stage-3 convolution has 138 - 274 tiles for 256 CUs -- two networks' tiles in one
+// launch fill the chip with tiles of twice the arithmetic intensity, and the pair costs one launch latency instead of two
+// (DESIGN.md 4); with Sync-BN both networks' exchanges are issued from this one thread in one order on every rank.
+extern "C" int pxl_net_forward_pair(pxl_net* n0, pxl_net* n1, const float* params0, const float* params1, const void* packed0,
+                                    const void* packed1, float* running0, float* running1, const float* x0, const float* x1,
+                                    float* logits0, float* prob0, float* logits1, float* prob1, void* arena0, void* arena1,
+                                    size_t arena_bytes0, size_t arena_bytes1, int training0, int training1, void* stream) {
+  PXL_REQUIRE(n0 && n1 && n0 != n1 && n0->planned && n1->planned && params0 && params1 && packed0 && packed1 && x0 && x1 && arena0 && arena1,
+              "net_forward_pair: bad argument (plan both networks first)");
+  PXL_REQUIRE(n0->ops.size() == n1->ops.size() && n0->B == n1->B && n0->H == n1->H && n0->W == n1->W && n0->dtype == n1->dtype &&
+              n0->in_parts == 0 && n1->in_parts == 0, "net_forward_pair: the two networks must run the same program on the same shape");
+  for (size_t i = 0; i < n0->ops.size(); ++i)
+    PXL_REQUIRE(n0->ops[i].d.kind == n1->ops[i].d.kind, "net_forward_pair: op %zu differs between the networks", i);
+  if (arena_bytes0 < n0->arena_bytes || arena_bytes1 < n1->arena_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_forward_pair: arena too small");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  pxl_net* nets[2] = {n0, n1};
+  void* arenas[2] = {arena0, arena1};
+  const int trainings[2] = {training0, training1};
+  for (int k = 0; k < 2; ++k) {
+    if (trainings[k] && nets[k]->stats_region_bytes)
+      PXL_CHECK_HIP(hipMemsetAsync(at(arenas[k], nets[k]->stats_region_off), 0, nets[k]->stats_region_bytes, s));
+    if (nets[k]->ibn_region_bytes)
+      PXL_CHECK_HIP(hipMemsetAsync(at(arenas[k], nets[k]->ibn_region_off), 0, nets[k]->ibn_region_bytes, s));
+  }
+  const FwdCtx ctx[2] = {{params0, packed0, running0, x0, logits0, prob0, arena0, training0, stream},
+                         {params1, packed1, running1, x1, logits1, prob1, arena1, training1, stream}};
+  n0->pairs_last = 0;
+  for (size_t i = 0; i < n0->ops.size(); ++i) {
+    if (n0->ops[i].d.kind != PXL_OP_CONV || n0->profile || n1->profile) {
+      // (the finalize-folding element-wise kernels of the two networks -- residual joins, BN + ReLU -- pair up as well:
+      // eltwise.hip holds the first network's launch back until the second one's arrives)
+      pxl_elt_pair_begin();
+      for (int k = 0; k < 2; ++k) {
+        bool fin = false;
+        const int rc = forward_op(nets[k], i, ctx[k], 0, &fin);
+        if (rc != PXL_OK) { (void)pxl_elt_pair_end(); return rc; }
+      }
+      const int rc = pxl_elt_pair_end();
+      if (rc != PXL_OK) return rc;
+      continue;
+    }
+    bool fin[2] = {false, false};
+    void* slot[2] = {nullptr, nullptr};
+    // both halves on the tile configuration tuned for the PAIR (twice the tiles per launch: larger tiles win), or on the first
+    // network's own choice when the pair has not been tuned
+    const int pcfg = n0->ops[i].pair_cfg != -2 ? n0->ops[i].pair_cfg : n0->ops[i].fwd.tile_cfg;
+    for (int k = 0; k < 2; ++k) {
+      const int keep = nets[k]->ops[i].fwd.tile_cfg;
+      nets[k]->ops[i].fwd.tile_cfg = pcfg;
+      pxl_dma_capture_begin(&slot[k]);
+      const int rc = forward_op(nets[k], i, ctx[k], 1, &fin[k]);
+      pxl_dma_capture_end();
+      nets[k]->ops[i].fwd.tile_cfg = keep;
+      if (rc != PXL_OK) { (void)pxl_dma_launch_captured(slot[0], slot[1]); return rc; }
+    }
+    const int pr = pxl_dma_launch_captured(slot[0], slot[1]);
+    if (pr < 0) return pr;
+    n0->pairs_last += pr;
+    pxl_elt_pair_begin();
+    for (int k = 0; k < 2; ++k) {
+      const int rc = forward_op(nets[k], i, ctx[k], 2, &fin[k]);
+      if (rc != PXL_OK) { (void)pxl_elt_pair_end(); return rc; }
+    }
+    const int rce = pxl_elt_pair_end();
+    if (rce != PXL_OK) return rce;
+  }
+  return PXL_OK;
+}
+
+// convolutions the last pxl_net_forward_pair(n, ...) issued as paired launches (tests / bench)
+extern "C" int pxl_net_pairs(const pxl_net* n) { return n ? n->pairs_last : 0; }
+
+// Tile selection for the paired forward: every convolution of the pair timed as ONE launch per candidate configuration
+// (pxl_net_tune times single launches: with twice the tiles per launch the larger tiles win -- tools/cbench --pair: 160 x 128
+// instead of 64 x 128 on the stage-3 shapes, the pair at 1.4 - 1.7x a single launch instead of 2x).  Both networks planned,
+// packed; arenas are clobbered (call it at warm-up, like pxl_net_tune).  Results do not depend on the choice.
+extern "C" int pxl_net_tune_pair(pxl_net* n0, pxl_net* n1, const float* params0, const float* params1, const void* packed0,
+                                 const void* packed1, void* arena0, void* arena1, size_t arena_bytes0, size_t arena_bytes1,
+                                 void* stream) {
+  PXL_REQUIRE(n0 && n1 && n0 != n1 && n0->planned && n1->planned && params0 && params1 && packed0 && packed1 && arena0 && arena1,
+              "net_tune_pair: bad argument");
+  PXL_REQUIRE(n0->ops.size() == n1->ops.size() && n0->B == n1->B && n0->H == n1->H && n0->W == n1->W && n0->dtype == n1->dtype,
+              "net_tune_pair: the two networks must run the same program on the same shape");
+  if (arena_bytes0 < n0->arena_bytes || arena_bytes1 < n1->arena_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_tune_pair: arena too small");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipEvent_t ea, eb;
+  PXL_CHECK_HIP(hipEventCreate(&ea));
+  PXL_CHECK_HIP(hipEventCreate(&eb));
+  pxl_net* nets[2] = {n0, n1};
+  const FwdCtx ctx[2] = {{params0, packed0, nullptr, nullptr, nullptr, nullptr, arena0, 1, stream},
+                         {params1, packed1, nullptr, nullptr, nullptr, nullptr, arena1, 1, stream}};
+  for (int k = 0; k < 2; ++k)
+    if (nets[k]->stats_region_bytes) PXL_CHECK_HIP(hipMemsetAsync(at(k ? arena1 : arena0, nets[k]->stats_region_off), 0, nets[k]->stats_region_bytes, s));
+  int rc_all = PXL_OK;
+  for (size_t i = 0; i < n0->ops.size(); ++i) {
+    OpInfo& op = n0->ops[i];
+    if (op.d.kind != PXL_OP_CONV || op.patch || n1->ops[i].d.kind != PXL_OP_CONV) continue;      // (the stem reads x: not available here)
+    const TensorInfo& tout = n0->tensors[op.d.out];
+    int best_cfg = -2; float best = 1e30f;
+    for (int cfg = 8; cfg < 36; ++cfg) {
+      if (cfg >= 12 && cfg < 16) continue;
+      if (cfg >= 20 && cfg != 29 && tout.Cp < 128) continue;
+      if (cfg == 35 && tout.Cp < 256) continue;
+      float t_best = 1e30f; bool ok = true;
+      for (int rep = 0; rep < 4 && ok; ++rep) {               // one warm-up + three timed launches
+        void* slot[2] = {nullptr, nullptr};
+        if (rep) ok = hipEventRecord(ea, s) == hipSuccess;
+        for (int k = 0; k < 2 && ok; ++k) {
+          const int keep = nets[k]->ops[i].fwd.tile_cfg;
+          nets[k]->ops[i].fwd.tile_cfg = cfg;
+          bool fin = false;
+          pxl_dma_capture_begin(&slot[k]);
+          ok = forward_op(nets[k], i, ctx[k], 1, &fin) == PXL_OK;
+          pxl_dma_capture_end();
+          nets[k]->ops[i].fwd.tile_cfg = keep;
+        }
+        const int pr = pxl_dma_launch_captured(slot[0], slot[1]);
+        if (pr != 1) ok = false;                              // not pairable with this configuration (or an error): not a candidate
+        if (ok && rep) {
+          float ms = 0.f;
+          ok = hipEventRecord(eb, s) == hipSuccess && hipEventSynchronize(eb) == hipSuccess && hipEventElapsedTime(&ms, ea, eb) == hipSuccess;
+          if (ok && ms < t_best) t_best = ms;
+        }
+      }
+      (void)hipGetLastError();
+      if (ok && t_best < best) { best = t_best; best_cfg = cfg; }
+    }
+    op.pair_cfg = best_cfg;
+    n1->ops[i].pair_cfg = best_cfg;
+  }
+  (void)hipStreamSynchronize(s);
+  (void)hipEventDestroy(ea);
+  (void)hipEventDestroy(eb);
+  return rc_all;
 }
 
 extern "C" int pxl_net_set_wgrad(pxl_net* net, int enable) {

@@ -10,7 +10,7 @@
 // low-latency protocol).  Two slot sets alternate by epoch parity: a rank can only be one exchange ahead of the slowest
 // rank (it needs that rank's words of the current exchange before it returns), so the set it overwrites next has been
 // read by everyone.  A spin that exceeds the time-out (a peer died) raises the context's status word instead of hanging
-// the GPU.
+// the GPU; the word is sticky (see the kernel).
 #include <cstring>
 #include <new>
 
@@ -31,6 +31,11 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a, f
                                                              unsigned epoch) {
   const int par = epoch & 1u;
   const size_t set = (size_t)par * a.world * a.slot;
+  // sticky abort: once an exchange of this context has given up on a peer, every later one posts its words (the peers may
+  // still be alive and waiting for them) but does not wait -- a dead peer costs ONE time-out, not one per exchange (an MT
+  // step has ~310 of them).  The sums are invalid from then on; the host sees the status word (pxl_peer_status, polled by
+  // dist.poll_peers every few steps) and moves the statistics to RCCL / torch.distributed.
+  const bool aborted = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     // my element into my slot of every rank's buffer (my own included: the sum below reads every slot the same way)
     const unsigned long long word = ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(buf[i]);
@@ -43,6 +48,7 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a, f
     for (int q = 0; q < a.world; ++q) {
       unsigned long long w = __hip_atomic_load(mine + (size_t)q * a.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       while ((unsigned)(w >> 32) != epoch) {
+        if (aborted) break;
         if (t0 == 0) t0 = wall_clock64();
         __builtin_amdgcn_s_sleep(1);
         if (wall_clock64() - t0 > a.timeout_ticks) {

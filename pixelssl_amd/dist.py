@@ -178,7 +178,8 @@ def native_comms():
 
 _peer = {"ok": None, "ctxs": [], "hook": None}
 PEER_SLOT_FLOATS = 4096            # 2 * 2048 channels: the widest BatchNorm of the ResNet trunks in one exchange
-PEER_TIMEOUT_MS = int(os.environ.get("PXL_PEER_TIMEOUT_MS", "20000"))
+PEER_TIMEOUT_MS = int(os.environ.get("PXL_PEER_TIMEOUT_MS", "2000"))       # one exchange is ~6 us; 2 s is a dead (or wedged) peer
+PEER_POLL_STEPS = int(os.environ.get("PXL_PEER_POLL_STEPS", "20"))
 
 
 def _all_agree(flag, dev):
@@ -215,11 +216,14 @@ def open_peer_context():
         stream = torch.cuda.current_stream().cuda_stream
         probe_ok = True
         for k in range(64):
+            # (every rank issues ALL 64 exchanges whatever it has seen so far: a rank that stopped at its first mismatch
+            # would leave the others spinning in the exchanges it skipped, and the call sequences would diverge)
             n = (64, 256, 1024, PEER_SLOT_FLOATS, PEER_SLOT_FLOATS + 192)[k % 5]
             v = torch.arange(n, device=dev, dtype=torch.float32) * (rk + 1) + k
             want = torch.arange(n, device=dev, dtype=torch.float32) * (ws * (ws + 1) / 2) + k * ws
-            probe_ok = probe_ok and h.pxl_peer_allreduce_sum(ctx, v.data_ptr(), n, stream) == 0
-            probe_ok = probe_ok and bool(torch.equal(v, want))
+            issued = h.pxl_peer_allreduce_sum(ctx, v.data_ptr(), n, stream) == 0
+            same = bool(torch.equal(v, want))
+            probe_ok = probe_ok and issued and same
         st = ctypes.c_int(0)
         probe_ok = probe_ok and h.pxl_peer_status(ctx, ctypes.byref(st)) == 0 and st.value == 0
         good = _all_agree(probe_ok, dev)
@@ -253,6 +257,55 @@ def check_peers():
         if st.value:
             raise _lib.PixelHipError("peer-mapped Sync-BN exchange: rank %d gave up waiting for rank %d after %d ms"
                                      % (rank(), st.value - 1, PEER_TIMEOUT_MS))
+
+
+_poll = {"calls": 0, "fallbacks": 0}
+
+
+def poll_peers(cores=None):
+    """Called once per training step (cheap: does something every PEER_POLL_STEPS-th call).  COLLECTIVE on those calls:
+    every rank reads the status words of its peer-mapped exchange contexts, the ranks agree (MAX) on whether any exchange
+    has timed out, and if one has, EVERY rank moves the Sync-BN statistics of every network to the RCCL / torch.distributed
+    path for the rest of the run (the contexts are retired; the statistics of the steps since the time-out were invalid
+    on some rank -- that is logged, the run continues on valid sums instead of finishing the epoch on garbage).
+    -> True when a fall-back happened in this call."""
+    if not _peer["ctxs"] or not is_distributed():
+        return False
+    _poll["calls"] += 1
+    if _poll["calls"] % PEER_POLL_STEPS:
+        return False
+    import ctypes
+    from . import _lib
+    worst = 0
+    for ctx in _peer["ctxs"]:
+        st = ctypes.c_int(0)
+        _lib.check(_lib.lib().pxl_peer_status(ctx, ctypes.byref(st)))
+        worst = max(worst, st.value)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    flag = torch.tensor([float(worst)], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if flag.item() == 0:
+        return False
+    from .utils import logger
+    logger.log_warn("peer-mapped Sync-BN exchange timed out (rank %d: local status %d); the statistics move to %s for the rest "
+                    "of the run\n" % (rank(), worst, "RCCL" if _native["comms"] else "torch.distributed"))
+    retired, _peer["ctxs"] = _peer["ctxs"], []
+    _peer["ok"] = False
+    ws = world_size()
+    for m in _peer.get("cores", []):
+        if getattr(m, "_pxl_peer", None) is None:
+            continue
+        m._pxl_peer = None
+        comm = getattr(m, "_pxl_comm", None)
+        if comm is not None:
+            m.set_sync_native(_native["hook"], comm, ws)
+        else:
+            m.set_sync(_sync_stats_callback, ws)
+    torch.cuda.synchronize()
+    for ctx in retired:
+        _lib.lib().pxl_peer_destroy(ctx)
+    _poll["fallbacks"] += 1
+    return True
 
 
 def rccl_ranks():
@@ -309,6 +362,7 @@ def attach(model):
             peer = open_peer_context() if sync_bn else None
             if peer is not None:
                 m._pxl_peer = peer
+                _peer.setdefault("cores", []).append(m)       # (poll_peers re-wires them if an exchange ever times out)
                 m.set_sync_native(_peer["hook"], peer, ws)
                 sync_bn = False                         # wired; the branches below only handle the gradient path
             if comms:                      # networks take the communicators in creation order (identical on all ranks)

@@ -657,6 +657,7 @@ class SegNetCore(nn.Module):
             if self._cur.eval_arena is None:
                 self._cur.eval_arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
             arena = self._cur.eval_arena
+            self._cur.arena_gen = getattr(self._cur, "arena_gen", 0) + 1      # (an earlier no-grad DeferredHead on this arena is stale now)
             logits, prob = self._forward_raw(x, arena, parts=parts)
         return logits, prob, (_LatentHandle(self, arena, self._cur) if self.has_latent else None)
 
@@ -788,10 +789,29 @@ class DeferredHead:
         self.core, self.arena, self.plan, self.batch = core, arena, plan, batch
         self.bn_training, self.trainable = bn_training, trainable
         self.has_grad = False           # functional.head_losses wrote d(loss)/d(low-res logits) into the plan's scratch
+        # The low-resolution gradient lives in the PLAN's shared scratch and a no-grad pass lives in the plan's reused
+        # eval arena: any later pass / head_losses / backward on the same plan overwrites them.  Stamps of the plan's
+        # generation counters at the time this pass (and its gradient) were written make a stale use an error instead of
+        # a silently wrong gradient / prediction.
+        plan.arena_gen = getattr(plan, "arena_gen", 0) + (0 if trainable else 1)
+        self._arena_gen = plan.arena_gen if not trainable else None
+        self._grad_gen = None
+
+    def _check_arena(self, what):
+        if self._arena_gen is not None and self._arena_gen != getattr(self.plan, "arena_gen", 0):
+            raise _lib.PixelHipError("DeferredHead.%s: this no-grad pass has been overwritten by a later pass on the same plan "
+                                     "(its arena is the plan's reused evaluation arena); materialize() it before the next pass" % what)
+
+    def mark_grad(self):
+        """functional.head_losses wrote d(loss)/d(low-res logits) of THIS pass into the plan's scratch"""
+        self.plan.grad_gen = getattr(self.plan, "grad_gen", 0) + 1
+        self._grad_gen = self.plan.grad_gen
+        self.has_grad = True
 
     def materialize(self, want_prob=True):
         """-> (logits, softmax) NCHW fp32 at full resolution, detached (what forward() would have returned)."""
         core = self.core
+        self._check_arena("materialize")
         H, W = self.plan.out_size
         logits = torch.empty(self.batch, core.num_classes, H, W, device=core._device, dtype=torch.float32)
         prob = torch.empty_like(logits) if want_prob else None
@@ -803,6 +823,9 @@ class DeferredHead:
         gradient buffer, exactly like the autograd path of forward())."""
         if not (self.trainable and self.has_grad):
             raise _lib.PixelHipError("DeferredHead.backward: no gradient to propagate (no-grad pass, or head_losses not called)")
+        if self._grad_gen != getattr(self.plan, "grad_gen", 0):
+            raise _lib.PixelHipError("DeferredHead.backward: the low-resolution gradient of this pass has been overwritten (another "
+                                     "head_losses / backward ran on the same plan in between)")
         core, pl = self.core, self.plan
         core.ensure_grad_views()
         s = core._store
@@ -814,6 +837,56 @@ class DeferredHead:
         if hook is not None and core._wgrad_on:
             hook(core)
         self.has_grad = False
+        pl.grad_gen = getattr(pl, "grad_gen", 0) + 1        # (the backward pass used the scratch: nothing in it is a seam gradient now)
+
+
+def forward_deferred_pair(core_a, xa, core_b, xb):
+    """SegNetCore.forward_deferred of TWO networks that run the same program (Mean Teacher's student and teacher, GCT's l and
+    r task models) as ONE lockstep executor pass on the current stream: every convolution of the pair is one launch
+    (csrc/net.cpp: pxl_net_forward_pair).  -> (DeferredHead a, DeferredHead b), each exactly what its own forward_deferred
+    would have returned (bit-identical tensors), or None when the pair cannot run this way (different programs / shapes, a
+    plan without the fused seam) -- the caller then runs the two passes separately."""
+    if type(core_a) is not type(core_b) or core_a is core_b or not (xa.is_cuda and xb.is_cuda) or tuple(xa.shape) != tuple(xb.shape):
+        return None
+    if len(core_a._pb.ops) != len(core_b._pb.ops) or core_a._code != core_b._code or core_a._profile_on or core_b._profile_on:
+        return None
+    heads, plans, arenas, flags, xs = [], [], [], [], []
+    for core, x in ((core_a, xa), (core_b, xb)):
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        need_graph = torch.is_grad_enabled() and any(p.requires_grad for p in core._param_list[:1])
+        core._plan(B, H, W, None, inference=not need_graph and not core.training)
+        if not lib().pxl_net_head_loss_supported(core._cur.net):
+            return None
+        core._ensure_packed()
+        if need_graph:
+            arena = torch.empty(core._arena_bytes, device=x.device, dtype=torch.uint8)
+        else:
+            if core._cur.eval_arena is None:
+                core._cur.eval_arena = torch.empty(core._arena_bytes, device=x.device, dtype=torch.uint8)
+            arena = core._cur.eval_arena
+        if core.keep_arena:
+            core._last_arena = arena
+        plans.append(core._cur); arenas.append(arena); xs.append(x)
+        flags.append((bool(core.training and not core.freeze_bn), need_graph))
+    pa, pb = plans
+    if core_a.autotune and getattr(pa, "pair_tuned_with", None) is not pb.net and not pa.inference and not pb.inference:
+        # tile configuration of every paired launch, measured (csrc/net.cpp: pxl_net_tune_pair); scratch arenas: warm-up only
+        tmp = [torch.zeros(c._arena_bytes, device=xs[0].device, dtype=torch.uint8) for c in (core_a, core_b)]
+        check(lib().pxl_net_tune_pair(pa.net, pb.net, ptr(core_a._store.params), ptr(core_b._store.params), ptr(pa.packed), ptr(pb.packed),
+                                      ptr(tmp[0]), ptr(tmp[1]), tmp[0].numel(), tmp[1].numel(), stream_ptr()))
+        del tmp
+        pa.pair_tuned_with = pb.net
+    check(lib().pxl_net_forward_pair(pa.net, pb.net, ptr(core_a._store.params), ptr(core_b._store.params), ptr(pa.packed), ptr(pb.packed),
+                                     ptr(core_a._store.running), ptr(core_b._store.running), ptr(xs[0]), ptr(xs[1]), None, None, None, None,
+                                     ptr(arenas[0]), ptr(arenas[1]), arenas[0].numel(), arenas[1].numel(), int(flags[0][0]), int(flags[1][0]),
+                                     stream_ptr()))
+    for core, (training, _) in zip((core_a, core_b), flags):
+        if training:
+            core._nbt += 1
+    for core, pl, arena, x, (training, need_graph) in zip((core_a, core_b), plans, arenas, xs, flags):
+        heads.append(DeferredHead(core, arena, pl, x.shape[0], training, need_graph))
+    return heads[0], heads[1]
 
 
 class _LatentHandle:
@@ -859,6 +932,7 @@ class _SegNetFn(torch.autograd.Function):
         if dlatent is not None:
             dlatent = dlatent.contiguous().float()
             check(lib().pxl_net_seed_latent_grad(pl.net, ptr(pl.scratch), pl.scratch.numel(), ptr(dlatent), stream_ptr()))
+        pl.grad_gen = getattr(pl, "grad_gen", 0) + 1          # (a seam gradient parked in this plan's scratch is gone after this pass)
         check(lib().pxl_net_backward(pl.net, ptr(s.params), ptr(pl.packed), ptr(dlogits), ptr(dprob), ptr(prob),
                                      ptr(s.grads), ptr(ctx.arena), ctx.arena.numel(), ptr(pl.scratch),
                                      pl.scratch.numel(), int(ctx.bn_training), stream_ptr()))

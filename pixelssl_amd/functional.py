@@ -136,11 +136,14 @@ def head_losses(s_head, t_head, gt, n_ce, mse_lo, mse_hi, ce_weight, mse_weight,
         raise ValueError("head_losses: gt %s does not hold %d maps of %d x %d" % (tuple(gt.shape), n_ce, H, W))
     sums = torch.empty(2 * B + 1, device=gt.device, dtype=torch.float32)
     pl = s_head.plan
+    s_head._check_arena("head_losses")
+    if t_head is not None:
+        t_head._check_arena("head_losses")
     check(lib().pxl_net_head_loss(pl.net, ptr(s_head.arena), t_head.plan.net if t_head is not None else None,
                                   ptr(t_head.arena) if t_head is not None else None, ptr(gt), int(ignore_index), int(n_ce),
                                   int(mse_lo), int(mse_hi), float(ce_weight), float(mse_weight), ptr(pl.scratch),
                                   pl.scratch.numel(), ptr(sums), stream_ptr()))
-    s_head.has_grad = True
+    s_head.mark_grad()
     return sums[:n_ce], (sums[B:B + n_ce] if t_head is not None else None), sums[2 * B]
 
 

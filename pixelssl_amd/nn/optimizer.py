@@ -57,15 +57,19 @@ def _sync_foreign_grads(groups):
     from .. import dist as pdist
     if not pdist.is_distributed():
         return
-    ps = [p for foreign in groups for p in foreign if p.grad is not None]
+    pdist.poll_peers()       # (once per optimizer step: every PEER_POLL_STEPS-th call checks the peer-mapped exchanges)
+    # EVERY foreign parameter takes part, with zeros where this rank has no gradient: the set of tensors with a gradient
+    # may differ from rank to rank (a conditional branch in a plugin model), and all-reduces of different lengths hang
+    ps = [p for foreign in groups for p in foreign]
     if not ps:
         return
-    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])
     pdist.allreduce_mean_(flat)
     off = 0
     for p in ps:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        n = p.numel()
+        if p.grad is not None:
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
         off += n
 
 

@@ -182,6 +182,28 @@ class SSLMT(ssl_base._SSLBase):
         expressions, tests/test_seam.py)."""
         from .. import functional as PF
         from ..sseg.model import _DeferredResulter
+        # Student and teacher run the SAME program on the same shape: one lockstep executor pass can issue every convolution
+        # (and finalize-folding element-wise kernel) of the pair as ONE launch (engine.forward_deferred_pair; twice the tiles
+        # per launch, half the launches, one enqueue thread and one stream).  Measured on one MI355X (profiles/r04_pair_ab.txt):
+        # the paired convolutions take 0.79x the time of two single launches, but the lockstep pass has nothing left to overlap
+        # the memory-bound joins with -- 12.8 ms / step against 12.4 ms for the two passes on two streams.  So: two streams on
+        # one rank; the paired pass with Sync-BN (multi-rank), where it puts every rank's statistic exchanges into ONE
+        # program order on ONE stream (no cross-queue spin hazard between the two networks' exchange kernels, no idle teacher
+        # stream while the host enqueues the student).  PXL_PAIR_FORWARD=1 / 0 forces it on / off.
+        from .. import dist as pdist
+        pair_mode = os.environ.get('PXL_PAIR_FORWARD')
+        if pair_mode == '1' or (pair_mode is None and pdist.is_distributed()):
+            from ..engine import forward_deferred_pair
+            s_core, t_core = getattr(self.s_model.module, 'model', None), getattr(self.t_model.module, 'model', None)
+            pair = None
+            if s_core is not None and t_core is not None and len(s_inp) == 1 and len(t_inp) == 1:
+                # (the teacher's parameters are detached -- ssl_mt.py:99-101 -- so its half of the pair keeps no graph)
+                teacher_needs_grad = any(p_.requires_grad for p_ in getattr(t_core, '_param_list', [None])[:1] if p_ is not None)
+                if hasattr(s_core, '_pb') and hasattr(t_core, '_pb') and not teacher_needs_grad:
+                    pair = forward_deferred_pair(s_core, s_inp[0], t_core, t_inp[0])
+            if pair is not None:
+                s_head, t_head = pair
+                return self._seam_losses_and_update(s_head, t_head, s_inp, l_gt, lbs, ramp, cur_step)
         side = self._teacher_stream()
 
         def teacher_pass():
@@ -210,6 +232,11 @@ class SSLMT(ssl_base._SSLBase):
             t_head.arena.record_stream(main)
         else:
             t_head = teacher_pass()
+        return self._seam_losses_and_update(s_head, t_head, s_inp, l_gt, lbs, ramp, cur_step)
+
+    def _seam_losses_and_update(self, s_head, t_head, s_inp, l_gt, lbs, ramp, cur_step):
+        from .. import functional as PF
+        from ..sseg.model import _DeferredResulter
         B = s_inp[0].shape[0]
         lo, hi = (0, B) if self.args.cons_for_labeled else ((lbs, B) if self.args.unlabeled_batch_size > 0 else (0, 0))
         w_cons = ramp * self.args.cons_scale

@@ -35,12 +35,22 @@ def role_stream(role, device=None, index=0):
     dealt round-robin over the queues that are not the main stream's."""
     if not torch.cuda.is_available():
         return None
-    key = (int(role) + int(index))
+    key = (int(role), int(index))
     s = _cache.get(key)
     if s is None:
         from ._lib import lib
-        init()
-        p = lib().pxl_stream_role(key)
+        nq = init()
+        # index 0: the role's own queue.  Further lanes of a role are dealt over the OTHER queues (lane 1 of AUX with three
+        # queues used to be role 3 -> queue 0 = SIDE's, the stream the labeled pass holds, and (AUX, 1) / (SIDE, 3) shared
+        # one cache entry): the role's own queue comes last in the rotation
+        if int(index) == 0 or nq <= 1:
+            slot = int(role)
+        else:
+            own = int(role) % nq
+            others = [q for q in range(nq) if q != own and (q != SIDE % nq or int(role) == SIDE)] or [q for q in range(nq) if q != own]
+            order = others + [own]                      # e.g. AUX lanes with three queues: AUX, WGRAD, AUX, WGRAD ... never SIDE
+            slot = order[(int(index) - 1) % len(order)]
+        p = lib().pxl_stream_role(slot)
         if p:
             dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
             s = torch.cuda.ExternalStream(int(p), device=dev)

@@ -302,3 +302,24 @@ def test_bench_two_ranks_on_one_gpu_through_torchrun():
     assert d["rccl_ranks"] == 0 and d["grad_buckets"] >= 5          # 176 MB of gradients in 32 MB buckets
     assert d["peer_contexts"] == 2                                  # student + teacher: Sync-BN over the peer-mapped exchange
     assert d["value"] > 0 and all(v == v and abs(v) < 1e6 for v in d["final_losses"].values())
+
+
+def test_bench_self_spawns_its_ranks_gct():
+    """`python bench.py --gpus 2 --algo gct` with NO launcher environment: bench.py starts the two ranks itself under
+    torch.distributed.run (it can no longer fall back to one GPU silently) -- here with both ranks on cuda:0 over gloo, on
+    the GCT workload north_star's >= 6x scaling target is quoted on (dual task model + flaw detector, Sync-BN in all three
+    networks, bucketed gradient exchange)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PXL_FORCE_DEVICE="0", PXL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--algo", "gct", "--size", "129", "--steps", "2", "--warmup", "1",
+           "--lbs", "1", "--ubs", "1", "--no-kernel-events"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=root, env=env, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["algorithm"] == "ssl_gct" and d["config"]["global_batch"] == 4
+    assert d["checked"]["n_gpus_equals_gpus_flag"] is True and d["peer_contexts"] >= 2
+    assert d["value"] > 0 and all(v == v and abs(v) < 1e6 for v in d["final_losses"].values())

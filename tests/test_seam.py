@@ -235,3 +235,53 @@ def test_suponly_step_fused_seam_equals_generic_path(monkeypatch):
     assert pf.shape == pg.shape and rel(pf, pg.detach()) < 2e-4
     af = results["1"][2]["activated_pred"][0]
     assert torch.allclose(af.sum(1), torch.ones_like(af.sum(1)), atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_mt_step_paired_forward_equals_two_passes(dtype, monkeypatch):
+    """The paired student || teacher forward (csrc/net.cpp: pxl_net_forward_pair -- every convolution and finalize-folding
+    element-wise kernel of the two networks as ONE launch) against the two separate passes on two streams: same losses,
+    same weights after three iterations (the pair only changes which launch computes a tile, never how), and the pass
+    really issued paired launches."""
+    import torch_oracle as TO
+    from pixelssl_amd._lib import lib
+    _Shallow.patch(monkeypatch)
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PXL_PAIR_FORWARD", mode)
+        a, P, popt, plr = _mt_algo(dtype, 129, 2, 2)
+        torch.manual_seed(5)
+        algo = P.ssl_algorithm.ssl_mt.ssl_mt(a, {"model": P.sseg.model.deeplabv2()}, {"model": popt.sgd(a)},
+                                            {"model": plr.polynomiallr(a)}, {"model": P.sseg.criterion.sseg_criterion()}, None)
+        s_core, t_core = algo.s_model.module.model, algo.t_model.module.model
+        gen = torch.Generator().manual_seed(3)
+        s_core.reset_parameters(gen)
+        t_core.reset_parameters(gen)
+        _condition(s_core)
+        _condition(t_core)
+        algo.s_model.train()
+        algo.t_model.train()
+        losses = []
+        for i in range(3):
+            x, gt = TO.synthetic_batch(4, 129, 2, seed=40 + i, block=32)
+            out, s_res, t_res = algo.train_step((x.to(DEV),), (gt.to(DEV),), i + 2, 6)
+            losses.append({k: v.item() for k, v in out.items()})
+        torch.cuda.synchronize()
+        pairs = lib().pxl_net_pairs(s_core._cur.net)
+        results[mode] = (losses, {k: v.detach().float().cpu().clone() for k, v in s_core.state_dict().items()},
+                         {k: v.detach().float().cpu().clone() for k, v in t_core.state_dict().items()}, pairs)
+    # (the fp32 engine's convolutions run on the generic register-staged kernel, which has no paired form: its lockstep pass
+    # issues them one after the other and pairs only the element-wise kernels)
+    assert results["0"][3] == 0 and (results["1"][3] >= 10 or dtype == "fp32"), "paired launches: %s / %s" % (results["1"][3], results["0"][3])
+    for i, (lp, ls) in enumerate(zip(results["1"][0], results["0"][0])):
+        print("mt %s iteration %d paired %s separate %s" % (dtype, i, lp, ls))
+        tol = (2e-6 if i == 0 else 2e-4) if dtype == "fp32" else (1e-3 if i == 0 else 5e-3)
+        for k in ls:
+            assert abs(lp[k] - ls[k]) <= tol * abs(ls[k]) + 1e-8, (i, k, lp, ls)
+    for which in (1, 2):
+        for k, v in results["0"][which].items():
+            if "num_batches" in k:
+                continue
+            assert close(results["1"][which][k], v, 2e-5 if dtype == "fp32" else 2e-3, 5e-8 if dtype == "fp32" else 5e-7), \
+                (which, k, rel(results["1"][which][k], v))

@@ -66,7 +66,7 @@ static void* dev_random_bf16(size_t n, float scale, unsigned seed) {
 
 struct Problem {
   pxl_conv_desc fwd, bwd;
-  void *x, *y, *wf, *wt; float* stats;
+  void *x, *y, *wf, *wt; float* stats; float* dw; int creal;
   size_t nx, ny; double flops; int M;
 };
 
@@ -92,12 +92,32 @@ static Problem make_problem(const Shape& sh, int B, unsigned seed) {
   p.wt = dev_random_bf16((size_t)sh.cin * f.ntaps * cop, 0.05f, seed + 4);
   CK(hipMalloc((void**)&p.stats, 4 * 2 * (size_t)cop * sizeof(float)));
   CK(hipMemset(p.stats, 0, 4 * 2 * (size_t)cop * sizeof(float)));
+  CK(hipMalloc((void**)&p.dw, (size_t)sh.cout * f.ntaps * cip * sizeof(float)));
+  CK(hipMemset(p.dw, 0, (size_t)sh.cout * f.ntaps * cip * sizeof(float)));
+  p.creal = sh.cin;
   p.flops = 2.0 * B * Ho * Ho * (double)sh.cout * sh.k * sh.k * sh.cin;
   p.M = B * Ho * Ho;
   return p;
 }
-static void free_problem(Problem& p) { (void)hipFree(p.x); (void)hipFree(p.y); (void)hipFree(p.wf); (void)hipFree(p.wt); (void)hipFree(p.stats); }
+static void free_problem(Problem& p) { (void)hipFree(p.x); (void)hipFree(p.y); (void)hipFree(p.wf); (void)hipFree(p.wt); (void)hipFree(p.stats); (void)hipFree(p.dw); }
 
+static int launch_wgrad(const Problem& p, int cfg, hipStream_t s) {
+  pxl_conv_desc q = p.fwd; q.tile_cfg = cfg;
+  return pxl_conv_wgrad(&q, p.x, nullptr, nullptr, p.y, p.dw, p.creal, p.fwd.Cin, s);
+}
+static double time_wgrad(const Problem& p, int cfg, int iters, hipStream_t s, hipEvent_t a, hipEvent_t b) {
+  if (launch_wgrad(p, cfg, s) != PXL_OK) return -1.0;
+  CK(hipStreamSynchronize(s));
+  double best = 1e30;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) if (launch_wgrad(p, cfg, s) != PXL_OK) return -1.0;
+    CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    best = std::min(best, (double)ms * 1e3 / iters);
+  }
+  return best;
+}
 static int launch(const Problem& p, bool dgrad, int cfg, hipStream_t s) {
   if (!dgrad) { pxl_conv_desc q = p.fwd; q.tile_cfg = cfg;
     return pxl_conv_igemm(&q, p.x, p.wf, p.y, nullptr, nullptr, nullptr, nullptr, p.stats, nullptr, 0, s); }
@@ -175,6 +195,31 @@ static void check_cfg(Problem& p, bool dgrad, int cfg, hipStream_t s) {
     }
   }
   printf(" chk:%d %.1e/%.1e%s", cfg, mx > 0 ? md / mx : md, smx > 0 ? smd / smx : smd, bad ? " NAN!" : "");
+}
+
+extern "C" void pxl_dma_capture_begin(void** slot);
+extern "C" void pxl_dma_capture_end(void);
+extern "C" int pxl_dma_launch_captured(void* slot0, void* slot1);
+// the forward convolution of TWO operand sets as one paired launch (what pxl_net_forward_pair issues for student || teacher)
+static int launch_pair(const Problem& p0, const Problem& p1, int cfg, hipStream_t s) {
+  void* sl[2] = {nullptr, nullptr};
+  pxl_dma_capture_begin(&sl[0]); int rc = launch(p0, false, cfg, s); pxl_dma_capture_end();
+  pxl_dma_capture_begin(&sl[1]); if (rc == PXL_OK) rc = launch(p1, false, cfg, s); pxl_dma_capture_end();
+  const int pr = pxl_dma_launch_captured(sl[0], sl[1]);
+  return rc != PXL_OK ? rc : (pr < 0 ? pr : (pr == 1 ? PXL_OK : -100));
+}
+static double time_pair(const Problem& p0, const Problem& p1, int cfg, int iters, hipStream_t s, hipEvent_t a, hipEvent_t b) {
+  if (launch_pair(p0, p1, cfg, s) != PXL_OK) return -1.0;
+  CK(hipStreamSynchronize(s));
+  double best = 1e30;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) if (launch_pair(p0, p1, cfg, s) != PXL_OK) return -1.0;
+    CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    best = std::min(best, (double)ms * 1e3 / iters);
+  }
+  return best;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -454,24 +499,27 @@ static void floor_stream(const char* name, const Problem& p, int iters, hipStrea
 }
 
 int main(int argc, char** argv) {
-  std::string only, cfgs_s = "-1", modes = "fwd,dgrad", trace;
-  int iters = 20, B = 8; bool dual = false, do_floor = false, check = false;
+  std::string only, cfgs_s = "-1", wcfgs_s = "-1,8,9,10,11,12,13", modes = "fwd,dgrad", trace;
+  int iters = 20, B = 8; bool dual = false, do_floor = false, check = false, pair = false;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&]() { return std::string(i + 1 < argc ? argv[++i] : ""); };
     if (a == "--only") only = val();
     else if (a == "--cfgs") cfgs_s = val();
+    else if (a == "--wcfgs") wcfgs_s = val();
     else if (a == "--modes") modes = val();
     else if (a == "--iters") iters = atoi(val().c_str());
     else if (a == "--batch") B = atoi(val().c_str());
     else if (a == "--dual") dual = true;
     else if (a == "--floor") do_floor = true;
     else if (a == "--check") check = true;
+    else if (a == "--pair") pair = true;
     else if (a == "--trace") trace = val();
     else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 64; }
   }
-  std::vector<int> cfgs;
+  std::vector<int> cfgs, wcfgs;
   for (size_t p = 0; p < cfgs_s.size();) { cfgs.push_back(atoi(cfgs_s.c_str() + p)); p = cfgs_s.find(',', p); if (p == std::string::npos) break; ++p; }
+  for (size_t p = 0; p < wcfgs_s.size();) { wcfgs.push_back(atoi(wcfgs_s.c_str() + p)); p = wcfgs_s.find(',', p); if (p == std::string::npos) break; ++p; }
   auto wanted = [&](const char* n) {
     if (only.empty()) return true;
     for (size_t p = 0; p < only.size();) {
@@ -583,25 +631,51 @@ int main(int argc, char** argv) {
   for (const Shape& sh : SHAPES) {
     if (!wanted(sh.name)) continue;
     Problem p0 = make_problem(sh, B, 1), p1;
-    if (dual) p1 = make_problem(sh, B, 2);
+    if (dual || pair) p1 = make_problem(sh, B, 2);
     printf("%-9s %5d %5d %1d %1d %1d %4d %6d |", sh.name, sh.cin, sh.cout, sh.k, sh.s, sh.d, sh.H, p0.M);
     for (const char* mode : {"fwd", "dgrad"}) {
       if (modes.find(mode) == std::string::npos) continue;
       const bool dg = mode[0] == 'd';
-      double best = 1e30;
+      double best = 1e30, best_pair = 1e30;
       for (int cfg : cfgs) {
         const double t = time_single(p0, dg, cfg, iters, s0, ea, eb);
         if (t < 0) { printf(" %s:%d ERR", mode, cfg); continue; }
         printf(" %s:%d %6.1f (%5.0f)", mode, cfg, t, p0.flops / t * 1e-6);
         if (check) check_cfg(p0, dg, cfg, s0);
         if (dual) { const double t2 = time_dual(p0, p1, dg, cfg, iters, s0, s1); printf(" [%6.1f]", t2); }
+        if (pair && !dg) {
+          const double t2 = time_pair(p0, p1, cfg, iters, s0, ea, eb);
+          printf(" {pair %6.1f}", t2);
+          if (t2 > 0) { best_pair = std::min(best_pair, t2); }
+          if (check && t2 > 0) {        // both halves of the pair against their single launches
+            std::vector<uint16_t> r0(p0.ny), r1(p1.ny), g0(p0.ny), g1(p1.ny);
+            launch(p0, false, cfg, s0); launch(p1, false, cfg, s0); CK(hipStreamSynchronize(s0));
+            CK(hipMemcpy(r0.data(), p0.y, p0.ny * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), p1.y, p1.ny * 2, hipMemcpyDeviceToHost));
+            CK(hipMemset(p0.y, 0xff, p0.ny * 2)); CK(hipMemset(p1.y, 0xff, p1.ny * 2));
+            launch_pair(p0, p1, cfg, s0); CK(hipStreamSynchronize(s0));
+            CK(hipMemcpy(g0.data(), p0.y, p0.ny * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(g1.data(), p1.y, p1.ny * 2, hipMemcpyDeviceToHost));
+            printf(" %s", (r0 == g0 && r1 == g1) ? "same" : "PAIR-DIFFERS!");
+          }
+        }
         best = std::min(best, t);
       }
       if (best < 1e29) tot[mode] += best * sh.cnt;
+      if (best_pair < 1e29) tot["pair(2 nets)"] += best_pair * sh.cnt;
+    }
+    if (modes.find("wgrad") != std::string::npos) {
+      double best = 1e30;
+      for (int cfg : wcfgs) {
+        if ((cfg == 8 || cfg == 9 || cfg == 13) && p0.fwd.Cin % 128 != 0) continue;
+        const double t = time_wgrad(p0, cfg, iters, s0, ea, eb);
+        if (t < 0) { printf(" wgrad:%d ERR", cfg); continue; }
+        printf(" wgrad:%d %6.1f (%5.0f)", cfg, t, p0.flops / t * 1e-6);
+        best = std::min(best, t);
+      }
+      if (best < 1e29) tot["wgrad"] += best * sh.cnt;
     }
     totf += p0.flops * sh.cnt;
     printf("\n"); fflush(stdout);
-    free_problem(p0); if (dual) free_problem(p1);
+    free_problem(p0); if (dual || pair) free_problem(p1);
   }
   for (auto& kv : tot) printf("sum over net (%s, best cfg per shape x count): %.3f ms -> %.1f TFLOP/s\n", kv.first.c_str(), kv.second * 1e-3, totf / kv.second * 1e-6);
   return 0;

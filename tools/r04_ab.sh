@@ -15,7 +15,7 @@ def parse(f):
     for l in open(f):
         if '|' not in l or l.startswith('shape'): continue
         name=l.split()[0]
-        for m in re.finditer(r'(fwd|dgrad):(-?\d+)\s+([\d.]+) \(', l):
+        for m in re.finditer(r'(fwd|dgrad|wgrad):(-?\d+)\s+([\d.]+) \(', l):
             d[(name,m.group(1),int(m.group(2)))]=float(m.group(3))
     return d
 b=[parse(f) for f in sorted(glob.glob(out+'/base_*.txt'))]
