@@ -75,7 +75,7 @@ def main(which):
         MA.main(size=513, lbs=2, ubs=2, seed=221, iters=2, gamma3=GAMMA3, out="adv_cond_513.pt", block=32)
     if "cutmix513" in which:
         import make_golden_cutmix as MC
-        MC.main(size=513, lbs=2, ubs=2, seed=231, iters=2, gamma3=GAMMA3, out="cutmix_cond_513.pt", block=32)
+        MC.main(size=513, lbs=2, ubs=4, seed=231, iters=2, gamma3=GAMMA3, out="cutmix_cond_513.pt", block=32)
     if "cct513" in which:
         import make_golden_cct as MCC
         MCC.case_cct(size=513, lbs=2, ubs=2, seed=241, iters=2, rng_seed=9753, gamma3=GAMMA3, out="cct_cut_cond_513.pt", block=32,

@@ -1,8 +1,9 @@
 """Multi-step parity on CONDITIONED initial weights (oracle/make_golden_conditioned.py, torch_oracle.condition_state).
 
 Six iterations of the reference's own `_train` loops (SupOnly / MT / AdvSSL / CutMix / GCT / CCT, DeepLab-v2 and PSPNet,
-full ResNet-101, train-mode BN, shipped hyper-parameters) at 129 x 129 from weights whose bottleneck-output BN gammas
-are scaled by 0.1.  On these weights the reference arithmetic reproduces itself (fp32 vs fp64 < 1e-6 in every logged
+full ResNet-101, train-mode BN, shipped hyper-parameters) at 129 x 129 -- and, for every BASELINE.json workload (MT: four
+iterations at 4 + 4; AdvSSL / CutMix / GCT / CCT with G-Cutout: two iterations at 2 + 2 resp. 2 + 4) at the BASELINE crop size
+513 x 513 -- from weights whose bottleneck-output BN gammas are scaled by 0.1.  On these weights the reference arithmetic reproduces itself (fp32 vs fp64 < 1e-6 in every logged
 loss), so the bars below bite:
 
   * every logged loss of every iteration within LOSS_TOL of the reference's (fp32 engine; the stated band for bf16),
@@ -273,13 +274,14 @@ def test_mt_at_the_baseline_configuration(dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["adv_cond_129.pt", "adv_cond_513.pt"], ids=["129", "513"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_advssl_six_iterations(dtype):
+def test_advssl_six_iterations(dtype, fixture):
     import torch_oracle as TO
     import adv_oracle as AO
     import pixelssl_amd as P
     from pixelssl_amd.nn import optimizer as popt, lrer as plr
-    fx = _fx("adv_cond_129.pt")
+    fx = _fx(fixture)
     args = _args(fx, dtype, adv_for_labeled=True, labeled_adv_scale=0.01, unlabeled_adv_scale=0.001, discriminator_lr=1e-4,
                  discriminator_power=0.9, unlabeled_for_discriminator=True, discriminator_scale=1.0)
     algo = P.ssl_algorithm.ssl_adv.ssl_adv(args, {"model": P.sseg.model.deeplabv2()}, {"model": popt.sgd(args)},
@@ -303,12 +305,13 @@ def test_advssl_six_iterations(dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["cutmix_cond_129.pt", "cutmix_cond_513.pt"], ids=["129", "513"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_cutmix_six_iterations(dtype):
+def test_cutmix_six_iterations(dtype, fixture):
     import torch_oracle as TO
     import pixelssl_amd as P
     from pixelssl_amd.nn import optimizer as popt, lrer as plr
-    fx = _fx("cutmix_cond_129.pt")
+    fx = _fx(fixture)
     args = _args(fx, dtype, cons_type="mse", cons_scale=fx["cons_scale"], cons_rampup_epochs=0,
                  cons_threshold=fx["cons_threshold"], ema_decay=0.99, mask_prop_range=(0.5, 0.5))
     algo = P.ssl_algorithm.ssl_cutmix.ssl_cutmix(args, {"model": P.sseg.model.deeplabv2()}, {"model": popt.sgd(args)},
@@ -336,13 +339,14 @@ def test_cutmix_six_iterations(dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["gct_cond_129.pt", "gct_cond_513.pt"], ids=["129", "513"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_gct_six_iterations(dtype):
+def test_gct_six_iterations(dtype, fixture):
     import torch_oracle as TO
     import gct_oracle as GO
     import pixelssl_amd as P
     from pixelssl_amd.nn import optimizer as popt, lrer as plr
-    fx = _fx("gct_cond_129.pt")
+    fx = _fx(fixture)
     args = _args(fx, dtype, ssl_mode="gct", fc_ssl_scale=1.0, dc_ssl_scale=100.0, dc_threshold=0.6, dc_rampup_epochs=3,
                  fd_lr=1e-4, fd_scale=10.0, mu=0.5, nu=1)
     algo = P.ssl_algorithm.ssl_gct.ssl_gct(args, {"model": P.sseg.model.deeplabv2()}, {"model": popt.sgd(args)},
@@ -423,9 +427,11 @@ def test_cct_six_iterations(dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["cct_cut_cond_129.pt", "cct_cut_cond_513.pt"], ids=["129", "513"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_cct_six_iterations_with_gcutout(dtype):
-    """BASELINE.json config 5: K = 7 auxiliary decoders INCLUDING G-Cutout.  Fixture = six iterations of the reference's
+def test_cct_six_iterations_with_gcutout(dtype, fixture):
+    """BASELINE.json config 5: K = 7 auxiliary decoders INCLUDING G-Cutout.  Fixture = six iterations (129 x 129) / two
+    iterations at the BASELINE crop size (513 x 513: oracle/make_golden_conditioned.py cct513) of the reference's
     own SSLCCT._train with its CutOutDecoder (ssl_cct.py:597-650) running on a stand-in for cv2.findContours
     (oracle/cct_oracle.py: find_contours_stand_in; OpenCV is not installed); the fixture carries the boxes that call
     returned and the random.randint draws, `inject_draw` feeds them to the engine's decoder.  Pinned by this test:
@@ -436,7 +442,7 @@ def test_cct_six_iterations_with_gcutout(dtype):
     import pixelssl_amd as P
     from pixelssl_amd.nn import optimizer as popt, lrer as plr
     from pixelssl_amd.sseg.func import SSEGFunc
-    fx = _fx("cct_cut_cond_129.pt")
+    fx = _fx(fixture)
     assert fx["with_cut"] and [k for k, _ in fx["decoders"]] == ["vat", "drop", "cut", "context", "object", "fd", "fn"]
     args = _args(fx, dtype, models={"model": "pspnet"}, cons_scale=30.0, cons_rampup_epochs=5, ad_lr_scale=10.0,
                  vat_dec_num=1, vat_dec_xi=1e-6, vat_dec_eps=2.0, drop_dec_num=1, drop_dec_rate=0.5, drop_dec_spatial=True,
