@@ -9,7 +9,7 @@
 #   all                        the whole GPU suite, -x
 #   smoke                      __graft_entry__.smoke()
 #   bench[=<bench.py args>]    python bench.py <args>                      -> bench_<n>.json   (default: driver defaults)
-#   q[=<bench.py args>]        the timed line only (--no-cpu-baseline --no-kernel-events --no-miou --no-fp32-leg)
+#   q[=<bench.py args>]        the timed line only (--no-cpu-baseline --no-kernel-events --no-miou --no-fp32-leg --no-fixture-parity)
 #   ab=<ENV=V,ENV=V>[@<args>]  q-style run under environment switches      -> ab_<n>.json
 #   prof[=<bench.py args>]     rocprofv3 --kernel-trace --stats of a q run + kernel_stats.csv + step_breakdown.txt
 #   pmc=<counters>[@<args>]    one rocprofv3 --pmc pass (counters comma-separated; kernel-trace only) -> pmc_<n>/
@@ -23,7 +23,7 @@ TAG="${1:?tag}"; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-Q="--no-cpu-baseline --no-kernel-events --no-miou --no-fp32-leg"
+Q="--no-cpu-baseline --no-kernel-events --no-miou --no-fp32-leg --no-fixture-parity"
 rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/gpu.txt; nproc >> $OUT/gpu.txt
 n=0
 line() { python - "$1" <<'PY'
