@@ -13,7 +13,25 @@ third-party dependency that is NOT installed in this image and not vendored by t
 "parity unpinned": `external_contour_boxes` below restates the published algorithm (Suzuki-Abe border following,
 RETR_EXTERNAL + CHAIN_APPROX_SIMPLE: outer borders of the 8-connected foreground components that are not enclosed by
 another component, vertices = direction changes of the traced border) and the product's host routine is checked
-against it, but neither could be compared with OpenCV here.
+against it, but neither could be compared with OpenCV here.  What is restated, and from where (OpenCV 3.4 / 4.x,
+modules/imgproc/src/contours.cpp, recalled -- there is no network and no OpenCV in this image):
+  * start pixels: the raster scan opens an outer border at a 0 -> 1 transition (`cvFindNextContour`); in RETR_EXTERNAL
+    mode it skips hole borders and any outer border met while the last marked border pixel on the row is a positively
+    marked one, i.e. while the scan is inside an already traced outer border -- the components kept are those that touch
+    the background connected to the frame;
+  * vertex rule (`icvFetchContour`, CHAIN_APPROX_SIMPLE): `prev_s` starts at -1 and the current point is written
+    whenever the chain code of the step leaving it differs from the previous step's, so the start pixel is always a
+    vertex and every later vertex is a change of direction; an isolated pixel is one point.  The raster-first pixel of a
+    component is left going SW/S/SE/E and re-entered going W/NW/N/NE, never the same code, so "number of circular
+    direction changes" (below) equals OpenCV's count; the count does not depend on the tracing sense;
+  * list ORDER (`icvEndProcessContour`): in RETR_EXTERNAL / RETR_LIST mode each finished contour is linked in FRONT of
+    its siblings (`contour->h_next = parent->first_child; parent->first_child = contour`), and `cv::findContours` walks
+    `h_next` from the first one, so the list is newest-found first = REVERSE raster order of the start pixels (the
+    familiar "contours come back bottom-to-top").  The order matters here: ssl_cct.py:637-638 draws two
+    `random.randint` per kept contour in list order.  Round 4 switched this file and csrc/contour.cpp from raster to
+    reverse-raster order and regenerated the G-Cutout fixtures.
+tests/test_cct.py holds hand-derived known answers for these three rules (nested blobs, a 3n+1-vertex staircase either
+side of the `> 50` filter, two blobs whose raster and list orders differ); a vector from a real OpenCV is still missing.
 
 Randomness: the reference draws from four host RNG streams (torch CPU generator: I-VAT's `torch.rand`, Dropout2d,
 F-Noise's Uniform.sample; numpy: F-Drop's threshold; python `random`: G-Cutout).  Every decoder function below takes
@@ -142,7 +160,8 @@ _NB8 = ((0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1))   
 
 def external_contour_boxes(mask, min_vertices=50):
     """Bounding boxes (min_x, max_x, min_y, max_y) of the external contours of a binary image whose CHAIN_APPROX_SIMPLE
-    polygon has more than `min_vertices` vertices (ssl_cct.py:630-636), in raster order of the contour's first pixel."""
+    polygon has more than `min_vertices` vertices (ssl_cct.py:630-636), in OpenCV's list order: newest-found first, i.e.
+    REVERSE raster order of the contours' first pixels (see the header)."""
     return [box for nvert, box in _external_contours(mask) if nvert > min_vertices]
 
 
@@ -188,7 +207,7 @@ def _external_contours(mask):
             ys = [p[0] for p in comp]
             xs = [p[1] for p in comp]
             boxes.append((nvert, (min(xs) - 1, max(xs) - 1, min(ys) - 1, max(ys) - 1)))
-    return boxes
+    return boxes[::-1]                     # each finished contour is linked in front of the earlier ones (header)
 
 
 def _traced_vertices(pad, y0, x0):

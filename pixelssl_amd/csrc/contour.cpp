@@ -3,8 +3,11 @@
 // third-party dependency, so this is a from-scratch restatement of the published behaviour: outer borders of the
 // 8-connected foreground components that are not enclosed by another component, kept when their border polygon (the
 // traced border with straight runs collapsed to their end points) has more than `min_vertices` vertices; the result is
-// the bounding box of each kept contour in raster order of its first pixel.  Runs on the CPU like the reference's
-// (the mask is 513x513 bytes per sample); parity with OpenCV itself is unpinned (see oracle/cct_oracle.py).
+// the bounding box of each kept contour in OpenCV's list order -- newest-found first, i.e. REVERSE raster order of the
+// contours' first pixels (each finished contour is linked in front of its siblings; the order decides which
+// random.randint draw of ssl_cct.py:637-638 lands on which box).  Runs on the CPU like the reference's (the mask is
+// 513x513 bytes per sample); parity with OpenCV itself is unpinned (see oracle/cct_oracle.py for the three rules restated
+// and tests/test_cct.py for the hand-derived known answers).
 #include <vector>
 #include <cstdint>
 #include <cstring>
@@ -112,6 +115,10 @@ extern "C" int pxl_external_contour_boxes_host(const uint8_t* mask, int H, int W
       }
       ++n;
     }
+  // raster order of discovery -> list order (newest first); only the boxes that fitted are stored
+  const int stored = n < max_boxes ? n : max_boxes;
+  for (int i = 0, j = stored - 1; i < j; ++i, --j)
+    for (int k = 0; k < 4; ++k) { const int t = boxes[4 * i + k]; boxes[4 * i + k] = boxes[4 * j + k]; boxes[4 * j + k] = t; }
   *nboxes = n;
   return PXL_OK;
 }

@@ -136,14 +136,18 @@ def sub_scale(a, b, scale):
 
 def external_contour_boxes(mask_np, min_vertices=50, max_boxes=1024):
     """Host: bounding boxes (min_x, max_x, min_y, max_y) of the external contours with > min_vertices polygon vertices
-    (what cv2.findContours + the `c.shape[0] > 50` filter of ssl_cct.py:627-632 keep)."""
+    (what cv2.findContours + the `c.shape[0] > 50` filter of ssl_cct.py:627-632 keep), in cv2's list order (newest-found
+    first = reverse raster order of the contours' first pixels, csrc/contour.cpp)."""
     import ctypes
     m = np.ascontiguousarray(mask_np, dtype=np.uint8)
-    boxes = (ctypes.c_int * (4 * max_boxes))()
-    n = ctypes.c_int()
-    check(lib().pxl_external_contour_boxes_host(m.ctypes.data, m.shape[0], m.shape[1], int(min_vertices), boxes, max_boxes,
-                                                ctypes.byref(n)))
-    return [tuple(boxes[4 * i:4 * i + 4]) for i in range(min(n.value, max_boxes))]
+    while True:
+        boxes = (ctypes.c_int * (4 * max(max_boxes, 1)))()
+        n = ctypes.c_int()
+        check(lib().pxl_external_contour_boxes_host(m.ctypes.data, m.shape[0], m.shape[1], int(min_vertices), boxes,
+                                                    max_boxes, ctypes.byref(n)))
+        if n.value <= max_boxes:
+            return [tuple(boxes[4 * i:4 * i + 4]) for i in range(n.value)]
+        max_boxes = n.value                  # more contours than the buffer: ask again with room for all of them
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -92,6 +92,108 @@ def test_contour_boxes_host_routine_matches_restatement():
     assert len(C.external_contour_boxes(ring, 4)) == 1     # the island inside the hole is not an external contour
 
 
+def _staircase(n, y0=0, x0=0, H=None, W=None):
+    """n steps of 2 x 2 pixels: rows 2i, 2i+1 hold x in [0, 2(i+1))."""
+    m = np.zeros((H or 2 * n + y0 + 1, W or 2 * n + x0 + 1), np.uint8)
+    for i in range(n):
+        m[y0 + 2 * i:y0 + 2 * i + 2, x0:x0 + 2 * (i + 1)] = 1
+    return m
+
+
+def test_contour_known_answers_by_hand():
+    """Hand-derived answers for the three rules cct_oracle.py's header restates from OpenCV's contours.cpp (vertex rule,
+    external-only, list order), checked on BOTH the oracle and the C-ABI host routine.  Derived on paper from the rules,
+    not from either implementation; a vector produced by a real OpenCV is still missing (parity stays unpinned).
+
+    Vertex rule: the point is written when the step leaving it has another chain code than the step that reached it; the
+    start pixel always is.
+      * filled w x h rectangle (w, h >= 2): the four corners                                              -> 4
+      * one pixel: the isolated-pixel branch writes it once                                                -> 1
+      * 1 x n line: left end (start) and right end (E turns to W)                                          -> 2
+      * plus sign with arms of length a (a >= 1, 1 px wide): each arm tip is 1 vertex (out and back along
+        the same pixels), each passage through an inner-corner diagonal is a direction change at both
+        ends ... counted below as 12 for a >= 2 (4 tips + 8 diagonal ends) -- see the derivation in the body
+      * staircase of n 2x2 steps: top-left, bottom-left, bottom-right, then per step above the last
+        {turn W at its top-right, turn NW one pixel left, turn N one pixel up-left}, and the first
+        step's top-right                                                                                   -> 3n + 1
+        so n = 16 gives 49 (dropped by `> 50`), n = 17 gives 52 (kept)."""
+    import cct_oracle as CO
+    from pixelssl_amd.ssl_algorithm import ssl_cct as C
+
+    def both(m, mv):
+        a, b = CO.external_contour_boxes(m, mv), C.external_contour_boxes(m, mv)
+        assert a == b, (a, b)
+        return a
+
+    def nverts(m):
+        (n, box), = CO._external_contours(m)
+        # the host routine has no vertex output: bracket the count with the filter threshold
+        assert C.external_contour_boxes(m, n - 1) == [box] and C.external_contour_boxes(m, n) == []
+        return n
+
+    rect = np.zeros((12, 15), np.uint8)
+    rect[3:8, 2:11] = 1
+    assert nverts(rect) == 4 and both(rect, 3) == [(2, 10, 3, 7)]
+    dot = np.zeros((5, 5), np.uint8)
+    dot[2, 3] = 1
+    assert nverts(dot) == 1 and both(dot, 0) == [(3, 3, 2, 2)]
+    line = np.zeros((5, 12), np.uint8)
+    line[2, 1:10] = 1
+    assert nverts(line) == 2
+    # plus sign, arms of 3: from the top tip (start) the border runs S down the arm to the centre's upper neighbour,
+    # SW... no: 8-connected following cuts each inner corner with ONE diagonal step between the two arms' innermost
+    # pixels, so the chain is  S.. | SW | W.. (tip: W->E) E.. | SE? -- written out for arms of 3 centred at (5, 5):
+    #   (5,2) S (5,3) S (5,4) SW (4,5) W (3,5) W (2,5) | E (3,5) E (4,5) SE (5,6) S (5,7) S (5,8) | N (5,7) N (5,6)
+    #   NE (6,5) E (7,5) E (8,5) | W (7,5) W (6,5) NW (5,4) N (5,3) N (5,2)
+    # direction changes (the point where the code changes): start(5,2), (5,4) S->SW, (4,5) SW->W, (2,5) W->E,
+    # (4,5) E->SE, (5,6) SE->S, (5,8) S->N, (5,6) N->NE, (6,5) NE->E, (8,5) E->W, (6,5) W->NW, (5,4) NW->N  -> 12
+    plus = np.zeros((11, 11), np.uint8)
+    plus[2:9, 5] = 1
+    plus[5, 2:9] = 1
+    assert nverts(plus) == 12 and both(plus, 11) == [(2, 8, 2, 8)]
+    for n in (1, 2, 5, 16, 17):
+        assert nverts(_staircase(n)) == 3 * n + 1
+    assert both(_staircase(16), 50) == []                            # 49 vertices: dropped by the `> 50` filter
+    assert both(_staircase(17), 50) == [(0, 33, 0, 33)]              # 52 vertices: kept
+
+    # external only: a ring with an island in its hole -> the island is NOT reported, the ring's box is
+    nest = np.zeros((40, 40), np.uint8)
+    nest[4:36, 4:36] = 1
+    nest[10:30, 10:30] = 0
+    nest[15:25, 15:25] = 1
+    assert both(nest, 3) == [(4, 35, 4, 35)]
+    nest[18:22, 18:22] = 0                                           # a hole inside the island changes nothing
+    assert both(nest, 3) == [(4, 35, 4, 35)]
+    # a blob inside a cavity that is open to the frame IS external (U shape with a block between its arms)
+    u = np.zeros((30, 30), np.uint8)
+    u[5:25, 5:9] = 1
+    u[5:25, 20:24] = 1
+    u[21:25, 5:24] = 1
+    u[8:12, 12:17] = 1
+    # list order: newest-found first.  Raster order of the start pixels is U (5, 5) then the block (8, 12); the list
+    # returns the block first
+    assert both(u, 3) == [(12, 16, 8, 11), (5, 23, 5, 24)]
+
+    # two blobs whose raster order and list order differ, both above the `> 50` filter: staircase A starts at row 1,
+    # staircase B (to its right) at row 3 -> found A then B, listed B then A
+    two = np.zeros((40, 80), np.uint8)
+    two[1:36, 0:36] |= _staircase(17, H=35, W=36)
+    two[3:38, 40:76] |= _staircase(17, H=35, W=36)
+    assert both(two, 50) == [(40, 73, 3, 36), (0, 33, 1, 34)]
+    # same row start: the left one is found first, listed last
+    two = np.zeros((40, 80), np.uint8)
+    two[2:37, 0:36] |= _staircase(17, H=35, W=36)
+    two[2:37, 40:76] |= _staircase(17, H=35, W=36)
+    assert both(two, 50) == [(40, 73, 2, 35), (0, 33, 2, 35)]
+    # the erase-window draws follow that order (ssl_cct.py:633-640): first pair of draws -> first listed box
+    pred = torch.from_numpy(np.stack([1 - two, two]).astype(np.float32))[None]
+    msk, _ = CO.cutout_mask(pred, 0.4, (40, 80), rnd=iter([0.0, 0.0, 0.99, 0.99]))
+    msk = msk[0, 0].numpy()
+    # boxes are 33 wide / high: window int(33 * .4) = 13, start in [0, int(33 * .6)] = [0, 19]
+    assert msk[2, 40] == 0 and msk[14, 52] == 0 and msk[15, 53] == 1      # B: window at its top-left (u = 0, 0)
+    assert msk[2, 0] == 1 and msk[21, 19] == 0 and msk[33, 31] == 0       # A: window at offset 19, 19 (u = .99, .99)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu
