@@ -11,7 +11,11 @@ using namespace pxl_dma;
 // 1 if the descriptor / operand combination can run on the LDS-DMA kernel
 extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_scale, const void* workspace) {
   (void)workspace;
-  if (d->dtype != PXL_BF16 || in_scale != nullptr) return 0;
+  if ((d->dtype != PXL_BF16 && d->dtype != PXL_F32) || in_scale != nullptr) return 0;
+  // fp32 operands: conv_dma_f32.hip (PXL_F32_DMA=0 keeps the fp32 engine on the generic kernels, for A/B runs)
+  static const bool f32_on = getenv("PXL_F32_DMA") == nullptr || getenv("PXL_F32_DMA")[0] != '0';
+  const long es = d->dtype == PXL_F32 ? 4 : 2;
+  if (d->dtype == PXL_F32 && !f32_on) return 0;
   if (d->Cin % 64 != 0 || d->Cout % 8 != 0 || (d->div != 1 && d->div != 2)) return 0;
   if (d->div == 2 && d->out_stride != 1) return 0;
   if (d->div == 2) {
@@ -22,8 +26,13 @@ extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_sca
     static const int max_taps = getenv("PXL_DMA_STRIDED_DGRAD") ? atoi(getenv("PXL_DMA_STRIDED_DGRAD")) : 64;
     if (d->ntaps > max_taps) return 0;
   }
-  if ((long)d->Kreal * d->ntaps * d->Cin * 2 >= (1L << 31)) return 0;
+  if ((long)d->Kreal * d->ntaps * d->Cin * es >= (1L << 31)) return 0;
   if ((long)d->B * d->Ho * d->Wo >= (1L << 24)) return 0;      // float-reciprocal pixel decomposition in the prologue
+  if (d->dtype == PXL_F32) {
+    // 32-bit byte offsets (int arithmetic in the prologue, bit 31 = "out of range")
+    if ((long)d->B * d->Hi * d->Wi * d->Cin * es >= (1L << 31)) return 0;
+    if ((long)d->B * d->Ho * d->Wo * d->Cout * es >= (1L << 32) - 256) return 0;
+  }
   return 1;
 }
 
@@ -36,6 +45,7 @@ extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_sca
 // 28..35: 8-wave workgroups (two waves per SIMD): 28 = 64x128, 29 = 128x64, 30 / 31 = 128x128 as 2x4 / 4x2 waves (2 stages),
 // 32 = 64x128, 33 = 128x128 (3 stages), 34 = 256x128, 35 = 128x256 (2 stages)
 namespace { int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes, void* stream); }
+int pxl_dma_f32_launch(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s);   // conv_dma_f32.hip
 
 extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
                             const void* addend, float* stats, void* workspace, size_t ws_bytes, void* stream) {
@@ -55,7 +65,7 @@ extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* 
 extern "C" int pxl_conv_dma_trace(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
                                   float* stats, unsigned* trace, void* stream) {
   PXL_REQUIRE(d && in && w && out && trace, "conv_dma_trace: null argument");
-  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || (d->tile_cfg >= 0 && d->tile_cfg < 8))
+  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || d->dtype != PXL_BF16 || (d->tile_cfg >= 0 && d->tile_cfg < 8))
     return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_trace: descriptor is not eligible for the LDS-DMA kernel");
   DmaArgs a;
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
@@ -74,7 +84,7 @@ extern "C" int pxl_conv_dma_trace(const pxl_conv_desc* d, const void* in, const 
 extern "C" int pxl_conv_dma_finalize(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
                                      float* stats, const pxl_bn_fin* fin, unsigned* counter, void* stream) {
   PXL_REQUIRE(d && in && w && out && stats && fin && fin->coef && counter && fin->count > 0.f, "conv_dma_finalize: bad argument");
-  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || (d->tile_cfg >= 0 && d->tile_cfg < 8) || !fin->training)
+  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || d->dtype != PXL_BF16 || (d->tile_cfg >= 0 && d->tile_cfg < 8) || !fin->training)
     return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_finalize: descriptor is not eligible for the LDS-DMA kernel");
   DmaArgs a;
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
@@ -96,7 +106,8 @@ extern "C" int pxl_conv_dma_bnin(const pxl_conv_desc* d, const void* y, const vo
   PXL_REQUIRE(d && y && w && out && bin && bin->coef && bin->count > 0.f, "conv_dma_bnin: bad argument");
   PXL_REQUIRE(bin->training ? (bin->stats != nullptr && bin->nrep >= 1) : (bin->running_mean && bin->running_var),
               "conv_dma_bnin: missing statistics");
-  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || d->div != 1 || d->Cin > 512 || (d->tile_cfg >= 0 && d->tile_cfg < 8))
+  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || d->dtype != PXL_BF16 || d->div != 1 || d->Cin > 512 ||
+      (d->tile_cfg >= 0 && d->tile_cfg < 8))
     return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_bnin: descriptor is not eligible for the BN-on-load kernel");
   DmaArgs a;
   a.in = y; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
@@ -217,11 +228,13 @@ int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes,
   a.ntaps = d->ntaps; a.so = d->out_stride;
   a.div_shift = d->div == 2 ? 1 : 0;
   a.M = d->B * d->Ho * d->Wo;
+  const bool f32 = d->dtype == PXL_F32;
+  const size_t es = f32 ? 4 : 2;
   a.Ktot = d->ntaps * d->Cin;
-  a.nk = a.Ktot / 64;
+  a.nk = a.Ktot / (f32 ? 32 : 64);            // a K step is one 128-byte row segment
   a.tiles_m = a.tiles_n = 0;
-  a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->Cin * 2);
-  a.w_bytes = (unsigned)((size_t)d->Kreal * a.Ktot * 2);
+  a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->Cin * es);
+  a.w_bytes = (unsigned)((size_t)d->Kreal * a.Ktot * es);
   std::memset(&a.g1, 0, sizeof(a.g1));
   for (int t = 0; t < 64; ++t)
     a.taps[t] = t < d->ntaps ? (((int)d->dy[t]) << 16) | (((int)d->dx[t]) & 0xffff) : 0;
@@ -233,6 +246,15 @@ int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes,
   gather |= d->div != 1;
   gather |= (d->Ho - 1) * d->out_stride >= d->Hi || (d->Wo - 1) * d->out_stride >= d->Wi;
   int cfg = d->tile_cfg;
+  if (f32) {
+    // conv_dma_f32.hip: plain launches only (the fp32 engine materialises its activations and finalizes on its own)
+    if (a.fin.coef != nullptr || a.bin.coef != nullptr || a.trace != nullptr)
+      return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: BN-on-load / in-kernel finalize / trace are bf16 launches");
+    if (cfg < 8) cfg = a.Cout <= 64 ? 17 : 18;        // MFMA-bound: the small 2-stage tiles (3 workgroups per CU)
+    if (cfg >= 12 && cfg < 16) cfg -= 4;
+    if (cfg >= 20) cfg = 16 + (cfg & 3);
+    return pxl_dma_f32_launch(cfg, a, gather, sk, ws_bytes, s);
+  }
   if (cfg < 8) {
     const long t128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 128);
     if (a.Cout <= 64) cfg = 9;

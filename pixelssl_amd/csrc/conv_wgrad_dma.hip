@@ -13,6 +13,7 @@
 //   * the 16-byte chunk index is XOR-swizzled with the pixel row so that the 4 pixel rows touched by one
 //     transposing read hit distinct banks (source-side swizzle, LDS image stays lane-linear).
 // Pipeline: conv_dma.hip's (NST-stage ring, counted vmcnt, raw s_barrier, asm fragment reads).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -325,17 +326,25 @@ int launch_wdma(const WDmaArgs& a, bool gather, int splits_hint, hipStream_t str
 
 }  // namespace
 
+int pxl_conv_wgrad_dma_f32(const pxl_conv_desc* d, const void* in, const void* dy, float* dw, int creal, int dw_cpitch,
+                           void* stream);      // conv_wgrad_dma_f32.hip
+
 extern "C" int pxl_conv_wgrad_dma_eligible(const pxl_conv_desc* d, const float* in_scale) {
-  if (d->dtype != PXL_BF16 || in_scale != nullptr) return 0;
+  if ((d->dtype != PXL_BF16 && d->dtype != PXL_F32) || in_scale != nullptr) return 0;
+  // fp32 operands: conv_wgrad_dma_f32.hip (PXL_F32_DMA=0 keeps the fp32 engine on the generic kernels, for A/B runs)
+  static const bool f32_on = getenv("PXL_F32_DMA") == nullptr || getenv("PXL_F32_DMA")[0] != '0';
+  if (d->dtype == PXL_F32 && !f32_on) return 0;
+  const long es = d->dtype == PXL_F32 ? 4 : 2;
   if (d->Cin % 64 != 0 || d->Cout % 8 != 0 || d->div != 1) return 0;
-  if ((long)d->B * d->Hi * d->Wi * d->Cin * 2 * 2 >= (1L << 32)) return 0;    // one image of slack for the ragged tail
-  if ((long)(d->B * d->Ho * d->Wo + 64) * d->Cout * 2 >= (1L << 31)) return 0;
+  if ((long)d->B * d->Hi * d->Wi * d->Cin * es * 2 >= (1L << 32)) return 0;    // one image of slack for the ragged tail
+  if ((long)(d->B * d->Ho * d->Wo + 64) * d->Cout * es >= (1L << 31)) return 0;
   return 1;
 }
 
 // tile_cfg 8/9 = 128x128 tile (3/2-stage ring), 10/11 = 64x64, 12 = 128(out) x 64(in), 13 = 64 x 128
 extern "C" int pxl_conv_wgrad_dma(const pxl_conv_desc* d, const void* in, const void* dy, float* dw, int creal,
                                   int dw_cpitch, void* stream) {
+  if (d->dtype == PXL_F32) return pxl_conv_wgrad_dma_f32(d, in, dy, dw, creal, dw_cpitch, stream);
   WDmaArgs a;
   a.in = in; a.dy = dy; a.dw = dw;
   a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin;

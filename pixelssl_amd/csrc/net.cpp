@@ -189,6 +189,11 @@ struct pxl_net {
   // backward of a residual join (ReLU mask + the main branch BN's sums) inside the data gradient that completes the
   // gradient of the join's output (PXL_FUSE_JOIN=0: separate pxl_residual_bwd_reduce launch)
   bool fuse_join = getenv("PXL_FUSE_JOIN") == nullptr || getenv("PXL_FUSE_JOIN")[0] != '0';
+  // fp32 engine on the LDS-DMA kernels (conv_dma_f32.hip, conv_wgrad_dma_f32.hip): like the bf16 engine it then materialises
+  // relu(bn(y)) for its convolutions (they read plain operands) and fuses the BatchNorm-backward sums into the data
+  // gradients.  PXL_F32_DMA=0: the generic kernels with BN-apply in their prologue (rounds 1-3), for A/B runs
+  bool f32_dma = getenv("PXL_F32_DMA") == nullptr || getenv("PXL_F32_DMA")[0] != '0';
+  bool plain_operands() const { return dtype == PXL_BF16 || (dtype == PXL_F32 && f32_dma); }
   // folding the forward finalize into its consumer removes 104 launches per pass; every block of the consumer re-reduces
   // the statistics replicas, which was slower with 32 replicas (round 1: 15.7 vs 15.0 ms / step) and is faster with 4
   // (round 2: 14.98 vs 15.17): on by default, PXL_FUSE_BN_FINALIZE=0 restores the separate pxl_bn_finalize launches
@@ -573,7 +578,7 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
   for (auto& op : n->ops) {
     const pxl_op& d = op.d;
     int bn = -1, t = -1;
-    if (d.kind == PXL_OP_CONV && d.bn_in0 >= 0 && n->dtype == PXL_BF16) { bn = d.bn_in0; t = d.in0; }
+    if (d.kind == PXL_OP_CONV && d.bn_in0 >= 0 && n->plain_operands()) { bn = d.bn_in0; t = d.in0; }
     if (d.kind == PXL_OP_HEAD && d.bn_in1 >= 0) { bn = d.bn_in1; t = d.in1; }     // activated latent: any dtype
     if (bn < 0) continue;
     BnInfo& b = n->bns[bn];
@@ -641,7 +646,7 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
   // BN-backward reduce fused into the data gradient that writes d(relu(bn(y))): y must have exactly one consumer
   // (that convolution) and the launch must be eligible for the LDS-DMA kernel
   for (auto& b : n->bns) b.fused_reduce_op = -1;
-  if (n->dtype == PXL_BF16 && n->fuse_bn_reduce) {
+  if (n->plain_operands() && n->fuse_bn_reduce) {
     std::vector<int> uses(n->tensors.size(), 0);
     for (auto& op : n->ops) {
       const pxl_op& d = op.d;
@@ -671,7 +676,7 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
   // pass), read it as a plain operand and run on the LDS-DMA kernel; every other consumer must be a convolution or the
   // identity input of the next join (they only add their share before it)
   for (auto& op : n->ops) op.join_op = op.join_conv = -1;
-  if (n->dtype == PXL_BF16 && n->fuse_bn_reduce && n->fuse_join) {
+  if (n->plain_operands() && n->fuse_bn_reduce && n->fuse_join) {
     for (size_t j = 0; j < n->ops.size(); ++j) {
       const pxl_op& dj = n->ops[j].d;
       if (dj.kind != PXL_OP_RESIDUAL || dj.bn_in0 < 0) continue;
@@ -859,6 +864,7 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
       for (int cfg = dma ? 8 : 0; cfg < (dma ? 36 : 8); ++cfg) {
         if (!dma && (cfg & 3) == 3 && tout.Cp > 64) continue;
         if (dma && cfg >= 12 && cfg < 16) continue;          // 4-stage rings never won on the ResNet shapes
+        if (dma && n->dtype == PXL_F32 && cfg >= 20) continue;      // fp32 kernel: the 2x2-wave tiles only (conv_dma_f32.hip)
         if (dma && cfg >= 20 && cfg != 29 && tout.Cp < 128) continue;     // tall / 8-wave tiles are 128 channels wide (29: 128 x 64)
         if (dma && cfg == 35 && tout.Cp < 256) continue;
         if (dma && !allowed(cfg)) continue;
@@ -892,6 +898,7 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
       for (int cfg = dma ? 8 : 0; cfg < (dma ? 36 : 8); ++cfg) {
         if (!dma && (cfg & 3) == 3 && tin.Cp > 64) continue;
         if (dma && cfg >= 12 && cfg < 16) continue;
+        if (dma && n->dtype == PXL_F32 && cfg >= 20) continue;
         if (dma && cfg >= 20 && cfg != 29 && tin.Cp < 128) continue;
         if (dma && cfg == 35 && tin.Cp < 256) continue;
         if (dma && !allowed(cfg)) continue;

@@ -117,8 +117,18 @@ DMA_CASES = [
 def test_conv_dma_forward_and_dgrad(case, cfg):
     """LDS-DMA kernel: forward (every tile configuration, 3- and 4-stage rings), bias + addend + BN statistics
     on the coalesced read-back pass, and the data gradient of stride-1 convolutions."""
+    _dma_forward_and_dgrad(case, cfg, torch.bfloat16)
+
+
+@pytest.mark.parametrize("case", DMA_CASES, ids=[c[0] for c in DMA_CASES])
+@pytest.mark.parametrize("cfg", [-1, 8, 9, 10, 11, 16, 17, 18, 19])
+def test_conv_dma_f32_forward_and_dgrad(case, cfg):
+    """fp32 LDS-DMA kernel (csrc/conv_dma_f32.hip, v_mfma_f32_32x32x2_f32): the same checks against torch's fp32 convolution."""
+    _dma_forward_and_dgrad(case, cfg, torch.float32)
+
+
+def _dma_forward_and_dgrad(case, cfg, dtype):
     ops = _ops()
-    dtype = torch.bfloat16
     name, B, Cin, Cout, H, W, k, s, d, p = case
     g = torch.Generator().manual_seed(_seed(name) + 7)
     x = qround(torch.randn(B, Cin, H, W, generator=g), dtype).requires_grad_(True)
@@ -280,14 +290,17 @@ def test_conv_with_bn_apply_on_load(case, cfg, training):
         assert torch.equal(out_a[..., :Cout], out_b[..., :Cout])
 
 
-@pytest.mark.parametrize("cfg", [-1, 8, 10, 11, 18, 20, 21, 26, 28, 30, 34])
+_FUSED_CFGS = [(c, torch.bfloat16) for c in (-1, 8, 10, 11, 18, 20, 21, 26, 28, 30, 34)] + \
+              [(c, torch.float32) for c in (-1, 8, 11, 17, 18)]
+
+
+@pytest.mark.parametrize("cfg,dtype", _FUSED_CFGS, ids=["%s-%d" % ("f32" if t == torch.float32 else "bf16", c) for c, t in _FUSED_CFGS])
 @pytest.mark.parametrize("shape", [(2, 128, 64, 17, 19, 3, 1, 1), (3, 64, 256, 9, 13, 1, 1, 0), (2, 192, 128, 12, 12, 3, 2, 2)])
-def test_conv_dgrad_with_fused_bn_backward_reduce(shape, cfg):
+def test_conv_dgrad_with_fused_bn_backward_reduce(shape, cfg, dtype):
     """pxl_conv_dgrad_bnreduce == pxl_conv_igemm (data gradient) followed by pxl_bn_bwd_reduce over the tensor just
     written: identical din, and the [sum gd, sum gd*xhat] vectors of the stored (rounded) values, with and without an
-    addend and the ReLU mask."""
+    addend and the ReLU mask.  bf16 and fp32 LDS-DMA kernels."""
     ops = _ops()
-    dtype = torch.bfloat16
     B, Cin, Cout, H, W, k, d, p = shape
     g = torch.Generator().manual_seed(B * 100 + Cin + k)
     w = qround(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype)
@@ -316,13 +329,15 @@ def test_conv_dgrad_with_fused_bn_backward_reduce(shape, cfg):
             assert rel_err(sums.cpu(), rs.cpu()) < 1e-4, (shape, cfg, relu, addend is not None)
 
 
-@pytest.mark.parametrize("cfg", [-1, 9, 10, 18, 20, 26, 28, 31, 35])
+_JOIN_CFGS = [(c, torch.bfloat16) for c in (-1, 9, 10, 18, 20, 26, 28, 31, 35)] + [(c, torch.float32) for c in (-1, 9, 10, 16, 19)]
+
+
+@pytest.mark.parametrize("cfg,dtype", _JOIN_CFGS, ids=["%s-%d" % ("f32" if t == torch.float32 else "bf16", c) for c, t in _JOIN_CFGS])
 @pytest.mark.parametrize("shape", [(2, 128, 64, 17, 19, 1, 1, 0), (3, 64, 256, 9, 13, 1, 1, 0), (2, 256, 128, 12, 12, 3, 1, 1)])
-def test_conv_dgrad_with_fused_residual_join_backward(shape, cfg):
+def test_conv_dgrad_with_fused_residual_join_backward(shape, cfg, dtype):
     """pxl_conv_dgrad_joinreduce == pxl_conv_igemm (data gradient + addend) followed by pxl_residual_bwd_reduce: the stored
-    tensor is the ReLU-masked gradient (bit-identical) and the sums are bn3's [sum g, sum g * xhat]."""
+    tensor is the ReLU-masked gradient (bit-identical) and the sums are bn3's [sum g, sum g * xhat].  bf16 and fp32."""
     ops = _ops()
-    dtype = torch.bfloat16
     B, Cin, Cout, H, W, k, d, p = shape
     g = torch.Generator().manual_seed(B * 100 + Cin + k + 7)
     w = qround(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype)
@@ -366,12 +381,13 @@ WDMA_CASES = [
 ]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
 @pytest.mark.parametrize("case", WDMA_CASES, ids=[c[0] for c in WDMA_CASES])
 @pytest.mark.parametrize("cfg", [-1, 8, 9, 10, 11, 12, 13])
-def test_conv_wgrad_dma(case, cfg):
-    """LDS-DMA weight gradient (ds_read_b64_tr_b16 fragments): accumulates on top of a non-zero buffer."""
+def test_conv_wgrad_dma(case, cfg, dtype):
+    """LDS-DMA weight gradient (bf16: ds_read_b64_tr_b16 fragments, csrc/conv_wgrad_dma.hip; fp32: ds_read_b32 +
+    v_mfma_f32_32x32x2_f32, csrc/conv_wgrad_dma_f32.hip): accumulates on top of a non-zero buffer."""
     ops = _ops()
-    dtype = torch.bfloat16
     name, B, Cin, Cout, H, W, k, s, d, p = case
     g = torch.Generator().manual_seed(_seed(name) + 3)
     x = qround(torch.randn(B, Cin, H, W, generator=g), dtype)

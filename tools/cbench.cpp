@@ -52,9 +52,19 @@ static uint16_t f2bf(float f) {
   return (uint16_t)(u >> 16);
 }
 
+static bool g_f32 = false;       // --f32: fp32 operands (conv_dma_f32.hip / conv_wgrad_dma_f32.hip), timing modes only
 static void* dev_random_bf16(size_t n, float scale, unsigned seed) {
-  std::vector<uint16_t> h(n);
   unsigned s = seed * 2654435761u + 12345u;
+  if (g_f32) {
+    std::vector<float> hf(n);
+    for (size_t i = 0; i < n; ++i) {
+      s = s * 1664525u + 1013904223u;
+      hf[i] = (((s >> 8) & 0xffff) / 65536.f + ((s >> 24) & 0xff) / 256.f - 1.0f) * scale;
+    }
+    void* d; CK(hipMalloc(&d, n * 4)); CK(hipMemcpy(d, hf.data(), n * 4, hipMemcpyHostToDevice));
+    return d;
+  }
+  std::vector<uint16_t> h(n);
   for (size_t i = 0; i < n; ++i) {
     s = s * 1664525u + 1013904223u;
     const float u = ((s >> 8) & 0xffff) / 65536.f + ((s >> 24) & 0xff) / 256.f - 1.0f;      // roughly triangular in (-1, 1)
@@ -76,7 +86,7 @@ static Problem make_problem(const Shape& sh, int B, unsigned seed) {
   const int Ho = (sh.H + 2 * pad - sh.d * (sh.k - 1) - 1) / sh.s + 1;
   const int cip = pitch(sh.cin), cop = pitch(sh.cout);
   pxl_conv_desc f; memset(&f, 0, sizeof(f));
-  f.dtype = PXL_BF16; f.B = B; f.Hi = sh.H; f.Wi = sh.H; f.Cin = cip; f.Ho = Ho; f.Wo = Ho; f.Cout = cop; f.Kreal = sh.cout;
+  f.dtype = g_f32 ? PXL_F32 : PXL_BF16; f.B = B; f.Hi = sh.H; f.Wi = sh.H; f.Cin = cip; f.Ho = Ho; f.Wo = Ho; f.Cout = cop; f.Kreal = sh.cout;
   f.ntaps = sh.k * sh.k; f.out_stride = sh.s; f.div = 1; f.relu_in = 0; f.tile_cfg = -1; f.stats_rep = 4; f.split_k = 1;
   for (int r = 0; r < sh.k; ++r)
     for (int c = 0; c < sh.k; ++c) { f.dy[r * sh.k + c] = (int16_t)(r * sh.d - pad); f.dx[r * sh.k + c] = (int16_t)(c * sh.d - pad); }
@@ -511,6 +521,7 @@ int main(int argc, char** argv) {
     else if (a == "--iters") iters = atoi(val().c_str());
     else if (a == "--batch") B = atoi(val().c_str());
     else if (a == "--dual") dual = true;
+    else if (a == "--f32") g_f32 = true;
     else if (a == "--floor") do_floor = true;
     else if (a == "--check") check = true;
     else if (a == "--pair") pair = true;
@@ -641,7 +652,7 @@ int main(int argc, char** argv) {
         const double t = time_single(p0, dg, cfg, iters, s0, ea, eb);
         if (t < 0) { printf(" %s:%d ERR", mode, cfg); continue; }
         printf(" %s:%d %6.1f (%5.0f)", mode, cfg, t, p0.flops / t * 1e-6);
-        if (check) check_cfg(p0, dg, cfg, s0);
+        if (check && !g_f32) check_cfg(p0, dg, cfg, s0);
         if (dual) { const double t2 = time_dual(p0, p1, dg, cfg, iters, s0, s1); printf(" [%6.1f]", t2); }
         if (pair && !dg) {
           const double t2 = time_pair(p0, p1, cfg, iters, s0, ea, eb);
