@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--cpu-warmup", type=int, default=3)
     p.add_argument("--cpu-budget-s", type=float, default=45.0, help="the CPU legs stop adding timed steps past this budget")
     p.add_argument("--no-miou", action="store_true")
+    p.add_argument("--host-profile", action="store_true",
+                   help="cProfile of the timed steps (top functions by own time -> stderr): where a host-bound step spends its time")
     p.add_argument("--no-seq-leg", action="store_true", help="skip the one-kernel-at-a-time roofline leg (stream overlap off, per-launch events)")
     p.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32_parity_mode leg (the engine mode that meets the 1e-3 parity bar)")
     p.add_argument("--fp32-steps", type=int, default=5)
@@ -451,12 +453,27 @@ def main():
         one_step(it)
     fence()
     # ---- the timed region: exactly K steps, nothing but the training iteration inside
+    prof = None
+    if a.host_profile:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     last = None
     for it in range(a.warmup, a.warmup + a.steps):
         last = one_step(it)
+    host_enqueue = time.perf_counter() - t0          # host time to ENQUEUE the K steps (== elapsed: the step is host-bound)
     fence()
     elapsed = time.perf_counter() - t0
+    if prof is not None:
+        import io
+        import pstats
+        prof.disable()
+        buf = io.StringIO()
+        st = pstats.Stats(prof, stream=buf)
+        st.sort_stats("tottime").print_stats(45)
+        st.sort_stats("cumulative").print_stats(60)
+        sys.stderr.write(buf.getvalue())
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -494,7 +511,8 @@ def main():
         gb = per_gpu * world
         out = {"metric": "training images/sec (513x513, 21-cls)", "value": round(gb * a.steps / elapsed, 3),
                "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(1e3 * elapsed / a.steps, 3), "host_enqueue_ms_per_step": round(1e3 * host_enqueue / a.steps, 3),
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": "%s sseg, %s/ResNet-101, %dx%dx%d (%d labeled + %d unlabeled) per GPU, "
                                       "21 classes" % ({"mt": "MT (mean-teacher)", "adv": "AdvSSL (+ FC discriminator)",

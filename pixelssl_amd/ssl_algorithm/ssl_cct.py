@@ -134,6 +134,17 @@ def sub_scale(a, b, scale):
     return out
 
 
+_CONTOUR_POOL = None
+
+
+def _contour_pool():
+    global _CONTOUR_POOL
+    if _CONTOUR_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _CONTOUR_POOL = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1), thread_name_prefix="pxl-contour")
+    return _CONTOUR_POOL
+
+
 def external_contour_boxes(mask_np, min_vertices=50, max_boxes=1024):
     """Host: bounding boxes (min_x, max_x, min_y, max_y) of the external contours with > min_vertices polygon vertices
     (what cv2.findContours + the `c.shape[0] > 50` filter of ssl_cct.py:627-632 keep), in cv2's list order (newest-found
@@ -287,8 +298,13 @@ class CutOutDecoder(_AuxDecoder):
         draws = iter(draws) if draws is not None else None
         used, used_boxes = [], []
         out = np.ones((B, H, W), dtype=np.float32)
+        if boxes_in is None:
+            # one host thread per sample (the C routine runs without the GIL): the search is ~2 ms per 513 x 513 mask and
+            # sat on the step's critical path (the host enqueues nothing meanwhile)
+            boxes_in = list(_contour_pool().map(lambda m: external_contour_boxes(m, self.min_vertices), [fg[b] for b in range(B)])) \
+                if B > 1 else [external_contour_boxes(fg[0], self.min_vertices)]
         for b in range(B):
-            boxes = boxes_in[b] if boxes_in is not None else external_contour_boxes(fg[b], self.min_vertices)
+            boxes = boxes_in[b]
             used_boxes.append([tuple(int(v) for v in bx) for bx in boxes])
             for (min_w, max_w, min_h, max_h) in boxes:
                 bb_w, bb_h = max_w - min_w, max_h - min_h
