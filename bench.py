@@ -530,6 +530,12 @@ def main():
                "rccl_ranks": pdist.rccl_ranks(), "grad_buckets": int(cores[0].grad_buckets()),
                # networks whose Sync-BN statistics go through the peer-mapped one-shot exchange (csrc/peer.hip)
                "peer_contexts": pdist.peer_contexts()}
+        if a.algo == "mt" and getattr(cores[0], "_cur", None) is not None:
+            # paired student || teacher pass (the default with Sync-BN): convolutions issued as ONE launch for both networks and
+            # Sync-BN statistics exchanges that carried both networks' sums (csrc/net.cpp: pxl_net_forward_pair)
+            from pixelssl_amd._lib import lib as _pl
+            out["paired_convs"] = int(_pl().pxl_net_pairs(cores[0]._cur.net))
+            out["paired_stat_exchanges"] = int(_pl().pxl_net_pair_syncs(cores[0]._cur.net))
         # what the line claims about the job, checked before it is printed: N ranks, every one of them on the RCCL
         # communicators (unless the run was explicitly put on another backend / onto one shared GPU for a test)
         shared = os.environ.get("PXL_FORCE_DEVICE") is not None or os.environ.get("PXL_DIST_BACKEND") not in (None, "nccl")

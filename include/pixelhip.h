@@ -619,6 +619,8 @@ int pxl_net_forward_pair(pxl_net* n0, pxl_net* n1, const float* params0, const f
 int pxl_net_tune_pair(pxl_net* n0, pxl_net* n1, const float* params0, const float* params1, const void* packed0,
                       const void* packed1, void* arena0, void* arena1, size_t arena_bytes0, size_t arena_bytes1, void* stream);
 int pxl_net_pairs(const pxl_net* n);
+/* Sync-BN statistics exchanges the last paired pass issued for BOTH networks in one launch (pxl_peer_allreduce_fold). */
+int pxl_net_pair_syncs(const pxl_net* n);
 
 /* enable = 0: backward skips every parameter gradient (a frozen discriminator only relays dL/dinput) */
 int pxl_net_set_wgrad(pxl_net* net, int enable);
@@ -667,6 +669,11 @@ void pxl_peer_destroy(pxl_peer* peer);
 /* in-place all-reduce(sum) of n floats at device pointer buf, enqueued on `stream`: one kernel per slot_floats floats.
  * Every rank issues the same call sequence on a context; one context per concurrently running network. */
 int pxl_peer_allreduce_sum(pxl_peer* peer, float* buf, long n, void* stream);
+/* Sync-BN statistics in ONE launch (sync_batchnorm/batchnorm.py:56-78: sum, ssum of the local batch -> master -> broadcast):
+ * buf0, and buf1 when given (the same BatchNorm of a second network: the student || teacher pass of pxl_net_forward_pair), hold
+ * nrep replicas [nrep][n] of the local sums; the replicas are folded, both vectors exchanged together, the all-reduced sums
+ * land in replica 0 of each.  Stands in for pxl_bn_fold_replicas + pxl_peer_allreduce_sum per network. */
+int pxl_peer_allreduce_fold(pxl_peer* peer, float* buf0, float* buf1, long n, int nrep, void* stream);
 int pxl_peer_allreduce_hook(void* user, float* buf, int n, void* stream);      /* pxl_allreduce_fn signature */
 /* *status = 0, or k > 0: an exchange gave up waiting for rank k-1 (its result is invalid).  Synchronises the device. */
 int pxl_peer_status(pxl_peer* peer, int* status);

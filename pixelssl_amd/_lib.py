@@ -179,6 +179,7 @@ SIGNATURES = {
     "pxl_peer_open": (_I, [_P, _P]),
     "pxl_peer_destroy": (None, [_P]),
     "pxl_peer_allreduce_sum": (_I, [_P, _P, _L, _P]),
+    "pxl_peer_allreduce_fold": (_I, [_P, _P, _P, _L, _I, _P]),
     "pxl_peer_allreduce_hook": (_I, [_P, _P, _I, _P]),
     "pxl_peer_status": (_I, [_P, C.POINTER(_I)]),
     "pxl_net_create": (_I, [_I, _I, C.POINTER(Op), _I, C.POINTER(BnDesc), _I, _I, C.POINTER(_P)]),
@@ -198,6 +199,7 @@ SIGNATURES = {
     "pxl_net_forward_pair": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _Z, _I, _I, _P]),
     "pxl_net_tune_pair": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _Z, _P]),
     "pxl_net_pairs": (_I, [_P]),
+    "pxl_net_pair_syncs": (_I, [_P]),
     "pxl_net_latent": (_I, [_P, _P, _P, _P]),
     "pxl_net_latent_shape": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "pxl_net_read_tensor": (_I, [_P, _P, _I, _I, _P, _P, _P]),

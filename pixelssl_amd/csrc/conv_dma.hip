@@ -305,7 +305,8 @@ extern "C" int pxl_dma_launch_captured(void* slot0, void* slot1) {
                       x.ntaps == y.ntaps && x.so == y.so && x.div_shift == y.div_shift && x.stats_rep == y.stats_rep &&
                       (x.bias != nullptr) == (y.bias != nullptr) && (x.stats != nullptr) == (y.stats != nullptr) &&
                       (x.bin.coef != nullptr) == (y.bin.coef != nullptr) && x.bin_relu == y.bin_relu &&
-                      (x.bin_z != nullptr) == (y.bin_z != nullptr) && std::memcmp(x.taps, y.taps, sizeof(x.taps)) == 0 &&
+                      std::memcmp(x.taps, y.taps, sizeof(x.taps)) == 0 &&          // (bin_z: per network, the kernel tests its own pointer)
+
                       (x.bin.coef == nullptr || (x.bin.nrep == y.bin.nrep && x.bin.count == y.bin.count && x.bin.training == y.bin.training &&
                                                  x.bin.momentum == y.bin.momentum && x.bin.eps == y.bin.eps && x.bin.clamp_var == y.bin.clamp_var &&
                                                  (x.bin.running_mean != nullptr) == (y.bin.running_mean != nullptr) &&

@@ -47,6 +47,9 @@ int pxl_head_loss(int dtype, int B, int h, int w, int Cp, int C, int H, int W, i
                   const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight,
                   float mse_weight, void* dlow, void* workspace, size_t ws_bytes, float* sums, void* stream);
 int pxl_conv_wgrad_dma_eligible(const pxl_conv_desc* d, const float* in_scale);
+struct pxl_peer;
+int pxl_peer_allreduce_hook(void* user, float* buf, int n, void* stream);
+int pxl_peer_allreduce_fold(pxl_peer* p, float* buf0, float* buf1, long n, int nrep, void* stream);
 }
 
 namespace {
@@ -180,6 +183,8 @@ struct pxl_net {
   bool bucket_ok = false;          // parameter offsets grow with the op index: suffixes of the op list = suffixes of the buffer
   int grad_buckets_last = 0;       // buckets issued by the last backward (tests / bench)
   int pairs_last = 0;              // convolutions the last paired forward issued as one launch for both networks
+  int pair_syncs_last = 0;         // ... Sync-BN exchanges it issued for both networks at once
+  bool pair_sync = getenv("PXL_PAIR_SYNC") == nullptr || getenv("PXL_PAIR_SYNC")[0] != '0';
   bool bn_onload = getenv("PXL_BN_ONLOAD") == nullptr || getenv("PXL_BN_ONLOAD")[0] != '0';
   bool wgrad_on = true;
   bool pack_dgrad = true;          // false: pxl_net_pack skips the transposed (data-gradient) weights (no-grad networks)
@@ -946,7 +951,21 @@ struct FwdCtx {
 // convolution launch, 2: what follows it (Sync-BN exchange, finalize, activation) -- so that the paired pass
 // (pxl_net_forward_pair) can issue the convolution of two networks as ONE launch between the halves; *fin_flag carries
 // "the convolution finalized its BatchNorm itself" from half 1 to half 2.
-int forward_op(pxl_net* n, size_t i, const FwdCtx& c, int phase, bool* fin_flag) {
+// sync_done (phase 2 only): the Sync-BN exchange of this op's BatchNorm has already been performed by the caller (the paired
+// pass exchanges the statistics of both networks in one launch): replica 0 holds the all-reduced sums.
+// Sync-BN statistics of one network: fold the replicas, all-reduce [2C] over the ranks.  With the peer-mapped exchange both
+// happen in ONE launch (pxl_peer_allreduce_fold), otherwise fold + the hook (RCCL / torch.distributed).
+int sync_stats(pxl_net* n, float* stats, int count, int nrep, void* stream) {
+  if (n->sync == &pxl_peer_allreduce_hook)
+    return pxl_peer_allreduce_fold(reinterpret_cast<pxl_peer*>(n->sync_user), stats, nullptr, count, nrep, stream);
+  int rc = pxl_bn_fold_replicas(count, nrep, stats, stream);
+  if (rc != PXL_OK) return rc;
+  rc = n->sync(n->sync_user, stats, count, stream);
+  if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_forward: SyncBN all-reduce hook failed (%d)", rc);
+  return PXL_OK;
+}
+
+int forward_op(pxl_net* n, size_t i, const FwdCtx& c, int phase, bool* fin_flag, bool sync_done = false) {
   const float* params = c.params; const void* packed = c.packed; float* running = c.running; const float* x = c.x;
   float* logits = c.logits; float* prob = c.prob; void* arena = c.arena; const int training = c.training; void* stream = c.stream;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1041,10 +1060,10 @@ int forward_op(pxl_net* n, size_t i, const FwdCtx& c, int phase, bool* fin_flag)
           BnInfo& b = n->bns[d.bn_out];
           int nrep = STATS_REP;
           if (training && n->sync && n->world > 1) {
-            rc = pxl_bn_fold_replicas(2 * b.d.C, STATS_REP, fat(arena, b.stats_off), stream);
-            if (rc != PXL_OK) return rc;
-            rc = n->sync(n->sync_user, fat(arena, b.stats_off), 2 * b.d.C, stream);
-            if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_forward: SyncBN all-reduce hook failed (%d)", rc);
+            if (!sync_done) {
+              rc = sync_stats(n, fat(arena, b.stats_off), 2 * b.d.C, STATS_REP, stream);
+              if (rc != PXL_OK) return rc;
+            }
             nrep = 1;
           }
           b.fin_nrep = nrep;
@@ -1234,6 +1253,7 @@ extern "C" int pxl_net_forward_pair(pxl_net* n0, pxl_net* n1, const float* param
   const FwdCtx ctx[2] = {{params0, packed0, running0, x0, logits0, prob0, arena0, training0, stream},
                          {params1, packed1, running1, x1, logits1, prob1, arena1, training1, stream}};
   n0->pairs_last = 0;
+  n0->pair_syncs_last = 0;
   for (size_t i = 0; i < n0->ops.size(); ++i) {
     if (n0->ops[i].d.kind != PXL_OP_CONV || n0->profile || n1->profile) {
       // (the finalize-folding element-wise kernels of the two networks -- residual joins, BN + ReLU -- pair up as well:
@@ -1265,9 +1285,24 @@ extern "C" int pxl_net_forward_pair(pxl_net* n0, pxl_net* n1, const float* param
     const int pr = pxl_dma_launch_captured(slot[0], slot[1]);
     if (pr < 0) return pr;
     n0->pairs_last += pr;
+    // Sync-BN: the statistics of the SAME BatchNorm of both networks travel in one exchange (one launch folds the replicas
+    // of both, posts 2 x 2C words, sums them): both networks on the peer-mapped path, neither finalized by its convolution
+    bool sync_done = false;
+    {
+      const pxl_op& d0 = n0->ops[i].d; const pxl_op& d1 = n1->ops[i].d;
+      if (d0.bn_out >= 0 && d1.bn_out >= 0 && training0 && training1 && !fin[0] && !fin[1] && n0->world > 1 && n1->world > 1 &&
+          n0->sync == &pxl_peer_allreduce_hook && n1->sync == &pxl_peer_allreduce_hook && n0->pair_sync &&
+          n0->bns[d0.bn_out].d.C == n1->bns[d1.bn_out].d.C) {
+        const int rc = pxl_peer_allreduce_fold(reinterpret_cast<pxl_peer*>(n0->sync_user), fat(arena0, n0->bns[d0.bn_out].stats_off),
+                                               fat(arena1, n1->bns[d1.bn_out].stats_off), 2 * n0->bns[d0.bn_out].d.C, STATS_REP, stream);
+        if (rc != PXL_OK) return rc;
+        sync_done = true;
+        ++n0->pair_syncs_last;
+      }
+    }
     pxl_elt_pair_begin();
     for (int k = 0; k < 2; ++k) {
-      const int rc = forward_op(nets[k], i, ctx[k], 2, &fin[k]);
+      const int rc = forward_op(nets[k], i, ctx[k], 2, &fin[k], sync_done);
       if (rc != PXL_OK) { (void)pxl_elt_pair_end(); return rc; }
     }
     const int rce = pxl_elt_pair_end();
@@ -1278,6 +1313,8 @@ extern "C" int pxl_net_forward_pair(pxl_net* n0, pxl_net* n1, const float* param
 
 // convolutions the last pxl_net_forward_pair(n, ...) issued as paired launches (tests / bench)
 extern "C" int pxl_net_pairs(const pxl_net* n) { return n ? n->pairs_last : 0; }
+// ... Sync-BN statistics exchanges the last paired pass issued for both networks at once (pxl_peer_allreduce_fold)
+extern "C" int pxl_net_pair_syncs(const pxl_net* n) { return n ? n->pair_syncs_last : 0; }
 
 // Tile selection for the paired forward: every convolution of the pair timed as ONE launch per candidate configuration
 // (pxl_net_tune times single launches: with twice the tiles per launch the larger tiles win -- tools/cbench --pair: 160 x 128

@@ -27,8 +27,11 @@ struct PeerArgs {
   long long timeout_ticks;               // of the 100 MHz wall clock
 };
 
-__global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a, float* __restrict__ buf, int n,
-                                                             unsigned epoch) {
+// The logical vector is [buf0[0..n_each) | buf1[0..n_each)] (buf1 == nullptr: one vector); this launch exchanges its elements
+// base .. base + m.  nrep > 1: the operands are statistics replicas [nrep][n_each] that are folded on the way in (what
+// pxl_bn_fold_replicas did in a launch of its own); the all-reduced sum lands in replica 0.
+__global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a, float* __restrict__ buf0, float* __restrict__ buf1,
+                                                             int n_each, int nrep, int base, int m, unsigned epoch) {
   const int par = epoch & 1u;
   const size_t set = (size_t)par * a.world * a.slot;
   // sticky abort: once an exchange of this context has given up on a peer, every later one posts its words (the peers may
@@ -36,9 +39,13 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a, f
   // step has ~310 of them).  The sums are invalid from then on; the host sees the status word (pxl_peer_status, polled by
   // dist.poll_peers every few steps) and moves the statistics to RCCL / torch.distributed.
   const bool aborted = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+    const int g = base + i;
+    float* const src = g < n_each ? buf0 + g : buf1 + (g - n_each);
+    float v = src[0];
+    for (int r = 1; r < nrep; ++r) v += src[(size_t)r * n_each];
     // my element into my slot of every rank's buffer (my own included: the sum below reads every slot the same way)
-    const unsigned long long word = ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(buf[i]);
+    const unsigned long long word = ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v);
     for (int r = 0; r < a.world; ++r)
       __hip_atomic_store(a.slots[r] + set + (size_t)a.rank * a.slot + i, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // every rank's element from MY buffer, in rank order (identical on every rank)
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a, f
       }
       acc += __uint_as_float((unsigned)w);
     }
-    buf[i] = acc;
+    src[0] = acc;
   }
 }
 
@@ -141,24 +148,41 @@ extern "C" void pxl_peer_destroy(pxl_peer* p) {
   delete p;
 }
 
-// in-place all-reduce(sum) of n floats at device pointer buf, enqueued on `stream`; vectors longer than the slot go in
-// several exchanges.  Every rank must issue the same sequence of calls on a context.
-extern "C" int pxl_peer_allreduce_sum(pxl_peer* p, float* buf, long n, void* stream) {
-  PXL_REQUIRE(p && buf && n > 0, "peer_allreduce_sum: bad argument");
-  PXL_REQUIRE(p->opened || p->world == 1, "peer_allreduce_sum: peer buffers not opened (pxl_peer_open)");
+namespace {
+int peer_exchange(pxl_peer* p, float* buf0, float* buf1, long n_each, int nrep, void* stream) {
+  PXL_REQUIRE(p->opened || p->world == 1, "peer_allreduce: peer buffers not opened (pxl_peer_open)");
   PeerArgs a;
   for (int r = 0; r < MAXW; ++r) a.slots[r] = r < p->world ? reinterpret_cast<unsigned long long*>(p->mapped[r]) : nullptr;
   a.status = reinterpret_cast<unsigned*>(p->local + p->status_off);
   a.rank = p->rank; a.world = p->world; a.slot = p->slot; a.timeout_ticks = p->timeout_ticks;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  for (long off = 0; off < n; off += p->slot) {
-    const int m = (int)((n - off) < p->slot ? (n - off) : p->slot);
+  const long total = buf1 != nullptr ? 2 * n_each : n_each;
+  for (long off = 0; off < total; off += p->slot) {
+    const int m = (int)((total - off) < p->slot ? (total - off) : p->slot);
     p->epoch += 1;
     if (p->epoch == 0) p->epoch = 2;            // 0 is what the zero-filled buffer carries; keep the parity sequence
-    hipLaunchKernelGGL(peer_allreduce_kernel, dim3(m > 1024 ? 4 : 1), dim3(256), 0, s, a, buf + off, m, p->epoch);
+    hipLaunchKernelGGL(peer_allreduce_kernel, dim3(m > 1024 ? 4 : 1), dim3(256), 0, s, a, buf0, buf1, (int)n_each, nrep, (int)off, m,
+                       p->epoch);
   }
   PXL_LAUNCH_CHECK();
   return PXL_OK;
+}
+}  // namespace
+
+// in-place all-reduce(sum) of n floats at device pointer buf, enqueued on `stream`; vectors longer than the slot go in
+// several exchanges.  Every rank must issue the same sequence of calls on a context.
+extern "C" int pxl_peer_allreduce_sum(pxl_peer* p, float* buf, long n, void* stream) {
+  PXL_REQUIRE(p && buf && n > 0 && n < (1L << 30), "peer_allreduce_sum: bad argument");
+  return peer_exchange(p, buf, nullptr, n, 1, stream);
+}
+
+// Sync-BN statistics in ONE launch: buf0 (and buf1, optional: the same BatchNorm of a second network -- the MT student ||
+// teacher pass of pxl_net_forward_pair) hold nrep replicas [nrep][n] of the local sums; the replicas are folded, the sums of
+// both vectors exchanged together, and the all-reduced vector lands in replica 0 of each.  Replaces pxl_bn_fold_replicas +
+// pxl_peer_allreduce_sum per network (4 launches and 2 exchanges per BatchNorm of a paired pass -> 1 and 1).
+extern "C" int pxl_peer_allreduce_fold(pxl_peer* p, float* buf0, float* buf1, long n, int nrep, void* stream) {
+  PXL_REQUIRE(p && buf0 && n > 0 && n < (1L << 29) && nrep >= 1, "peer_allreduce_fold: bad argument");
+  return peer_exchange(p, buf0, buf1, n, nrep, stream);
 }
 
 extern "C" int pxl_peer_allreduce_hook(void* user, float* buf, int n, void* stream) {

@@ -177,7 +177,7 @@ def native_comms():
 
 
 _peer = {"ok": None, "ctxs": [], "hook": None}
-PEER_SLOT_FLOATS = 4096            # 2 * 2048 channels: the widest BatchNorm of the ResNet trunks in one exchange
+PEER_SLOT_FLOATS = 8192            # 2 networks x 2 * 2048 channels: the widest BatchNorm of a student || teacher pair in one exchange
 PEER_TIMEOUT_MS = int(os.environ.get("PXL_PEER_TIMEOUT_MS", "2000"))       # one exchange is ~6 us; 2 s is a dead (or wedged) peer
 PEER_POLL_STEPS = int(os.environ.get("PXL_PEER_POLL_STEPS", "20"))
 

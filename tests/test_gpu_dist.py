@@ -100,6 +100,22 @@ def _peer_worker(rank, world, port, q):
             _lib.check(h.pxl_peer_allreduce_sum(b, w.data_ptr(), n, s2.cuda_stream))
         torch.cuda.current_stream().wait_stream(s2)
         bad += int(not torch.equal(v, rv)) + int(not torch.equal(w, rw))
+    # folded + paired form (pxl_peer_allreduce_fold: what the paired student || teacher pass issues per BatchNorm): 4 replicas of
+    # two vectors, folded in replica order, exchanged together; lengths that fit one exchange, fill it, and straddle two
+    for k in range(60):
+        n = (128, 2048, 4096, 4096 + 320, 12, 8192)[k % 6]
+        v4 = torch.randn(4, n, device="cuda", generator=g)
+        w4 = torch.randn(4, n, device="cuda", generator=g)
+        rv = ((v4[0] + v4[1]) + v4[2]) + v4[3]
+        rw = ((w4[0] + w4[1]) + w4[2]) + w4[3]
+        dist.all_reduce(rv)
+        dist.all_reduce(rw)
+        single = k % 2 == 1
+        _lib.check(h.pxl_peer_allreduce_fold(a, v4.data_ptr(), None if single else w4.data_ptr(), n, 4,
+                                             torch.cuda.current_stream().cuda_stream))
+        if single:
+            _lib.check(h.pxl_peer_allreduce_fold(a, w4.data_ptr(), None, n, 4, torch.cuda.current_stream().cuda_stream))
+        bad += int(not torch.equal(v4[0], rv)) + int(not torch.equal(w4[0], rw))
     pdist.check_peers()
     # time per exchange, 2C = 2048 floats (a layer-3 BatchNorm), back to back on one stream
     v = torch.randn(2048, device="cuda", generator=g)
@@ -301,6 +317,10 @@ def test_bench_two_ranks_on_one_gpu_through_torchrun():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 4 and d["config"]["sync_bn"] is True
     assert d["rccl_ranks"] == 0 and d["grad_buckets"] >= 5          # 176 MB of gradients in 32 MB buckets
     assert d["peer_contexts"] == 2                                  # student + teacher: Sync-BN over the peer-mapped exchange
+    # with Sync-BN the two forwards run as ONE paired pass: every DMA convolution one launch for both networks, and every
+    # BatchNorm's statistics of both networks in ONE peer exchange (104 BatchNorms of ResNet-101; 71 of the 105 convolutions pair,
+    # the rest are the stem, the split-K ASPP and launches that differ between the networks)
+    assert d["paired_convs"] >= 60 and d["paired_stat_exchanges"] >= 100, (d["paired_convs"], d["paired_stat_exchanges"])
     assert d["value"] > 0 and all(v == v and abs(v) < 1e6 for v in d["final_losses"].values())
 
 
