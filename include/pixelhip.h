@@ -618,6 +618,10 @@ int pxl_net_forward_pair(pxl_net* n0, pxl_net* n1, const float* params0, const f
                          size_t arena_bytes0, size_t arena_bytes1, int training0, int training1, void* stream);
 int pxl_net_tune_pair(pxl_net* n0, pxl_net* n1, const float* params0, const float* params1, const void* packed0,
                       const void* packed1, void* arena0, void* arena1, size_t arena_bytes0, size_t arena_bytes1, void* stream);
+/* Forward passes that follow update the BatchNorm running statistics as if each had run `times` times on the same batch
+ * (momentum 1 - (1-m)^times).  For a caller that would run the SAME forward twice with unchanged weights -- SSLGCT's step-0
+ * no-grad pass and its step-1 pass (ssl_gct.py:196-200, 403) -- and runs it once.  times = 1: the plain update. */
+int pxl_net_set_bn_repeat(pxl_net* net, int times);
 int pxl_net_pairs(const pxl_net* n);
 /* Sync-BN statistics exchanges the last paired pass issued for BOTH networks in one launch (pxl_peer_allreduce_fold). */
 int pxl_net_pair_syncs(const pxl_net* n);

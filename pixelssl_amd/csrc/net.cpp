@@ -16,6 +16,7 @@
 // forward pass (kept until its backward); `scratch` holds gradient buffers; `packed` the weights
 // in kernel layout (fwd + transposed).  288 GB of HBM3E means no recomputation and no buffer
 // aliasing games: every tensor gets its own slot.
+#include <cmath>
 #include <vector>
 #include <cstring>
 #include <cstdlib>
@@ -184,6 +185,8 @@ struct pxl_net {
   int grad_buckets_last = 0;       // buckets issued by the last backward (tests / bench)
   int pairs_last = 0;              // convolutions the last paired forward issued as one launch for both networks
   int pair_syncs_last = 0;         // ... Sync-BN exchanges it issued for both networks at once
+  int bn_repeat = 1;               // running statistics updated as if this pass ran bn_repeat times (pxl_net_set_bn_repeat)
+  float eff_momentum(float m) const { return bn_repeat <= 1 ? m : 1.f - powf(1.f - m, (float)bn_repeat); }
   bool pair_sync = getenv("PXL_PAIR_SYNC") == nullptr || getenv("PXL_PAIR_SYNC")[0] != '0';
   bool bn_onload = getenv("PXL_BN_ONLOAD") == nullptr || getenv("PXL_BN_ONLOAD")[0] != '0';
   bool wgrad_on = true;
@@ -818,7 +821,7 @@ pxl_bn_fin make_fin(const pxl_net* n, const BnInfo& b, const float* params, floa
   f.beta = params + b.d.beta_off;
   f.running_mean = running ? running + b.d.rmean_off : nullptr;
   f.running_var = running ? running + b.d.rvar_off : nullptr;
-  f.momentum = b.d.momentum;
+  f.momentum = n->eff_momentum(b.d.momentum);
   f.eps = b.d.eps;
   f.training = training;
   f.clamp_var = (n->world > 1 || n->force_clamp) ? 1 : 0;
@@ -1078,7 +1081,7 @@ int forward_op(pxl_net* n, size_t i, const FwdCtx& c, int phase, bool* fin_flag,
           } else {
             rc = pxl_bn_finalize(b.d.C, fat(arena, b.stats_off), nrep, (float)b.M * n->world, params + b.d.gamma_off,
                                  params + b.d.beta_off, running ? running + b.d.rmean_off : nullptr,
-                                 running ? running + b.d.rvar_off : nullptr, b.d.momentum, b.d.eps, training,
+                                 running ? running + b.d.rvar_off : nullptr, n->eff_momentum(b.d.momentum), b.d.eps, training,
                                  (n->world > 1 || n->force_clamp) ? 1 : 0, fat(arena, b.coef_off), stream);
             if (rc != PXL_OK) return rc;
             if (b.has_z)
@@ -1150,7 +1153,7 @@ int forward_op(pxl_net* n, size_t i, const FwdCtx& c, int phase, bool* fin_flag,
         rc = pxl_ibn_coef(n->B, tin.Cp, nb, HW, (float)n->B * HW * n->world, fat(arena, op.ibn_sums),
                           exchange ? fat(arena, op.ibn_bn) : nullptr,
                           params + b.d.gamma_off, params + b.d.beta_off, running ? running + b.d.rmean_off : nullptr,
-                          running ? running + b.d.rvar_off : nullptr, b.d.momentum, b.d.eps, train,
+                          running ? running + b.d.rvar_off : nullptr, n->eff_momentum(b.d.momentum), b.d.eps, train,
                           (n->world > 1 || n->force_clamp) ? 1 : 0, fat(arena, op.ibn_coef), stream);
         if (rc != PXL_OK) return rc;
         rc = pxl_ibn_apply_fwd(dt, n->B, HW, tin.Cp, at(arena, tin.off), fat(arena, op.ibn_coef), d.slope,
@@ -1383,6 +1386,16 @@ extern "C" int pxl_net_tune_pair(pxl_net* n0, pxl_net* n1, const float* params0,
 extern "C" int pxl_net_set_wgrad(pxl_net* net, int enable) {
   PXL_REQUIRE(net, "net_set_wgrad: null net");
   net->wgrad_on = enable != 0;
+  return PXL_OK;
+}
+
+// The following forward passes update the BatchNorm running statistics as if each of them had run `times` times on the same
+// batch: running <- (1-m)^times running + (1 - (1-m)^times) batch, i.e. momentum 1 - (1-m)^times.  For callers that would
+// otherwise run the SAME forward twice with unchanged weights (SSLGCT's step-0 no-grad pass and step-1 pass, ssl_gct.py:196-200
+// + 403) and run it once instead.  times = 1 restores the plain update.
+extern "C" int pxl_net_set_bn_repeat(pxl_net* net, int times) {
+  PXL_REQUIRE(net && times >= 1 && times <= 16, "net_set_bn_repeat: bad argument");
+  net->bn_repeat = times;
   return PXL_OK;
 }
 

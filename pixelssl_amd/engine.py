@@ -466,6 +466,8 @@ class SegNetCore(nn.Module):
             pl.arena_bytes = lib().pxl_net_arena_bytes(pl.net)
             if self._sync_cb is not None:
                 check(lib().pxl_net_set_sync(pl.net, self._sync_cb, getattr(self, "_sync_user", None), self._sync_world))
+            if getattr(self, "_bn_repeat", 1) != 1:
+                check(lib().pxl_net_set_bn_repeat(pl.net, self._bn_repeat))
             gs = getattr(self, "_grad_sync", None)
             if gs is not None:
                 check(lib().pxl_net_set_grad_sync(pl.net, gs[0], gs[1], gs[2], gs[3], self._store.np))
@@ -597,6 +599,14 @@ class SegNetCore(nn.Module):
             check(lib().pxl_net_set_sync(pl.net, fn, user, world_size))
 
     # -- execution --------------------------------------------------------------------------
+    def set_bn_repeat(self, times):
+        """The following forward passes update the BatchNorm running statistics as if each ran `times` times on its batch
+        (csrc/net.cpp: pxl_net_set_bn_repeat) -- for callers that replace two identical passes by one."""
+        if int(times) != getattr(self, '_bn_repeat', 1):
+            for pl in self._all_plans():
+                check(lib().pxl_net_set_bn_repeat(pl.net, int(times)))
+            self._bn_repeat = int(times)
+
     def set_wgrad(self, enable):
         """enable=False: backward only relays dL/dinput (a frozen discriminator inside the task model's step)."""
         if bool(enable) != self._wgrad_on:

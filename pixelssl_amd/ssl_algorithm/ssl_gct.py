@@ -349,6 +349,20 @@ def _define_sslgct():
                 self._r_stream = streams.role_stream(streams.SIDE) if on else None
             return self._r_stream
 
+        def _reusable_cores(self):
+            """The two task models' executors when PXL_GCT_REUSE_FORWARD=1 and both are deterministic DeepLab-v2 programs in
+            training mode, else None (see train_step)."""
+            if os.environ.get('PXL_GCT_REUSE_FORWARD', '0') != '1':
+                return None
+            from ..engine import DeepLabV2Core
+            cores = []
+            for m in (self.l_model, self.r_model):
+                core = getattr(getattr(m, 'module', m), 'model', None)
+                if not isinstance(core, DeepLabV2Core) or not core.training:
+                    return None
+                cores.append(core)
+            return cores
+
         def _task_model_iter(self, mid, lbs, inp, gt, dc_gt, fc_mask, dc_rampup_scale, resulter=None):
             a = self.args
             model, criterion = (self.l_model, self.l_criterion) if mid == 'l' else (self.r_model, self.r_criterion)
@@ -409,10 +423,27 @@ def _define_sslgct():
                 return res
 
             # ---- step 0: no-grad task forwards, flaw-detector forwards whose graphs are kept for step 2
-            with torch.no_grad():
-                l_res, r_res = pair(lambda: self.l_model.forward(inp)[0], lambda: keep(self.r_model.forward(inp)[0]))
-                l_prob = tool.dict_value(l_res, 'activated_pred')
-                r_prob = tool.dict_value(r_res, 'activated_pred')
+            # PXL_GCT_REUSE_FORWARD=1 (opt-in, off by default): the reference runs every task model TWICE per iteration on the
+            # same batch with the same weights -- no-grad here, with a graph in step 1 (ssl_gct.py:196-200, 403); nothing between
+            # the two passes changes a task model, so they produce the same tensors, and the only trace of the repetition is
+            # the second running-statistics update.  With the switch on, the step-1 pass runs HERE (with its graph), the
+            # running statistics take both updates at once (momentum 1 - (1-m)^2: pxl_net_set_bn_repeat) and step 1 reuses it.
+            # Only for networks whose forward is a pure function of (weights, batch): the DeepLab-v2 executor (no dropout).
+            reuse_cores = self._reusable_cores()
+            l_fwd = r_fwd = None
+            if reuse_cores is not None:
+                for c in reuse_cores:
+                    c.set_bn_repeat(2)
+                l_fwd, r_fwd = pair(lambda: self.l_model.forward(inp)[0], lambda: keep(self.r_model.forward(inp)[0]))
+                for c in reuse_cores:
+                    c.set_bn_repeat(1)
+                l_prob = tuple(t.detach() for t in tool.dict_value(l_fwd, 'activated_pred'))
+                r_prob = tuple(t.detach() for t in tool.dict_value(r_fwd, 'activated_pred'))
+            else:
+                with torch.no_grad():
+                    l_res, r_res = pair(lambda: self.l_model.forward(inp)[0], lambda: keep(self.r_model.forward(inp)[0]))
+                    l_prob = tool.dict_value(l_res, 'activated_pred')
+                    r_prob = tool.dict_value(r_res, 'activated_pred')
             fd_core.set_wgrad(True)
             l_flawmap = tool.dict_value(self.fd_model.forward(inp, l_prob[0])[0], 'flawmap')
             r_flawmap = tool.dict_value(self.fd_model.forward(inp, r_prob[0])[0], 'flawmap')
@@ -429,7 +460,8 @@ def _define_sslgct():
             # engine runs each network's backward on the stream of its forward -- and both optimizer steps.
             fd_core.set_wgrad(False)
             out = {}
-            l_fwd, r_fwd = pair(lambda: self.l_model.forward(inp)[0], lambda: keep(self.r_model.forward(inp)[0]))
+            if l_fwd is None:
+                l_fwd, r_fwd = pair(lambda: self.l_model.forward(inp)[0], lambda: keep(self.r_model.forward(inp)[0]))
             losses = []
             for mid, resulter, dc_gt, fc_mask in (('l', l_fwd, l_dc_gt, l_fc_mask), ('r', r_fwd, r_dc_gt, r_fc_mask)):
                 loss, parts = self._task_model_iter(mid, lbs, inp, gt, dc_gt, fc_mask, dc_rampup_scale, resulter)

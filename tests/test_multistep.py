@@ -342,6 +342,20 @@ def test_cutmix_six_iterations(dtype, fixture):
 @pytest.mark.parametrize("fixture", ["gct_cond_129.pt", "gct_cond_513.pt"], ids=["129", "513"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_gct_six_iterations(dtype, fixture):
+    _gct_six_iterations(dtype, fixture)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gct_six_iterations_one_forward_per_task_model(dtype, monkeypatch):
+    """PXL_GCT_REUSE_FORWARD=1 (opt-in): the step-0 no-grad pass and the step-1 pass of each task model are ONE pass whose
+    running statistics take both updates (pxl_net_set_bn_repeat) -- same fixture, same bars (losses, weights, running statistics
+    are part of the compared state)."""
+    monkeypatch.setenv("PXL_GCT_REUSE_FORWARD", "1")
+    _gct_six_iterations(dtype, "gct_cond_129.pt", expect_reuse=True)
+
+
+def _gct_six_iterations(dtype, fixture, expect_reuse=False):
     import torch_oracle as TO
     import gct_oracle as GO
     import pixelssl_amd as P
@@ -360,6 +374,7 @@ def test_gct_six_iterations(dtype, fixture):
     algo.fd_model.module.load_state_dict(fd)
     for m in (algo.l_model, algo.r_model, algo.fd_model):
         m.train()
+    assert (algo._reusable_cores() is not None) == expect_reuse
     for i, s in enumerate(fx["data_seeds"]):
         x, gt = TO.synthetic_batch(fx["lbs"] + fx["ubs"], fx["size"], fx["lbs"], seed=s, block=fx["block"])
         out = algo.train_step((x.to(DEV),), (gt.to(DEV),), i, fx["rampup_iters"])
