@@ -678,6 +678,10 @@ int pxl_peer_allreduce_sum(pxl_peer* peer, float* buf, long n, void* stream);
  * nrep replicas [nrep][n] of the local sums; the replicas are folded, both vectors exchanged together, the all-reduced sums
  * land in replica 0 of each.  Stands in for pxl_bn_fold_replicas + pxl_peer_allreduce_sum per network. */
 int pxl_peer_allreduce_fold(pxl_peer* peer, float* buf0, float* buf1, long n, int nrep, void* stream);
+/* BatchNorm backward of a multi-rank pass in ONE launch (sync_batchnorm/batchnorm.py's backward through _sync_master): sums =
+ * [sum(dz) | sum(dz * xhat)] of the local batch; dbeta += sums[0..C), dgamma += sums[C..2C) from the LOCAL values (either may be
+ * NULL), then sums <- all-reduce(sums).  Stands in for pxl_bn_param_grad + pxl_peer_allreduce_sum. */
+int pxl_peer_allreduce_bnbwd(pxl_peer* peer, float* sums, int C, float* dgamma, float* dbeta, void* stream);
 int pxl_peer_allreduce_hook(void* user, float* buf, int n, void* stream);      /* pxl_allreduce_fn signature */
 /* *status = 0, or k > 0: an exchange gave up waiting for rank k-1 (its result is invalid).  Synchronises the device. */
 int pxl_peer_status(pxl_peer* peer, int* status);

@@ -180,6 +180,7 @@ SIGNATURES = {
     "pxl_peer_destroy": (None, [_P]),
     "pxl_peer_allreduce_sum": (_I, [_P, _P, _L, _P]),
     "pxl_peer_allreduce_fold": (_I, [_P, _P, _P, _L, _I, _P]),
+    "pxl_peer_allreduce_bnbwd": (_I, [_P, _P, _I, _P, _P, _P]),
     "pxl_peer_allreduce_hook": (_I, [_P, _P, _I, _P]),
     "pxl_peer_status": (_I, [_P, C.POINTER(_I)]),
     "pxl_net_create": (_I, [_I, _I, C.POINTER(Op), _I, C.POINTER(BnDesc), _I, _I, C.POINTER(_P)]),

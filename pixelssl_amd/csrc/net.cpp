@@ -51,6 +51,7 @@ int pxl_conv_wgrad_dma_eligible(const pxl_conv_desc* d, const float* in_scale);
 struct pxl_peer;
 int pxl_peer_allreduce_hook(void* user, float* buf, int n, void* stream);
 int pxl_peer_allreduce_fold(pxl_peer* p, float* buf0, float* buf1, long n, int nrep, void* stream);
+int pxl_peer_allreduce_bnbwd(pxl_peer* p, float* sums, int C, float* dgamma, float* dbeta, void* stream);
 }
 
 namespace {
@@ -1872,11 +1873,16 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
           if (training && n->sync && n->world > 1) {
             // affine gradients from the LOCAL sums (the gradient all-reduce averages them over the ranks), then
             // the batch-mean terms of dy from the all-reduced sums
-            rc = pxl_bn_param_grad(b.d.C, fat(scratch, b.bsum_off), dgam, dbet, stream);
-            if (rc != PXL_OK) return rc;
+            if (n->sync == &pxl_peer_allreduce_hook) {       // both in one launch on the peer-mapped path
+              rc = pxl_peer_allreduce_bnbwd(reinterpret_cast<pxl_peer*>(n->sync_user), fat(scratch, b.bsum_off), b.d.C, dgam, dbet, stream);
+              if (rc != PXL_OK) return rc;
+            } else {
+              rc = pxl_bn_param_grad(b.d.C, fat(scratch, b.bsum_off), dgam, dbet, stream);
+              if (rc != PXL_OK) return rc;
+              rc = n->sync(n->sync_user, fat(scratch, b.bsum_off), 2 * b.d.C, stream);
+              if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_backward: SyncBN all-reduce hook failed (%d)", rc);
+            }
             dgam = dbet = nullptr;
-            rc = n->sync(n->sync_user, fat(scratch, b.bsum_off), 2 * b.d.C, stream);
-            if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_backward: SyncBN all-reduce hook failed (%d)", rc);
           }
           rc = pxl_bn_bwd_apply_fused(dt, M, tout.Cp, dy_in, at(arena, tout.off), coef, fat(scratch, b.bsum_off),
                                       (float)b.M * n->world, training, b.relu, dgam, dbet, dy, stream);

@@ -30,8 +30,12 @@ struct PeerArgs {
 // The logical vector is [buf0[0..n_each) | buf1[0..n_each)] (buf1 == nullptr: one vector); this launch exchanges its elements
 // base .. base + m.  nrep > 1: the operands are statistics replicas [nrep][n_each] that are folded on the way in (what
 // pxl_bn_fold_replicas did in a launch of its own); the all-reduced sum lands in replica 0.
+// add_lo / add_hi (optional, single-vector exchanges): the LOCAL value of element g is also accumulated into add_lo[g] for
+// g < n_each / 2 and into add_hi[g - n_each / 2] above -- the BatchNorm backward's d(beta) += sum(dz), d(gamma) += sum(dz * xhat),
+// which the multi-rank pass takes from the local sums before they are all-reduced (pxl_bn_param_grad's launch).
 __global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a, float* __restrict__ buf0, float* __restrict__ buf1,
-                                                             int n_each, int nrep, int base, int m, unsigned epoch) {
+                                                             int n_each, int nrep, int base, int m, unsigned epoch,
+                                                             float* __restrict__ add_lo, float* __restrict__ add_hi) {
   const int par = epoch & 1u;
   const size_t set = (size_t)par * a.world * a.slot;
   // sticky abort: once an exchange of this context has given up on a peer, every later one posts its words (the peers may
@@ -44,6 +48,8 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a, f
     float* const src = g < n_each ? buf0 + g : buf1 + (g - n_each);
     float v = src[0];
     for (int r = 1; r < nrep; ++r) v += src[(size_t)r * n_each];
+    if (g < n_each / 2) { if (add_lo != nullptr) add_lo[g] += v; }
+    else if (g < n_each) { if (add_hi != nullptr) add_hi[g - n_each / 2] += v; }
     // my element into my slot of every rank's buffer (my own included: the sum below reads every slot the same way)
     const unsigned long long word = ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v);
     for (int r = 0; r < a.world; ++r)
@@ -149,7 +155,8 @@ extern "C" void pxl_peer_destroy(pxl_peer* p) {
 }
 
 namespace {
-int peer_exchange(pxl_peer* p, float* buf0, float* buf1, long n_each, int nrep, void* stream) {
+int peer_exchange(pxl_peer* p, float* buf0, float* buf1, long n_each, int nrep, void* stream, float* add_lo = nullptr,
+                  float* add_hi = nullptr) {
   PXL_REQUIRE(p->opened || p->world == 1, "peer_allreduce: peer buffers not opened (pxl_peer_open)");
   PeerArgs a;
   for (int r = 0; r < MAXW; ++r) a.slots[r] = r < p->world ? reinterpret_cast<unsigned long long*>(p->mapped[r]) : nullptr;
@@ -162,7 +169,7 @@ int peer_exchange(pxl_peer* p, float* buf0, float* buf1, long n_each, int nrep, 
     p->epoch += 1;
     if (p->epoch == 0) p->epoch = 2;            // 0 is what the zero-filled buffer carries; keep the parity sequence
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3(m > 1024 ? 4 : 1), dim3(256), 0, s, a, buf0, buf1, (int)n_each, nrep, (int)off, m,
-                       p->epoch);
+                       p->epoch, add_lo, add_hi);
   }
   PXL_LAUNCH_CHECK();
   return PXL_OK;
@@ -183,6 +190,14 @@ extern "C" int pxl_peer_allreduce_sum(pxl_peer* p, float* buf, long n, void* str
 extern "C" int pxl_peer_allreduce_fold(pxl_peer* p, float* buf0, float* buf1, long n, int nrep, void* stream) {
   PXL_REQUIRE(p && buf0 && n > 0 && n < (1L << 29) && nrep >= 1, "peer_allreduce_fold: bad argument");
   return peer_exchange(p, buf0, buf1, n, nrep, stream);
+}
+
+// BatchNorm backward, multi-rank: sums = [sum(dz) | sum(dz * xhat)] ([2C], local).  dbeta += sums[0..C), dgamma += sums[C..2C)
+// from the LOCAL values (the gradient all-reduce averages the parameter gradients over the ranks), then sums <- all-reduce(sums)
+// for the batch-mean terms of the data gradient -- pxl_bn_param_grad + pxl_peer_allreduce_sum in one launch.
+extern "C" int pxl_peer_allreduce_bnbwd(pxl_peer* p, float* sums, int C, float* dgamma, float* dbeta, void* stream) {
+  PXL_REQUIRE(p && sums && C > 0, "peer_allreduce_bnbwd: bad argument");
+  return peer_exchange(p, sums, nullptr, 2L * C, 1, stream, dbeta, dgamma);
 }
 
 extern "C" int pxl_peer_allreduce_hook(void* user, float* buf, int n, void* stream) {

@@ -116,6 +116,17 @@ def _peer_worker(rank, world, port, q):
         if single:
             _lib.check(h.pxl_peer_allreduce_fold(a, w4.data_ptr(), None, n, 4, torch.cuda.current_stream().cuda_stream))
         bad += int(not torch.equal(v4[0], rv)) + int(not torch.equal(w4[0], rw))
+    # BatchNorm-backward form: local sums accumulated into the parameter gradients, then all-reduced, in one launch
+    for k in range(12):
+        C = (64, 256, 2048, 40)[k % 4]
+        sums = torch.randn(2 * C, device="cuda", generator=g)
+        dgam, dbet = torch.randn(C, device="cuda", generator=g), torch.randn(C, device="cuda", generator=g)
+        want_g, want_b, want_s = dgam + sums[C:], dbet + sums[:C], sums.clone()
+        dist.all_reduce(want_s)
+        _lib.check(h.pxl_peer_allreduce_bnbwd(a, sums.data_ptr(), C, dgam.data_ptr() if k % 3 else None, dbet.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream))
+        bad += int(not torch.equal(sums, want_s)) + int(not torch.equal(dbet, want_b))
+        bad += int(not torch.equal(dgam, want_g)) if k % 3 else 0
     pdist.check_peers()
     # time per exchange, 2C = 2048 floats (a layer-3 BatchNorm), back to back on one stream
     v = torch.randn(2048, device="cuda", generator=g)
