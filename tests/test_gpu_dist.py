@@ -26,7 +26,7 @@ def _worker(rank, world, port, q, peer="1"):
     # 0.25 MB gradient buckets: the 8.9 M-parameter test trunk is exchanged in > 10 buckets issued from inside the backward
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), PXL_FORCE_DEVICE="0", PXL_DIST_BACKEND="gloo", PXL_AUTOTUNE="0",
-                      PXL_GRAD_BUCKET_MB="0.25")
+                      PXL_GRAD_BUCKET_MB=os.environ.get("PXL_TEST_BUCKET_MB", "0.25"))      # (override: tools/diag_2rank.py)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     sys.path.insert(0, os.path.join(root, "oracle"))
@@ -55,7 +55,8 @@ def _worker(rank, world, port, q, peer="1"):
         # numpy arrays are pickled by value (torch tensors would be passed as shared-memory handles that die with the worker)
         out[str(dtype)] = dict(logits=logits.detach().float().cpu().numpy(), grads=core.flat.grads.detach().cpu().numpy().copy(),
                                rmean=core.flat.running.detach().cpu().numpy().copy())
-        assert core.grad_buckets() > 10, core.grad_buckets()         # the exchange ran bucketed, inside pxl_net_backward
+        if "PXL_TEST_BUCKET_MB" not in os.environ:
+            assert core.grad_buckets() > 10, core.grad_buckets()     # the exchange ran bucketed, inside pxl_net_backward
         # a second backward into the same (already averaged) buffers: accumulation stays exact (mean of identical = same)
         logits2, _, _ = core(x[sl].cuda())
         PF.cross_entropy_per_sample(logits2, gt[sl].cuda(), 255).mean().backward()
@@ -257,8 +258,12 @@ def _compare_with_full_batch(res, state, x, gt, rel):
         r0, r1 = ({k: torch.from_numpy(v) for k, v in res[r][str(dtype)].items()} for r in (0, 1))
         # both ranks hold the same averaged gradient, equal to the full-batch gradient
         assert rel(r0["grads"], r1["grads"]) < 1e-6
-        # accumulating a second backward on top of the exchanged buffers doubles the gradient (2 x the same batch)
-        assert rel(r0["grads2"], 2 * r0["grads"]) < (2e-3 if dtype == torch.float32 else 6e-2) and rel(r0["grads2"], r1["grads2"]) < 1e-6
+        # accumulating a second backward on top of the exchanged buffers doubles the gradient (2 x the same batch).  The fp32
+        # bar is 2e-2, not 1e-5: two runs of the SAME fp32 step differ by one of a few discrete amounts -- 3e-6, 5.6e-4, 2.7e-3
+        # (tools/diag_2rank.py: single-rank run-to-run 5.62e-4; the same levels in every configuration, one or two ranks) -- a
+        # pre-activation of this seeded trunk within an ulp of zero at the layer4.0 / layer3.0 joins takes one ReLU branch or
+        # the other depending on the order of the fp32 statistics atomics; a lost or doubled contribution would score ~0.5
+        assert rel(r0["grads2"], 2 * r0["grads"]) < (2e-2 if dtype == torch.float32 else 6e-2) and rel(r0["grads2"], r1["grads2"]) < 1e-6
         e_g = rel(r0["grads"], core.flat.grads.detach().cpu())
         e_l = rel(torch.cat([r0["logits"], r1["logits"]]), logits.detach().cpu())
         e_r = rel(r0["rmean"], core.flat.running.detach().cpu())
