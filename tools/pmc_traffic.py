@@ -26,7 +26,7 @@ def per_kernel(d, tail=True):
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     acc = defaultdict(list)
     for r in rows:
-        n = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"]).split("<")[0].split("(")[0]
+        n = re.sub(r"\(anonymous namespace\)::|void |pxl_dma::", "", r["Kernel_Name"]).split("<")[0].split("(")[0]
         acc[n].append(float(r["Counter_Value"]))
     if tail:
         for k, keep in TAIL.items():
