@@ -178,7 +178,9 @@ def native_comms():
 
 _peer = {"ok": None, "ctxs": [], "hook": None}
 PEER_SLOT_FLOATS = 8192            # 2 networks x 2 * 2048 channels: the widest BatchNorm of a student || teacher pair in one exchange
-PEER_TIMEOUT_MS = int(os.environ.get("PXL_PEER_TIMEOUT_MS", "2000"))       # one exchange is ~6 us; 2 s is a dead (or wedged) peer
+PEER_TIMEOUT_MS = int(os.environ.get("PXL_PEER_TIMEOUT_MS", "10000"))      # one exchange is ~6 us; 10 s is a dead (or wedged) peer.  (The
+# ranks are aligned after every per-rank autotune -- align_after_tune below -- so start-up skew does not come near it; a time-out is
+# sticky and costs its 10 s once.)
 PEER_POLL_STEPS = int(os.environ.get("PXL_PEER_POLL_STEPS", "20"))
 
 
@@ -239,6 +241,15 @@ def open_peer_context():
     if _peer["hook"] is None:
         _peer["hook"] = ctypes.cast(h.pxl_peer_allreduce_hook, _lib.ALLREDUCE_FN)
     return ctx
+
+
+def align_after_tune():
+    """Host barrier after a per-rank autotune (engine: pxl_net_tune / pxl_net_tune_pair time ~3000 candidate launches, a few seconds
+    whose length differs from rank to rank): without it the first Sync-BN exchange of the faster rank spins for the difference, and a
+    difference beyond the exchange time-out would retire the peer-mapped path for the whole run.  COLLECTIVE: every rank plans and tunes
+    the same shapes in the same order."""
+    if is_distributed() and os.environ.get("PXL_TUNE_BARRIER", "1") != "0":
+        dist.barrier()
 
 
 def peer_contexts():

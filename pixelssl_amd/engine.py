@@ -526,6 +526,8 @@ class SegNetCore(nn.Module):
                                      stream_ptr()))
             self._store.grads.copy_(keep)
             del arena
+            from . import dist as _pdist
+            _pdist.align_after_tune()
         pl.tuned = True
 
     def _pack_stream(self):
@@ -887,6 +889,8 @@ def forward_deferred_pair(core_a, xa, core_b, xb):
                                       ptr(tmp[0]), ptr(tmp[1]), tmp[0].numel(), tmp[1].numel(), stream_ptr()))
         del tmp
         pa.pair_tuned_with = pb.net
+        from . import dist as _pdist
+        _pdist.align_after_tune()
     check(lib().pxl_net_forward_pair(pa.net, pb.net, ptr(core_a._store.params), ptr(core_b._store.params), ptr(pa.packed), ptr(pb.packed),
                                      ptr(core_a._store.running), ptr(core_b._store.running), ptr(xs[0]), ptr(xs[1]), None, None, None, None,
                                      ptr(arenas[0]), ptr(arenas[1]), arenas[0].numel(), arenas[1].numel(), int(flags[0][0]), int(flags[1][0]),
