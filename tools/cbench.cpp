@@ -42,6 +42,9 @@ static const Shape SHAPES[] = {
     {"l3.3x3", 256, 256, 3, 1, 1, 33, 22},    {"l4.1x1a", 1024, 512, 1, 1, 1, 33, 1},   {"l4.3x3d2", 512, 512, 3, 1, 2, 33, 1},
     {"l4.1x1b", 512, 2048, 1, 1, 1, 33, 3},   {"l4.ds", 1024, 2048, 1, 1, 1, 33, 1},    {"l4.1x1c", 2048, 512, 1, 1, 1, 33, 2},
     {"l4.3x3d4", 512, 512, 3, 1, 4, 33, 1},
+    // GCT flaw detector (4x4 kernels, pad 1; ssl_gct.py:539-585): only with --only fd
+    {"fd.conv2", 64, 128, 4, 2, 1, 256, 0},   {"fd.conv2_1", 128, 128, 4, 1, 1, 128, 0}, {"fd.conv3", 128, 256, 4, 2, 1, 127, 0},
+    {"fd.conv3_1", 256, 256, 4, 1, 1, 63, 0}, {"fd.conv4", 256, 512, 4, 2, 1, 62, 0},    {"fd.conv4_1", 512, 512, 4, 1, 1, 31, 0},
 };
 
 static int pitch(int c) { return c <= 8 ? 8 : (c + 31) / 32 * 32; }
@@ -640,7 +643,7 @@ int main(int argc, char** argv) {
   printf("%-9s %5s %5s %1s %1s %1s %4s %6s |", "shape", "Cin", "Cout", "k", "s", "d", "H", "M");
   printf(" mode:cfg us (TFLOP/s)%s\n", dual ? " [pair on two streams: us per pair]" : "");
   for (const Shape& sh : SHAPES) {
-    if (!wanted(sh.name)) continue;
+    if (!wanted(sh.name) || (only.empty() && strncmp(sh.name, "fd.", 3) == 0)) continue;
     Problem p0 = make_problem(sh, B, 1), p1;
     if (dual || pair) p1 = make_problem(sh, B, 2);
     printf("%-9s %5d %5d %1d %1d %1d %4d %6d |", sh.name, sh.cin, sh.cout, sh.k, sh.s, sh.d, sh.H, p0.M);
