@@ -622,6 +622,9 @@ int pxl_net_tune_pair(pxl_net* n0, pxl_net* n1, const float* params0, const floa
  * (momentum 1 - (1-m)^times).  For a caller that would run the SAME forward twice with unchanged weights -- SSLGCT's step-0
  * no-grad pass and its step-1 pass (ssl_gct.py:196-200, 403) -- and runs it once.  times = 1: the plain update. */
 int pxl_net_set_bn_repeat(pxl_net* net, int times);
+/* enable = 1: pxl_net_tune times every forward tile candidate with TWO copies of the launch in flight on two streams -- for a
+ * network whose forward runs beside a copy of itself (SSLMT's student || teacher, ssl_mt.py:166-180).  Before the first pass. */
+int pxl_net_set_tune_dual(pxl_net* net, int enable);
 int pxl_net_pairs(const pxl_net* n);
 /* Sync-BN statistics exchanges the last paired pass issued for BOTH networks in one launch (pxl_peer_allreduce_fold). */
 int pxl_net_pair_syncs(const pxl_net* n);

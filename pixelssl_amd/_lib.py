@@ -201,6 +201,7 @@ SIGNATURES = {
     "pxl_net_tune_pair": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _Z, _P]),
     "pxl_net_pairs": (_I, [_P]),
     "pxl_net_set_bn_repeat": (_I, [_P, _I]),
+    "pxl_net_set_tune_dual": (_I, [_P, _I]),
     "pxl_net_pair_syncs": (_I, [_P]),
     "pxl_net_latent": (_I, [_P, _P, _P, _P]),
     "pxl_net_latent_shape": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),

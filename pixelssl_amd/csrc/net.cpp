@@ -186,6 +186,7 @@ struct pxl_net {
   int grad_buckets_last = 0;       // buckets issued by the last backward (tests / bench)
   int pairs_last = 0;              // convolutions the last paired forward issued as one launch for both networks
   int pair_syncs_last = 0;         // ... Sync-BN exchanges it issued for both networks at once
+  int tune_dual = -1;              // pxl_net_set_tune_dual: forward tiles timed with two copies in flight (-1: PXL_TUNE_DUAL, default off)
   int bn_repeat = 1;               // running statistics updated as if this pass ran bn_repeat times (pxl_net_set_bn_repeat)
   float eff_momentum(float m) const { return bn_repeat <= 1 ? m : 1.f - powf(1.f - m, (float)bn_repeat); }
   bool pair_sync = getenv("PXL_PAIR_SYNC") == nullptr || getenv("PXL_PAIR_SYNC")[0] != '0';
@@ -810,6 +811,25 @@ float time_launch(F&& fn, hipStream_t s, hipEvent_t a, hipEvent_t b, int reps) {
   }
   return best;
 }
+// the same with TWO copies of the launch in flight, one per stream (what the MT forward does with student || teacher: a tile that
+// is best alone is not always best next to a copy of itself -- tools/cbench --dual): returns the time until both are done
+template <typename F>
+float time_launch_dual(F&& fn, hipStream_t s, hipStream_t s2, hipEvent_t a, hipEvent_t b, hipEvent_t b2, int reps) {
+  if (fn(s) != PXL_OK || fn(s2) != PXL_OK) return -1.f;
+  if (hipStreamSynchronize(s2) != hipSuccess) return -1.f;
+  float best = 1e30f;
+  for (int r = 0; r < reps; ++r) {
+    if (hipEventRecord(a, s) != hipSuccess || hipStreamWaitEvent(s2, a, 0) != hipSuccess) return -1.f;
+    if (fn(s) != PXL_OK || fn(s2) != PXL_OK) return -1.f;
+    if (hipEventRecord(b, s) != hipSuccess || hipEventRecord(b2, s2) != hipSuccess) return -1.f;
+    if (hipEventSynchronize(b) != hipSuccess || hipEventSynchronize(b2) != hipSuccess) return -1.f;
+    float m1 = 0.f, m2 = 0.f;
+    if (hipEventElapsedTime(&m1, a, b) != hipSuccess || hipEventElapsedTime(&m2, a, b2) != hipSuccess) return -1.f;
+    const float ms = m1 > m2 ? m1 : m2;
+    if (ms < best) best = ms;
+  }
+  return best;
+}
 }  // namespace
 
 namespace {
@@ -845,6 +865,18 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
   PXL_CHECK_HIP(hipEventCreate(&b));
   const int reps = 3;
   int rc_all = PXL_OK;
+  // forward tiles timed with two copies of the launch in flight on two streams, for networks whose forward runs next to a copy of
+  // itself (the MT student || teacher on two streams: pxl_net_set_tune_dual; PXL_TUNE_DUAL=0 / 1 overrides).  Measured (DESIGN.md 4,
+  // round 4): MT 12.35 -> 12.25 ms; SupOnly (nothing runs beside its forward) 7.27 -> 7.49 ms, which is why it is per network
+  hipStream_t dual_s = nullptr;
+  hipEvent_t b2 = nullptr;
+  const char* td_env = getenv("PXL_TUNE_DUAL");
+  if (td_env != nullptr ? td_env[0] == '1' : n->tune_dual == 1) {
+    // (the placement pool's SIDE stream: probed to sit on another hardware queue than the caller's, csrc/streams.hip)
+    dual_s = reinterpret_cast<hipStream_t>(pxl_stream_role(PXL_STREAM_SIDE));
+    if (dual_s == s) dual_s = reinterpret_cast<hipStream_t>(pxl_stream_role(PXL_STREAM_WGRAD));
+    PXL_CHECK_HIP(hipEventCreate(&b2));
+  }
   // PXL_TUNE_CFGS="11,17,18": restrict the LDS-DMA tile candidates (experiments: the tuner times every launch ALONE, while
   // in the step two or three streams share the CUs' LDS -- smaller footprints co-reside better); unset = all of them
   std::vector<int> allow;
@@ -890,6 +922,9 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
                                                           stats, &bin, bi.relu, n->pack_dgrad ? at(arena, bi.z_off) : nullptr, stream);
                                   return rc1; }, s, a, b, reps);
           if (t < 0 && rc1 == PXL_ERR_UNSUPPORTED) continue;        // this tile + the coefficient table do not fit
+        } else if (dual_s != nullptr && dma && !op.ws_bytes) {
+          t = time_launch_dual([&](hipStream_t st) { return pxl_conv_igemm(&q, cin.ptr, at(packed, op.wf_off), at(arena, tout.off), sc, sh, bias,
+                                                                           nullptr, stats, nullptr, 0, st); }, s, dual_s, a, b, b2, reps);
         } else {
           t = time_launch([&]() { return pxl_conv_igemm(&q, cin.ptr, at(packed, op.wf_off), at(arena, tout.off),
                                                         sc, sh, bias, nullptr, stats, op.ws_bytes ? at(arena, op.ws_off) : nullptr,
@@ -939,6 +974,7 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
   }
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);
+  if (b2 != nullptr) (void)hipEventDestroy(b2);
   if (rc_all != PXL_OK) return pxl_set_error(rc_all, "net_tune: a candidate launch failed: %s", pxl_last_error());
   return PXL_OK;
 }
@@ -1397,6 +1433,15 @@ extern "C" int pxl_net_set_wgrad(pxl_net* net, int enable) {
 extern "C" int pxl_net_set_bn_repeat(pxl_net* net, int times) {
   PXL_REQUIRE(net && times >= 1 && times <= 16, "net_set_bn_repeat: bad argument");
   net->bn_repeat = times;
+  return PXL_OK;
+}
+
+// enable = 1: pxl_net_tune times every forward tile candidate with TWO copies of the launch in flight on two streams and keeps the
+// tile whose pair finishes first -- for a network whose forward pass runs beside a copy of itself (Mean Teacher's student ||
+// teacher on two streams).  Call before the first forward pass of a shape (the pass that tunes).
+extern "C" int pxl_net_set_tune_dual(pxl_net* net, int enable) {
+  PXL_REQUIRE(net, "net_set_tune_dual: null net");
+  net->tune_dual = enable != 0 ? 1 : 0;
   return PXL_OK;
 }
 

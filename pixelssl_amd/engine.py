@@ -518,6 +518,8 @@ class SegNetCore(nn.Module):
             if pl.wt_ready is not None:
                 torch.cuda.current_stream().wait_event(pl.wt_ready)
             # per-shape tile selection, measured on this GPU (csrc/net.cpp: pxl_net_tune)
+            if getattr(self, "tune_dual", False):
+                check(lib().pxl_net_set_tune_dual(pl.net, 1))
             arena = torch.zeros(pl.arena_bytes, device=self._device, dtype=torch.uint8)
             pl.scratch.zero_()
             keep = self._store.grads.clone()

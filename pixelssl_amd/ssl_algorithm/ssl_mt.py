@@ -205,6 +205,12 @@ class SSLMT(ssl_base._SSLBase):
                 s_head, t_head = pair
                 return self._seam_losses_and_update(s_head, t_head, s_inp, l_gt, lbs, ramp, cur_step)
         side = self._teacher_stream()
+        if side is not None:
+            # the two forward passes run the same launches side by side: their tiles are tuned that way (engine: tune_dual)
+            for m_ in (self.s_model, self.t_model):
+                core_ = getattr(m_.module, 'model', None)
+                if core_ is not None and hasattr(core_, '_pb') and not getattr(core_, 'tune_dual', False):
+                    core_.tune_dual = True
 
         def teacher_pass():
             with torch.no_grad():
