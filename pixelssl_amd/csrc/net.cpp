@@ -830,6 +830,26 @@ float time_launch_dual(F&& fn, hipStream_t s, hipStream_t s2, hipEvent_t a, hipE
   }
   return best;
 }
+// the candidate's own duration on stream s while `load` (three launches) keeps stream s2 busy: data-gradient tiles are
+// chosen beside the weight gradient that runs next to them in the backward pass
+template <typename F, typename L>
+float time_launch_loaded(F&& fn, L&& load, hipStream_t s, hipStream_t s2, hipEvent_t a, hipEvent_t b, hipEvent_t b2, int reps) {
+  if (fn() != PXL_OK || load(s2) != PXL_OK) return -1.f;
+  if (hipStreamSynchronize(s2) != hipSuccess) return -1.f;
+  float best = 1e30f;
+  for (int r = 0; r < reps; ++r) {
+    if (hipEventRecord(b2, s) != hipSuccess || hipStreamWaitEvent(s2, b2, 0) != hipSuccess) return -1.f;
+    for (int k = 0; k < 3; ++k) if (load(s2) != PXL_OK) return -1.f;
+    if (hipEventRecord(a, s) != hipSuccess) return -1.f;
+    if (fn() != PXL_OK) return -1.f;
+    if (hipEventRecord(b, s) != hipSuccess) return -1.f;
+    if (hipEventSynchronize(b) != hipSuccess || hipStreamSynchronize(s2) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.f;
+    if (ms < best) best = ms;
+  }
+  return best;
+}
 }  // namespace
 
 namespace {
@@ -871,7 +891,9 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
   hipStream_t dual_s = nullptr;
   hipEvent_t b2 = nullptr;
   const char* td_env = getenv("PXL_TUNE_DUAL");
-  if (td_env != nullptr ? td_env[0] == '1' : n->tune_dual == 1) {
+  // PXL_TUNE_BWD_LOAD=1 (experiment): data-gradient tiles timed beside the convolution's weight gradient on a second stream
+  const bool bwd_load = getenv("PXL_TUNE_BWD_LOAD") != nullptr && getenv("PXL_TUNE_BWD_LOAD")[0] == '1';
+  if ((td_env != nullptr ? td_env[0] == '1' : n->tune_dual == 1) || bwd_load) {
     // (the placement pool's SIDE stream: probed to sit on another hardware queue than the caller's, csrc/streams.hip)
     dual_s = reinterpret_cast<hipStream_t>(pxl_stream_role(PXL_STREAM_SIDE));
     if (dual_s == s) dual_s = reinterpret_cast<hipStream_t>(pxl_stream_role(PXL_STREAM_WGRAD));
@@ -935,26 +957,6 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
       }
       op.fwd.tile_cfg = best_cfg;
     }
-    // data gradient
-    if (d.need_dgrad && n->pack_dgrad) {
-      int best_cfg = -1; float best = 1e30f;
-      const bool dma = pxl_conv_dma_eligible(&op.bwd, nullptr, nullptr) != 0;
-      for (int cfg = dma ? 8 : 0; cfg < (dma ? 36 : 8); ++cfg) {
-        if (!dma && (cfg & 3) == 3 && tin.Cp > 64) continue;
-        if (dma && cfg >= 12 && cfg < 16) continue;
-        if (dma && n->dtype == PXL_F32 && cfg >= 20) continue;
-        if (dma && cfg >= 20 && cfg != 29 && tin.Cp < 128) continue;
-        if (dma && cfg == 35 && tin.Cp < 256) continue;
-        if (dma && !allowed(cfg)) continue;
-        pxl_conv_desc q = op.bwd; q.tile_cfg = cfg;
-        float t = time_launch([&]() { return pxl_conv_igemm(&q, at(scratch, tout.goff), at(packed, op.wt_off), at(scratch, tin.goff),
-                                                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream); },
-                              s, a, b, reps);
-        if (t < 0) { rc_all = PXL_ERR_HIP; continue; }
-        if (t < best) { best = t; best_cfg = cfg; }
-      }
-      op.bwd.tile_cfg = best_cfg;
-    }
     // weight gradient (per tap group)
     for (int g = 0; g < d.ngroups && n->pack_dgrad; ++g) {
       int best_cfg = -1; float best = 1e30f;
@@ -970,6 +972,35 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
         if (t < best) { best = t; best_cfg = cfg; }
       }
       op.grp[g].tile_cfg = best_cfg;
+    }
+    // data gradient
+    if (d.need_dgrad && n->pack_dgrad) {
+      int best_cfg = -1; float best = 1e30f;
+      const bool dma = pxl_conv_dma_eligible(&op.bwd, nullptr, nullptr) != 0;
+      for (int cfg = dma ? 8 : 0; cfg < (dma ? 36 : 8); ++cfg) {
+        if (!dma && (cfg & 3) == 3 && tin.Cp > 64) continue;
+        if (dma && cfg >= 12 && cfg < 16) continue;
+        if (dma && n->dtype == PXL_F32 && cfg >= 20) continue;
+        if (dma && cfg >= 20 && cfg != 29 && tin.Cp < 128) continue;
+        if (dma && cfg == 35 && tin.Cp < 256) continue;
+        if (dma && !allowed(cfg)) continue;
+        pxl_conv_desc q = op.bwd; q.tile_cfg = cfg;
+        auto cand = [&]() { return pxl_conv_igemm(&q, at(scratch, tout.goff), at(packed, op.wt_off), at(scratch, tin.goff),
+                                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream); };
+        float t;
+        if (bwd_load && dual_s != nullptr && dma && n->wgrad_on) {
+          // beside this convolution's (already tuned) weight gradient, as in the backward pass
+          const int creal = op.patch ? op.patch_K : d.cin;
+          t = time_launch_loaded(cand, [&](hipStream_t st) { return pxl_conv_wgrad(&op.grp[0], cin.ptr, sc, sh, at(scratch, tout.goff),
+                                                                                 grads + d.w_off[0], creal, creal, st); },
+                                 s, dual_s, a, b, b2, reps);
+        } else {
+          t = time_launch(cand, s, a, b, reps);
+        }
+        if (t < 0) { rc_all = PXL_ERR_HIP; continue; }
+        if (t < best) { best = t; best_cfg = cfg; }
+      }
+      op.bwd.tile_cfg = best_cfg;
     }
   }
   (void)hipEventDestroy(a);
