@@ -165,6 +165,11 @@ extern "C" int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy,
 }
 
 namespace {
+// PXL_S2_CLASSES=0: stride-2 data gradients as ONE launch that walks every tap (rounds 1-3), for A/B runs
+bool s2_classes_on() {
+  static const bool on = getenv("PXL_S2_CLASSES") == nullptr || getenv("PXL_S2_CLASSES")[0] != '0';
+  return on;
+}
 // (LDS bytes of a tile configuration: the coefficient table of a BN-on-load launch must fit next to the ring -- checked before
 // a launch is captured for pairing, where it could no longer fall back)
 size_t dma_cfg_ring_bytes(int cfg) {
@@ -237,7 +242,8 @@ int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes,
   a.w_bytes = (unsigned)((size_t)d->Kreal * a.Ktot * es);
   std::memset(&a.g1, 0, sizeof(a.g1));
   for (int t = 0; t < 64; ++t)
-    a.taps[t] = t < d->ntaps ? (((int)d->dy[t]) << 16) | (((int)d->dx[t]) & 0xffff) : 0;
+    a.taps[t] = t < d->ntaps ? tap_encode(t, d->dy[t], d->dx[t]) : 0;
+  a.sub_mul = 1; a.sub_py = a.sub_px = 0; a.out_H = d->Ho; a.out_W = d->Wo;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // taps at offset (0,0) only and every output pixel inside the input: no bounds logic at all
   bool gather = false;
@@ -253,14 +259,47 @@ int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes,
     if (cfg < 8) cfg = a.Cout <= 64 ? 17 : 18;        // MFMA-bound: the small 2-stage tiles (3 workgroups per CU)
     if (cfg >= 12 && cfg < 16) cfg -= 4;
     if (cfg >= 20) cfg = 16 + (cfg & 3);
-    return pxl_dma_f32_launch(cfg, a, gather, sk, ws_bytes, s);
-  }
-  if (cfg < 8) {
+  } else if (cfg < 8) {
     const long t128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 128);
     if (a.Cout <= 64) cfg = 9;
     else if (t128 >= 384) cfg = 8;
     else cfg = 9;
   }
+  // (bf16 1x1 stride-2: three read-back-only launches cost what the one zero-filled K loop costs -- 45.6 vs 43.0 us, 36.5 vs 38.2:
+  // kept as one launch; fp32: 283 -> 127 us)
+  if (d->div == 2 && s2_classes_on() && (f32 || d->ntaps >= 4)) {
+    // Data gradient of a stride-2 convolution, one launch per output-parity class.  An output pixel (y, x) only receives the
+    // taps with (y + dy) and (x + dx) even: 1 / 2 / 2 / 4 of a 3x3's nine, 4 each of a 4x4's sixteen.  The single-launch form
+    // walks EVERY tap for every pixel and lets the parity test zero 3 of 4 (harmless while the bf16 loop waits for the DMA
+    // path anyway, 4x the MFMA time in fp32 and on the large 4x4 detector layers); here each class is its own sub-grid launch
+    // over exactly its taps, writing rows (2 oy + py, 2 ox + px) of the same output tensor.
+    int count[4] = {0, 0, 0, 0};
+    for (int t = 0; t < d->ntaps; ++t) ++count[(d->dy[t] & 1) * 2 + (d->dx[t] & 1)];
+    // class (py, px) takes the taps with dy parity == py and dx parity == px.  A class without taps (three of the four of a 1x1
+    // stride-2 convolution) is a launch with a K loop of ZERO steps: the read-back pass alone (zeros + addend, the fused sums)
+    if (a.ws == nullptr) {
+      const int ksteps_per_tap = a.Cin / (f32 ? 32 : 64);
+      for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+          const int Hs = (d->Ho - py + 1) / 2, Ws = (d->Wo - px + 1) / 2;
+          if (Hs <= 0 || Ws <= 0) continue;
+          DmaArgs c = a;
+          c.Ho = Hs; c.Wo = Ws; c.M = d->B * Hs * Ws;
+          c.sub_mul = 2; c.sub_py = py; c.sub_px = px;
+          int k = 0;
+          for (int t = 0; t < d->ntaps; ++t)
+            if ((d->dy[t] & 1) == py && (d->dx[t] & 1) == px) c.taps[k++] = tap_encode(t, d->dy[t], d->dx[t]);
+          for (int t = k; t < 64; ++t) c.taps[t] = 0;
+          c.nk = k * ksteps_per_tap;
+          if (k == 0) { c.taps[0] = a.taps[0]; k = 1; }        // (the prologue still issues its first tiles: any valid tap)
+          c.ntaps = k;
+          const int rc = f32 ? pxl_dma_f32_launch(cfg, c, true, 1, 0, s) : dma_dispatch(cfg, c, true, 1, 0, s, 1);
+          if (rc != PXL_OK) return rc;
+        }
+      return PXL_OK;
+    }
+  }
+  if (f32) return pxl_dma_f32_launch(cfg, a, gather, sk, ws_bytes, s);
   DmaCapture* cap = tl_capture;
   if (cap != nullptr && cap->armed && !cap->held && cfg >= 8 && cfg <= 35 && a.addend == nullptr && a.bn_y == nullptr &&
       a.fin.coef == nullptr && a.trace == nullptr && (a.ws == nullptr || sk == 1 || a.stats != nullptr)) {

@@ -73,6 +73,8 @@ __global__ __launch_bounds__(256, ((BM / 64) * (BN / 64) <= 2 ? 3 : 2)) void con
       int b, r, oy, ox;
       fast_divmod(m, HoWo, inv_howo, b, r);
       fast_divmod(r, p.Wo, inv_wo, oy, ox);
+      oy = oy * p.sub_mul + p.sub_py;                  // (sub-grid launches: the pixel this row stands for; else * 1 + 0)
+      ox = ox * p.sub_mul + p.sub_px;
       a_iy[q] = in ? oy * p.so : -(1 << 20);
       a_ix[q] = in ? ox * p.so : 0;
       a_img[q] = b * p.Hi * p.Wi * p.Cin * ES + chunk * 16;
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(256, ((BM / 64) * (BN / 64) <= 2 ? 3 : 2)) void con
   auto set_tap = [&](int t) {
     if constexpr (GATHER) {
       const int tp = p.taps[min(t, p.ntaps - 1)];
-      const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
+      const int dy = tap_dy(tp), dx = tap_dx(tp);
+      kwb = tap_wt(tp) * cin_bytes + kcb;            // this tap's slice of the weight row (a launch may walk a subset of the taps)
       const int tapoff = (dy * p.Wi + dx) * p.Cin * ES;
       if (p.div_shift == 0) {
 #pragma unroll
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256, ((BM / 64) * (BN / 64) <= 2 ? 3 : 2)) void con
       load_cvec<4>(p.bn_coef + 3 * p.Cout + n, bn_sh);
     }
   }
-  const unsigned out_bytes = (unsigned)((size_t)p.M * p.Cout * ES);
+  const unsigned out_bytes = p.sub_mul != 1 ? (unsigned)((size_t)p.B * p.out_H * p.out_W * p.Cout * ES) : (unsigned)((size_t)p.M * p.Cout * ES);
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.addend), 0, out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_bny = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bn_y), 0, out_bytes, 0x00020000);
@@ -259,7 +262,13 @@ __global__ __launch_bounds__(256, ((BM / 64) * (BN / 64) <= 2 ? 3 : 2)) void con
 #pragma unroll
     for (int q = 0; q < PG; ++q) {
       const int m = m0 + (g0 + q) * RPP + er;
-      vo[q] = (m < p.M && ncol) ? (unsigned)(((size_t)m * p.Cout + n) * ES) : EOOB;
+      size_t pix = (size_t)m;
+      if (p.sub_mul != 1) {               // row of a sub-grid launch -> pixel of the full tensor
+        const int b = m / HoWo, r = m - b * HoWo;
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        pix = ((size_t)b * p.out_H + oy * p.sub_mul + p.sub_py) * p.out_W + ox * p.sub_mul + p.sub_px;
+      }
+      vo[q] = (m < p.M && ncol) ? (unsigned)((pix * p.Cout + n) * ES) : EOOB;
     }
     if (has_add) {
 #pragma unroll
@@ -350,8 +359,8 @@ int launch_dma_f32(const DmaArgs& a, bool gather, int want_split, size_t ws_byte
     if (splitk > p.nk) splitk = p.nk;
     if (splitk < 1) splitk = 1;
   }
-  p.nk_per = cdiv(p.nk, splitk);
-  splitk = cdiv(p.nk, p.nk_per);
+  p.nk_per = p.nk > 0 ? cdiv(p.nk, splitk) : 0;
+  splitk = p.nk > 0 ? cdiv(p.nk, p.nk_per) : 1;          // (nk == 0: a read-back-only launch of a tap-less parity class)
   if (splitk > 1) PXL_CHECK_HIP(hipMemsetAsync(p.ws, 0, (size_t)p.M * p.Cout * sizeof(float), stream));
   else p.ws = nullptr;
   constexpr size_t smem = (size_t)f32_lds_bytes(BM, BN, NST);

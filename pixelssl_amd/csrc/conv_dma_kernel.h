@@ -73,8 +73,17 @@ struct DmaArgs {
     void* bin_z;
   } g1;
   unsigned* trace;   // TRACE kernels (tools/cbench): [workgroup][TRACE_WORDS] cycle stamps of wave 0, else unused
-  int taps[64];      // (dy << 16) | (dx & 0xffff)
+  // Output sub-grid (data gradient of a stride-2 convolution, one launch per output-parity class): row m of this launch is
+  // pixel (b, oy, ox) of a [B][Ho][Wo] SUB-grid and stands for pixel (oy * sub_mul + sub_py, ox * sub_mul + sub_px) of the
+  // [B][out_H][out_W] tensor -- for the gather (which taps of which source pixel) and for every row address of the read-back
+  // pass (output, addend, BN input, join mask).  sub_mul == 1: off.
+  int sub_mul, sub_py, sub_px, out_H, out_W;
+  int taps[64];      // (weight tap index << 24) | ((dy & 0xfff) << 12) | (dx & 0xfff): a launch may walk a SUBSET of the taps
 };
+__host__ __device__ inline int tap_encode(int wt, int dy, int dx) { return (int)(((unsigned)wt << 24) | (((unsigned)dy & 0xfffu) << 12) | ((unsigned)dx & 0xfffu)); }
+__device__ __forceinline__ int tap_dy(int tp) { return (tp << 8) >> 20; }
+__device__ __forceinline__ int tap_dx(int tp) { return (tp << 20) >> 20; }
+__device__ __forceinline__ unsigned tap_wt(int tp) { return (unsigned)tp >> 24; }
 
 // timeline probe (tools/cbench.cpp; never on the product path): per workgroup, words 0..63 = s_memtime stamps of wave 0
 // (0 entry, 1 prologue issued, 2 + k = end of K step k (first 52), then loop drained / tile staged / pass 0 / pass 1 / stores
@@ -195,6 +204,7 @@ struct EpiCtx {
   int er, ec, m0, M, Cout, n; bool ncol;
   __amdgpu_buffer_rsrc_t r_out, r_add, r_bny, r_msk;
   const float* bias; const float* bn_coef; int Kreal;
+  int sub_mul, sub_py, sub_px, sub_hw, sub_w, out_H, out_W;      // output sub-grid (DmaArgs): generic (EM < 0) read-back only
 };
 // Two rules, both from tools/cbench --trace (3.1-5.6 us of a 12 us workgroup sat in the round-3 loop):
 //  * straight-line code: out-of-tile rows / padded channel chunks are out-of-range BUFFER offsets (loads return 0, stores
@@ -239,7 +249,15 @@ __device__ __forceinline__ void epi_passes(STAMP&& stamp, const EpiCtx& c, float
 #pragma unroll
     for (int q = 0; q < PG; ++q) {
       const int m = c.m0 + (g0 + q) * RPP + c.er;
-      vo[q] = (g0 + q < NPASS && m < c.M && c.ncol) ? (unsigned)(((size_t)m * c.Cout + c.n) * 2) : EOOB;
+      size_t pix = (size_t)m;
+      if constexpr (EM < 0) {
+        if (c.sub_mul != 1) {               // row of a sub-grid launch -> pixel of the full tensor
+          const int b = m / c.sub_hw, r = m - b * c.sub_hw;
+          const int oy = r / c.sub_w, ox = r - oy * c.sub_w;
+          pix = ((size_t)b * c.out_H + oy * c.sub_mul + c.sub_py) * c.out_W + ox * c.sub_mul + c.sub_px;
+        }
+      }
+      vo[q] = (g0 + q < NPASS && m < c.M && c.ncol) ? (unsigned)((pix * c.Cout + c.n) * 2) : EOOB;
     }
     if (has_add) {
 #pragma unroll
@@ -411,6 +429,8 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
       int b, r, oy, ox;
       fast_divmod(m, HoWo, inv_howo, b, r);            // m < 2^24 (pxl_conv_dma_eligible)
       fast_divmod(r, p.Wo, inv_wo, oy, ox);
+      oy = oy * p.sub_mul + p.sub_py;                  // (sub-grid launches: the pixel this row stands for; else * 1 + 0)
+      ox = ox * p.sub_mul + p.sub_px;
       a_iy[q] = in ? oy * p.so : -(1 << 20);
       a_ix[q] = in ? ox * p.so : 0;
       a_img[q] = b * p.Hi * p.Wi * p.Cin * 2 + chunk * 16;
@@ -435,7 +455,8 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
   auto set_tap = [&](int t) {
     if constexpr (GATHER) {
       const int tp = p.taps[min(t, p.ntaps - 1)];
-      const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
+      const int dy = tap_dy(tp), dx = tap_dx(tp);
+      kwb = tap_wt(tp) * cin_bytes + kcb;            // this tap's slice of the weight row (a launch may walk a subset of the taps)
       const int tapoff = (dy * p.Wi + dx) * p.Cin * 2;
       if (p.div_shift == 0) {
 #pragma unroll
@@ -701,7 +722,8 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
   {
     EpiCtx c;
     c.T = T; c.er = er; c.ec = ec; c.m0 = m0; c.M = p.M; c.Cout = p.Cout; c.n = n; c.ncol = ncol;
-    const unsigned out_bytes = (unsigned)((size_t)p.M * p.Cout * 2);
+    const unsigned out_bytes = p.sub_mul != 1 ? (unsigned)((size_t)p.B * p.out_H * p.out_W * p.Cout * 2) : (unsigned)((size_t)p.M * p.Cout * 2);
+    c.sub_mul = p.sub_mul; c.sub_py = p.sub_py; c.sub_px = p.sub_px; c.sub_hw = HoWo; c.sub_w = p.Wo; c.out_H = p.out_H; c.out_W = p.out_W;
     c.r_out = __builtin_amdgcn_make_buffer_rsrc(a_out, 0, out_bytes, 0x00020000);
     c.r_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.addend), 0, out_bytes, 0x00020000);
     c.r_bny = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bn_y), 0, out_bytes, 0x00020000);
@@ -847,8 +869,8 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
     if (splitk > p.nk) splitk = p.nk;
     if (splitk < 1) splitk = 1;
   }
-  p.nk_per = cdiv(p.nk, splitk);
-  splitk = cdiv(p.nk, p.nk_per);
+  p.nk_per = p.nk > 0 ? cdiv(p.nk, splitk) : 0;
+  splitk = p.nk > 0 ? cdiv(p.nk, p.nk_per) : 1;          // (nk == 0: a read-back-only launch of a tap-less parity class)
   if (splitk > 1) PXL_CHECK_HIP(hipMemsetAsync(p.ws, 0, (size_t)p.M * p.Cout * sizeof(float), stream));
   else p.ws = nullptr;
   const bool bnin = p.bin.coef != nullptr;
@@ -868,6 +890,7 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
   int em = (p.addend ? 1 : 0) | (p.bias ? 2 : 0) | (has_stats ? 4 : 0) | (has_bnr ? 8 : 0) | (has_mask ? 16 : 0) |
            ((has_bnr && !has_mask && p.bn_relu) ? 32 : 0);
   if (splitk > 1) em = -2;
+  else if (p.sub_mul != 1) em = -1;          // sub-grid row addresses: the generic read-back
   int rc;
 #define PXL_EM(E) case E: rc = gather ? launch_one<BM, BN, WM, WN, NST, true, false, false, E>(g, b, smem, stream, p) \
                                        : launch_one<BM, BN, WM, WN, NST, false, false, false, E>(g, b, smem, stream, p); break;
