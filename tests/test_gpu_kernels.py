@@ -329,6 +329,53 @@ def test_conv_dgrad_with_fused_bn_backward_reduce(shape, cfg, dtype):
             assert rel_err(sums.cpu(), rs.cpu()) < 1e-4, (shape, cfg, relu, addend is not None)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+@pytest.mark.parametrize("cfg", [-1, 10, 17, 18])
+@pytest.mark.parametrize("shape", [(2, 128, 64, 17, 19, 3, 1), (3, 64, 128, 12, 13, 4, 1), (2, 128, 192, 9, 9, 1, 0)],
+                         ids=["3x3s2", "4x4s2", "1x1s2"])
+def test_stride2_dgrad_per_parity_class_with_fused_epilogue(shape, cfg, dtype, monkeypatch):
+    """Data gradient of a stride-2 convolution as one launch per output-parity class (csrc/conv_dma.hip: output sub-grid + tap
+    subset; tap-less classes of the 1x1 = zero-step launches), with the addend and the fused BatchNorm-backward sums reading
+    through the same sub-grid row addresses: equal to the single launch that walks every tap (PXL_S2_CLASSES=0 is read once per
+    process, so the single-launch reference is the GENERIC kernel, tile_cfg 1: another summation order) + a separate reduction;
+    odd sizes."""
+    ops = _ops()
+    B, Cin, Cout, H, W, k, p = shape
+    g = torch.Generator().manual_seed(B * 100 + Cin + k + 11)
+    w = qround(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k), dtype)
+    taps = ops.fwd_taps(k, k, 1, p)
+    Ho, Wo = (H + 2 * p - k) // 2 + 1, (W + 2 * p - k) // 2 + 1
+    dy = to_nhwc(qround(torch.randn(B, Cout, Ho, Wo, generator=g), dtype), Cout, dtype)
+    _, wt = pack_w(w, dtype, Cin, kp=Cout)
+    y = to_nhwc(qround(torch.randn(B, Cin, H, W, generator=g), dtype), Cin, dtype)
+    add = to_nhwc(qround(torch.randn(B, Cin, H, W, generator=g), dtype), Cin, dtype)
+    coef = torch.cat([torch.randn(Cin, generator=g) * 0.1, torch.rand(Cin, generator=g) + 0.5,
+                      torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3]).to(DEV)
+    mk = lambda c: ops.conv_desc(dtype, B, Ho, Wo, Cout, H, W, Cin, Cin, [(-a, -b) for a, b in taps], out_stride=1, div=2, tile_cfg=c)
+    from pixelssl_amd._lib import lib, check, ptr, stream_ptr, dtype_code
+    for relu in (1, 0):
+        for addend in (None, add):
+            ref = torch.empty(B, H, W, Cin, device=DEV, dtype=dtype)
+            ops.conv_igemm(mk(1), dy, wt, ref, addend=addend)                      # generic kernel: every tap, parity test
+            got = torch.full((B, H, W, Cin), 7.0, device=DEV, dtype=dtype)
+            sums = torch.zeros(2 * Cin, device=DEV)
+            ops.conv_dgrad_bnreduce(mk(cfg), dy, wt, got, y, coef, relu, sums, addend=addend)
+            rs = torch.zeros(2 * Cin, device=DEV)            # the separate reduction over the tensor the class launches STORED
+            check(lib().pxl_bn_bwd_reduce(dtype_code(dtype), B * H * W, Cin, ptr(got), ptr(y), ptr(coef), relu, ptr(rs), 1,
+                                          stream_ptr()))
+            torch.cuda.synchronize()
+            # (another summation order: fp32 1e-6; bf16 one rounding step of the stored value)
+            assert rel_err(got.float().cpu(), ref.float().cpu()) < (1e-6 if dtype == torch.float32 else 4e-3), (shape, cfg, relu)
+            assert rel_err(sums.cpu(), rs.cpu()) < 1e-4, (shape, cfg, relu, addend is not None)
+    # against torch: the transposed convolution
+    xg = torch.zeros(B, Cin, H, W, requires_grad=True)
+    F.conv2d(xg, w.float(), None, 2, p).backward(from_nhwc(dy, Cout))
+    plain = torch.empty(B, H, W, Cin, device=DEV, dtype=dtype)
+    ops.conv_igemm(mk(cfg), dy, wt, plain)
+    torch.cuda.synchronize()
+    assert rel_err(from_nhwc(plain, Cin), xg.grad) < TOL[dtype], (shape, cfg)
+
+
 _JOIN_CFGS = [(c, torch.bfloat16) for c in (-1, 9, 10, 18, 20, 26, 28, 31, 35)] + [(c, torch.float32) for c in (-1, 9, 10, 16, 19)]
 
 
