@@ -4,7 +4,8 @@
 //
 // This is the fast path behind pxl_conv_igemm for plain (already activated) bf16 inputs: forward
 // 1x1 / 3x3 / atrous / strided convolutions and the data gradients of stride-1 convolutions.
-// Differences to conv_igemm.hip (which stays the generic / fp32-parity kernel):
+// Differences to conv_igemm.hip (the generic kernel: operands that are not plain, channel pitches that are not multiples of 64;
+// fp32 operands have their own build of this pipeline in conv_dma_f32.hip):
 //   * tiles go HBM/L2 -> LDS directly (`buffer_load_dwordx4 ... lds`), 1 KiB per wave-instruction,
 //     no register staging and no per-element VALU in the K loop.  Zero padding, ragged M and padded
 //     output channels are lanes whose buffer offset is out of range: the buffer descriptor makes
