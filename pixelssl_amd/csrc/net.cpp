@@ -90,6 +90,7 @@ struct BnInfo {
   // also produces this BN's backward sums (no separate reduce pass); -1 = no
   int fused_reduce_op = -1;
   int fin_nrep = 1;        // replicas of the forward sums at finalize time (1 after a Sync-BN fold + all-reduce)
+  int nrep = 0;            // replicas of the forward statistics vector (STATS_REP; PXL_DETERMINISTIC: one per 64 pixel rows)
   // forward: the finalize of this BN is folded into the kernel that applies it (z materialisation or the residual
   // join that is its only consumer) instead of a pxl_bn_finalize launch
   bool fin_in_consumer = false;
@@ -215,6 +216,15 @@ struct pxl_net {
   bool conv_finalize = getenv("PXL_CONV_FINALIZE") != nullptr && getenv("PXL_CONV_FINALIZE")[0] == '1';
   // tests: use the reference's multi-device variance formula clamp(var, eps) on a single rank too
   bool force_clamp = getenv("PXL_FORCE_CLAMP_VAR") != nullptr;
+  // PXL_DETERMINISTIC=1: a bit-reproducible FORWARD pass.  The forward's only order-dependent arithmetic is fp32 atomics: the
+  // BatchNorm statistics that the convolution epilogues add into a few replicas, and split-K partial sums.  Here every
+  // statistics vector gets one replica per 64 pixel rows -- a replica then receives at most two adds (tiles are >= 32 rows), and
+  // a + b is commutative --, the replicas are folded in index order by ONE kernel (no finalize folded into consumers, no
+  // BN-apply on load: those re-reduce the replicas in every workgroup), and no convolution splits K.  Slower (thousands of
+  // replicas for the early layers); for parity runs: pre-activations within an ulp of zero no longer take a different ReLU
+  // branch from run to run (tools/diag_2rank.py).  The BACKWARD pass keeps its atomics (BatchNorm-backward sums, pixel-split
+  // weight gradients): its run-to-run differences are rounding-sized (1e-6), not branch-sized.
+  bool deterministic = getenv("PXL_DETERMINISTIC") != nullptr && getenv("PXL_DETERMINISTIC")[0] == '1';
 };
 
 namespace {
@@ -319,6 +329,7 @@ extern "C" int pxl_net_create(int dtype, int num_classes, const pxl_op* ops, int
   n->dtype = dtype;
   n->esize = dtype == PXL_F32 ? 4 : 2;
   n->classes = num_classes;
+  if (n->deterministic) { n->bn_onload = false; n->fuse_bn_finalize = false; n->conv_finalize = false; }
   n->ops.resize(nops);
   n->bns.resize(nbns);
   n->tensors.resize(ntensors);
@@ -425,13 +436,8 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
   n->planned = false;
   for (auto& t : n->tensors) t = TensorInfo();
   size_t arena = 0, scratch = 0, packed = 0;
-  // BN statistics first (contiguous -> one memset per pass)
-  n->stats_region_off = arena;
-  for (auto& b : n->bns) {
-    b.stats_off = arena; arena += align_up(STATS_REP * 2 * (size_t)b.d.C * 4);
-    b.cnt_off = arena; arena += ALIGN;
-  }
-  n->stats_region_bytes = arena - n->stats_region_off;
+  // (BN statistics: contiguous -> one memset per pass; allocated after the ops below, when every BatchNorm's pixel count is known)
+  for (auto& b : n->bns) b.M = 0;
   for (auto& b : n->bns) { b.coef_off = arena; arena += align_up(4 * (size_t)b.d.C * 4); }
   n->bsum_region_off = scratch;
   for (auto& b : n->bns) { b.bsum_off = scratch; scratch += align_up(2 * (size_t)b.d.C * 4); }
@@ -583,6 +589,18 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
       default:
         return pxl_set_error(PXL_ERR_ARG, "net_plan: unknown op kind %d", d.kind);
     }
+  }
+  n->stats_region_off = arena;
+  for (auto& b : n->bns) {
+    b.nrep = (n->deterministic && b.M > 0) ? (b.M + 63) / 64 : STATS_REP;
+    b.stats_off = arena; arena += align_up((size_t)b.nrep * 2 * (size_t)b.d.C * 4);
+    b.cnt_off = arena; arena += ALIGN;
+  }
+  n->stats_region_bytes = arena - n->stats_region_off;
+  for (auto& op : n->ops) {
+    if (op.d.kind != PXL_OP_CONV) continue;
+    if (op.d.bn_out >= 0) op.fwd.stats_rep = n->bns[op.d.bn_out].nrep;
+    if (n->deterministic) op.fwd.split_k = 1;
   }
   for (auto& b : n->bns) b.has_z = false;
   for (auto& op : n->ops) {
@@ -937,7 +955,7 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
           // the launch the forward pass will make: BatchNorm finalize + apply on load (its K loop carries the transform, so the
           // best tile is not the plain kernel's); statistics of the zeroed arena, running statistics left alone
           BnInfo& bi = n->bns[d.bn_in0];
-          bi.fin_nrep = STATS_REP;
+          bi.fin_nrep = bi.nrep;
           const pxl_bn_fin bin = make_fin(n, bi, params, nullptr, arena, 1);
           int rc1 = PXL_OK;
           t = time_launch([&]() { rc1 = pxl_conv_dma_bnin(&q, at(arena, tin.off), at(packed, op.wf_off), at(arena, tout.off), bias,
@@ -1129,10 +1147,10 @@ int forward_op(pxl_net* n, size_t i, const FwdCtx& c, int phase, bool* fin_flag,
                                   b.relu, at(arena, b.z_off), stream);
         } else if (d.bn_out >= 0) {
           BnInfo& b = n->bns[d.bn_out];
-          int nrep = STATS_REP;
+          int nrep = b.nrep;
           if (training && n->sync && n->world > 1) {
             if (!sync_done) {
-              rc = sync_stats(n, fat(arena, b.stats_off), 2 * b.d.C, STATS_REP, stream);
+              rc = sync_stats(n, fat(arena, b.stats_off), 2 * b.d.C, b.nrep, stream);
               if (rc != PXL_OK) return rc;
             }
             nrep = 1;
@@ -1363,9 +1381,9 @@ extern "C" int pxl_net_forward_pair(pxl_net* n0, pxl_net* n1, const float* param
       const pxl_op& d0 = n0->ops[i].d; const pxl_op& d1 = n1->ops[i].d;
       if (d0.bn_out >= 0 && d1.bn_out >= 0 && training0 && training1 && !fin[0] && !fin[1] && n0->world > 1 && n1->world > 1 &&
           n0->sync == &pxl_peer_allreduce_hook && n1->sync == &pxl_peer_allreduce_hook && n0->pair_sync &&
-          n0->bns[d0.bn_out].d.C == n1->bns[d1.bn_out].d.C) {
+          n0->bns[d0.bn_out].d.C == n1->bns[d1.bn_out].d.C && n0->bns[d0.bn_out].nrep == n1->bns[d1.bn_out].nrep) {
         const int rc = pxl_peer_allreduce_fold(reinterpret_cast<pxl_peer*>(n0->sync_user), fat(arena0, n0->bns[d0.bn_out].stats_off),
-                                               fat(arena1, n1->bns[d1.bn_out].stats_off), 2 * n0->bns[d0.bn_out].d.C, STATS_REP, stream);
+                                               fat(arena1, n1->bns[d1.bn_out].stats_off), 2 * n0->bns[d0.bn_out].d.C, n0->bns[d0.bn_out].nrep, stream);
         if (rc != PXL_OK) return rc;
         sync_done = true;
         ++n0->pair_syncs_last;
