@@ -241,6 +241,9 @@ int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes,
   a.in_bytes = (unsigned)((size_t)d->B * d->Hi * d->Wi * d->Cin * es);
   a.w_bytes = (unsigned)((size_t)d->Kreal * a.Ktot * es);
   std::memset(&a.g1, 0, sizeof(a.g1));
+  for (int t = 0; t < d->ntaps; ++t)
+    if (d->dy[t] < -2047 || d->dy[t] > 2047 || d->dx[t] < -2047 || d->dx[t] > 2047)
+      return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: tap offset (%d, %d) outside the 12-bit fields of the tap list", (int)d->dy[t], (int)d->dx[t]);
   for (int t = 0; t < 64; ++t)
     a.taps[t] = t < d->ntaps ? tap_encode(t, d->dy[t], d->dx[t]) : 0;
   a.sub_mul = 1; a.sub_py = a.sub_px = 0; a.out_H = d->Ho; a.out_W = d->Wo;

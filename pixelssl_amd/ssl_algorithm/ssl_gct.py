@@ -434,9 +434,11 @@ def _define_sslgct():
             if reuse_cores is not None:
                 for c in reuse_cores:
                     c.set_bn_repeat(2)
-                l_fwd, r_fwd = pair(lambda: self.l_model.forward(inp)[0], lambda: keep(self.r_model.forward(inp)[0]))
-                for c in reuse_cores:
-                    c.set_bn_repeat(1)
+                try:
+                    l_fwd, r_fwd = pair(lambda: self.l_model.forward(inp)[0], lambda: keep(self.r_model.forward(inp)[0]))
+                finally:
+                    for c in reuse_cores:
+                        c.set_bn_repeat(1)
                 l_prob = tuple(t.detach() for t in tool.dict_value(l_fwd, 'activated_pred'))
                 r_prob = tuple(t.detach() for t in tool.dict_value(r_fwd, 'activated_pred'))
             else:
