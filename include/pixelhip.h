@@ -688,6 +688,13 @@ int pxl_peer_allreduce_bnbwd(pxl_peer* peer, float* sums, int C, float* dgamma, 
 int pxl_peer_allreduce_hook(void* user, float* buf, int n, void* stream);      /* pxl_allreduce_fn signature */
 /* *status = 0, or k > 0: an exchange gave up waiting for rank k-1 (its result is invalid).  Synchronises the device. */
 int pxl_peer_status(pxl_peer* peer, int* status);
+/* The same word read from mapped host memory, WITHOUT synchronising the device: the exchange that times out writes it there
+ * as well, so the host can look at it at every optimizer step (dist.poll_peers).  -1: no host mirror on this context.
+ * A timed-out exchange returns NaN in every element whose peer word did not arrive (never a stale word): the step that used
+ * it is detectably invalid.  Reference: sync_batchnorm/comm.py:59-137 blocks forever on a dead replica thread. */
+int pxl_peer_status_nosync(const pxl_peer* peer);
+/* exchanges issued on this context so far (identical on every rank by construction; bench.py: exchanges per step) */
+long pxl_peer_exchanges(const pxl_peer* peer);
 
 /* Measurement aid (bench.py roofline leg): bracket every contraction launch of this net with HIP
  * events on the launch stream.  kind 0 = implicit-GEMM conv (forward + data gradient), 1 = weight
@@ -698,6 +705,54 @@ int pxl_net_profile_read(pxl_net* net, int kind, double* ms, long* launches, dou
 /* algorithmic operand bytes (activations in + weights + output, each once) of the launches stamped since the last
  * call, per kind; resets the counter */
 int pxl_net_profile_bytes(pxl_net* net, int kind, double* bytes);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Per-step scalars in device memory (captured training steps)                                  */
+/* ------------------------------------------------------------------------------------------ */
+/* A training iteration whose launches are replayed from a hipGraph must not carry values that change from step to step in
+ * its kernel arguments.  The three that do in the reference's loops -- the learning rate per parameter group
+ * (nn/lrer.py:143-179), the EMA coefficient (ssl_mt.py:359-363) and the ramped consistency weight (nn/func.py:44-52,
+ * ssl_mt.py:190-196) -- live in a small device block that pxl_hyper_set fills EAGERLY right before the graph launch; the
+ * *_hp entry points are the same kernels reading them from there (bit-identical arithmetic). */
+/* dst[0..n) <- vals[0..n), n <= 32; `vals` is a HOST array copied into the launch arguments at enqueue time (no staging buffer) */
+int pxl_hyper_set(float* dst, const float* vals, int n, void* stream);
+int pxl_sgd_step_hp(long n, float* p, const float* g, float* buf, const float* lr_dev, float momentum, float weight_decay,
+                    int first_step, void* stream);
+int pxl_ema_update_hp(long n, float* teacher, const float* student, const float* alpha_dev, void* stream);
+int pxl_head_loss_hp(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
+                     const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight,
+                     const float* mse_weight_dev, void* dlow, void* workspace, size_t ws_bytes, float* sums, void* stream);
+int pxl_net_head_loss_hp(pxl_net* net, const void* arena, const pxl_net* teacher, const void* t_arena, const float* gt,
+                         int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight, const float* mse_weight_dev,
+                         void* scratch, size_t scratch_bytes, float* sums, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Seams between the translation units of the library                                          */
+/* ------------------------------------------------------------------------------------------ */
+/* Exported because csrc/net.cpp, tools/cbench.cpp and the kernel tests reach them across object files; a host that drives the
+ * library through the entry points above never needs them.  They stand in for the same reference call sites as the
+ * dispatchers that forward to them (pxl_conv_igemm / pxl_conv_wgrad: backbone/resnet.py:30-50, deeplab_v2.py:81-85). */
+/* 1 when the LDS-DMA kernel (conv_dma_kernel.h: tiles HBM/L2 -> LDS by buffer_load ... lds) can run this launch: plain
+ * operands (no in_scale / in_shift prologue), Cin % 64 == 0 (bf16) / % 32 == 0 (fp32), 16-byte-aligned pitches. */
+int pxl_conv_dma_eligible(const pxl_conv_desc* desc, const float* in_scale, const void* workspace);
+/* the LDS-DMA launch itself (pxl_conv_igemm forwards here when eligible); arguments as pxl_conv_igemm without the prologue */
+int pxl_conv_dma(const pxl_conv_desc* desc, const void* in, const void* w, void* out, const float* bias, const void* addend,
+                 float* stats, void* workspace, size_t ws_bytes, void* stream);
+/* split-K epilogue shared by both convolution kernels: out[m][n] = T(ws[m][n] + bias[n]) for n < Kreal, 0 above */
+int pxl_splitk_finish(int dtype, long total, int Cout, int Kreal, const float* ws, const float* bias, void* out, void* stream);
+/* weight-gradient twins of the two above (pxl_conv_wgrad forwards here when eligible) */
+int pxl_conv_wgrad_dma_eligible(const pxl_conv_desc* desc, const float* in_scale);
+int pxl_conv_wgrad_dma(const pxl_conv_desc* desc, const void* in, const void* dy, float* dw, int creal, int dw_cpitch, void* stream);
+/* Paired launches (pxl_net_forward_pair; ssl_mt.py:166-180, the two forwards of one iteration): between begin(&slot) and end()
+ * the calling THREAD's next LDS-DMA convolution is recorded into *slot instead of launched; pxl_dma_launch_captured issues what
+ * two brackets recorded -- ONE launch (gridDim.z = 2) when geometry and tile agree, else one after the other -- and frees the
+ * slots.  -> 1 paired, 0 issued separately, < 0 error.  pxl_elt_pair_begin / _end: the same bracket for the finalize-folding
+ * row-streaming kernels (residual join, BN + ReLU) of the two networks. */
+void pxl_dma_capture_begin(void** slot);
+void pxl_dma_capture_end(void);
+int pxl_dma_launch_captured(void* slot0, void* slot1);
+void pxl_elt_pair_begin(void);
+int pxl_elt_pair_end(void);
 
 #ifdef __cplusplus
 }

@@ -183,6 +183,19 @@ SIGNATURES = {
     "pxl_peer_allreduce_bnbwd": (_I, [_P, _P, _I, _P, _P, _P]),
     "pxl_peer_allreduce_hook": (_I, [_P, _P, _I, _P]),
     "pxl_peer_status": (_I, [_P, C.POINTER(_I)]),
+    "pxl_peer_status_nosync": (_I, [_P]),
+    "pxl_peer_exchanges": (_L, [_P]),
+    # seams between the library's translation units (include/pixelhip.h, last section)
+    "pxl_conv_dma_eligible": (_I, [C.POINTER(ConvDesc), _P, _P]),
+    "pxl_conv_dma": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "pxl_splitk_finish": (_I, [_I, _L, _I, _I, _P, _P, _P, _P]),
+    "pxl_conv_wgrad_dma_eligible": (_I, [C.POINTER(ConvDesc), _P]),
+    "pxl_conv_wgrad_dma": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _I, _P]),
+    "pxl_dma_capture_begin": (None, [C.POINTER(_P)]),
+    "pxl_dma_capture_end": (None, []),
+    "pxl_dma_launch_captured": (_I, [_P, _P]),
+    "pxl_elt_pair_begin": (None, []),
+    "pxl_elt_pair_end": (_I, []),
     "pxl_net_create": (_I, [_I, _I, C.POINTER(Op), _I, C.POINTER(BnDesc), _I, _I, C.POINTER(_P)]),
     "pxl_net_destroy": (None, [_P]),
     "pxl_net_plan": (_I, [_P, _I, _I, _I]),
@@ -223,6 +236,11 @@ SIGNATURES = {
     "pxl_net_head_loss_supported": (_I, [_P]),
     "pxl_net_head_forward": (_I, [_P, _P, _P, _P, _P]),
     "pxl_net_head_loss": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _Z, _P, _P]),
+    "pxl_hyper_set": (_I, [_P, _P, _I, _P]),
+    "pxl_sgd_step_hp": (_I, [_L, _P, _P, _P, _P, _F, _F, _I, _P]),
+    "pxl_ema_update_hp": (_I, [_L, _P, _P, _P, _P]),
+    "pxl_head_loss_hp": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _Z, _P, _P]),
+    "pxl_net_head_loss_hp": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _Z, _P, _P]),
     "pxl_net_backward_low": (_I, [_P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
     "pxl_net_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
 }

@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256) void head_loss_rows_kernel(int C, int Cp, int 
                                                              const T* __restrict__ t_low, const float* __restrict__ gt,
                                                              int ignore_index, int n_ce, int mse_lo, int mse_hi,
                                                              float ce_scale, float mse_scale, float inv_hw, float inv_mse_n,
-                                                             float* __restrict__ tmp, float* __restrict__ sums, int B) {
+                                                             float* __restrict__ tmp, float* __restrict__ sums, int B,
+                                                             const float* __restrict__ mse_w_dev) {
+  if (mse_w_dev != nullptr) mse_scale *= mse_w_dev[0];      // (consistency weight in device memory: pxl_head_loss_hp)
   extern __shared__ float g[];   // [C][W+1] | ci0[W] ci1[W] cl1[W] | srow[2][w][C] | trow[2][w][C]
   __shared__ float red[4];
   const int y = blockIdx.x, b = blockIdx.y;
@@ -355,7 +357,8 @@ __global__ __launch_bounds__(256) void head_loss_cells_kernel(int Cp, int h, int
                                                               const T* __restrict__ t_low, const float* __restrict__ gt,
                                                               int ignore_index, int n_ce, int mse_lo, int mse_hi,
                                                               float ce_scale, float mse_scale, float* __restrict__ dacc,
-                                                              float* __restrict__ part, int B) {
+                                                              float* __restrict__ part, int B, const float* __restrict__ mse_w_dev) {
+  if (mse_w_dev != nullptr) mse_scale *= mse_w_dev[0];      // (consistency weight in device memory: pxl_head_loss_hp)
   __shared__ float corner[4][2][4 * C];      // [wave][student | teacher][corner k = 2 * dy + dx][c]
   __shared__ float tr[4][(2 * C + 1) * 65];    // [wave][A0 rows | A1 rows | lx][lane], pitch 65
   __shared__ float lsum[4][3];
@@ -644,10 +647,11 @@ extern "C" size_t pxl_head_loss_lds_bytes(int w, int C, int W) {
 // mean) (ramp * cons_scale).  Outputs: dlow [B][h][w][Cp] (engine dtype) = d(final loss)/d(s_low); sums [2*B + 1]
 // fp32, zeroed here: per-sample student CE, per-sample teacher CE, the MSE mean over samples [mse_lo, mse_hi).
 // workspace: pxl_upsample_bwd_workspace(B, w, C, H) bytes.
-extern "C" int pxl_head_loss(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
-                             const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi,
-                             float ce_weight, float mse_weight, void* dlow, void* workspace, size_t ws_bytes, float* sums,
-                             void* stream) {
+namespace {
+int head_loss_impl(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
+                   const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi,
+                   float ce_weight, float mse_weight, const float* mse_w_dev, void* dlow, void* workspace, size_t ws_bytes, float* sums,
+                   void* stream) {
   PXL_REQUIRE(s_low && dlow && workspace && sums, "head_loss: null argument");
   PXL_REQUIRE(n_ce == 0 || gt != nullptr, "head_loss: labels missing");
   PXL_REQUIRE(C >= 1 && C <= MAXC && C <= Cp, "head_loss: C=%d unsupported (max %d)", C, MAXC);
@@ -685,13 +689,13 @@ extern "C" int pxl_head_loss(int dtype, int B, int h, int w, int Cp, int C, int 
     if (dtype == PXL_F32) {
       hipLaunchKernelGGL((head_loss_cells_kernel<float, 21>), dim3(nblk), dim3(256), 0, s, Cp, h, w, H, W, sy, sx, align,
                          (const float*)s_low, (const float*)t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_scale_, mse_scale_,
-                         dacc, part, B);
+                         dacc, part, B, mse_w_dev);
       hipLaunchKernelGGL(head_loss_finish_kernel<float>, dim3(nconv + B), dim3(256), 0, s, B, h, w, C, Cp, dacc, (float*)dlow, part,
                          1.f / hw, inv_mse_n_, n_ce, t_low != nullptr ? 1 : 0, sums);
     } else {
       hipLaunchKernelGGL((head_loss_cells_kernel<bf16_t, 21>), dim3(nblk), dim3(256), 0, s, Cp, h, w, H, W, sy, sx, align,
                          (const bf16_t*)s_low, (const bf16_t*)t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_scale_, mse_scale_,
-                         dacc, part, B);
+                         dacc, part, B, mse_w_dev);
       hipLaunchKernelGGL(head_loss_finish_kernel<bf16_t>, dim3(nconv + B), dim3(256), 0, s, B, h, w, C, Cp, dacc, (bf16_t*)dlow, part,
                          1.f / hw, inv_mse_n_, n_ce, t_low != nullptr ? 1 : 0, sums);
     }
@@ -705,11 +709,11 @@ extern "C" int pxl_head_loss(int dtype, int B, int h, int w, int Cp, int C, int 
   if (dtype == PXL_F32)
     hipLaunchKernelGGL(head_loss_rows_kernel<float>, dim3(H, B), dim3(256), smem, s, C, Cp, h, w, H, W, sy, sx, align,
                        (const float*)s_low, (const float*)t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_scale, mse_scale,
-                       1.f / hw, inv_mse_n, (float*)workspace, sums, B);
+                       1.f / hw, inv_mse_n, (float*)workspace, sums, B, mse_w_dev);
   else
     hipLaunchKernelGGL(head_loss_rows_kernel<bf16_t>, dim3(H, B), dim3(256), smem, s, C, Cp, h, w, H, W, sy, sx, align,
                        (const bf16_t*)s_low, (const bf16_t*)t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_scale, mse_scale,
-                       1.f / hw, inv_mse_n, (float*)workspace, sums, B);
+                       1.f / hw, inv_mse_n, (float*)workspace, sums, B, mse_w_dev);
   PXL_LAUNCH_CHECK();
   const long total = (long)B * h * w * Cp;
   int grid = (int)((total + 255) / 256);
@@ -723,3 +727,24 @@ extern "C" int pxl_head_loss(int dtype, int B, int h, int w, int Cp, int C, int 
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
+}  // namespace
+
+extern "C" int pxl_head_loss(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
+                             const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi,
+                             float ce_weight, float mse_weight, void* dlow, void* workspace, size_t ws_bytes, float* sums,
+                             void* stream) {
+  return head_loss_impl(dtype, B, h, w, Cp, C, H, W, align_corners, s_low, t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_weight,
+                        mse_weight, nullptr, dlow, workspace, ws_bytes, sums, stream);
+}
+
+// pxl_head_loss with the consistency weight d(final loss)/d(MSE mean) in DEVICE memory (*mse_weight_dev, a per-step scalar:
+// ramp-up x cons_scale, ssl_mt.py:190-196): the launch arguments no longer change from step to step (hipGraph replay)
+extern "C" int pxl_head_loss_hp(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
+                                const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi,
+                                float ce_weight, const float* mse_weight_dev, void* dlow, void* workspace, size_t ws_bytes,
+                                float* sums, void* stream) {
+  PXL_REQUIRE(mse_weight_dev != nullptr, "head_loss_hp: null weight pointer");
+  return head_loss_impl(dtype, B, h, w, Cp, C, H, W, align_corners, s_low, t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_weight,
+                        1.0f, mse_weight_dev, dlow, workspace, ws_bytes, sums, stream);
+}
+

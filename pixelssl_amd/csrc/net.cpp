@@ -47,6 +47,9 @@ size_t pxl_head_loss_lds_bytes(int w, int C, int W);
 int pxl_head_loss(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
                   const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight,
                   float mse_weight, void* dlow, void* workspace, size_t ws_bytes, float* sums, void* stream);
+int pxl_head_loss_hp(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
+                     const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight,
+                     const float* mse_weight_dev, void* dlow, void* workspace, size_t ws_bytes, float* sums, void* stream);
 int pxl_conv_wgrad_dma_eligible(const pxl_conv_desc* d, const float* in_scale);
 struct pxl_peer;
 int pxl_peer_allreduce_hook(void* user, float* buf, int n, void* stream);
@@ -1611,9 +1614,10 @@ extern "C" int pxl_net_backward_low(pxl_net* n, const float* params, const void*
 // Fused training seam on the low-resolution logits of one (student) or two (student + teacher) forward passes held in
 // their arenas: per-sample CE of both networks, the MSE consistency term and d(loss)/d(student low-res logits) into the
 // student's gradient slot (csrc/head.hip: pxl_head_loss).  `teacher` / `t_arena` NULL: no teacher terms.
-extern "C" int pxl_net_head_loss(pxl_net* n, const void* arena, const pxl_net* teacher, const void* t_arena, const float* gt,
-                                 int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight, float mse_weight,
-                                 void* scratch, size_t scratch_bytes, float* sums, void* stream) {
+namespace {
+int net_head_loss_impl(pxl_net* n, const void* arena, const pxl_net* teacher, const void* t_arena, const float* gt,
+                       int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight, float mse_weight, const float* mse_weight_dev,
+                       void* scratch, size_t scratch_bytes, float* sums, void* stream) {
   PXL_REQUIRE(n && n->planned && arena && scratch && sums && n->head_op >= 0, "net_head_loss: bad argument (plan first)");
   if (scratch_bytes < n->scratch_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_head_loss: scratch too small");
   const pxl_op& d = n->ops[n->head_op].d;
@@ -1626,9 +1630,30 @@ extern "C" int pxl_net_head_loss(pxl_net* n, const void* arena, const pxl_net* t
                 teacher->Ho == n->Ho && teacher->Wo == n->Wo, "net_head_loss: student and teacher plans differ");
     t_low = at(t_arena, tl.off);
   }
+  if (mse_weight_dev != nullptr)
+    return pxl_head_loss_hp(n->dtype, n->B, low.H, low.W, low.Cp, n->classes, n->Ho, n->Wo, d.stride, at(arena, low.off), t_low, gt,
+                            ignore_index, n_ce, mse_lo, mse_hi, ce_weight, mse_weight_dev, at(scratch, low.goff),
+                            at(scratch, n->up_ws_off), n->up_ws_bytes, sums, stream);
   return pxl_head_loss(n->dtype, n->B, low.H, low.W, low.Cp, n->classes, n->Ho, n->Wo, d.stride, at(arena, low.off), t_low, gt,
                        ignore_index, n_ce, mse_lo, mse_hi, ce_weight, mse_weight, at(scratch, low.goff), at(scratch, n->up_ws_off),
                        n->up_ws_bytes, sums, stream);
+}
+}  // namespace
+
+extern "C" int pxl_net_head_loss(pxl_net* n, const void* arena, const pxl_net* teacher, const void* t_arena, const float* gt,
+                                 int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight, float mse_weight,
+                                 void* scratch, size_t scratch_bytes, float* sums, void* stream) {
+  return net_head_loss_impl(n, arena, teacher, t_arena, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_weight, mse_weight, nullptr, scratch,
+                            scratch_bytes, sums, stream);
+}
+
+// ... with the consistency weight read from device memory (a captured training step: the weight ramps up from step to step)
+extern "C" int pxl_net_head_loss_hp(pxl_net* n, const void* arena, const pxl_net* teacher, const void* t_arena, const float* gt,
+                                    int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight, const float* mse_weight_dev,
+                                    void* scratch, size_t scratch_bytes, float* sums, void* stream) {
+  PXL_REQUIRE(mse_weight_dev != nullptr, "net_head_loss_hp: null weight pointer");
+  return net_head_loss_impl(n, arena, teacher, t_arena, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_weight, 0.f, mse_weight_dev, scratch,
+                            scratch_bytes, sums, stream);
 }
 
 // The HEAD op alone (up-sampling + soft-max of the low-resolution logits held in `arena`): materialises the

@@ -8,9 +8,12 @@
 
 namespace {
 
+// lr_dev != NULL: the learning rate is read from device memory (a per-step hyper-parameter block, pxl_hyper_set): the launch
+// then carries nothing that changes from step to step and can be replayed from a captured hipGraph
 __global__ __launch_bounds__(256) void sgd_kernel(long n, float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ buf, float lr, float momentum,
-                                                  float wd, int first) {
+                                                  float wd, int first, const float* __restrict__ lr_dev) {
+  if (lr_dev != nullptr) lr = lr_dev[0];
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float pv = p[i];
     const float d = g[i] + wd * pv;
@@ -38,7 +41,8 @@ __global__ __launch_bounds__(256) void sgd_general_kernel(long n, float* __restr
 }
 
 __global__ __launch_bounds__(256) void ema_kernel(long n, float* __restrict__ t, const float* __restrict__ s,
-                                                  float alpha) {
+                                                  float alpha, const float* __restrict__ alpha_dev) {
+  if (alpha_dev != nullptr) alpha = alpha_dev[0];
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     t[i] = t[i] * alpha + (1.f - alpha) * s[i];
 }
@@ -74,7 +78,37 @@ extern "C" int pxl_sgd_step(long n, float* p, const float* g, float* buf, float 
                             float weight_decay, int first_step, void* stream) {
   PXL_REQUIRE(p && g && buf && n > 0, "sgd_step: bad argument");
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, p, g,
-                     buf, lr, momentum, weight_decay, first_step);
+                     buf, lr, momentum, weight_decay, first_step, (const float*)nullptr);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+// pxl_sgd_step with the learning rate in DEVICE memory (*lr_dev, written by pxl_hyper_set before the step): same arithmetic
+extern "C" int pxl_sgd_step_hp(long n, float* p, const float* g, float* buf, const float* lr_dev, float momentum,
+                               float weight_decay, int first_step, void* stream) {
+  PXL_REQUIRE(p && g && buf && lr_dev && n > 0, "sgd_step_hp: bad argument");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n, p, g,
+                     buf, 0.f, momentum, weight_decay, first_step, lr_dev);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+namespace {
+struct HyperVals { float v[32]; };
+__global__ void hyper_set_kernel(float* __restrict__ dst, HyperVals h, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = h.v[threadIdx.x];
+}
+}  // namespace
+
+// dst[0..n) <- vals[0..n) (n <= 32), `vals` a HOST array whose content is copied into the launch's arguments at enqueue time:
+// no staging buffer that a host running several steps ahead of the device could overwrite.  The per-step scalars of a captured
+// training step (learning rates, EMA coefficient, ramp-up weight: lrer.py:143-179, ssl_mt.py:359-363, nn/func.py:44-52) go through
+// here, eagerly, right before the graph launch; the captured kernels read them from `dst`.
+extern "C" int pxl_hyper_set(float* dst, const float* vals, int n, void* stream) {
+  PXL_REQUIRE(dst && vals && n >= 1 && n <= 32, "hyper_set: bad argument (1 <= n <= 32)");
+  HyperVals h;
+  for (int i = 0; i < 32; ++i) h.v[i] = i < n ? vals[i] : 0.f;
+  hipLaunchKernelGGL(hyper_set_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dst, h, n);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -92,7 +126,16 @@ extern "C" int pxl_sgd_step_general(long n, float* p, const float* g, float* buf
 extern "C" int pxl_ema_update(long n, float* teacher, const float* student, float alpha, void* stream) {
   PXL_REQUIRE(teacher && student && n > 0, "ema_update: bad argument");
   hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n,
-                     teacher, student, alpha);
+                     teacher, student, alpha, (const float*)nullptr);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+// pxl_ema_update with the coefficient in DEVICE memory (*alpha_dev): same arithmetic
+extern "C" int pxl_ema_update_hp(long n, float* teacher, const float* student, const float* alpha_dev, void* stream) {
+  PXL_REQUIRE(teacher && student && alpha_dev && n > 0, "ema_update_hp: bad argument");
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n,
+                     teacher, student, 0.f, alpha_dev);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

@@ -23,6 +23,7 @@ constexpr int MAXW = 16;
 struct PeerArgs {
   unsigned long long* slots[MAXW];       // every rank's buffer: [2][world][slot] words {epoch << 32 | float bits}
   unsigned* status;                      // local: != 0 after a time-out
+  unsigned* host_status;                 // the same word in mapped host memory: the host polls it without a device sync
   int rank, world, slot;
   long long timeout_ticks;               // of the 100 MHz wall clock
 };
@@ -40,8 +41,10 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a, f
   const size_t set = (size_t)par * a.world * a.slot;
   // sticky abort: once an exchange of this context has given up on a peer, every later one posts its words (the peers may
   // still be alive and waiting for them) but does not wait -- a dead peer costs ONE time-out, not one per exchange (an MT
-  // step has ~310 of them).  The sums are invalid from then on; the host sees the status word (pxl_peer_status, polled by
-  // dist.poll_peers every few steps) and moves the statistics to RCCL / torch.distributed.
+  // step has ~310 of them).  The sums are invalid from then on and SAY so: every element whose peer word did not arrive is
+  // written back as NaN (never the stale word of an older exchange), so the losses and the update of that step are NaN; the host
+  // reads the status word from mapped host memory at every optimizer step (pxl_peer_status_nosync, dist.poll_peers) and aborts
+  // the run -- or, opt-in, moves the statistics to RCCL / torch.distributed.
   const bool aborted = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
     const int g = base + i;
@@ -58,21 +61,26 @@ __global__ __launch_bounds__(256) void peer_allreduce_kernel(const PeerArgs a, f
     const unsigned long long* mine = a.slots[a.rank] + set + i;
     float acc = 0.f;
     long long t0 = 0;
+    bool valid = true;
     for (int q = 0; q < a.world; ++q) {
       unsigned long long w = __hip_atomic_load(mine + (size_t)q * a.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       while ((unsigned)(w >> 32) != epoch) {
-        if (aborted) break;
+        if (aborted) { valid = false; break; }
         if (t0 == 0) t0 = wall_clock64();
         __builtin_amdgcn_s_sleep(1);
         if (wall_clock64() - t0 > a.timeout_ticks) {
           atomicExch(a.status, 1u + (unsigned)q);
+          if (a.host_status != nullptr)
+            __hip_atomic_store(a.host_status, 1u + (unsigned)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          valid = false;
           break;
         }
         w = __hip_atomic_load(mine + (size_t)q * a.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
+      if (!valid) break;              // (the word that is there belongs to an older exchange: never added)
       acc += __uint_as_float((unsigned)w);
     }
-    src[0] = acc;
+    src[0] = valid ? acc : __uint_as_float(0x7fc00000u);
   }
 }
 
@@ -84,6 +92,7 @@ struct pxl_peer {
   char* local = nullptr;
   char* mapped[MAXW] = {};
   bool opened = false;
+  unsigned* host_status = nullptr;       // hipHostMalloc'ed mirror of the status word (NULL: not available)
   unsigned epoch = 0;
   long long timeout_ticks = 0;
 };
@@ -118,6 +127,14 @@ extern "C" int pxl_peer_create(int rank, int world, int slot_floats, int timeout
     return pxl_set_error(PXL_ERR_HIP, "peer_create: hipMemset failed: %s", hipGetErrorString(e));
   }
   p->mapped[rank] = p->local;
+  // host-visible mirror of the status word: written once, by the exchange that times out; read by the host every step
+  void* hs = nullptr;
+  if (hipHostMalloc(&hs, 64, hipHostMallocMapped) == hipSuccess) {
+    p->host_status = static_cast<unsigned*>(hs);
+    *p->host_status = 0u;
+  } else {
+    (void)hipGetLastError();
+  }
   *out = p;
   return PXL_OK;
 }
@@ -151,6 +168,7 @@ extern "C" void pxl_peer_destroy(pxl_peer* p) {
   for (int r = 0; r < p->world; ++r)
     if (r != p->rank && p->mapped[r]) (void)hipIpcCloseMemHandle(p->mapped[r]);
   if (p->local) (void)hipFree(p->local);
+  if (p->host_status) (void)hipHostFree(p->host_status);
   delete p;
 }
 
@@ -161,6 +179,7 @@ int peer_exchange(pxl_peer* p, float* buf0, float* buf1, long n_each, int nrep, 
   PeerArgs a;
   for (int r = 0; r < MAXW; ++r) a.slots[r] = r < p->world ? reinterpret_cast<unsigned long long*>(p->mapped[r]) : nullptr;
   a.status = reinterpret_cast<unsigned*>(p->local + p->status_off);
+  a.host_status = p->host_status;
   a.rank = p->rank; a.world = p->world; a.slot = p->slot; a.timeout_ticks = p->timeout_ticks;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const long total = buf1 != nullptr ? 2 * n_each : n_each;
@@ -202,6 +221,17 @@ extern "C" int pxl_peer_allreduce_bnbwd(pxl_peer* p, float* sums, int C, float* 
 
 extern "C" int pxl_peer_allreduce_hook(void* user, float* buf, int n, void* stream) {
   return pxl_peer_allreduce_sum(reinterpret_cast<pxl_peer*>(user), buf, (long)n, stream) == PXL_OK ? 0 : 1;
+}
+
+// Exchanges issued on this context so far (every rank issues the same sequence: the counter doubles as a consistency check).
+extern "C" long pxl_peer_exchanges(const pxl_peer* p) { return p ? (long)p->epoch : 0; }
+
+// The status word as the host sees it WITHOUT synchronising the device (mapped host memory the timing-out exchange writes):
+// 0 = no exchange that has COMPLETED so far timed out; cheap enough for every optimizer step.  -1: no host mirror (use
+// pxl_peer_status).
+extern "C" int pxl_peer_status_nosync(const pxl_peer* p) {
+  if (!p || !p->host_status) return -1;
+  return (int)__atomic_load_n(p->host_status, __ATOMIC_RELAXED);
 }
 
 // 0 = every exchange so far met its peers; k > 0 = an exchange gave up waiting for rank k-1 (synchronises the device)

@@ -178,10 +178,15 @@ def native_comms():
 
 _peer = {"ok": None, "ctxs": [], "hook": None}
 PEER_SLOT_FLOATS = 8192            # 2 networks x 2 * 2048 channels: the widest BatchNorm of a student || teacher pair in one exchange
-PEER_TIMEOUT_MS = int(os.environ.get("PXL_PEER_TIMEOUT_MS", "10000"))      # one exchange is ~6 us; 10 s is a dead (or wedged) peer.  (The
-# ranks are aligned after every per-rank autotune -- align_after_tune below -- so start-up skew does not come near it; a time-out is
-# sticky and costs its 10 s once.)
+PEER_TIMEOUT_MS = int(os.environ.get("PXL_PEER_TIMEOUT_MS", "20000"))      # one exchange is ~6 us; 20 s is a dead (or wedged) peer,
+# well above ordinary rank skew (a per-rank autotune, a rank-0 checkpoint save or validation pass).  A time-out is sticky and costs its
+# 20 s once; the exchange that times out returns NaN sums (csrc/peer.hip), never stale ones.
+# What a time-out does: by default the run ABORTS at the next optimizer step (poll_peers reads the status word from mapped host
+# memory every step, no device sync) -- at most one update on NaN statistics, and that one is detectably invalid.
+# PXL_PEER_FALLBACK=1 (opt-in): every PEER_POLL_STEPS-th step the ranks agree on the status and move the statistics to RCCL /
+# torch.distributed for the rest of the run instead; check_peers() at the epoch end still reports that it happened.
 PEER_POLL_STEPS = int(os.environ.get("PXL_PEER_POLL_STEPS", "20"))
+PEER_FALLBACK = os.environ.get("PXL_PEER_FALLBACK", "0") == "1"
 
 
 def _all_agree(flag, dev):
@@ -244,11 +249,20 @@ def open_peer_context():
 
 
 def align_after_tune():
-    """Host barrier after a per-rank autotune (engine: pxl_net_tune / pxl_net_tune_pair time ~3000 candidate launches, a few seconds
-    whose length differs from rank to rank): without it the first Sync-BN exchange of the faster rank spins for the difference, and a
-    difference beyond the exchange time-out would retire the peer-mapped path for the whole run.  COLLECTIVE: every rank plans and tunes
-    the same shapes in the same order."""
-    if is_distributed() and os.environ.get("PXL_TUNE_BARRIER", "1") != "0":
+    """Optional host barrier after a per-rank autotune (engine: pxl_net_tune / pxl_net_tune_pair time ~3000 candidate launches, a few
+    seconds whose length differs from rank to rank).  OFF by default since round 5: it is a collective hidden inside a forward pass,
+    which deadlocks when only some ranks meet an untuned shape (a rank-0-only pass, an uneven last batch, a rank-dependent branch of
+    a plug-in model).  Without it the first Sync-BN exchange of the faster rank simply spins for the difference -- seconds, against
+    an exchange time-out of 20 s (PXL_PEER_TIMEOUT_MS).  PXL_TUNE_BARRIER=1 restores it for jobs whose ranks provably plan and tune
+    the same shapes in the same order (INTEGRATION.md)."""
+    if is_distributed() and os.environ.get("PXL_TUNE_BARRIER", "0") == "1":
+        dist.barrier()
+
+
+def epoch_barrier():
+    """Host barrier at an epoch boundary (ssl_base.train): after it the ranks start their first Sync-BN exchange within
+    microseconds of each other, whatever rank 0 did in between (checkpoint, validation, logging)."""
+    if is_distributed() and os.environ.get("PXL_EPOCH_BARRIER", "1") != "0":
         dist.barrier()
 
 
@@ -257,41 +271,69 @@ def peer_contexts():
     return len(_peer["ctxs"])
 
 
+def _peer_error(status):
+    from . import _lib
+    return _lib.PixelHipError("peer-mapped Sync-BN exchange: rank %d gave up waiting for rank %d after %d ms; the statistics of "
+                              "that exchange (and of every later one on the context) are NaN" % (rank(), status - 1, PEER_TIMEOUT_MS))
+
+
 def check_peers():
-    """Raise if any peer-mapped exchange of this process timed out (its sums were invalid).  Synchronises the device:
-    call it at a checkpoint / epoch boundary, not per step."""
+    """Raise if any peer-mapped exchange of this process timed out (its sums were invalid) -- including one that a
+    PXL_PEER_FALLBACK=1 run has already recovered from by moving to RCCL: the steps between the time-out and the fall-back
+    trained on invalid statistics, and the epoch-end guard of ssl_base.train() has to say so.  Synchronises the device: call it at
+    a checkpoint / epoch boundary, not per step."""
     import ctypes
     from . import _lib
+    if _peer.get("timed_out") is not None:
+        raise _peer_error(_peer["timed_out"])
     for ctx in _peer["ctxs"]:
         st = ctypes.c_int(0)
         _lib.check(_lib.lib().pxl_peer_status(ctx, ctypes.byref(st)))
         if st.value:
-            raise _lib.PixelHipError("peer-mapped Sync-BN exchange: rank %d gave up waiting for rank %d after %d ms"
-                                     % (rank(), st.value - 1, PEER_TIMEOUT_MS))
+            _peer["timed_out"] = st.value
+            raise _peer_error(st.value)
 
 
 _poll = {"calls": 0, "fallbacks": 0}
 
 
+def _local_peer_status(sync=False):
+    """worst status word of this process's contexts; without `sync` read from the mapped host mirror (no device sync)"""
+    import ctypes
+    from . import _lib
+    h = _lib.lib()
+    worst = 0
+    for ctx in _peer["ctxs"]:
+        v = -1 if sync else h.pxl_peer_status_nosync(ctx)
+        if v < 0:
+            st = ctypes.c_int(0)
+            _lib.check(h.pxl_peer_status(ctx, ctypes.byref(st)))
+            v = st.value
+        worst = max(worst, v)
+    return worst
+
+
 def poll_peers(cores=None):
-    """Called once per training step (cheap: does something every PEER_POLL_STEPS-th call).  COLLECTIVE on those calls:
-    every rank reads the status words of its peer-mapped exchange contexts, the ranks agree (MAX) on whether any exchange
-    has timed out, and if one has, EVERY rank moves the Sync-BN statistics of every network to the RCCL / torch.distributed
-    path for the rest of the run (the contexts are retired; the statistics of the steps since the time-out were invalid
-    on some rank -- that is logged, the run continues on valid sums instead of finishing the epoch on garbage).
+    """Called once per optimizer step.  Every call reads this process's exchange status words from mapped host memory (free: no
+    device sync, no collective); a time-out raises PixelHipError -- the run stops within one optimizer step of the first NaN
+    statistics instead of training on them (the peers time out on this rank's missing words and stop the same way).
+    PXL_PEER_FALLBACK=1 (opt-in) replaces the abort by the round-4 behaviour: every PEER_POLL_STEPS-th call is COLLECTIVE, the ranks
+    agree (MAX) on whether any exchange has timed out, and if one has, EVERY rank moves the Sync-BN statistics of every network to
+    the RCCL / torch.distributed path for the rest of the run; the time-out stays on record (check_peers raises at the epoch end).
     -> True when a fall-back happened in this call."""
     if not _peer["ctxs"] or not is_distributed():
         return False
     _poll["calls"] += 1
+    if not PEER_FALLBACK:
+        worst = _local_peer_status()
+        if worst:
+            _peer["timed_out"] = worst
+            raise _peer_error(worst)
+        return False
     if _poll["calls"] % PEER_POLL_STEPS:
         return False
-    import ctypes
     from . import _lib
-    worst = 0
-    for ctx in _peer["ctxs"]:
-        st = ctypes.c_int(0)
-        _lib.check(_lib.lib().pxl_peer_status(ctx, ctypes.byref(st)))
-        worst = max(worst, st.value)
+    worst = _local_peer_status(sync=True)
     dev = torch.device("cuda", torch.cuda.current_device())
     flag = torch.tensor([float(worst)], device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
@@ -299,7 +341,9 @@ def poll_peers(cores=None):
         return False
     from .utils import logger
     logger.log_warn("peer-mapped Sync-BN exchange timed out (rank %d: local status %d); the statistics move to %s for the rest "
-                    "of the run\n" % (rank(), worst, "RCCL" if _native["comms"] else "torch.distributed"))
+                    "of the run; up to %d optimizer steps ran on NaN statistics\n"
+                    % (rank(), worst, "RCCL" if _native["comms"] else "torch.distributed", PEER_POLL_STEPS))
+    _peer["timed_out"] = int(flag.item())
     retired, _peer["ctxs"] = _peer["ctxs"], []
     _peer["ok"] = False
     ws = world_size()
@@ -317,6 +361,13 @@ def poll_peers(cores=None):
         _lib.lib().pxl_peer_destroy(ctx)
     _poll["fallbacks"] += 1
     return True
+
+
+def peer_exchanges():
+    """Exchanges issued so far on this process's peer-mapped contexts (bench.py: exchanges per step)."""
+    from . import _lib
+    h = _lib.lib()
+    return sum(int(h.pxl_peer_exchanges(ctx)) for ctx in _peer["ctxs"])
 
 
 def rccl_ranks():

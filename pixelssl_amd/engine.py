@@ -637,7 +637,9 @@ class SegNetCore(nn.Module):
                                     ptr(x), ptr(logits), ptr(prob), ptr(arena), arena.numel(), int(training),
                                     stream_ptr()))
         if training:
-            self._nbt += 1          # every BN's num_batches_tracked is a view of this buffer
+            # every BN's num_batches_tracked is a view of this buffer; a pass that stands for `_bn_repeat` identical passes
+            # (set_bn_repeat: SSLGCT's PXL_GCT_REUSE_FORWARD) counts as that many, like its running statistics
+            self._nbt += getattr(self, "_bn_repeat", 1)
         return logits, prob
 
     def _bn_leaves(self):
@@ -899,7 +901,7 @@ def forward_deferred_pair(core_a, xa, core_b, xb):
                                      stream_ptr()))
     for core, (training, _) in zip((core_a, core_b), flags):
         if training:
-            core._nbt += 1
+            core._nbt += getattr(core, "_bn_repeat", 1)
     for core, pl, arena, x, (training, need_graph) in zip((core_a, core_b), plans, arenas, xs, flags):
         heads.append(DeferredHead(core, arena, pl, x.shape[0], training, need_graph))
     return heads[0], heads[1]

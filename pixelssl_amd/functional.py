@@ -119,12 +119,13 @@ def task_consistency(logits, gt, ce_values, target, lo, hi, ignore_index=255):
     return _TaskConsistency.apply(logits, gt, ce_values.detach(), target.detach(), int(lo), int(hi), int(ignore_index))
 
 
-def head_losses(s_head, t_head, gt, n_ce, mse_lo, mse_hi, ce_weight, mse_weight, ignore_index=255):
+def head_losses(s_head, t_head, gt, n_ce, mse_lo, mse_hi, ce_weight, mse_weight, ignore_index=255, mse_weight_dev=None):
     """The training seam on the low-resolution logits of deferred forward passes (engine.DeferredHead; csrc/head.hip:
     pxl_head_loss): per-sample cross-entropy of the student and of the teacher on the first `n_ce` samples
     (task/sseg/criterion.py:24-38), the MSE between their predictions over samples [mse_lo, mse_hi) (ssl_mt.py:179-184)
     and d(loss)/d(student low-res logits) for loss = ce_weight * sum(CE_student) + mse_weight * MSE, left in the
     student's executor for s_head.backward().  t_head None: student terms only.
+    mse_weight_dev: device address of mse_weight (graph.HyperBlock.ptr) -- a captured step reads the ramped weight from there.
     -> (student CE [n_ce], teacher CE [n_ce] or None, MSE mean scalar), detached fp32 device tensors."""
     _gpu(gt)
     gt = gt.contiguous().float()
@@ -139,10 +140,16 @@ def head_losses(s_head, t_head, gt, n_ce, mse_lo, mse_hi, ce_weight, mse_weight,
     s_head._check_arena("head_losses")
     if t_head is not None:
         t_head._check_arena("head_losses")
-    check(lib().pxl_net_head_loss(pl.net, ptr(s_head.arena), t_head.plan.net if t_head is not None else None,
-                                  ptr(t_head.arena) if t_head is not None else None, ptr(gt), int(ignore_index), int(n_ce),
-                                  int(mse_lo), int(mse_hi), float(ce_weight), float(mse_weight), ptr(pl.scratch),
-                                  pl.scratch.numel(), ptr(sums), stream_ptr()))
+    if mse_weight_dev is not None:
+        check(lib().pxl_net_head_loss_hp(pl.net, ptr(s_head.arena), t_head.plan.net if t_head is not None else None,
+                                         ptr(t_head.arena) if t_head is not None else None, ptr(gt), int(ignore_index), int(n_ce),
+                                         int(mse_lo), int(mse_hi), float(ce_weight), mse_weight_dev, ptr(pl.scratch),
+                                         pl.scratch.numel(), ptr(sums), stream_ptr()))
+    else:
+        check(lib().pxl_net_head_loss(pl.net, ptr(s_head.arena), t_head.plan.net if t_head is not None else None,
+                                      ptr(t_head.arena) if t_head is not None else None, ptr(gt), int(ignore_index), int(n_ce),
+                                      int(mse_lo), int(mse_hi), float(ce_weight), float(mse_weight), ptr(pl.scratch),
+                                      pl.scratch.numel(), ptr(sums), stream_ptr()))
     s_head.mark_grad()
     return sums[:n_ce], (sums[B:B + n_ce] if t_head is not None else None), sums[2 * B]
 

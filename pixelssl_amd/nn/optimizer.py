@@ -65,11 +65,19 @@ def _sync_foreign_grads(groups):
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])
     pdist.allreduce_mean_(flat)
+    # which tensors received a gradient on ANY rank (one more small all-reduce): those step with the mean on EVERY rank -- a
+    # rank that had none contributed zeros to the mean and must apply it too, or the replicas drift apart; tensors without a
+    # gradient anywhere keep grad = None (the optimizers skip them, like torch's)
+    had = torch.tensor([0.0 if p.grad is None else 1.0 for p in ps], device=flat.device)
+    pdist.allreduce_sum_(had)
+    had = had.tolist()
     off = 0
-    for p in ps:
+    for k, p in enumerate(ps):
         n = p.numel()
         if p.grad is not None:
             p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        elif had[k] > 0:
+            p.grad = flat[off:off + n].view_as(p).clone()
         off += n
 
 
@@ -173,8 +181,22 @@ class FusedSGD(_FlatStateMixin, Optimizer):
             if not hasattr(store, 'momentum'):
                 store.momentum = torch.zeros_like(store.params)
         self._steps_taken = 0
+        FusedSGD._instances += 1
+        self._hp_name = 'sgd%d' % FusedSGD._instances
 
+    _instances = 0
     _STATE_KEYS = (('momentum_buffer', 'momentum'),)
+
+    def hyper_values(self):
+        """the per-step scalars of the next step() for a captured training step (graph.HyperBlock.upload): one learning rate
+        per parameter group, as the lr scheduler left them"""
+        return {'%s.lr%d' % (self._hp_name, gi): float(g['lr']) for gi, g in enumerate(self.param_groups)}
+
+    def after_replayed_step(self):
+        """host bookkeeping of one step() that a graph replay performed on the device"""
+        self._steps_taken += 1
+        for store in self._stores.values():
+            store.touch()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -182,13 +204,19 @@ class FusedSGD(_FlatStateMixin, Optimizer):
         first = self._steps_taken == 0
         self._steps_taken += 1
         _sync_foreign_grads(self._foreign)
-        for group, runs, foreign in zip(self.param_groups, self._runs, self._foreign):
+        from .. import graph as pgraph
+        hyper = pgraph.current_hyper()          # a captured step: the learning rates are read from device memory
+        for gi, (group, runs, foreign) in enumerate(zip(self.param_groups, self._runs, self._foreign)):
             lr, mom, wd = float(group['lr']), float(group['momentum']), float(group['weight_decay'])
             damp, nest = float(group.get('dampening', 0.0)), bool(group.get('nesterov', False))
+            if hyper is not None and (damp != 0.0 or nest or foreign):
+                raise _lib.PixelHipError('FusedSGD: a captured step supports plain momentum SGD over engine parameters only')
+            lr_dev = hyper.ptr('%s.lr%d' % (self._hp_name, gi)) if hyper is not None else None
             for store, off, n in runs:
                 if damp == 0.0 and not nest:
                     # (buf starts at zero, so m * 0 + d = d: the plain kernel needs no first-step flag)
-                    ops.sgd_step(store.params[off:off + n], store.grads[off:off + n], store.momentum[off:off + n], lr, mom, wd)
+                    ops.sgd_step(store.params[off:off + n], store.grads[off:off + n], store.momentum[off:off + n], lr, mom, wd,
+                                 lr_dev=lr_dev)
                 else:
                     _lib.check(_lib.lib().pxl_sgd_step_general(n, _lib.ptr(store.params[off:off + n]), _lib.ptr(store.grads[off:off + n]),
                                                                _lib.ptr(store.momentum[off:off + n]), lr, mom, damp, wd, int(nest),

@@ -299,9 +299,16 @@ def upsample_softmax_bwd(dtype, dlogits, dprob, prob, h, w, Cp, align_corners=Tr
     return dlow
 
 
-def sgd_step(p, g, buf, lr, momentum, weight_decay):
-    check(lib().pxl_sgd_step(p.numel(), ptr(p), ptr(g), ptr(buf), lr, momentum, weight_decay, 0, stream_ptr()))
+def sgd_step(p, g, buf, lr, momentum, weight_decay, lr_dev=None):
+    """lr_dev: device address of the learning rate (graph.HyperBlock.ptr) -- a captured step reads it from there"""
+    if lr_dev is not None:
+        check(lib().pxl_sgd_step_hp(p.numel(), ptr(p), ptr(g), ptr(buf), lr_dev, momentum, weight_decay, 0, stream_ptr()))
+    else:
+        check(lib().pxl_sgd_step(p.numel(), ptr(p), ptr(g), ptr(buf), lr, momentum, weight_decay, 0, stream_ptr()))
 
 
-def ema_update(teacher, student, alpha):
-    check(lib().pxl_ema_update(teacher.numel(), ptr(teacher), ptr(student), alpha, stream_ptr()))
+def ema_update(teacher, student, alpha, alpha_dev=None):
+    if alpha_dev is not None:
+        check(lib().pxl_ema_update_hp(teacher.numel(), ptr(teacher), ptr(student), alpha_dev, stream_ptr()))
+    else:
+        check(lib().pxl_ema_update(teacher.numel(), ptr(teacher), ptr(student), alpha, stream_ptr()))

@@ -30,10 +30,13 @@ class _SSLBase:
         self._build(model_funcs, optimizer_funcs, lrer_funcs, criterion_funcs, task_func)
 
     def train(self, data_loader, epoch):
+        # multi-rank: the ranks enter an epoch together -- a rank-0 checkpoint save or an uneven validation pass before it must not
+        # eat into the time-out of the first Sync-BN exchange (an explicit collective at a boundary every rank reaches; no-op on one)
+        from .. import dist as pdist
+        pdist.epoch_barrier()
         self._train(data_loader, epoch)
         # multi-rank: an epoch whose peer-mapped Sync-BN exchanges timed out trained on invalid statistics -- fail here, loudly
         # (one device synchronisation per epoch; no-op on one rank)
-        from .. import dist as pdist
         pdist.check_peers()
 
     def validate(self, data_loader, epoch):
@@ -72,6 +75,9 @@ class _SSLBase:
         from rank to rank (a torch.distributed group is not thread-safe; two RCCL communicators can dead-lock on it)."""
         import os
         from .. import dist as pdist
+        from .. import graph as pgraph
+        if pgraph.current_hyper() is not None:     # a step that is (about to be) captured is enqueued by ONE thread
+            return None
         # the first iterations autotune (tile timings of one network must not be measured under the other network's
         # kernels, and the tuner is entered from one thread only): the helper thread starts with the third call
         self._enq_calls = getattr(self, '_enq_calls', 0) + 1

@@ -11,6 +11,7 @@ from ..nn import func
 from ..nn.module import patch_replication_callback, GaussianNoiseLayer
 from ..functional import MSELoss
 from .. import ops, streams
+from .. import graph as pgraph
 from . import ssl_base
 
 
@@ -90,10 +91,16 @@ class SSLMT(ssl_base._SSLBase):
             s_inp = t_inp = tuple(inp)     # noise disabled => one tensor serves both passes
         ramp = func.sigmoid_rampup(cur_step, total_rampup_steps)
 
+        seam = lbs > 0 and type(self.cons_criterion) is MSELoss and \
+            self._seam_fusable([self.s_model, self.t_model], self.s_criterion, s_inp, gt)
+        if seam and s_inp is t_inp and not getattr(getattr(self.s_model.module, 'model', None), '_profile_on', False):
+            sg = self._step_graph(lbs)
+            if sg is not None:          # the iteration as ONE hipGraph launch (pixelssl_amd/graph.py)
+                outs = sg.step((s_inp[0], gt[0]), (cur_step, total_rampup_steps))
+                return (dict(s_task_loss=outs[0], t_task_loss=outs[1], cons_loss=outs[2]),) + tuple(self._graph_resulters)
         self.s_optimizer.zero_grad()
         l_gt = func.split_tensor_tuple(gt, 0, lbs)
-        if lbs > 0 and type(self.cons_criterion) is MSELoss and \
-                self._seam_fusable([self.s_model, self.t_model], self.s_criterion, s_inp, gt):
+        if seam:
             return self._train_step_fused_seam(s_inp, t_inp, l_gt, lbs, ramp, cur_step)
 
         def teacher_pass():
@@ -173,6 +180,45 @@ class SSLMT(ssl_base._SSLBase):
         return dict(s_task_loss=s_task_loss.detach(), t_task_loss=t_task_loss.detach(),
                     cons_loss=cons_loss.detach()), s_resulter, t_resulter
 
+    def _step_graph(self, lbs):
+        """The StepGraph of the fused-seam iteration, or None (PXL_GRAPH=0, several ranks, an optimizer / scheduler the captured
+        step does not cover).  Captured body = _train_step_fused_seam in hyper mode: the ramped consistency weight, the learning
+        rates and the EMA coefficient are read from device memory (graph.HyperBlock), everything else is the eager step."""
+        if hasattr(self, '_sgraph'):
+            return self._sgraph
+        from .. import dist as pdist
+        from ..nn.optimizer import FusedSGD
+        self._sgraph = None
+        ok = pgraph.enabled() and not pdist.is_distributed() and type(self.s_optimizer) is FusedSGD and \
+            os.environ.get('PXL_PAIR_FORWARD') != '1' and not any(self.s_optimizer._foreign) and \
+            all(float(g.get('dampening', 0.0)) == 0.0 and not g.get('nesterov', False) for g in self.s_optimizer.param_groups)
+        if not ok:
+            return None
+
+        def body(x, g0):
+            self.s_optimizer.zero_grad()
+            losses, s_res, t_res = self._train_step_fused_seam((x,), (x,), (g0[:lbs],), lbs, None, None)
+            self._graph_resulters = (s_res, t_res)
+            return losses['s_task_loss'], losses['t_task_loss'], losses['cons_loss']
+
+        def scalars(cur_step, total_rampup_steps):
+            vals = dict(self.s_optimizer.hyper_values())
+            vals['ema_alpha'] = min(1 - 1 / (cur_step + 1), self.args.ema_decay)
+            vals['w_cons'] = func.sigmoid_rampup(cur_step, total_rampup_steps) * self.args.cons_scale
+            return vals
+
+        def after_replay():          # the host half of optimizer.step / EMA / scheduler that the body did while being recorded
+            self.s_optimizer.after_replayed_step()
+            for m_ in (self.t_model,):
+                core_ = getattr(m_.module, 'model', None)
+                if core_ is not None and hasattr(core_, 'mark_params_changed'):
+                    core_.mark_params_changed()
+            if not self.args.is_epoch_lrer:
+                self.s_lrer.step()
+
+        self._sgraph = pgraph.StepGraph(body, scalars, after_replay, torch.device('cuda', torch.cuda.current_device()))
+        return self._sgraph
+
     def _train_step_fused_seam(self, s_inp, t_inp, l_gt, lbs, ramp, cur_step):
         """The same iteration with the seam between the two forward passes and the backward pass fused
         (functional.head_losses): both networks stop at their low-resolution logits, one kernel evaluates the student's
@@ -245,8 +291,14 @@ class SSLMT(ssl_base._SSLBase):
         from ..sseg.model import _DeferredResulter
         B = s_inp[0].shape[0]
         lo, hi = (0, B) if self.args.cons_for_labeled else ((lbs, B) if self.args.unlabeled_batch_size > 0 else (0, 0))
-        w_cons = ramp * self.args.cons_scale
-        ce_s, ce_t, mse = PF.head_losses(s_head, t_head, l_gt[0], lbs, lo, hi, 1.0 / lbs, w_cons, self.args.ignore_index)
+        hyper = pgraph.current_hyper()
+        if hyper is not None:       # captured step: the ramped weight is a device scalar (uploaded by StepGraph before the launch)
+            ce_s, ce_t, mse = PF.head_losses(s_head, t_head, l_gt[0], lbs, lo, hi, 1.0 / lbs, None, self.args.ignore_index,
+                                             mse_weight_dev=hyper.ptr('w_cons'))
+            w_cons = hyper.tensor('w_cons')
+        else:
+            w_cons = ramp * self.args.cons_scale
+            ce_s, ce_t, mse = PF.head_losses(s_head, t_head, l_gt[0], lbs, lo, hi, 1.0 / lbs, w_cons, self.args.ignore_index)
         s_task_loss, t_task_loss = torch.mean(ce_s), torch.mean(ce_t)
         cons_loss = w_cons * mse
         s_head.backward()
@@ -331,13 +383,17 @@ class SSLMT(ssl_base._SSLBase):
         """alpha = min(1 - 1/(step+1), decay); parameters only, BN buffers evolve by the teacher's own
         forward (ssl_mt.py:359-363).  Engine task models: one fused launch over the flat parameter buffers; any other
         TaskModel (a plugin's torch model): the reference's per-parameter walk."""
-        alpha = min(1 - 1 / (cur_step + 1), ema_decay)
+        hyper = pgraph.current_hyper()
+        alpha = min(1 - 1 / (cur_step + 1), ema_decay) if hyper is None else None
         s_core, t_core = getattr(s_model.module, 'model', None), getattr(t_model.module, 'model', None)
         if hasattr(s_core, 'flat') and hasattr(t_core, 'flat') and s_core.flat.np == t_core.flat.np and \
                 len(list(s_model.parameters())) == len(s_core._param_list):
-            ops.ema_update(t_core.flat.params, s_core.flat.params, alpha)
+            ops.ema_update(t_core.flat.params, s_core.flat.params, alpha,
+                           alpha_dev=hyper.ptr('ema_alpha') if hyper is not None else None)
             t_core.mark_params_changed()
             return
+        if hyper is not None:
+            raise RuntimeError('a captured step needs engine task models (flat parameter stores) for the EMA update')
         with torch.no_grad():
             for t_param, s_param in zip(t_model.parameters(), s_model.parameters()):
                 t_param.mul_(alpha).add_(s_param.detach(), alpha=1 - alpha)

@@ -274,7 +274,7 @@ def test_mt_at_the_baseline_configuration(dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fixture", ["adv_cond_129.pt", "adv_cond_513.pt"], ids=["129", "513"])
+@pytest.mark.parametrize("fixture", ["adv_cond_129.pt", "adv_cond_513.pt", "adv_cond_513_b8.pt"], ids=["129", "513", "513b8"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_advssl_six_iterations(dtype, fixture):
     import torch_oracle as TO
@@ -339,7 +339,7 @@ def test_cutmix_six_iterations(dtype, fixture):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fixture", ["gct_cond_129.pt", "gct_cond_513.pt"], ids=["129", "513"])
+@pytest.mark.parametrize("fixture", ["gct_cond_129.pt", "gct_cond_513.pt", "gct_cond_513_b8.pt"], ids=["129", "513", "513b8"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_gct_six_iterations(dtype, fixture):
     _gct_six_iterations(dtype, fixture)
@@ -384,6 +384,11 @@ def _gct_six_iterations(dtype, fixture, expect_reuse=False):
         # reference on them (make_golden_gct_train.py); they get 10 x the loss tolerance
         # (bf16: the consistency loss counts pixels whose handled flaw map is above the 0.6 threshold -> 30 %)
         _check_losses("gct", i, got, fx["per_iter"][i], dtype, loose=("fc", "dc", "fd"), very_loose=("dc",) if dtype == "bf16" else ())
+    # the reference runs every task model twice per iteration in train mode (ssl_gct.py:196-200 + 403): num_batches_tracked
+    # advances by 2 per iteration, whether the engine ran the two passes or one pass that stands for both
+    for m in (algo.l_model, algo.r_model):
+        nbt = m.module.model.state_dict()["backbone.bn1.num_batches_tracked"]
+        assert int(nbt) == 2 * len(fx["data_seeds"]), "num_batches_tracked %d after %d iterations" % (int(nbt), len(fx["data_seeds"]))
     _check_weights("gct l " + dtype, algo.l_model.module.model.state_dict(), fx["l_updates"], dtype)
     _check_weights("gct r " + dtype, algo.r_model.module.model.state_dict(), fx["r_updates"], dtype)
     fsd = OrderedDict((k, v) for k, v in algo.fd_model.module.state_dict().items())
@@ -442,7 +447,7 @@ def test_cct_six_iterations(dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fixture", ["cct_cut_cond_129.pt", "cct_cut_cond_513.pt"], ids=["129", "513"])
+@pytest.mark.parametrize("fixture", ["cct_cut_cond_129.pt", "cct_cut_cond_513.pt", "cct_cut_cond_513_b8.pt"], ids=["129", "513", "513b8"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_cct_six_iterations_with_gcutout(dtype, fixture):
     """BASELINE.json config 5: K = 7 auxiliary decoders INCLUDING G-Cutout.  Fixture = six iterations (129 x 129) / two
