@@ -530,6 +530,10 @@ def main():
                "rccl_ranks": pdist.rccl_ranks(), "grad_buckets": int(cores[0].grad_buckets()),
                # networks whose Sync-BN statistics go through the peer-mapped one-shot exchange (csrc/peer.hip)
                "peer_contexts": pdist.peer_contexts()}
+        sg = getattr(algo, "_sgraph", None)
+        # the iteration as ONE hipGraph launch (pixelssl_amd/graph.py; PXL_GRAPH=0 turns it off): replays inside this process so far
+        out["graph"] = ({"captured": sg.graph is not None, "replays": int(sg.replays), "failed": sg.failed} if sg is not None
+                        else {"captured": False, "replays": 0, "failed": None})
         if a.algo == "mt" and getattr(cores[0], "_cur", None) is not None:
             # paired student || teacher pass (the default with Sync-BN): convolutions issued as ONE launch for both networks and
             # Sync-BN statistics exchanges that carried both networks' sums (csrc/net.cpp: pxl_net_forward_pair)
