@@ -534,6 +534,18 @@ int pxl_net_set_sync(pxl_net* net, pxl_allreduce_fn fn, void* user, int world_si
  * work is considered done.  bucket_floats = 0: one exchange at the end.  fn = NULL: off.  Use a communicator of its own
  * for fn (RCCL runs the collectives of one communicator in issue order, a bucket must not queue behind Sync-BN). */
 int pxl_net_set_grad_sync(pxl_net* net, pxl_allreduce_fn fn, void* user, int world_size, long bucket_floats, long total_floats);
+/* Parameter update pipelined behind the backward pass.  The reference steps the optimizer after `loss.backward()` has
+ * returned (ssl_mt.py:198-204: backward, optimizer.step, EMA update), i.e. SGD over 44.6 M parameters, the EMA and the
+ * re-packing of the kernel-layout weights sit between two iterations with nothing beside them.  With a hook installed,
+ * pxl_net_backward hands every bucket grads[lo, hi) of the flat gradient buffer to `fn` as soon as every kernel writing
+ * into it has been issued (after the all-reduce of pxl_net_set_grad_sync when both are set), on the communication stream,
+ * in descending address order; the host enqueues optimizer step / EMA / pxl_net_pack_range of that slice on `stream`.
+ * The call's stream waits for the last bucket.  bucket_floats: minimum bucket size; tail_floats > 0: one more boundary
+ * where at most that many floats of parameters remain below (a small last bucket: the next forward waits for it).
+ * Same update arithmetic, element by element, as one step over the whole buffer.  fn = NULL: off. */
+typedef int (*pxl_update_fn)(void* user, long lo, long hi, void* stream);
+int pxl_net_set_update_hook(pxl_net* net, pxl_update_fn fn, void* user, long bucket_floats, long tail_floats, long total_floats);
+int pxl_net_update_buckets(const pxl_net* net);      /* buckets the last backward handed to the hook */
 int pxl_net_grad_buckets(const pxl_net* net);        /* buckets issued by the last pxl_net_backward */
 /* autotune: time every tile configuration of every contraction on the planned shapes and keep the
  * fastest (call once after plan + pack; clobbers arena / scratch / grads contents; synchronises) */
@@ -543,6 +555,8 @@ int pxl_net_tune(pxl_net* net, const float* params, const void* packed, float* g
 int pxl_net_pack(pxl_net* net, const float* params, void* packed, void* stream);
 /* the same in two independent halves: which bit 0 = forward operand layout + biases (read by pxl_net_forward), bit 1 =
  * transposed data-gradient layout (first read by pxl_net_backward: pack it on a side stream next to the forward) */
+/* pxl_net_pack_parts for the convolutions whose master weights lie in params[lo, hi) (a bucket of the pipelined update) */
+int pxl_net_pack_range(pxl_net* net, const float* params, void* packed, int which, long lo, long hi, void* stream);
 int pxl_net_pack_parts(pxl_net* net, const float* params, void* packed, int which, void* stream);
 /* x NCHW fp32 [B,3,H,W] -> logits/prob NCHW fp32 [B,classes,H,W]; training selects batch statistics
  * (+ running-stat update) vs running statistics; the arena keeps what backward needs. */

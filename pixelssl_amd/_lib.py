@@ -58,6 +58,7 @@ class BnFin(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+UPDATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p)      # pxl_update_fn(user, lo, hi, stream)
 
 _P = C.c_void_p
 _I = C.c_int
@@ -206,6 +207,9 @@ SIGNATURES = {
     "pxl_net_set_sync": (_I, [_P, ALLREDUCE_FN, _P, _I]),
     "pxl_net_set_grad_sync": (_I, [_P, ALLREDUCE_FN, _P, _I, _L, _L]),
     "pxl_net_grad_buckets": (_I, [_P]),
+    "pxl_net_set_update_hook": (_I, [_P, UPDATE_FN, _P, _L, _L, _L]),
+    "pxl_net_update_buckets": (_I, [_P]),
+    "pxl_net_pack_range": (_I, [_P, _P, _P, _I, _L, _L, _P]),
     "pxl_net_tune": (_I, [_P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
     "pxl_net_pack": (_I, [_P, _P, _P, _P]),
     "pxl_net_pack_parts": (_I, [_P, _P, _P, _I, _P]),

@@ -185,6 +185,15 @@ struct pxl_net {
   hipStream_t comm_stream = nullptr;
   bool comm_owned = true;
   hipEvent_t comm_main_ev = nullptr, comm_side_ev = nullptr, comm_done_ev = nullptr;
+  // parameter update pipelined behind the backward pass (pxl_net_set_update_hook): the same buckets, handed to the host's
+  // optimizer as soon as their gradients are complete (and, multi-rank, all-reduced) -- SGD / EMA / weight re-packing of a
+  // bucket run on the communication stream next to the data gradients of the layers below instead of after the pass
+  pxl_update_fn update_fn = nullptr;
+  void* update_user = nullptr;
+  long update_bucket = 0;          // floats per update bucket (0: one call at the end)
+  long update_total = 0;
+  long update_tail = 0;            // a bucket boundary is forced where at most this many floats of parameters remain below
+  int update_buckets_last = 0;
   std::vector<long> op_lo;         // per op: lowest flat offset (floats) its backward writes a gradient to, or -1
   bool bucket_ok = false;          // parameter offsets grow with the op index: suffixes of the op list = suffixes of the buffer
   int grad_buckets_last = 0;       // buckets issued by the last backward (tests / bench)
@@ -398,6 +407,19 @@ extern "C" int pxl_net_set_grad_sync(pxl_net* net, pxl_allreduce_fn fn, void* us
 }
 
 extern "C" int pxl_net_grad_buckets(const pxl_net* net) { return net ? net->grad_buckets_last : 0; }
+
+extern "C" int pxl_net_set_update_hook(pxl_net* net, pxl_update_fn fn, void* user, long bucket_floats, long tail_floats,
+                                       long total_floats) {
+  PXL_REQUIRE(net && bucket_floats >= 0 && tail_floats >= 0 && total_floats >= 0, "net_set_update_hook: bad argument");
+  net->update_fn = fn;
+  net->update_user = user;
+  net->update_bucket = bucket_floats;
+  net->update_tail = tail_floats;
+  net->update_total = total_floats;
+  return PXL_OK;
+}
+
+extern "C" int pxl_net_update_buckets(const pxl_net* net) { return net ? net->update_buckets_last : 0; }
 
 extern "C" int pxl_net_profile(pxl_net* net, int enable) {
   PXL_REQUIRE(net, "net_profile: null net");
@@ -780,12 +802,29 @@ extern "C" size_t pxl_net_scratch_bytes(const pxl_net* n) { return n && n->plann
 // which: bit 0 = forward operand layout (+ summed biases), bit 1 = transposed data-gradient layout.  The two halves are
 // independent: the host packs the forward half on the stream of the forward pass and the data-gradient half, which is
 // first read by the backward pass, on a side stream that overlaps the forward.
+namespace {
+int net_pack_impl(pxl_net* n, const float* params, void* packed, int which, long lo, long hi, void* stream);
+}
+
 extern "C" int pxl_net_pack_parts(pxl_net* n, const float* params, void* packed, int which, void* stream) {
+  return net_pack_impl(n, params, packed, which, 0, -1, stream);
+}
+
+// The same for the convolutions whose master weights lie in params[lo, hi) only (a bucket of the pipelined parameter update,
+// pxl_net_set_update_hook: bucket boundaries fall between ops, so a convolution is inside or outside as a whole)
+extern "C" int pxl_net_pack_range(pxl_net* n, const float* params, void* packed, int which, long lo, long hi, void* stream) {
+  PXL_REQUIRE(lo >= 0 && hi >= lo, "net_pack_range: bad range");
+  return net_pack_impl(n, params, packed, which, lo, hi, stream);
+}
+
+namespace {
+int net_pack_impl(pxl_net* n, const float* params, void* packed, int which, long lo, long hi, void* stream) {
   PXL_REQUIRE(n && n->planned && params && packed && (which & 3) != 0, "net_pack: bad argument (plan first)");
   std::vector<pxl_pack_item> items;
   for (auto& op : n->ops) {
     const pxl_op& d = op.d;
     if (d.kind != PXL_OP_CONV) continue;
+    if (hi >= 0 && !(d.w_off[0] >= lo && d.w_off[0] < hi)) continue;
     const TensorInfo& tin = n->tensors[d.in0];
     const TensorInfo& tout = n->tensors[d.out];
     const int tpg = d.kh * d.kw;
@@ -808,8 +847,10 @@ extern "C" int pxl_net_pack_parts(pxl_net* n, const float* params, void* packed,
       if (rc != PXL_OK) return rc;
     }
   }
+  if (items.empty()) return PXL_OK;
   return pxl_pack_weights_batched(n->dtype, params, packed, items.data(), (int)items.size(), stream);
 }
+}  // namespace
 
 extern "C" int pxl_net_pack(pxl_net* n, const float* params, void* packed, void* stream) {
   return pxl_net_pack_parts(n, params, packed, 3, stream);
@@ -1751,9 +1792,12 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
   // ---- overlapped gradient exchange (multi-rank): flush [lo, hi) of the flat gradient buffer once every kernel writing
   // into it has been issued -- the communication stream waits for the main and the weight-gradient stream at that point
   const bool bucketing = n->grad_sync && n->grad_world > 1 && n->wgrad_on && n->grad_total > 0;
-  long grad_hi = n->grad_total;
+  const bool updating = n->update_fn != nullptr && n->wgrad_on && n->update_total > 0 && n->bucket_ok &&
+                        (!bucketing || n->update_total == n->grad_total);
+  long grad_hi = bucketing ? n->grad_total : n->update_total;
   n->grad_buckets_last = 0;
-  if (bucketing && !n->comm_stream) {
+  n->update_buckets_last = 0;
+  if ((bucketing || updating) && !n->comm_stream) {
     hipStream_t placed = reinterpret_cast<hipStream_t>(pxl_stream_role(PXL_STREAM_AUX));
     if (placed != nullptr && placed != s) {
       n->comm_stream = placed;
@@ -1766,23 +1810,34 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
     PXL_CHECK_HIP(hipEventCreateWithFlags(&n->comm_done_ev, hipEventDisableTiming));
   }
   auto flush = [&](long lo) -> int {
-    if (!bucketing || lo >= grad_hi) return PXL_OK;
+    if (!(bucketing || updating) || lo >= grad_hi) return PXL_OK;
     PXL_CHECK_HIP(hipEventRecord(n->comm_main_ev, s));
     PXL_CHECK_HIP(hipStreamWaitEvent(n->comm_stream, n->comm_main_ev, 0));
     if (forked) {
       PXL_CHECK_HIP(hipEventRecord(n->comm_side_ev, n->side));
       PXL_CHECK_HIP(hipStreamWaitEvent(n->comm_stream, n->comm_side_ev, 0));
     }
-    // (the hook takes an int count: buckets are far below 2^31 floats)
-    for (long o = lo; o < grad_hi; o += (1L << 30)) {
-      const long cnt = grad_hi - o < (1L << 30) ? grad_hi - o : (1L << 30);
-      const int rc = n->grad_sync(n->grad_user, grads + o, (int)cnt, n->comm_stream);
-      if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_backward: gradient all-reduce hook failed (%d)", rc);
+    if (forked2) {            // (a second weight-gradient stream: its kernels write into the bucket as well)
+      PXL_CHECK_HIP(hipEventRecord(n->join_ev2, n->side2));
+      PXL_CHECK_HIP(hipStreamWaitEvent(n->comm_stream, n->join_ev2, 0));
     }
-    const int rc2 = pxl_scale_inplace(grad_hi - lo, grads + lo, 1.0f / (float)n->grad_world, n->comm_stream);
-    if (rc2 != PXL_OK) return rc2;
+    if (bucketing) {
+      // (the hook takes an int count: buckets are far below 2^31 floats)
+      for (long o = lo; o < grad_hi; o += (1L << 30)) {
+        const long cnt = grad_hi - o < (1L << 30) ? grad_hi - o : (1L << 30);
+        const int rc = n->grad_sync(n->grad_user, grads + o, (int)cnt, n->comm_stream);
+        if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_backward: gradient all-reduce hook failed (%d)", rc);
+      }
+      const int rc2 = pxl_scale_inplace(grad_hi - lo, grads + lo, 1.0f / (float)n->grad_world, n->comm_stream);
+      if (rc2 != PXL_OK) return rc2;
+      ++n->grad_buckets_last;
+    }
+    if (updating) {           // the optimizer takes the finished (and averaged) bucket from here, on the same stream
+      const int rc = n->update_fn(n->update_user, lo, grad_hi, n->comm_stream);
+      if (rc != 0) return pxl_set_error(PXL_ERR_HIP, "net_backward: parameter-update hook failed (%d)", rc);
+      ++n->update_buckets_last;
+    }
     grad_hi = lo;
-    ++n->grad_buckets_last;
     return PXL_OK;
   };
 
@@ -2050,18 +2105,26 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
     }
     if (rc != PXL_OK) return rc;
     // everything that writes gradients at or above op_lo[i] has now been issued
-    if (bucketing && n->bucket_ok && n->grad_bucket > 0 && n->op_lo[i] >= 0 && grad_hi - n->op_lo[i] >= n->grad_bucket) {
-      rc = issue_wgrads(i);
-      if (rc != PXL_OK) return rc;
-      rc = flush(n->op_lo[i]);
-      if (rc != PXL_OK) return rc;
+    {
+      const long bsz = bucketing ? n->grad_bucket : n->update_bucket;
+      bool cut = (bucketing || updating) && n->bucket_ok && bsz > 0 && n->op_lo[i] >= 0 && grad_hi - n->op_lo[i] >= bsz;
+      // pipelined update: one more boundary just above the first layers (the stem), so that the LAST bucket -- the one whose
+      // update the next forward pass has to wait for -- is a few thousand parameters
+      if (!cut && updating && n->update_tail > 0 && n->op_lo[i] >= 0 && n->op_lo[i] <= n->update_tail && grad_hi > n->update_tail)
+        cut = true;
+      if (cut) {
+        rc = issue_wgrads(i);
+        if (rc != PXL_OK) return rc;
+        rc = flush(n->op_lo[i]);
+        if (rc != PXL_OK) return rc;
+      }
     }
   }
   {
     int rc = issue_wgrads(0);                    // (only when the program does not end in a convolution without data gradient)
     if (rc != PXL_OK) return rc;
   }
-  if (bucketing) {                               // the rest of the buffer (or all of it when bucketing is off)
+  if (bucketing || updating) {                   // the rest of the buffer (or all of it when bucketing is off)
     int rc = flush(0);
     if (rc != PXL_OK) return rc;
     PXL_CHECK_HIP(hipEventRecord(n->comm_done_ev, n->comm_stream));

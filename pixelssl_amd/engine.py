@@ -473,6 +473,9 @@ class SegNetCore(nn.Module):
                 check(lib().pxl_net_set_grad_sync(pl.net, gs[0], gs[1], gs[2], gs[3], self._store.np))
             if not self._wgrad_on:
                 check(lib().pxl_net_set_wgrad(pl.net, 0))
+            uh = getattr(self, "_update_hook", None)
+            if uh is not None and not inference:
+                check(lib().pxl_net_set_update_hook(pl.net, uh[0], None, uh[1], uh[2], self._store.np))
             if self._profile_on:
                 check(lib().pxl_net_profile(pl.net, 1))
             if inference:
@@ -564,6 +567,35 @@ class SegNetCore(nn.Module):
                 check(lib().pxl_net_set_grad_sync(pl.net, _lib.ALLREDUCE_FN(), None, 1, 0, 0))
             else:
                 check(lib().pxl_net_set_grad_sync(pl.net, fn, user, int(world_size), int(bucket_floats), self._store.np))
+
+    def set_update_hook(self, fn, bucket_floats=0, tail_floats=0):
+        """Parameter update pipelined behind the backward pass (csrc/net.cpp: pxl_net_set_update_hook): fn(lo, hi, stream) is
+        called from inside the backward for every finished bucket grads[lo, hi) of the flat gradient buffer, `stream` (an int) is
+        the HIP stream the bucket's update belongs on.  fn = None turns it off."""
+        if fn is None:
+            self._update_hook = None
+            for pl in self._plans.values():
+                check(lib().pxl_net_set_update_hook(pl.net, _lib.UPDATE_FN(), None, 0, 0, 0))
+            return
+
+        def _cb(user, lo, hi, stream):
+            try:
+                fn(int(lo), int(hi), int(stream or 0))
+                return 0
+            except Exception:       # never unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._update_hook = (_lib.UPDATE_FN(_cb), int(bucket_floats), int(tail_floats))
+        for pl in self._plans.values():
+            check(lib().pxl_net_set_update_hook(pl.net, self._update_hook[0], None, int(bucket_floats), int(tail_floats), self._store.np))
+
+    def update_buckets(self):
+        return lib().pxl_net_update_buckets(self._cur.net) if self._cur is not None else 0
+
+    def pack_range(self, plan, lo, hi, which=3):
+        """re-pack the kernel-layout weights of the convolutions whose master weights lie in params[lo, hi) (current stream)"""
+        check(lib().pxl_net_pack_range(plan.net, ptr(self._store.params), ptr(plan.packed), int(which), int(lo), int(hi), stream_ptr()))
 
     def grad_buckets(self):
         """buckets the last backward of the current plan exchanged (0 on one rank)"""

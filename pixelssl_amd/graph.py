@@ -15,8 +15,8 @@ streams) and replayed.  Two things make a step replayable:
 
 The captured body is exactly the eager body (`fn`), run in "hyper mode": the first `warmup` calls run it eagerly (autotune,
 lazy stream / event creation), the next call captures, later calls replay.  Any call whose input shapes differ from the
-captured ones runs eagerly (a short last batch).  PXL_GRAPH=0 turns the mechanism off; it is never used multi-rank (the
-peer-mapped Sync-BN exchanges carry an epoch counter in their arguments)."""
+captured ones runs eagerly (a short last batch).  Opt-in: PXL_GRAPH=1 (see enabled() for the measurement that keeps it off by
+default); it is never used multi-rank (the peer-mapped Sync-BN exchanges carry an epoch counter in their arguments)."""
 import ctypes
 import os
 
@@ -32,7 +32,12 @@ def current_hyper():
 
 
 def enabled():
-    return os.environ.get("PXL_GRAPH", "1") != "0"
+    """OFF unless PXL_GRAPH=1.  Measured on this image (ROCm 7.2, MI355X; DESIGN.md 4 round 5, profiles/r05_a_graph_*): the captured
+    MT step replays CORRECTLY (same losses / weights as the eager step, the 513 x 513 fixture included) but SLOWER -- 13.9 ms
+    against 12.5 ms eager: hipGraphLaunch spends as long on the host as the 704 eager launches do (8.9 vs 8.0 ms per step), and
+    the runtime executes the four captured branches almost one after the other (1.0 - 1.1 kernels in flight where the eager
+    streams keep 1.6 - 2.0)."""
+    return os.environ.get("PXL_GRAPH", "0") == "1"
 
 
 class HyperBlock:

@@ -180,6 +180,22 @@ class SSLMT(ssl_base._SSLBase):
         return dict(s_task_loss=s_task_loss.detach(), t_task_loss=t_task_loss.detach(),
                     cons_loss=cons_loss.detach()), s_resulter, t_resulter
 
+    def _update_pipeline(self, s_head, t_head):
+        """PipelinedUpdate for this student / teacher pair, or None: PXL_PIPE_UPDATE=0, an optimizer it does not cover (anything
+        but plain momentum SGD over the student's flat parameter store), task models that are not engine networks."""
+        if not hasattr(self, '_pipe'):
+            self._pipe = None
+            if os.environ.get('PXL_PIPE_UPDATE', '1') != '0':
+                from ..nn.optimizer import PipelinedUpdate
+                s_core, t_core = s_head.core, t_head.core
+                try:
+                    if len(list(self.s_model.parameters())) != len(s_core._param_list):
+                        raise ValueError('the student holds parameters outside its engine network')
+                    self._pipe = PipelinedUpdate(self.s_optimizer, s_core, t_core)
+                except ValueError as e:
+                    logger.log_info('pipelined parameter update off: %s\n' % e)
+        return self._pipe
+
     def _step_graph(self, lbs):
         """The StepGraph of the fused-seam iteration, or None (PXL_GRAPH=0, several ranks, an optimizer / scheduler the captured
         step does not cover).  Captured body = _train_step_fused_seam in hyper mode: the ramped consistency weight, the learning
@@ -208,11 +224,14 @@ class SSLMT(ssl_base._SSLBase):
             return vals
 
         def after_replay():          # the host half of optimizer.step / EMA / scheduler that the body did while being recorded
-            self.s_optimizer.after_replayed_step()
-            for m_ in (self.t_model,):
-                core_ = getattr(m_.module, 'model', None)
-                if core_ is not None and hasattr(core_, 'mark_params_changed'):
-                    core_.mark_params_changed()
+            if getattr(self, '_pipe', None) is not None:
+                self._pipe.replayed()
+            else:
+                self.s_optimizer.after_replayed_step()
+                for m_ in (self.t_model,):
+                    core_ = getattr(m_.module, 'model', None)
+                    if core_ is not None and hasattr(core_, 'mark_params_changed'):
+                        core_.mark_params_changed()
             if not self.args.is_epoch_lrer:
                 self.s_lrer.step()
 
@@ -301,9 +320,14 @@ class SSLMT(ssl_base._SSLBase):
             ce_s, ce_t, mse = PF.head_losses(s_head, t_head, l_gt[0], lbs, lo, hi, 1.0 / lbs, w_cons, self.args.ignore_index)
         s_task_loss, t_task_loss = torch.mean(ce_s), torch.mean(ce_t)
         cons_loss = w_cons * mse
+        pipe = self._update_pipeline(s_head, t_head)
+        if pipe is not None:
+            # SGD + EMA + weight re-packing bucket by bucket from inside the backward pass (nn/optimizer.py: PipelinedUpdate)
+            pipe.arm(s_head.plan, t_head.plan, None if hyper is not None else min(1 - 1 / (cur_step + 1), self.args.ema_decay), hyper)
         s_head.backward()
         self.s_optimizer.step()
-        self._update_ema_variables(self.s_model, self.t_model, self.args.ema_decay, cur_step)
+        if pipe is None:
+            self._update_ema_variables(self.s_model, self.t_model, self.args.ema_decay, cur_step)
         if not self.args.is_epoch_lrer:
             self.s_lrer.step()
         return dict(s_task_loss=s_task_loss.detach(), t_task_loss=t_task_loss.detach(),
