@@ -53,6 +53,7 @@ def parse():
     p.add_argument("--no-conditioned", action="store_true",
                    help="keep the raw reference initialisers (random-init ResNet-101 + x10 head lr diverges within ~20 steps; "
                         "default: bottleneck-output BN gammas x 0.1, the conditioning of the parity fixtures)")
+    p.add_argument("--no-scaling-legs", action="store_true", help="multi-rank runs: skip the GCT / exchange-timing legs after the MT line")
     p.add_argument("--no-fixture-parity", action="store_true", help="skip the parity_vs_fixture leg (mt_cond_513.pt replay, both dtypes)")
     p.add_argument("--decoders", type=int, default=7, choices=[7, 11],
                    help="CCT: 7 = one decoder of each kind (BASELINE.json config 5), 11 = the shipped script's setting "
@@ -383,6 +384,121 @@ def fp32_parity_leg(a, world, batches, fence):
                     "losses / weights are within 1e-3 of the reference (parity tests); same workload, same timing protocol"}
 
 
+def scaling_legs(a, world, batches, fence, dev, mt_ms_per_step):
+    """Multi-rank runs only (the driver's SCALE command is `python bench.py --gpus N`, which times MT): what a first run across
+    real GPUs has to show next to the MT line, each leg bounded to a few seconds and none of them able to take the MT line down
+    (every leg is wrapped; a failure is reported as a string).
+      scaling_gct            the workload north_star's ">= 6x at 8 GPUs" target is quoted on (GCT, BASELINE.json configs[2]):
+                             img/s over all ranks, ms/step, Sync-BN exchanges per step
+      sync_bn_exchange_us    one peer-mapped statistics exchange (2048 floats), HIP events around 200 back-to-back launches
+      grad_allreduce         the flat 178 MB gradient all-reduce alone (RCCL from C), and the MT step with the gradient exchange
+                             switched OFF: ms_per_step minus that = what the overlapped exchange still costs (`exposed_ms`)"""
+    import copy
+    import ctypes
+    import torch
+    from pixelssl_amd import dist as pdist, _lib
+    out = {}
+    per_gpu = a.lbs + a.ubs
+    # ---- one Sync-BN exchange over the peer-mapped buffers
+    try:
+        ctxs = pdist._peer["ctxs"]
+        if ctxs:
+            h = _lib.lib()
+            v = torch.ones(2048, device=dev)
+            st = torch.cuda.current_stream().cuda_stream
+            for _ in range(20):
+                h.pxl_peer_allreduce_sum(ctxs[0], v.data_ptr(), 2048, st)
+                v.fill_(1.0)
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(200):
+                h.pxl_peer_allreduce_sum(ctxs[0], v.data_ptr(), 2048, st)
+            e1.record()
+            e1.synchronize()
+            out["sync_bn_exchange_us"] = round(1e3 * e0.elapsed_time(e1) / 200, 2)
+        else:
+            out["sync_bn_exchange_us"] = None
+    except Exception as e:       # noqa: BLE001
+        out["sync_bn_exchange_us"] = "failed: %s" % e
+    # ---- the gradient all-reduce alone, and the MT step without it
+    try:
+        args = make_args(a, world)
+        algo, cores = build_algo(a, args)
+        if not a.no_conditioned:
+            condition(cores)
+        step = make_step(a, args, algo, batches)
+        for it in range(2):
+            step(it)
+        g = cores[0].flat.grads
+        comm = pdist._native.get("grad_comm")
+        if comm is not None:
+            st = torch.cuda.current_stream().cuda_stream
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                _lib.lib().pxl_comm_allreduce_sum(comm, g.data_ptr(), g.numel(), st)
+            e1.record()
+            e1.synchronize()
+            full_ms = e0.elapsed_time(e1) / 5
+        else:
+            full_ms = None
+        for c in cores:                      # gradient exchange off: every rank trains on its own gradients (timing only)
+            c.set_grad_sync(None, None, 1, 0)
+            c._post_backward_hook = None
+        for it in range(2, 4):
+            step(it)
+        fence()
+        t0 = time.perf_counter()
+        for it in range(4, 9):
+            step(it)
+        fence()
+        no_sync_ms = 1e3 * (time.perf_counter() - t0) / 5
+        t = torch.tensor([no_sync_ms], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        no_sync_ms = t.item()
+        out["grad_allreduce"] = {"full_buffer_ms": None if full_ms is None else round(full_ms, 3), "bytes": int(g.numel() * 4),
+                                 "mt_ms_per_step_without_gradient_exchange": round(no_sync_ms, 3),
+                                 "exposed_ms": round(mt_ms_per_step - no_sync_ms, 3)}
+        del algo, cores, step
+        torch.cuda.empty_cache()
+    except Exception as e:       # noqa: BLE001
+        out["grad_allreduce"] = "failed: %s" % e
+    # ---- GCT
+    try:
+        b = copy.copy(a)
+        b.algo = "gct"
+        args = make_args(b, world)
+        algo, cores = build_algo(b, args)
+        if not a.no_conditioned:
+            condition(cores)
+        step = make_step(b, args, algo, batches)
+        for it in range(2):
+            step(it)
+        fence()
+        x0 = pdist.peer_exchanges()
+        t0 = time.perf_counter()
+        n = 5
+        for it in range(2, 2 + n):
+            step(it)
+        fence()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+        out["scaling_gct"] = {"value": round(per_gpu * world * n / dt, 3), "unit": "img/s", "ms_per_step": round(1e3 * dt / n, 3), "steps": n,
+                              "warmup": 2, "n_gpus": world, "rccl_ranks": pdist.rccl_ranks(), "peer_contexts": pdist.peer_contexts(),
+                              "sync_bn_exchanges_per_step": round((pdist.peer_exchanges() - x0) / n, 1),
+                              "workload": "GCT sseg, dual DeepLab-v2/ResNet-101 + flaw detector, %dx%dx%d per GPU" % (per_gpu, a.size, a.size)}
+        pdist.check_peers()
+        del algo, cores, step
+        torch.cuda.empty_cache()
+    except Exception as e:       # noqa: BLE001
+        out["scaling_gct"] = "failed: %s" % e
+    return out
+
+
 def respawn_under_launcher(a):
     """`python bench.py --gpus N` with no launcher environment: start the N ranks ourselves (one process per GPU, the launch
     line of the docstring) and pass their output through -- the command cannot silently measure ONE GPU.  The reference's
@@ -581,6 +697,12 @@ def main():
             out["step_mfma_frac"] = round(out["value"] * flop_img / world / (peak * 1e12), 4) if a.size == 513 else None
         if world == 1 and not a.no_miou and a.algo in ("mt", "suponly") and a.size == 513:
             out["miou_vs_ref"] = miou_vs_oracle(cores[0], a)
+    scale_legs = None
+    if world > 1 and a.algo == "mt" and not a.no_scaling_legs:
+        ms = 1e3 * elapsed / a.steps
+        scale_legs = scaling_legs(a, world, batches, fence, dev, ms)
+        if rank == 0:
+            out.update(scale_legs)
     do_fp32 = a.dtype == "bf16" and not a.no_fp32_leg and world == 1      # (scaling runs stay the headline workload only)
     do_seq = world == 1 and not a.no_kernel_events and not a.no_seq_leg
     if do_fp32 or do_seq:

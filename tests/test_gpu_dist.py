@@ -338,6 +338,12 @@ def test_bench_two_ranks_on_one_gpu_through_torchrun():
     # the rest are the stem, the split-K ASPP and launches that differ between the networks)
     assert d["paired_convs"] >= 60 and d["paired_stat_exchanges"] >= 100, (d["paired_convs"], d["paired_stat_exchanges"])
     assert d["value"] > 0 and all(v == v and abs(v) < 1e6 for v in d["final_losses"].values())
+    # the legs a multi-rank MT run appends (round 5): the GCT workload the scaling target is quoted on, one peer exchange timed
+    # with HIP events, the MT step without its gradient exchange -- all three ran (a failed leg is reported as a string)
+    assert isinstance(d["scaling_gct"], dict) and d["scaling_gct"]["value"] > 0 and d["scaling_gct"]["n_gpus"] == 2, d["scaling_gct"]
+    assert d["scaling_gct"]["peer_contexts"] >= 5 and d["scaling_gct"]["sync_bn_exchanges_per_step"] > 100, d["scaling_gct"]
+    assert isinstance(d["sync_bn_exchange_us"], float) and 0 < d["sync_bn_exchange_us"] < 1e5, d["sync_bn_exchange_us"]
+    assert isinstance(d["grad_allreduce"], dict) and d["grad_allreduce"]["mt_ms_per_step_without_gradient_exchange"] > 0, d["grad_allreduce"]
 
 
 def test_bench_self_spawns_its_ranks_gct():
