@@ -181,11 +181,15 @@ class SSLMT(ssl_base._SSLBase):
                     cons_loss=cons_loss.detach()), s_resulter, t_resulter
 
     def _update_pipeline(self, s_head, t_head):
-        """PipelinedUpdate for this student / teacher pair, or None: PXL_PIPE_UPDATE=0, an optimizer it does not cover (anything
-        but plain momentum SGD over the student's flat parameter store), task models that are not engine networks."""
+        """PipelinedUpdate for this student / teacher pair, or None: not asked for (PXL_PIPE_UPDATE=1 opts in), an optimizer it does
+        not cover (anything but plain momentum SGD over the student's flat parameter store), task models that are not engine
+        networks.  OFF by default: measured neutral on one MI355X (MT 8 x 513 x 513, two pairs of runs in one call: 12.37 / 12.35 ms
+        with, 12.37 / 12.43 ms without; profiles/r05_b_pipe_*): the 0.7 ms of SGD + EMA + packing between two iterations do move
+        under the backward pass, and the backward pass gets 0.5 ms longer -- those kernels stream 2.2 GB at > 5 TB/s and the
+        data gradients beside them are bandwidth-bound themselves.  The step is the serial sum of its kernels' resource time."""
         if not hasattr(self, '_pipe'):
             self._pipe = None
-            if os.environ.get('PXL_PIPE_UPDATE', '1') != '0':
+            if os.environ.get('PXL_PIPE_UPDATE', '0') == '1':
                 from ..nn.optimizer import PipelinedUpdate
                 s_core, t_core = s_head.core, t_head.core
                 try:

@@ -70,7 +70,9 @@ def test_bucket_updates_equal_the_whole_buffer_step_bit_for_bit(dtype):
     s_plan = next(iter(s_core._plans.values()))
     t_plan = next(iter(t_core._plans.values()))
     alpha = 0.97
-    # ---- reference: one whole-buffer step, EMA, full re-pack
+    # ---- reference: one whole-buffer step, EMA, full re-pack (into zeroed buffers: regions no pack writes -- the teacher holds
+    # no data-gradient layouts -- are uninitialised memory otherwise)
+    s_plan.packed.zero_(); t_plan.packed.zero_()
     st.grads.copy_(grads)
     opt.step()
     ops.ema_update(tt.params, st.params, alpha)
