@@ -741,6 +741,28 @@ int pxl_net_head_loss_hp(pxl_net* net, const void* arena, const pxl_net* teacher
                          void* scratch, size_t scratch_bytes, float* sums, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Bit-reproducible reductions (the executor's PXL_DETERMINISTIC=1 mode)                        */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference's reductions (F.batch_norm, conv weight gradients, bias gradients, the criterion) run in whatever order the
+ * library picks; the default kernels here combine partial sums with fp32 atomics, whose order differs from launch to launch.
+ * These variants fix the order (one add per destination, or partials folded in index order), for parity runs:
+ *   - pxl_conv_dgrad_bnreduce / _joinreduce take desc->stats_rep replicas of bn_sums ([stats_rep][2C]; tile row t adds into
+ *     replica t % stats_rep), pxl_bn_bwd_reduce uses replica = row group when nrep >= #row groups (<= 256);
+ *     pxl_bn_fold_replicas folds them in index order;
+ *   - pxl_conv_wgrad: desc->split_k = 1 = ONE pixel split (every element of dw receives one add);
+ *   - pxl_colsum_ordered: one block per column slab;  pxl_residual_bwd_reduce_rep: pxl_residual_bwd_reduce with `nrep` replicas;
+ *   - pxl_head_loss_ex: pxl_head_loss / _hp (mse_weight_dev != NULL) with the kernel chosen (kernel_choice -1 auto, 0 row-wise,
+ *     1 cell-wise) and, ordered != 0, the row-wise kernel with its loss sums folded in row order (workspace:
+ *     pxl_upsample_bwd_workspace + B * H * 12 bytes). */
+int pxl_colsum_ordered(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream);
+int pxl_residual_bwd_reduce_rep(int dtype, int M, int C, const void* dout, const void* out, const void* y, const float* coef,
+                                void* g, void* g2, float* sums, int nrep, void* stream);
+int pxl_head_loss_ex(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
+                     const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight,
+                     float mse_weight, const float* mse_weight_dev, int kernel_choice, int ordered, void* dlow, void* workspace,
+                     size_t ws_bytes, float* sums, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Seams between the translation units of the library                                          */
 /* ------------------------------------------------------------------------------------------ */
 /* Exported because csrc/net.cpp, tools/cbench.cpp and the kernel tests reach them across object files; a host that drives the

@@ -240,6 +240,9 @@ SIGNATURES = {
     "pxl_net_head_loss_supported": (_I, [_P]),
     "pxl_net_head_forward": (_I, [_P, _P, _P, _P, _P]),
     "pxl_net_head_loss": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _Z, _P, _P]),
+    "pxl_colsum_ordered": (_I, [_I, _I, _I, _I, _P, _P, _P]),
+    "pxl_residual_bwd_reduce_rep": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "pxl_head_loss_ex": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _I, _I, _P, _P, _Z, _P, _P]),
     "pxl_hyper_set": (_I, [_P, _P, _I, _P]),
     "pxl_sgd_step_hp": (_I, [_L, _P, _P, _P, _P, _F, _F, _I, _P]),
     "pxl_ema_update_hp": (_I, [_L, _P, _P, _P, _P]),

@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(int M, int C, const 
     const int col = o / (2 * EPC), w = o % (2 * EPC);
     float v = 0.f;
     for (int r = 0; r < gq.rl; ++r) v += red[(r * gq.cg + col) * 2 * EPC + w];
-    float* rep = sums + (size_t)((blockIdx.y + blockIdx.x) % nrep) * 2 * C;
+    // enough replicas for one per row group: every (replica, channel) receives exactly ONE add (bit-reproducible sums once the
+    // replicas are folded in index order: PXL_DETERMINISTIC); fewer: spread the contention
+    float* rep = sums + (size_t)(nrep >= (int)gridDim.y ? blockIdx.y : (blockIdx.y + blockIdx.x) % nrep) * 2 * C;
     const int c = (blockIdx.x * gq.cg + col) * EPC + (w % EPC);
     atomicAdd(rep + (w / EPC) * C + c, v);
   }
@@ -349,12 +351,17 @@ extern "C" int pxl_bn_bwd_reduce(int dtype, int M, int C, const void* dz, const 
 
 // Backward of the bottleneck join out = relu(bn3(y) + res) fused with bn3's reduction: g = dout * (out > 0) is written
 // to `g` (and `g2`, the residual branch's copy, may be NULL) and sums[0..C) += sum g, sums[C..2C) += sum g * xhat(y).
-extern "C" int pxl_residual_bwd_reduce(int dtype, int M, int C, const void* dout, const void* out, const void* y,
-                                       const float* coef, void* g, void* g2, float* sums, void* stream) {
-  PXL_REQUIRE(dout && out && y && coef && g && sums && M > 0, "residual_bwd_reduce: bad argument");
+extern "C" int pxl_residual_bwd_reduce_rep(int dtype, int M, int C, const void* dout, const void* out, const void* y,
+                                           const float* coef, void* g, void* g2, float* sums, int nrep, void* stream) {
+  PXL_REQUIRE(dout && out && y && coef && g && sums && M > 0 && nrep >= 1, "residual_bwd_reduce: bad argument");
   PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "residual_bwd_reduce: bad dtype %d", dtype);
   PXL_REQUIRE(C % (dtype == PXL_F32 ? 4 : 8) == 0, "residual_bwd_reduce: C=%d is not 16-byte aligned", C);
-  return launch_bwd_reduce(dtype, M, C, dout, y, coef, 0, sums, 1, out, g, g2, stream);
+  return launch_bwd_reduce(dtype, M, C, dout, y, coef, 0, sums, nrep, out, g, g2, stream);
+}
+
+extern "C" int pxl_residual_bwd_reduce(int dtype, int M, int C, const void* dout, const void* out, const void* y,
+                                       const float* coef, void* g, void* g2, float* sums, void* stream) {
+  return pxl_residual_bwd_reduce_rep(dtype, M, C, dout, out, y, coef, g, g2, sums, 1, stream);
 }
 
 extern "C" int pxl_bn_bwd_apply_fused(int dtype, int M, int C, const void* dz, const void* y, const float* coef,

@@ -139,7 +139,9 @@ extern "C" int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, c
   a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = bn_relu; a.bn_mask = nullptr;
   a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
   pxl_conv_desc q = *d;
-  q.stats_rep = 1;
+  // bn_sums holds d->stats_rep replicas [stats_rep][2C] (<= 1: one vector); tile row t adds into replica t % stats_rep.  With at
+  // least as many replicas as tile rows every (replica, channel) receives one add per launch: bit-reproducible (PXL_DETERMINISTIC)
+  q.stats_rep = d->stats_rep >= 1 ? d->stats_rep : 1;
   return conv_dma_launch(&q, a, 1, 0, stream);
 }
 
@@ -160,7 +162,9 @@ extern "C" int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy,
   a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = 0; a.bn_mask = join_out;
   a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
   pxl_conv_desc q = *d;
-  q.stats_rep = 1;
+  // bn_sums holds d->stats_rep replicas [stats_rep][2C] (<= 1: one vector); tile row t adds into replica t % stats_rep.  With at
+  // least as many replicas as tile rows every (replica, channel) receives one add per launch: bit-reproducible (PXL_DETERMINISTIC)
+  q.stats_rep = d->stats_rep >= 1 ? d->stats_rep : 1;
   return conv_dma_launch(&q, a, 1, 0, stream);
 }
 

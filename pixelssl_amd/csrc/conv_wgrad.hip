@@ -324,13 +324,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 }
 
 template <typename T, int BMK, int BNC, int WM, int WN>
-int launch_cfg(const WgradArgs& a, hipStream_t stream) {
+int launch_cfg(const WgradArgs& a, hipStream_t stream, int splits_hint) {
   WgradArgs p = a;
   constexpr int BKP = WLayout<T>::BKP;
   p.tiles_k = cdiv(p.Kreal, BMK);
   p.tiles_c = cdiv(p.Ng, BNC);
   const int tiles = p.tiles_k * p.tiles_c;
-  int splits = 1024 / tiles;
+  int splits = splits_hint > 0 ? splits_hint : 1024 / tiles;
   const int max_splits = cdiv(p.M, BKP * 8);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -347,7 +347,7 @@ int launch_cfg(const WgradArgs& a, hipStream_t stream) {
 }
 
 template <typename T>
-int launch_wgrad(const WgradArgs& a, int force_cfg, hipStream_t stream) {
+int launch_wgrad(const WgradArgs& a, int force_cfg, hipStream_t stream, int splits_hint) {
   int cfg = force_cfg;
   if (cfg < 0) {
     if (a.Kreal <= 32) cfg = 2;
@@ -355,9 +355,9 @@ int launch_wgrad(const WgradArgs& a, int force_cfg, hipStream_t stream) {
     else cfg = 0;
   }
   switch (cfg) {
-    case 0: return launch_cfg<T, 128, 128, 2, 2>(a, stream);
-    case 1: return launch_cfg<T, 64, 64, 2, 2>(a, stream);
-    case 2: return launch_cfg<T, 32, 128, 1, 4>(a, stream);
+    case 0: return launch_cfg<T, 128, 128, 2, 2>(a, stream, splits_hint);
+    case 1: return launch_cfg<T, 64, 64, 2, 2>(a, stream, splits_hint);
+    case 2: return launch_cfg<T, 32, 128, 1, 4>(a, stream, splits_hint);
     default: return pxl_set_error(PXL_ERR_ARG, "conv_wgrad: unknown tile config %d", cfg);
   }
 }
@@ -398,6 +398,7 @@ extern "C" int pxl_conv_wgrad(const pxl_conv_desc* d, const void* in, const floa
   for (int t = 0; t < 64; ++t)
     a.taps[t] = t < d->ntaps ? (((int)d->dy[t]) << 16) | (((int)d->dx[t]) & 0xffff) : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d->dtype == PXL_F32) return launch_wgrad<float>(a, d->tile_cfg, s);
-  return launch_wgrad<bf16_t>(a, d->tile_cfg, s);
+  const int hint = d->split_k > 0 ? d->split_k : 0;       // 1: one add per element of dw (PXL_DETERMINISTIC)
+  if (d->dtype == PXL_F32) return launch_wgrad<float>(a, d->tile_cfg, s, hint);
+  return launch_wgrad<bf16_t>(a, d->tile_cfg, s, hint);
 }

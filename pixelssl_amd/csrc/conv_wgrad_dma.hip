@@ -367,13 +367,15 @@ extern "C" int pxl_conv_wgrad_dma(const pxl_conv_desc* d, const void* in, const 
     cfg = t128 >= 96 ? 8 : 10;
   }
   if (d->Cin % 128 != 0 && (cfg == 8 || cfg == 9 || cfg == 13)) cfg = 10;    // 128-channel column tiles need Cin % 128 == 0
+  // d->split_k > 0 forces the number of pixel splits; 1 = every element of dw receives ONE add (bit-reproducible: PXL_DETERMINISTIC)
+  const int hint = d->split_k > 0 ? d->split_k : 0;
   switch (cfg) {
-    case 8: return launch_wdma<128, 128, 3>(a, gather, 0, s);
-    case 9: return launch_wdma<128, 128, 2>(a, gather, 0, s);
-    case 10: return launch_wdma<64, 64, 3>(a, gather, 0, s);
-    case 11: return launch_wdma<64, 64, 2>(a, gather, 0, s);
-    case 12: return launch_wdma<128, 64, 3>(a, gather, 0, s);
-    case 13: return launch_wdma<64, 128, 3>(a, gather, 0, s);
+    case 8: return launch_wdma<128, 128, 3>(a, gather, hint, s);
+    case 9: return launch_wdma<128, 128, 2>(a, gather, hint, s);
+    case 10: return launch_wdma<64, 64, 3>(a, gather, hint, s);
+    case 11: return launch_wdma<64, 64, 2>(a, gather, hint, s);
+    case 12: return launch_wdma<128, 64, 3>(a, gather, hint, s);
+    case 13: return launch_wdma<64, 128, 3>(a, gather, hint, s);
     default: return pxl_set_error(PXL_ERR_ARG, "conv_wgrad_dma: unknown tile config %d", cfg);
   }
 }

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_f32_kernel(const WFArgs
 }
 
 template <int BN, int BC, int BKP, int NST>
-int launch_wf(const WFArgs& a, bool gather, hipStream_t stream) {
+int launch_wf(const WFArgs& a, bool gather, int splits_hint, hipStream_t stream) {
   WFArgs p = a;
   p.tiles_n = cdiv(p.Kreal, BN);
   p.ctiles_per_tap = p.Cin / BC;
@@ -264,7 +264,7 @@ int launch_wf(const WFArgs& a, bool gather, hipStream_t stream) {
   const int tiles = p.tiles_n * p.tiles_c;
   // pixel splits: enough workgroups to fill the chip twice over; every split costs one fp32 atomic per output element, so
   // never cut the reduction into pieces shorter than 8 steps
-  int splits = (512 + tiles / 2) / tiles;
+  int splits = splits_hint > 0 ? splits_hint : (512 + tiles / 2) / tiles;
   const int max_splits = cdiv(p.M, BKP * 8);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -320,13 +320,14 @@ int pxl_conv_wgrad_dma_f32(const pxl_conv_desc* d, const void* in, const void* d
     cfg = t128 >= 64 ? 9 : 11;
   }
   if (d->Cin % 128 != 0 && (cfg == 8 || cfg == 9 || cfg == 13)) cfg = 11;    // 128-channel column tiles need Cin % 128 == 0
+  const int hint = d->split_k > 0 ? d->split_k : 0;     // 1: one add per element of dw (PXL_DETERMINISTIC)
   switch (cfg) {
-    case 8: return launch_wf<128, 128, 32, 3>(a, gather, s);
-    case 9: return launch_wf<128, 128, 32, 2>(a, gather, s);
-    case 10: return launch_wf<64, 64, 64, 3>(a, gather, s);
-    case 11: return launch_wf<64, 64, 64, 2>(a, gather, s);
-    case 12: return launch_wf<128, 64, 32, 3>(a, gather, s);
-    case 13: return launch_wf<64, 128, 32, 3>(a, gather, s);
+    case 8: return launch_wf<128, 128, 32, 3>(a, gather, hint, s);
+    case 9: return launch_wf<128, 128, 32, 2>(a, gather, hint, s);
+    case 10: return launch_wf<64, 64, 64, 3>(a, gather, hint, s);
+    case 11: return launch_wf<64, 64, 64, 2>(a, gather, hint, s);
+    case 12: return launch_wf<128, 64, 32, 3>(a, gather, hint, s);
+    case 13: return launch_wf<64, 128, 32, 3>(a, gather, hint, s);
     default: return pxl_set_error(PXL_ERR_ARG, "conv_wgrad_dma (fp32): unknown tile config %d", cfg);
   }
 }

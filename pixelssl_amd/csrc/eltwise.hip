@@ -627,7 +627,18 @@ extern "C" int pxl_relu_mask(int dtype, long n, const void* dout, const void* ou
   return PXL_OK;
 }
 
+namespace {
+int colsum_impl(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream, bool one_block);
+}
 extern "C" int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream) {
+  return colsum_impl(dtype, M, Cp, Creal, x, out, stream, false);
+}
+// the same with ONE block per 256-chunk column slab: every out[c] receives one add (bit-reproducible; PXL_DETERMINISTIC)
+extern "C" int pxl_colsum_ordered(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream) {
+  return colsum_impl(dtype, M, Cp, Creal, x, out, stream, true);
+}
+namespace {
+int colsum_impl(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream, bool one_block) {
   PXL_REQUIRE(x && out && M > 0, "colsum: bad argument");
   PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "colsum: bad dtype");
   const int epc = dtype == PXL_F32 ? 4 : 8;
@@ -636,7 +647,7 @@ extern "C" int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, fl
   const int rl = 256 / (nch < 256 ? nch : 256);            // rows a block reads per pass
   int blocks = cdiv(M, rl * 8);                            // >= 8 passes per block
   if (blocks > 1024) blocks = 1024;
-  if (blocks < 1) blocks = 1;
+  if (blocks < 1 || one_block) blocks = 1;
   const int rpb = cdiv(M, blocks);
   blocks = cdiv(M, rpb);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -647,6 +658,7 @@ extern "C" int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, fl
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
+}  // namespace
 
 extern "C" int pxl_vec_sum4(int n, float* out, const float* a, const float* b, const float* c, const float* d,
                             void* stream) {

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void head_loss_rows_kernel(int C, int Cp, int 
                                                              int ignore_index, int n_ce, int mse_lo, int mse_hi,
                                                              float ce_scale, float mse_scale, float inv_hw, float inv_mse_n,
                                                              float* __restrict__ tmp, float* __restrict__ sums, int B,
-                                                             const float* __restrict__ mse_w_dev) {
+                                                             const float* __restrict__ mse_w_dev, float* __restrict__ rowpart) {
   if (mse_w_dev != nullptr) mse_scale *= mse_w_dev[0];      // (consistency weight in device memory: pxl_head_loss_hp)
   extern __shared__ float g[];   // [C][W+1] | ci0[W] ci1[W] cl1[W] | srow[2][w][C] | trow[2][w][C]
   __shared__ float red[4];
@@ -308,20 +308,30 @@ __global__ __launch_bounds__(256) void head_loss_rows_kernel(int C, int Cp, int 
     }
     tmp[(((size_t)b * H + y) * w + x0) * C + c] = acc;
   }
-  // loss sums: one atomic per block and quantity (as ce_fwd_kernel / mse_fwd_kernel do)
+  // loss sums: one atomic per block and quantity (as ce_fwd_kernel / mse_fwd_kernel do) -- or, rowpart != NULL, one plain
+  // store per block into rowpart[b][y][3], summed in row order by head_loss_rows_finish_kernel (bit-reproducible values)
   float v = wave_sum(acc_s);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* const part = rowpart != nullptr ? rowpart + ((size_t)b * H + y) * 3 : nullptr;
+  __syncthreads();
+  if (part != nullptr && threadIdx.x < 3) part[threadIdx.x] = 0.f;
   __syncthreads();
   if (ce) {
     if (lane == 0) red[wave] = v;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(sums + b, (red[0] + red[1] + red[2] + red[3]) * inv_hw);
+    if (threadIdx.x == 0) {
+      const float t = (red[0] + red[1] + red[2] + red[3]) * inv_hw;
+      if (part != nullptr) part[0] = t; else atomicAdd(sums + b, t);
+    }
     __syncthreads();
     if (has_t) {
       v = wave_sum(acc_t);
       if (lane == 0) red[wave] = v;
       __syncthreads();
-      if (threadIdx.x == 0) atomicAdd(sums + B + b, (red[0] + red[1] + red[2] + red[3]) * inv_hw);
+      if (threadIdx.x == 0) {
+        const float t = (red[0] + red[1] + red[2] + red[3]) * inv_hw;
+        if (part != nullptr) part[1] = t; else atomicAdd(sums + B + b, t);
+      }
       __syncthreads();
     }
   }
@@ -329,7 +339,27 @@ __global__ __launch_bounds__(256) void head_loss_rows_kernel(int C, int Cp, int 
     v = wave_sum(acc_m);
     if (lane == 0) red[wave] = v;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(sums + 2 * B, (red[0] + red[1] + red[2] + red[3]) * inv_mse_n);
+    if (threadIdx.x == 0) {
+      const float t = (red[0] + red[1] + red[2] + red[3]) * inv_mse_n;
+      if (part != nullptr) part[2] = t; else atomicAdd(sums + 2 * B, t);
+    }
+  }
+}
+
+// sums[b] = sum_y rowpart[b][y][0], sums[B + b] = sum_y rowpart[b][y][1], sums[2B] = sum_b sum_y rowpart[b][y][2], every sum in
+// index order by ONE thread (B * H <= a few thousand terms: microseconds; the point is the fixed order)
+__global__ void head_loss_rows_finish_kernel(int B, int H, const float* __restrict__ rowpart, float* __restrict__ sums) {
+  const int t = threadIdx.x;
+  if (t < 2 * B) {
+    const int b = t % B, q = t / B;
+    float v = 0.f;
+    for (int y = 0; y < H; ++y) v += rowpart[((size_t)b * H + y) * 3 + q];
+    sums[q * B + b] = v;
+  } else if (t == 2 * B) {
+    float v = 0.f;
+    for (int b = 0; b < B; ++b)
+      for (int y = 0; y < H; ++y) v += rowpart[((size_t)b * H + y) * 3 + 2];
+    sums[2 * B] = v;
   }
 }
 
@@ -648,10 +678,13 @@ extern "C" size_t pxl_head_loss_lds_bytes(int w, int C, int W) {
 // fp32, zeroed here: per-sample student CE, per-sample teacher CE, the MSE mean over samples [mse_lo, mse_hi).
 // workspace: pxl_upsample_bwd_workspace(B, w, C, H) bytes.
 namespace {
+// kernel_choice: -1 = PXL_HEAD_LOSS_CELLS / the heuristic, 0 = row-wise kernel, 1 = cell-wise kernel.  ordered: bit-reproducible
+// results -- the row-wise kernel (its gradient goes through plain stores) with the loss sums folded in row order; needs
+// B * H * 12 bytes of workspace beyond pxl_upsample_bwd_workspace (PXL_ERR_WORKSPACE otherwise).
 int head_loss_impl(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
                    const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi,
                    float ce_weight, float mse_weight, const float* mse_w_dev, void* dlow, void* workspace, size_t ws_bytes, float* sums,
-                   void* stream) {
+                   void* stream, int kernel_choice = -1, bool ordered = false) {
   PXL_REQUIRE(s_low && dlow && workspace && sums, "head_loss: null argument");
   PXL_REQUIRE(n_ce == 0 || gt != nullptr, "head_loss: labels missing");
   PXL_REQUIRE(C >= 1 && C <= MAXC && C <= Cp, "head_loss: C=%d unsupported (max %d)", C, MAXC);
@@ -670,7 +703,11 @@ int head_loss_impl(int dtype, int B, int h, int w, int Cp, int C, int H, int W, 
   // cell-wise kernel for large up-sampling factors (DeepLab: x16), row-wise kernel otherwise (PSPNet's head resizes a map
   // of nearly the output size: a "cell" there is a pixel or two).  PXL_HEAD_LOSS_CELLS=0/1 forces either.
   const char* fc_env = getenv("PXL_HEAD_LOSS_CELLS");          // (read per call: the tests cover both kernels)
-  const int force_cells = fc_env ? atoi(fc_env) : -1;
+  const int force_cells = (ordered || kernel_choice == 0) ? 0 : (kernel_choice == 1 ? 1 : (fc_env ? atoi(fc_env) : -1));
+  const size_t base_ws = pxl_upsample_bwd_workspace(B, w, C, H);
+  if (ordered && ws_bytes < base_ws + (size_t)B * H * 3 * sizeof(float))
+    return pxl_set_error(PXL_ERR_WORKSPACE, "head_loss: the ordered variant needs %zu more bytes of workspace", (size_t)B * H * 3 * sizeof(float));
+  float* const rowpart = ordered ? reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + base_ws) : nullptr;
   const long ncell = (long)B * h * w;
   const size_t cells_ws = (size_t)ncell * C * sizeof(float) + (size_t)((ncell + 3) / 4 * 4) * 3 * sizeof(float);
   const float xscale = w > 1 ? (float)(W - 1) / (float)(w - 1) : (float)W;     // widest cell ~ ceil(scale) + 1 pixels
@@ -709,12 +746,16 @@ int head_loss_impl(int dtype, int B, int h, int w, int Cp, int C, int H, int W, 
   if (dtype == PXL_F32)
     hipLaunchKernelGGL(head_loss_rows_kernel<float>, dim3(H, B), dim3(256), smem, s, C, Cp, h, w, H, W, sy, sx, align,
                        (const float*)s_low, (const float*)t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_scale, mse_scale,
-                       1.f / hw, inv_mse_n, (float*)workspace, sums, B, mse_w_dev);
+                       1.f / hw, inv_mse_n, (float*)workspace, sums, B, mse_w_dev, rowpart);
   else
     hipLaunchKernelGGL(head_loss_rows_kernel<bf16_t>, dim3(H, B), dim3(256), smem, s, C, Cp, h, w, H, W, sy, sx, align,
                        (const bf16_t*)s_low, (const bf16_t*)t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_scale, mse_scale,
-                       1.f / hw, inv_mse_n, (float*)workspace, sums, B, mse_w_dev);
+                       1.f / hw, inv_mse_n, (float*)workspace, sums, B, mse_w_dev, rowpart);
   PXL_LAUNCH_CHECK();
+  if (rowpart != nullptr) {
+    hipLaunchKernelGGL(head_loss_rows_finish_kernel, dim3(1), dim3(64 * ((2 * B + 1 + 63) / 64)), 0, s, B, H, rowpart, sums);
+    PXL_LAUNCH_CHECK();
+  }
   const long total = (long)B * h * w * Cp;
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
@@ -735,6 +776,17 @@ extern "C" int pxl_head_loss(int dtype, int B, int h, int w, int Cp, int C, int 
                              void* stream) {
   return head_loss_impl(dtype, B, h, w, Cp, C, H, W, align_corners, s_low, t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_weight,
                         mse_weight, nullptr, dlow, workspace, ws_bytes, sums, stream);
+}
+
+// pxl_head_loss / pxl_head_loss_hp (mse_weight_dev != NULL) with the kernel chosen by the caller and, `ordered` != 0, bit-reproducible
+// results (see head_loss_impl): the executor's PXL_DETERMINISTIC mode
+extern "C" int pxl_head_loss_ex(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
+                                const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi,
+                                float ce_weight, float mse_weight, const float* mse_weight_dev, int kernel_choice, int ordered,
+                                void* dlow, void* workspace, size_t ws_bytes, float* sums, void* stream) {
+  return head_loss_impl(dtype, B, h, w, Cp, C, H, W, align_corners, s_low, t_low, gt, ignore_index, n_ce, mse_lo, mse_hi, ce_weight,
+                        mse_weight_dev != nullptr ? 1.0f : mse_weight, mse_weight_dev, dlow, workspace, ws_bytes, sums, stream,
+                        kernel_choice, ordered != 0);
 }
 
 // pxl_head_loss with the consistency weight d(final loss)/d(MSE mean) in DEVICE memory (*mse_weight_dev, a per-step scalar:

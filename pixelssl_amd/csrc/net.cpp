@@ -16,6 +16,7 @@
 // forward pass (kept until its backward); `scratch` holds gradient buffers; `packed` the weights
 // in kernel layout (fwd + transposed).  288 GB of HBM3E means no recomputation and no buffer
 // aliasing games: every tensor gets its own slot.
+#include <algorithm>
 #include <cmath>
 #include <vector>
 #include <cstring>
@@ -34,6 +35,13 @@ int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, const void* 
 int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
                               const void* join_out, const void* bn_y, const float* bn_coef, float* bn_sums, void* stream);
 int pxl_colsum(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream);
+int pxl_colsum_ordered(int dtype, int M, int Cp, int Creal, const void* x, float* out, void* stream);
+int pxl_residual_bwd_reduce_rep(int dtype, int M, int C, const void* dout, const void* out, const void* y, const float* coef,
+                                void* g, void* g2, float* sums, int nrep, void* stream);
+int pxl_head_loss_ex(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* s_low,
+                     const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight,
+                     float mse_weight, const float* mse_weight_dev, int kernel_choice, int ordered, void* dlow, void* workspace,
+                     size_t ws_bytes, float* sums, void* stream);
 int pxl_stem_patches(int dtype, const float* x, void* P, int B, int C, int H, int W, int kh, int kw, int stride, int pad,
                      int Ho, int Wo, int Kp, void* stream);
 int pxl_nchw_parts_to_nhwc(int dtype, int nparts, const float* const* srcs, const int* chans, void* y, int B, int H, int W,
@@ -94,6 +102,7 @@ struct BnInfo {
   int fused_reduce_op = -1;
   int fin_nrep = 1;        // replicas of the forward sums at finalize time (1 after a Sync-BN fold + all-reduce)
   int nrep = 0;            // replicas of the forward statistics vector (STATS_REP; PXL_DETERMINISTIC: one per 64 pixel rows)
+  int bnrep = 1;           // replicas of the BACKWARD sums (scratch, bsum_off): 1; PXL_DETERMINISTIC: max(one per 64 rows, 256)
   // forward: the finalize of this BN is folded into the kernel that applies it (z materialisation or the residual
   // join that is its only consumer) instead of a pxl_bn_finalize launch
   bool fin_in_consumer = false;
@@ -234,8 +243,11 @@ struct pxl_net {
   // a + b is commutative --, the replicas are folded in index order by ONE kernel (no finalize folded into consumers, no
   // BN-apply on load: those re-reduce the replicas in every workgroup), and no convolution splits K.  Slower (thousands of
   // replicas for the early layers); for parity runs: pre-activations within an ulp of zero no longer take a different ReLU
-  // branch from run to run (tools/diag_2rank.py).  The BACKWARD pass keeps its atomics (BatchNorm-backward sums, pixel-split
-  // weight gradients): its run-to-run differences are rounding-sized (1e-6), not branch-sized.
+  // branch from run to run (tools/diag_2rank.py).  Round 5: the BACKWARD pass as well -- the BatchNorm-backward sums get one
+  // replica per 64 pixel rows (data-gradient epilogues) / per row group (reduce kernels), folded in index order; weight gradients
+  // run with ONE pixel split (every element of dw receives one add); bias column sums with one block per column slab; the
+  // training seam on the row-wise kernel with its loss sums folded in row order.  What stays unordered: the IBNorm statistics of
+  // the flaw detector, the flaw-map / CCT mask reductions and the loss sums of the stand-alone criterion kernels (values only).
   bool deterministic = getenv("PXL_DETERMINISTIC") != nullptr && getenv("PXL_DETERMINISTIC")[0] == '1';
 };
 
@@ -464,10 +476,7 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
   // (BN statistics: contiguous -> one memset per pass; allocated after the ops below, when every BatchNorm's pixel count is known)
   for (auto& b : n->bns) b.M = 0;
   for (auto& b : n->bns) { b.coef_off = arena; arena += align_up(4 * (size_t)b.d.C * 4); }
-  n->bsum_region_off = scratch;
-  for (auto& b : n->bns) { b.bsum_off = scratch; scratch += align_up(2 * (size_t)b.d.C * 4); }
-  n->bsum_region_bytes = scratch - n->bsum_region_off;
-  for (auto& b : n->bns) { b.bcoef_off = scratch; scratch += align_up(2 * (size_t)b.d.C * 4); }
+  // (the backward sums are planned after the ops, when every BatchNorm's pixel count is known: deterministic mode replicates them)
 
   auto plan_tensor = [&](int id, int h, int w, int c) {
     TensorInfo& t = n->tensors[id];
@@ -607,7 +616,8 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
         PXL_REQUIRE(n->tensors[d.in0].C == n->classes, "net_plan: head input has %d channels, expected %d",
                     n->tensors[d.in0].C, n->classes);
         n->up_ws_off = scratch;
-        n->up_ws_bytes = align_up((size_t)B * n->Ho * n->tensors[d.in0].W * n->classes * 4);
+        // (+ B * Ho * 3 floats: per-row loss partials of the ordered seam kernel, PXL_DETERMINISTIC)
+        n->up_ws_bytes = align_up((size_t)B * n->Ho * n->tensors[d.in0].W * n->classes * 4 + (size_t)B * n->Ho * 3 * 4);
         scratch += n->up_ws_bytes;
         break;
       }
@@ -615,6 +625,15 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
         return pxl_set_error(PXL_ERR_ARG, "net_plan: unknown op kind %d", d.kind);
     }
   }
+  n->bsum_region_off = scratch;
+  for (auto& b : n->bns) {
+    // PXL_DETERMINISTIC: one replica per 64 pixel rows for the data-gradient epilogues (tile rows are >= 64 rows apart there is at
+    // most one add per replica and channel per launch) and at least 256 for the stand-alone reduce kernels (<= 256 row groups)
+    b.bnrep = (n->deterministic && b.M > 0) ? std::max((b.M + 63) / 64, 256) : 1;
+    b.bsum_off = scratch; scratch += align_up((size_t)b.bnrep * 2 * (size_t)b.d.C * 4);
+  }
+  n->bsum_region_bytes = scratch - n->bsum_region_off;
+  for (auto& b : n->bns) { b.bcoef_off = scratch; scratch += align_up(2 * (size_t)b.d.C * 4); }
   n->stats_region_off = arena;
   for (auto& b : n->bns) {
     b.nrep = (n->deterministic && b.M > 0) ? (b.M + 63) / 64 : STATS_REP;
@@ -625,7 +644,10 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
   for (auto& op : n->ops) {
     if (op.d.kind != PXL_OP_CONV) continue;
     if (op.d.bn_out >= 0) op.fwd.stats_rep = n->bns[op.d.bn_out].nrep;
-    if (n->deterministic) op.fwd.split_k = 1;
+    if (n->deterministic) {
+      op.fwd.split_k = 1;
+      for (int g = 0; g < op.d.ngroups; ++g) op.grp[g].split_k = 1;      // weight gradients: ONE pixel split = one add per element
+    }
   }
   for (auto& b : n->bns) b.has_z = false;
   for (auto& op : n->ops) {
@@ -755,6 +777,14 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
       oc.join_op = (int)j;
       n->ops[j].join_conv = first;
     }
+  }
+  // data gradients that produce BatchNorm-backward sums in their epilogue: as many replicas as the BatchNorm's sums have
+  for (size_t i = 0; i < n->ops.size(); ++i) {
+    OpInfo& op = n->ops[i];
+    if (op.d.kind != PXL_OP_CONV) continue;
+    op.bwd.stats_rep = 1;
+    if (op.join_op >= 0) op.bwd.stats_rep = n->bns[n->ops[op.join_op].d.bn_in0].bnrep;
+    else if (op.d.bn_in0 >= 0 && n->bns[op.d.bn_in0].fused_reduce_op == (int)i) op.bwd.stats_rep = n->bns[op.d.bn_in0].bnrep;
   }
   // lowest gradient offset written by each op's backward, and whether those grow with the op index
   n->op_lo.assign(n->ops.size(), -1);
@@ -1671,6 +1701,10 @@ int net_head_loss_impl(pxl_net* n, const void* arena, const pxl_net* teacher, co
                 teacher->Ho == n->Ho && teacher->Wo == n->Wo, "net_head_loss: student and teacher plans differ");
     t_low = at(t_arena, tl.off);
   }
+  if (n->deterministic)       // bit-reproducible: row-wise kernel (plain stores), loss sums folded in row order
+    return pxl_head_loss_ex(n->dtype, n->B, low.H, low.W, low.Cp, n->classes, n->Ho, n->Wo, d.stride, at(arena, low.off), t_low, gt,
+                            ignore_index, n_ce, mse_lo, mse_hi, ce_weight, mse_weight, mse_weight_dev, 0, 1, at(scratch, low.goff),
+                            at(scratch, n->up_ws_off), n->up_ws_bytes, sums, stream);
   if (mse_weight_dev != nullptr)
     return pxl_head_loss_hp(n->dtype, n->B, low.H, low.W, low.Cp, n->classes, n->Ho, n->Wo, d.stride, at(arena, low.off), t_low, gt,
                             ignore_index, n_ce, mse_lo, mse_hi, ce_weight, mse_weight_dev, at(scratch, low.goff),
@@ -1871,7 +1905,8 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
         }
         if (rc != PXL_OK) return rc;
         if (dk.b_off[g] >= 0) {
-          rc = pxl_colsum(dt, Mk, tok.Cp, dk.cout, dyk, grads + dk.b_off[g], ws);
+          rc = n->deterministic ? pxl_colsum_ordered(dt, Mk, tok.Cp, dk.cout, dyk, grads + dk.b_off[g], ws)
+                                : pxl_colsum(dt, Mk, tok.Cp, dk.cout, dyk, grads + dk.b_off[g], ws);
           if (rc != PXL_OK) return rc;
         }
       }
@@ -1998,9 +2033,9 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
         if (rc != PXL_OK) return rc;
         if (!written[d.in1] && n->fuse_bn_reduce && b3.y_tensor == d.in0 && a.Cp == b3.d.C) {
           // relu mask + the main branch BN's backward sums in one pass
-          rc = pxl_residual_bwd_reduce(dt, n->B * a.H * a.W, a.Cp, at(scratch, o.goff), at(arena, o.off), at(arena, a.off),
-                                       fat(arena, b3.coef_off), at(scratch, a.goff), at(scratch, r.goff),
-                                       fat(scratch, b3.bsum_off), stream);
+          rc = pxl_residual_bwd_reduce_rep(dt, n->B * a.H * a.W, a.Cp, at(scratch, o.goff), at(arena, o.off), at(arena, a.off),
+                                           fat(arena, b3.coef_off), at(scratch, a.goff), at(scratch, r.goff),
+                                           fat(scratch, b3.bsum_off), b3.bnrep, stream);
           reduced[d.bn_in0] = 1;
           written[d.in1] = 1;
         } else if (!written[d.in1]) {
@@ -2039,7 +2074,11 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
           // one [2C] vector per BN (the reduce kernel issues one atomic per channel per block, no replicas needed);
           // already filled when the consumer's data gradient ran with the fused reduction
           if (b.fused_reduce_op < 0 && !reduced[d.bn_out]) {
-            rc = pxl_bn_bwd_reduce(dt, M, tout.Cp, dy_in, at(arena, tout.off), coef, b.relu, fat(scratch, b.bsum_off), 1, stream);
+            rc = pxl_bn_bwd_reduce(dt, M, tout.Cp, dy_in, at(arena, tout.off), coef, b.relu, fat(scratch, b.bsum_off), b.bnrep, stream);
+            if (rc != PXL_OK) return rc;
+          }
+          if (b.bnrep > 1) {      // PXL_DETERMINISTIC: the replicas of the sums, folded in index order into replica 0
+            rc = pxl_bn_fold_replicas(2 * b.d.C, b.bnrep, fat(scratch, b.bsum_off), stream);
             if (rc != PXL_OK) return rc;
           }
           float* dgam = grads + b.d.gamma_off;
