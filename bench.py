@@ -681,15 +681,46 @@ def main():
                     traffic_source = "profiles/traffic.json (%s)" % tj.get("measured", "separate rocprofv3 --pmc passes")
             except Exception:
                 traffic = None
-            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["achieved_tflops"],
-                               "peak": peak, "unit": "TFLOP/s", "frac": round(kern[dom]["achieved_tflops"] / peak, 4),
-                               "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": kern[dom]["avg_us"],
-                               "algorithmic_gflop_per_launch": kern[dom]["algorithmic_gflop_per_launch"],
-                               "algorithmic_bytes_per_launch": int(kern[dom]["algorithmic_mbytes_per_launch"] * 1e6),
+            # Which roof binds the dominant kernel: its arithmetic intensity against the ridge of the chip (dense MFMA peak / HBM
+            # peak).  Two intensities: algorithmic (operands once) and measured (flops over the PMC traffic, which also holds
+            # what the fused epilogues read and write); below the ridge the kernel is HBM-bound and `achieved` is its bandwidth.
+            HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+            ridge = peak * 1e12 / (HBM_PEAK_GBPS * 1e9)
+            us = kern[dom]["avg_us"]
+            gflop = kern[dom]["algorithmic_gflop_per_launch"]
+            abytes = kern[dom]["algorithmic_mbytes_per_launch"] * 1e6
+            inten_alg = gflop * 1e9 / abytes if abytes else None
+            inten_meas = gflop * 1e9 / traffic if traffic else None
+            hbm_bound = (inten_meas if inten_meas is not None else inten_alg or ridge) < ridge
+            mfma_view = {"achieved": kern[dom]["achieved_tflops"], "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(kern[dom]["achieved_tflops"] / peak, 4)}
+            hbm_view = {"achieved": round(abytes / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(abytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                        "traffic_gbps": round(traffic / (us * 1e-6) / 1e9, 1) if traffic else None,
+                        "traffic_frac": round(traffic / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None}
+            view = hbm_view if hbm_bound else mfma_view
+            out["roofline"] = {"kernel": dom, "bound": "hbm" if hbm_bound else "mfma", "achieved": view["achieved"],
+                               "peak": view["peak"], "unit": view["unit"], "frac": view["frac"],
+                               "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": us,
+                               "algorithmic_gflop_per_launch": gflop, "algorithmic_bytes_per_launch": int(abytes),
+                               "intensity_flop_per_byte": {"algorithmic": round(inten_alg, 1) if inten_alg else None,
+                                                           "measured": round(inten_meas, 1) if inten_meas else None,
+                                                           "ridge": round(ridge, 1)},
+                               "mfma": mfma_view, "hbm": hbm_view,
                                "measured": "second pass of the same K steps with per-launch HIP events (outside the timed region)",
                                "note": "kernels of two HIP streams overlap (teacher || student forward, wgrad || dgrad): "
                                        "per-launch event durations include the co-running kernel; step_mfma_frac is the "
                                        "whole-step figure"}
+            # whole step against the HBM roof: bytes of ONE step = PMC traffic per launch x launches per step over every kernel
+            # family (tools/bytes_per_step.py on this workload's trace; static like `traffic`: counters need their own passes)
+            try:
+                bj = json.load(open(os.path.join(ROOT, "profiles", "bytes_per_step.json")))
+                if a.algo == "mt" and a.dtype == "bf16" and a.size == 513 and per_gpu == 8:
+                    out["bytes_per_step"] = int(bj["bytes_per_step"])
+                    out["hbm_frac"] = round(bj["bytes_per_step"] / (elapsed / a.steps) / (HBM_PEAK_GBPS * 1e9), 4)
+                    out["bytes_per_step_source"] = "profiles/bytes_per_step.json (tools/bytes_per_step.py: " + " x ".join(bj.get("source", [])) + ")"
+            except Exception:
+                pass
             out["kernels"] = kern
             # whole-step view: algorithmic conv FLOPs per image over wall time
             # CCT: 3 x F_P (150.74 GFLOP) per image through the PSPNet, decoders ~0.05 GFLOP each

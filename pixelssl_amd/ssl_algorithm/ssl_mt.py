@@ -42,6 +42,9 @@ class SSLMT(ssl_base._SSLBase):
         self.s_model = self.t_model = None
         self.s_optimizer = self.s_lrer = self.s_criterion = self.cons_criterion = None
         self.gaussian_noiser = None
+        # opt-in execution modes, fixed when the algorithm is built (pixelssl_amd/graph.py, nn/optimizer.py: PipelinedUpdate)
+        self._want_graph = pgraph.enabled()
+        self._want_pipe = os.environ.get('PXL_PIPE_UPDATE', '0') == '1'
         if self.args.cons_for_labeled or self.args.unlabeled_batch_size > 0:
             if self.args.cons_scale < 0:
                 logger.log_err('The argument - cons_scale - is not set (or invalid)\n'
@@ -189,7 +192,7 @@ class SSLMT(ssl_base._SSLBase):
         data gradients beside them are bandwidth-bound themselves.  The step is the serial sum of its kernels' resource time."""
         if not hasattr(self, '_pipe'):
             self._pipe = None
-            if os.environ.get('PXL_PIPE_UPDATE', '0') == '1':
+            if self._want_pipe:
                 from ..nn.optimizer import PipelinedUpdate
                 s_core, t_core = s_head.core, t_head.core
                 try:
@@ -209,7 +212,7 @@ class SSLMT(ssl_base._SSLBase):
         from .. import dist as pdist
         from ..nn.optimizer import FusedSGD
         self._sgraph = None
-        ok = pgraph.enabled() and not pdist.is_distributed() and type(self.s_optimizer) is FusedSGD and \
+        ok = self._want_graph and not pdist.is_distributed() and type(self.s_optimizer) is FusedSGD and \
             os.environ.get('PXL_PAIR_FORWARD') != '1' and not any(self.s_optimizer._foreign) and \
             all(float(g.get('dampening', 0.0)) == 0.0 and not g.get('nesterov', False) for g in self.s_optimizer.param_groups)
         if not ok:

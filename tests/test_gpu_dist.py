@@ -174,8 +174,13 @@ def test_peer_mapped_exchange_two_processes_one_gpu():
     assert res[0]["bad"] == 0 and res[1]["bad"] == 0
 
 
-@pytest.mark.parametrize("peer", ["1", "0"])
-def test_two_ranks_one_gpu_match_full_batch_step(peer):
+@pytest.mark.parametrize("peer,det", [("1", False), ("0", False), ("1", True)], ids=["peer", "hook", "peer-deterministic"])
+def test_two_ranks_one_gpu_match_full_batch_step(peer, det, monkeypatch):
+    # det: the whole leg under PXL_DETERMINISTIC=1 (the spawned ranks inherit it): two forward passes of the same rank then take
+    # the same ReLU decisions, and "a second backward doubles the gradient" holds to rounding -- the bar is 1e-4 there instead of
+    # the 2e-2 the default mode needs for its order-dependent statistics atomics
+    if det:
+        monkeypatch.setenv("PXL_DETERMINISTIC", "1")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import torch_oracle as TO
     from pixelssl_amd import functional as PF
@@ -198,7 +203,7 @@ def test_two_ranks_one_gpu_match_full_batch_step(peer):
     # channels move the gradients by ~1e-2 while the logits agree to 1e-4
     os.environ["PXL_FORCE_CLAMP_VAR"] = "1"
     try:
-        _compare_with_full_batch(res, state, x, gt, rel)
+        _compare_with_full_batch(res, state, x, gt, rel, det)
     finally:                                   # (a failure must not leak the switch into the tests that follow)
         del os.environ["PXL_FORCE_CLAMP_VAR"]
     _compare_with_oracle(res, state, x, gt, rel)
@@ -244,7 +249,7 @@ def _compare_with_oracle(res, state, x, gt, rel):
     assert e_l < 1e-3 and e_r < 1e-3 and e_g < 5e-3, (e_l, e_g, e_r, worst)
 
 
-def _compare_with_full_batch(res, state, x, gt, rel):
+def _compare_with_full_batch(res, state, x, gt, rel, det=False):
     from pixelssl_amd import functional as PF
     from pixelssl_amd.engine import DeepLabV2Core
     for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, 6e-2)):
@@ -263,7 +268,11 @@ def _compare_with_full_batch(res, state, x, gt, rel):
         # (tools/diag_2rank.py: single-rank run-to-run 5.62e-4; the same levels in every configuration, one or two ranks) -- a
         # pre-activation of this seeded trunk within an ulp of zero at the layer4.0 / layer3.0 joins takes one ReLU branch or
         # the other depending on the order of the fp32 statistics atomics; a lost or doubled contribution would score ~0.5
-        assert rel(r0["grads2"], 2 * r0["grads"]) < (2e-2 if dtype == torch.float32 else 6e-2) and rel(r0["grads2"], r1["grads2"]) < 1e-6
+        d2 = rel(r0["grads2"], 2 * r0["grads"])
+        print("%s: second backward vs 2 x the first: %.2e%s" % (dtype, d2, " (deterministic mode)" if det else ""))
+        if det:       # reproducible ReLU decisions: what is left is the rounding of accumulating into an already-averaged buffer
+            assert d2 < (1e-4 if dtype == torch.float32 else 2e-2), d2
+        assert d2 < (2e-2 if dtype == torch.float32 else 6e-2) and rel(r0["grads2"], r1["grads2"]) < 1e-6
         e_g = rel(r0["grads"], core.flat.grads.detach().cpu())
         e_l = rel(torch.cat([r0["logits"], r1["logits"]]), logits.detach().cpu())
         e_r = rel(r0["rmean"], core.flat.running.detach().cpu())

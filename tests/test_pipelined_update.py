@@ -18,29 +18,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 DEV = "cuda"
 
 
-def _mt(dtype, env):
+def _mt(dtype, monkeypatch, env):
+    """(the switches are read when the algorithm / its executors are built -- the executors lazily, at the first step: they stay
+    set for the whole test, monkeypatch restores them)"""
     import pixelssl_amd as P
     from pixelssl_amd.nn import optimizer as popt, lrer as plr
     from test_multistep import _fx, _args, _deeplab_state
-    keep = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        fx = _fx("mt_cond_129.pt")
-        args = _args(fx, dtype, cons_for_labeled=False, cons_scale=1.0, cons_rampup_epochs=fx["rampup_iters"] / fx["max_iters"],
-                     ema_decay=0.99)
-        algo = P.ssl_algorithm.ssl_mt.ssl_mt(args, {"model": P.sseg.model.deeplabv2()}, {"model": popt.sgd(args)},
-                                            {"model": plr.polynomiallr(args)}, {"model": P.sseg.criterion.sseg_criterion()}, None)
-        algo.s_model.module.model.load_state_dict(_deeplab_state(fx["weight_seed"], fx["gamma3"]))
-        algo.t_model.module.model.load_state_dict(_deeplab_state(fx["weight_seed"] + 1, fx["gamma3"]))
-        algo.s_model.train()
-        algo.t_model.train()
-        return fx, algo
-    finally:
-        for k, v in keep.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    fx = _fx("mt_cond_129.pt")
+    args = _args(fx, dtype, cons_for_labeled=False, cons_scale=1.0, cons_rampup_epochs=3, ema_decay=0.99)
+    algo = P.ssl_algorithm.ssl_mt.ssl_mt(args, {"model": P.sseg.model.deeplabv2()}, {"model": popt.sgd(args)},
+                                        {"model": plr.polynomiallr(args)}, {"model": P.sseg.criterion.sseg_criterion()}, None)
+    algo.s_model.module.model.load_state_dict(_deeplab_state(fx["weight_seed"], fx["gamma3"]))
+    algo.t_model.module.model.load_state_dict(_deeplab_state(fx["weight_seed"] + 1, fx["gamma3"]))
+    algo.s_model.train()
+    algo.t_model.train()
+    return fx, algo
 
 
 def _steps(fx, algo, n=None):
@@ -56,10 +50,10 @@ def _steps(fx, algo, n=None):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_bucket_updates_equal_the_whole_buffer_step_bit_for_bit(dtype):
+def test_bucket_updates_equal_the_whole_buffer_step_bit_for_bit(dtype, monkeypatch):
     from pixelssl_amd import ops
     from pixelssl_amd.nn.optimizer import PipelinedUpdate
-    fx, algo = _mt(dtype, {"PXL_PIPE_UPDATE": "0", "PXL_GRAPH": "0"})
+    fx, algo = _mt(dtype, monkeypatch, {"PXL_PIPE_UPDATE": "0", "PXL_GRAPH": "0"})
     _steps(fx, algo, 2)                      # plans, tuned tiles, momentum buffers that are not zero
     s_core, t_core = algo.s_model.module.model, algo.t_model.module.model
     opt = algo.s_optimizer
@@ -107,8 +101,8 @@ def test_bucket_updates_equal_the_whole_buffer_step_bit_for_bit(dtype):
 
 
 @pytest.mark.gpu
-def test_the_executor_hands_out_buckets_that_tile_the_gradient_buffer():
-    fx, algo = _mt("bf16", {"PXL_PIPE_UPDATE": "1", "PXL_GRAPH": "0", "PXL_UPDATE_BUCKET_MB": "8"})
+def test_the_executor_hands_out_buckets_that_tile_the_gradient_buffer(monkeypatch):
+    fx, algo = _mt("bf16", monkeypatch, {"PXL_PIPE_UPDATE": "1", "PXL_GRAPH": "0", "PXL_UPDATE_BUCKET_MB": "8"})
     seen = []
     _steps(fx, algo, 1)
     pipe = algo._pipe
@@ -129,15 +123,15 @@ def test_the_executor_hands_out_buckets_that_tile_the_gradient_buffer():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_mt_with_the_pipelined_update_is_the_reference_iteration(dtype):
+def test_mt_with_the_pipelined_update_is_the_reference_iteration(dtype, monkeypatch):
     from test_multistep import _check_losses, _check_weights
     env = {"PXL_GRAPH": "0", "PXL_DETERMINISTIC": "1"}
-    fx, a0 = _mt(dtype, dict(env, PXL_PIPE_UPDATE="0"))
+    fx, a0 = _mt(dtype, monkeypatch, dict(env, PXL_PIPE_UPDATE="0"))
     l0 = _steps(fx, a0)
     s0 = {k: v.detach().float().cpu() for k, v in a0.s_model.module.model.state_dict().items()}
     t0 = {k: v.detach().float().cpu() for k, v in a0.t_model.module.model.state_dict().items()}
     del a0
-    fx, a1 = _mt(dtype, dict(env, PXL_PIPE_UPDATE="1"))
+    fx, a1 = _mt(dtype, monkeypatch, dict(env, PXL_PIPE_UPDATE="1"))
     l1 = _steps(fx, a1)
     assert a1._pipe is not None and a1._pipe.buckets >= 2 and a1.s_optimizer._steps_taken == len(l1)
     s1 = {k: v.detach().float().cpu() for k, v in a1.s_model.module.model.state_dict().items()}
