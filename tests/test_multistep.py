@@ -500,3 +500,40 @@ def test_cct_six_iterations_with_gcutout(dtype, fixture):
     else:
         _check_update_direction("cct+cut main bf16", main_sd, init, fx["main_updates"], min_cos=CCT_BF16_MIN_COS,
                                 ratio=CCT_BF16_RATIO, median_cos=CCT_BF16_MEDIAN_COS, skip=("psp.stages.0.",))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_mt_teacher_is_the_ema_of_the_student(dtype):
+    """The EMA path pinned on its own (BatchNorm gammas move by ulps per step, so the fixture's update-relative
+    bar reaches them only through its 4-ulp floor): after every iteration the teacher's parameters must be
+    alpha * teacher + (1 - alpha) * student with alpha = min(1 - 1 / (step + 1), ema_decay) (ssl_mt.py:359-363), evaluated here
+    in fp64 from snapshots of the engine's own student parameters -- every element within 2 fp32 ulp of it (two products and a
+    sum, each rounded once; the reference's `mul_().add_()` rounds the same three results)."""
+    import torch_oracle as TO
+    import pixelssl_amd as P
+    from pixelssl_amd.nn import optimizer as popt, lrer as plr
+    fx = _fx("mt_cond_129.pt")
+    args = _args(fx, dtype, cons_for_labeled=False, cons_scale=1.0, cons_rampup_epochs=3, ema_decay=0.99)
+    algo = P.ssl_algorithm.ssl_mt.ssl_mt(args, {"model": P.sseg.model.deeplabv2()}, {"model": popt.sgd(args)},
+                                        {"model": plr.polynomiallr(args)}, {"model": P.sseg.criterion.sseg_criterion()}, None)
+    s_core, t_core = algo.s_model.module.model, algo.t_model.module.model
+    s_core.load_state_dict(_deeplab_state(fx["weight_seed"], fx["gamma3"]))
+    t_core.load_state_dict(_deeplab_state(fx["weight_seed"] + 1, fx["gamma3"]))
+    algo.s_model.train()
+    algo.t_model.train()
+    worst = 0.0
+    for i, s in enumerate(fx["data_seeds"][:4]):
+        t_before = t_core.flat.params.detach().double().clone()
+        x, gt = TO.synthetic_batch(fx["lbs"] + fx["ubs"], fx["size"], fx["lbs"], seed=s, block=fx["block"])
+        algo.train_step((x.to(DEV),), (gt.to(DEV),), i, fx["rampup_iters"])
+        alpha = min(1 - 1 / (i + 1), 0.99)
+        want = alpha * t_before + (1 - alpha) * s_core.flat.params.detach().double()
+        got = t_core.flat.params.detach().double()
+        ulp = torch.clamp(want.abs(), min=1e-30) * EPS32
+        err = ((got - want).abs() / ulp).max().item()
+        moved = (got - t_before).abs().max().item()
+        worst = max(worst, err)
+        assert moved > 0 or i == 0, "the teacher did not move in iteration %d" % i
+        assert err <= 2.0, "iteration %d: teacher is %.2f ulp from the EMA of the student" % (i, err)
+    print("mt %s: teacher vs fp64 EMA of the engine's student, worst element %.2f ulp over 4 iterations" % (dtype, worst))
