@@ -24,8 +24,17 @@ __global__ void bn_finalize_kernel(int C, const float* __restrict__ stats, int n
   float mean, var;
   if (training) {
     float s1 = 0.f, s2 = 0.f;
+    if (nrep > 16) {
+      // many replicas (PXL_DETERMINISTIC: one per 64 pixel rows, thousands for the first layers): a sequential fp32 sum of
+      // that length costs accuracy in var = E[x^2] - mean^2 (513 x 513 logits 1.5e-3 off the reference against 5.8e-4 with
+      // four replicas); fp64 partial sums are exact to fp32 here and still a fixed order
+      double d1 = 0.0, d2 = 0.0;
+      for (int r = 0; r < nrep; ++r) { d1 += (double)stats[(size_t)r * 2 * C + c]; d2 += (double)stats[(size_t)r * 2 * C + C + c]; }
+      s1 = (float)d1; s2 = (float)d2;
+    } else {
 #pragma unroll 8
-    for (int r = 0; r < nrep; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
+      for (int r = 0; r < nrep; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
+    }
     mean = s1 / total_count;
     var = s2 / total_count - mean * mean;
     if (var < 0.f) var = 0.f;
@@ -62,6 +71,12 @@ __global__ void bn_param_grad_kernel(int C, const float* __restrict__ sums, floa
 __global__ void fold_replicas_kernel(int n, int nrep, float* __restrict__ buf) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (nrep > 16) {           // (see bn_finalize_kernel: long folds in fp64, same fixed order)
+    double d = 0.0;
+    for (int r = 0; r < nrep; ++r) d += (double)buf[(size_t)r * n + i];
+    buf[i] = (float)d;
+    return;
+  }
   float s = 0.f;
   for (int r = 0; r < nrep; ++r) s += buf[(size_t)r * n + i];
   buf[i] = s;

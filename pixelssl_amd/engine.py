@@ -309,7 +309,9 @@ class SegNetCore(nn.Module):
         self._profile_on = False
         self._anchor = None
         self.freeze_bn = False
-        self.autotune = os.environ.get("PXL_AUTOTUNE", "1") != "0"
+        # (PXL_DETERMINISTIC=1: no timing-dependent choices either -- the tile a tuner run picks decides how the statistics of a
+        # BatchNorm are grouped into partial sums, so two tuned processes need not agree in the last bits)
+        self.autotune = os.environ.get("PXL_AUTOTUNE", "1") != "0" and os.environ.get("PXL_DETERMINISTIC", "0") != "1"
         self.want_prob = True           # HEAD also returns softmax(logits) (segmentation nets; not the discriminators)
         self.has_latent = True
         self.differentiable_latent = False   # SSLCCT: the latent handed out by forward() carries autograd history
