@@ -544,6 +544,19 @@ int pxl_net_set_grad_sync(pxl_net* net, pxl_allreduce_fn fn, void* user, int wor
  * where at most that many floats of parameters remain below (a small last bucket: the next forward waits for it).
  * Same update arithmetic, element by element, as one step over the whole buffer.  fn = NULL: off. */
 typedef int (*pxl_update_fn)(void* user, long lo, long hi, void* stream);
+/* One convolution weight whose kernel (forward) layout is its master layout (channels_last, Cin % 32 == 0): floats
+ * params[off, off + n) -> bf16 at packed + s_pk (student) / + t_pk (the same op of a second network; -1: none). */
+typedef struct pxl_upd_seg { int64_t off, n, s_pk, t_pk; } pxl_upd_seg;
+/* the segments of `net` (and of `teacher`, a network with the same program, or NULL), sorted by off; -> count (>= 0), or < 0 */
+int pxl_net_update_segments(pxl_net* net, pxl_net* teacher, pxl_upd_seg* out, int cap);
+/* Fused update of params[lo, hi): momentum SGD -> EMA into `t` -> both networks' bf16 forward copies -> gradient zeroed, one
+ * pass (ssl_mt.py:198-204 + 359-363 + the re-packing pxl_net_pack does); same arithmetic as pxl_sgd_step / pxl_ema_update /
+ * pxl_net_pack element for element.  The weights the segments do not cover (stem patches, multi-rate heads, the transposed
+ * data-gradient copies) are packed by pxl_net_pack_range(which = 2 | 4). */
+int pxl_sgd_ema_pack(long lo, long hi, float* p, float* g, float* buf, float* t, int nruns, const long* run_start,
+                     const float* run_lr, const float* const* run_lr_dev, float momentum, float weight_decay, float alpha,
+                     const float* alpha_dev, const pxl_upd_seg* segs, int nseg, void* s_packed, void* t_packed, int zero_grad,
+                     void* stream);
 int pxl_net_set_update_hook(pxl_net* net, pxl_update_fn fn, void* user, long bucket_floats, long tail_floats, long total_floats);
 int pxl_net_update_buckets(const pxl_net* net);      /* buckets the last backward handed to the hook */
 int pxl_net_grad_buckets(const pxl_net* net);        /* buckets issued by the last pxl_net_backward */
@@ -555,7 +568,9 @@ int pxl_net_tune(pxl_net* net, const float* params, const void* packed, float* g
 int pxl_net_pack(pxl_net* net, const float* params, void* packed, void* stream);
 /* the same in two independent halves: which bit 0 = forward operand layout + biases (read by pxl_net_forward), bit 1 =
  * transposed data-gradient layout (first read by pxl_net_backward: pack it on a side stream next to the forward) */
-/* pxl_net_pack_parts for the convolutions whose master weights lie in params[lo, hi) (a bucket of the pipelined update) */
+/* pxl_net_pack_parts for the convolutions whose master weights lie in params[lo, hi) (a bucket of the pipelined update);
+ * which: 1 forward layouts, 2 transposed data-gradient layouts, 4 forward layouts of the convolutions pxl_net_update_segments
+ * does NOT list only (the rest was written by pxl_sgd_ema_pack) */
 int pxl_net_pack_range(pxl_net* net, const float* params, void* packed, int which, long lo, long hi, void* stream);
 int pxl_net_pack_parts(pxl_net* net, const float* params, void* packed, int which, void* stream);
 /* x NCHW fp32 [B,3,H,W] -> logits/prob NCHW fp32 [B,classes,H,W]; training selects batch statistics

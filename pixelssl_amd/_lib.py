@@ -44,6 +44,10 @@ class PackItem(C.Structure):
                 ("t_off", C.c_int32), ("Kp", C.c_int32)]
 
 
+class UpdSeg(C.Structure):
+    _fields_ = [("off", C.c_int64), ("n", C.c_int64), ("s_pk", C.c_int64), ("t_pk", C.c_int64)]
+
+
 class BnDesc(C.Structure):
     _fields_ = [("C", C.c_int32), ("gamma_off", C.c_int32), ("beta_off", C.c_int32),
                 ("rmean_off", C.c_int32), ("rvar_off", C.c_int32), ("eps", C.c_float),
@@ -210,6 +214,8 @@ SIGNATURES = {
     "pxl_net_set_update_hook": (_I, [_P, UPDATE_FN, _P, _L, _L, _L]),
     "pxl_net_update_buckets": (_I, [_P]),
     "pxl_net_pack_range": (_I, [_P, _P, _P, _I, _L, _L, _P]),
+    "pxl_net_update_segments": (_I, [_P, _P, C.POINTER(UpdSeg), _I]),
+    "pxl_sgd_ema_pack": (_I, [_L, _L, _P, _P, _P, _P, _I, C.POINTER(_L), C.POINTER(_F), C.POINTER(_P), _F, _F, _F, _P, _P, _I, _P, _P, _I, _P]),
     "pxl_net_tune": (_I, [_P, _P, _P, _P, _P, _Z, _P, _Z, _P]),
     "pxl_net_pack": (_I, [_P, _P, _P, _P]),
     "pxl_net_pack_parts": (_I, [_P, _P, _P, _I, _P]),

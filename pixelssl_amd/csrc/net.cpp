@@ -834,6 +834,35 @@ extern "C" size_t pxl_net_scratch_bytes(const pxl_net* n) { return n && n->plann
 // first read by the backward pass, on a side stream that overlaps the forward.
 namespace {
 int net_pack_impl(pxl_net* n, const float* params, void* packed, int which, long lo, long hi, void* stream);
+// the forward kernel layout of this convolution's weights is its master layout cast to bf16 (what pxl_sgd_ema_pack writes)
+inline bool fwd_is_cast(const pxl_net* n, const OpInfo& op) {
+  const pxl_op& d = op.d;
+  if (d.kind != PXL_OP_CONV || n->dtype != PXL_BF16 || op.patch || d.ngroups != 1) return false;
+  const TensorInfo& tin = n->tensors[d.in0];
+  const long total = (long)d.cout * d.kh * d.kw * d.cin;
+  return tin.Cp == d.cin && (total & 7) == 0 && (d.w_off[0] & 3) == 0 && (op.wf_off & 15) == 0;
+}
+}
+
+extern "C" int pxl_net_update_segments(pxl_net* n, pxl_net* t, pxl_upd_seg* out, int cap) {
+  PXL_REQUIRE(n && n->planned && out && cap > 0, "net_update_segments: bad argument (plan first)");
+  PXL_REQUIRE(t == nullptr || (t->planned && t->ops.size() == n->ops.size() && t->dtype == n->dtype),
+              "net_update_segments: the second network must run the same program");
+  int k = 0;
+  for (size_t i = 0; i < n->ops.size(); ++i) {
+    const OpInfo& op = n->ops[i];
+    if (!fwd_is_cast(n, op)) continue;
+    if (t != nullptr && !(fwd_is_cast(t, t->ops[i]) && t->ops[i].d.w_off[0] == op.d.w_off[0])) continue;
+    PXL_REQUIRE(k < cap, "net_update_segments: more than %d segments", cap);
+    out[k].off = op.d.w_off[0];
+    out[k].n = (int64_t)op.d.cout * op.d.kh * op.d.kw * op.d.cin;
+    out[k].s_pk = (int64_t)op.wf_off;
+    out[k].t_pk = t != nullptr ? (int64_t)t->ops[i].wf_off : -1;
+    ++k;
+  }
+  for (int a = 1; a < k; ++a)                      // sorted by offset (the parameter order of every built-in program already is)
+    for (int b = a; b > 0 && out[b].off < out[b - 1].off; --b) { pxl_upd_seg tmp = out[b]; out[b] = out[b - 1]; out[b - 1] = tmp; }
+  return k;
 }
 
 extern "C" int pxl_net_pack_parts(pxl_net* n, const float* params, void* packed, int which, void* stream) {
@@ -849,7 +878,7 @@ extern "C" int pxl_net_pack_range(pxl_net* n, const float* params, void* packed,
 
 namespace {
 int net_pack_impl(pxl_net* n, const float* params, void* packed, int which, long lo, long hi, void* stream) {
-  PXL_REQUIRE(n && n->planned && params && packed && (which & 3) != 0, "net_pack: bad argument (plan first)");
+  PXL_REQUIRE(n && n->planned && params && packed && (which & 7) != 0, "net_pack: bad argument (plan first)");
   std::vector<pxl_pack_item> items;
   for (auto& op : n->ops) {
     const pxl_op& d = op.d;
@@ -859,18 +888,20 @@ int net_pack_impl(pxl_net* n, const float* params, void* packed, int which, long
     const TensorInfo& tout = n->tensors[d.out];
     const int tpg = d.kh * d.kw;
     const bool want_t = (which & 2) && d.need_dgrad && n->pack_dgrad;
+    // which & 4: forward layouts only of the convolutions the fused update kernel does not write (pxl_net_update_segments)
+    const bool want_f = (which & 1) || ((which & 4) && !fwd_is_cast(n, op));
     for (int g = 0; g < d.ngroups; ++g) {
-      if (!(which & 1) && !want_t) continue;
+      if (!want_f && !want_t) continue;
       pxl_pack_item it;
       it.src_off = d.w_off[g];
-      it.wf_off = (which & 1) ? (int64_t)op.wf_off : -1;
+      it.wf_off = want_f ? (int64_t)op.wf_off : -1;
       it.wt_off = want_t ? (int64_t)op.wt_off : -1;
       it.K = d.cout; it.T = tpg; it.C = d.cin;
       it.Cp = tin.Cp; it.T_total = op.ntaps; it.t_off = g * tpg; it.Kp = tout.Cp;
       if (op.patch) { it.T = 1; it.C = op.patch_K; it.Cp = op.patch_Kp; it.T_total = 1; it.t_off = 0; }   // master [Cout][kh*kw*C] as is
       items.push_back(it);
     }
-    if ((which & 1) && d.b_off[0] >= 0) {
+    if ((which & 5) && d.b_off[0] >= 0) {
       const float* b[4] = {nullptr, nullptr, nullptr, nullptr};
       for (int g = 0; g < d.ngroups; ++g) b[g] = d.b_off[g] >= 0 ? params + d.b_off[g] : nullptr;
       int rc = pxl_vec_sum4(d.cout, fat(packed, op.bias_off), b[0], b[1], b[2], b[3], stream);

@@ -8,6 +8,23 @@
 
 namespace {
 
+// the update arithmetic, shared by the stand-alone kernels and the fused update kernel (one source = one contraction choice)
+// Written with explicit roundings -- the forms hipcc chose for the stand-alone kernels of rounds 1-4 (three fused multiply-adds
+// for SGD; two rounded products and a sum for the EMA, as torch's `mul_().add_()`): left to the compiler, the fused kernel
+// contracted the EMA into a multiply + fma and differed from the stand-alone kernel in the last bit.
+__device__ __forceinline__ float sgd_elem(float pv, float gv, float bv, float lr, float momentum, float wd, int first, float* b_out) {
+  const float d = __fmaf_rn(wd, pv, gv);
+  const float b = first ? d : __fmaf_rn(momentum, bv, d);
+  *b_out = b;
+  return __fmaf_rn(-lr, b, pv);
+}
+__device__ __forceinline__ float ema_elem(float tv, float sv, float alpha) {
+#pragma clang fp contract(off)
+  const float a = tv * alpha;
+  const float b = (1.f - alpha) * sv;
+  return a + b;
+}
+
 // lr_dev != NULL: the learning rate is read from device memory (a per-step hyper-parameter block, pxl_hyper_set): the launch
 // then carries nothing that changes from step to step and can be replayed from a captured hipGraph
 __global__ __launch_bounds__(256) void sgd_kernel(long n, float* __restrict__ p, const float* __restrict__ g,
@@ -15,11 +32,9 @@ __global__ __launch_bounds__(256) void sgd_kernel(long n, float* __restrict__ p,
                                                   float wd, int first, const float* __restrict__ lr_dev) {
   if (lr_dev != nullptr) lr = lr_dev[0];
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float pv = p[i];
-    const float d = g[i] + wd * pv;
-    const float b = first ? d : momentum * buf[i] + d;
+    float b;
+    p[i] = sgd_elem(p[i], g[i], buf[i], lr, momentum, wd, first, &b);
     buf[i] = b;
-    p[i] = pv - lr * b;
   }
 }
 
@@ -44,7 +59,61 @@ __global__ __launch_bounds__(256) void ema_kernel(long n, float* __restrict__ t,
                                                   float alpha, const float* __restrict__ alpha_dev) {
   if (alpha_dev != nullptr) alpha = alpha_dev[0];
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    t[i] = t[i] * alpha + (1.f - alpha) * s[i];
+    t[i] = ema_elem(t[i], s[i], alpha);
+}
+
+// Fused parameter update of params[lo, hi): SGD (per-run learning rates) -> EMA into the teacher (optional) -> the bf16
+// forward-layout copies of both networks' convolution weights (for every convolution whose kernel layout IS the master
+// layout, channels_last with Cin % 32 == 0: a cast), and the consumed gradient zeroed -- one pass, 32 B per parameter,
+// instead of SGD (20 B) + EMA (12 B) + two packing passes (6 B each) + a memset (4 B).  Same arithmetic as the stand-alone
+// kernels (sgd_elem / ema_elem / pack_bf2), element for element.
+struct UpdRuns { long start[8]; float lr[8]; const float* lr_dev[8]; int n; };
+__global__ __launch_bounds__(256) void sgd_ema_pack_kernel(long lo, long hi, float* __restrict__ p, float* __restrict__ g,
+                                                           float* __restrict__ buf, float* __restrict__ t, const UpdRuns runs,
+                                                           float momentum, float wd, float alpha, const float* __restrict__ alpha_dev,
+                                                           const pxl_upd_seg* __restrict__ segs, int nseg,
+                                                           unsigned char* __restrict__ s_pk, unsigned char* __restrict__ t_pk, int zero_grad) {
+  if (alpha_dev != nullptr) alpha = alpha_dev[0];
+  float lrs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) lrs[k] = k < runs.n ? (runs.lr_dev[k] != nullptr ? runs.lr_dev[k][0] : runs.lr[k]) : 0.f;
+  for (long i = lo + ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < hi; i += (long)gridDim.x * 1024) {
+    float lr = lrs[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) if (k < runs.n && i >= runs.start[k]) lr = lrs[k];
+    const float4 pv = *reinterpret_cast<const float4*>(p + i), gv = *reinterpret_cast<const float4*>(g + i),
+                 bv = *reinterpret_cast<const float4*>(buf + i);
+    float4 pn, bn;
+    pn.x = sgd_elem(pv.x, gv.x, bv.x, lr, momentum, wd, 0, &bn.x);
+    pn.y = sgd_elem(pv.y, gv.y, bv.y, lr, momentum, wd, 0, &bn.y);
+    pn.z = sgd_elem(pv.z, gv.z, bv.z, lr, momentum, wd, 0, &bn.z);
+    pn.w = sgd_elem(pv.w, gv.w, bv.w, lr, momentum, wd, 0, &bn.w);
+    *reinterpret_cast<float4*>(p + i) = pn;
+    *reinterpret_cast<float4*>(buf + i) = bn;
+    if (zero_grad) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 tn = pn;
+    if (t != nullptr) {
+      const float4 tv = *reinterpret_cast<const float4*>(t + i);
+      tn.x = ema_elem(tv.x, pn.x, alpha); tn.y = ema_elem(tv.y, pn.y, alpha);
+      tn.z = ema_elem(tv.z, pn.z, alpha); tn.w = ema_elem(tv.w, pn.w, alpha);
+      *reinterpret_cast<float4*>(t + i) = tn;
+    }
+    if (nseg > 0) {
+      int a = 0, b = nseg - 1;
+      while (a < b) {                          // last segment with off <= i
+        const int mid = (a + b + 1) >> 1;
+        if (segs[mid].off <= i) a = mid; else b = mid - 1;
+      }
+      const pxl_upd_seg sg = segs[a];
+      if (i >= sg.off && i < sg.off + sg.n) {
+        const long e = (i - sg.off) * 2;
+        if (s_pk != nullptr && sg.s_pk >= 0)
+          *reinterpret_cast<uint2*>(s_pk + sg.s_pk + e) = make_uint2(pack_bf2(pn.x, pn.y), pack_bf2(pn.z, pn.w));
+        if (t != nullptr && t_pk != nullptr && sg.t_pk >= 0)
+          *reinterpret_cast<uint2*>(t_pk + sg.t_pk + e) = make_uint2(pack_bf2(tn.x, tn.y), pack_bf2(tn.z, tn.w));
+      }
+    }
+  }
 }
 
 // torch.optim.Adam (no weight decay, no amsgrad): the FC discriminator / flaw detector optimizer (ssl_adv.py:101-102)
@@ -136,6 +205,32 @@ extern "C" int pxl_ema_update_hp(long n, float* teacher, const float* student, c
   PXL_REQUIRE(teacher && student && alpha_dev && n > 0, "ema_update_hp: bad argument");
   hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), n,
                      teacher, student, 0.f, alpha_dev);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+// see sgd_ema_pack_kernel.  run_start / run_lr / run_lr_dev: nruns <= 8 learning-rate runs of the flat buffer in ascending order
+// (run k covers [run_start[k], run_start[k + 1])); run_lr_dev[k] != NULL: that rate is read from device memory.  t / t_packed NULL:
+// no teacher.  segs: DEVICE array of nseg segments sorted by `off` (pxl_net_update_segments).  lo, hi, every segment: multiples of 4.
+extern "C" int pxl_sgd_ema_pack(long lo, long hi, float* p, float* g, float* buf, float* t, int nruns, const long* run_start,
+                                const float* run_lr, const float* const* run_lr_dev, float momentum, float weight_decay, float alpha,
+                                const float* alpha_dev, const pxl_upd_seg* segs, int nseg, void* s_packed, void* t_packed,
+                                int zero_grad, void* stream) {
+  PXL_REQUIRE(p && g && buf && hi > lo && lo >= 0 && (lo & 3) == 0 && (hi & 3) == 0, "sgd_ema_pack: bad range");
+  PXL_REQUIRE(nruns >= 1 && nruns <= 8 && run_start && run_lr, "sgd_ema_pack: 1..8 learning-rate runs");
+  PXL_REQUIRE(nseg == 0 || segs != nullptr, "sgd_ema_pack: null segment table");
+  UpdRuns r;
+  for (int k = 0; k < 8; ++k) {
+    r.start[k] = k < nruns ? run_start[k] : 0;
+    r.lr[k] = k < nruns ? run_lr[k] : 0.f;
+    r.lr_dev[k] = (k < nruns && run_lr_dev != nullptr) ? run_lr_dev[k] : nullptr;
+  }
+  r.n = nruns;
+  long blocks = ((hi - lo) / 4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(sgd_ema_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), lo, hi, p, g, buf,
+                     t, r, momentum, weight_decay, alpha, alpha_dev, segs, nseg, reinterpret_cast<unsigned char*>(s_packed),
+                     reinterpret_cast<unsigned char*>(t_packed), zero_grad);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

@@ -296,6 +296,11 @@ class PipelinedUpdate:
         self.armed = False
         self.covered = 0
         self.buckets = 0
+        # PXL_FUSED_UPDATE=1 (bf16 engine): SGD + EMA + the bf16 forward copies of both networks + the gradient memset as ONE
+        # kernel per bucket (csrc/optim.hip: pxl_sgd_ema_pack), same arithmetic element for element
+        self.fused = os.environ.get('PXL_FUSED_UPDATE', '0') == '1' and s_core._code == _lib.PXL_BF16 and \
+            (t_core is None or t_core._code == _lib.PXL_BF16)
+        self._segs = None
         mb = float(os.environ.get('PXL_UPDATE_BUCKET_MB', '16')) if bucket_mb is None else float(bucket_mb)
         tail = int(os.environ.get('PXL_UPDATE_TAIL_FLOATS', '300000')) if tail_floats is None else int(tail_floats)
         s_core.set_update_hook(self._on_bucket, int(mb * (1 << 20) / 4), tail)
@@ -310,6 +315,39 @@ class PipelinedUpdate:
         `hyper` is given: the captured step reads it -- and the learning rates -- from the device block)"""
         self.s_plan, self.t_plan, self.alpha, self.hyper = s_plan, t_plan, ema_alpha, hyper
         self.armed, self.covered, self.buckets = True, 0, 0
+        if self.fused and (self._segs is None or self._segs[0] is not s_plan or self._segs[1] is not t_plan):
+            import ctypes
+            arr = (_lib.UpdSeg * 512)()
+            n = _lib.lib().pxl_net_update_segments(s_plan.net, t_plan.net if t_plan is not None else None, arr, 512)
+            if n < 0:
+                _lib.check(n)
+            host = torch.tensor([[arr[k].off, arr[k].n, arr[k].s_pk, arr[k].t_pk] for k in range(n)], dtype=torch.int64).reshape(-1, 4)
+            self._segs = (s_plan, t_plan, host.to(self.s_core.flat.params.device), n)
+
+    def _fused_bucket(self, lo, hi):
+        import ctypes
+        opt, store, hyper = self.optimizer, self.s_core.flat, self.hyper
+        runs = sorted((off, gi) for gi, rr in enumerate(opt._runs) for _, off, _n in rr)
+        nr = len(runs)
+        if nr > 8:
+            raise _lib.PixelHipError('PipelinedUpdate: more than 8 learning-rate runs')
+        starts = (ctypes.c_long * nr)(*[r[0] for r in runs])
+        lrs = (ctypes.c_float * nr)(*[float(opt.param_groups[r[1]]['lr']) for r in runs])
+        devs = (ctypes.c_void_p * nr)(*[(hyper.ptr('%s.lr%d' % (opt._hp_name, r[1])) if hyper is not None else None) for r in runs])
+        g0 = opt.param_groups[0]
+        mom, wd = float(g0['momentum']), float(g0['weight_decay'])
+        if any(float(g['momentum']) != mom or float(g['weight_decay']) != wd for g in opt.param_groups):
+            raise _lib.PixelHipError('PipelinedUpdate (fused): momentum / weight decay must be the same in every parameter group')
+        t = self.t_core.flat.params if self.t_core is not None else None
+        _lib.check(_lib.lib().pxl_sgd_ema_pack(
+            lo, hi, _lib.ptr(store.params), _lib.ptr(store.grads), _lib.ptr(store.momentum), _lib.ptr(t), nr, starts, lrs, devs,
+            mom, wd, float(self.alpha) if self.alpha is not None else 0.0,
+            hyper.ptr('ema_alpha') if (hyper is not None and t is not None) else None,
+            _lib.ptr(self._segs[2]), self._segs[3], _lib.ptr(self.s_plan.packed),
+            _lib.ptr(self.t_plan.packed) if self.t_plan is not None else None, 1, _lib.stream_ptr()))
+        self.s_core.pack_range(self.s_plan, lo, hi, 2 | 4)
+        if self.t_core is not None:
+            self.t_core.pack_range(self.t_plan, lo, hi, 4)
 
     @torch.no_grad()
     def _on_bucket(self, lo, hi, stream):
@@ -318,6 +356,13 @@ class PipelinedUpdate:
             return
         opt, store = self.optimizer, self.s_core.flat
         hyper = self.hyper
+        if self.fused:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                self._fused_bucket(lo, hi)
+            self.covered += hi - lo
+            self.buckets += 1
+            self.pending = True
+            return
         with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
             for gi, (group, runs) in enumerate(zip(opt.param_groups, opt._runs)):
                 lr, mom, wd = float(group['lr']), float(group['momentum']), float(group['weight_decay'])

@@ -49,8 +49,11 @@ def _steps(fx, algo, n=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_bucket_updates_equal_the_whole_buffer_step_bit_for_bit(dtype, monkeypatch):
+@pytest.mark.parametrize("dtype,fused", [("fp32", "0"), ("bf16", "0"), ("bf16", "1")], ids=["fp32", "bf16", "bf16-fused"])
+def test_bucket_updates_equal_the_whole_buffer_step_bit_for_bit(dtype, fused, monkeypatch):
+    """fused = PXL_FUSED_UPDATE=1: SGD + EMA + both networks' bf16 forward copies + the gradient memset in ONE kernel per bucket
+    (csrc/optim.hip: pxl_sgd_ema_pack), the remaining layouts by pxl_net_pack_range(which = 2 | 4) -- the same bits"""
+    monkeypatch.setenv("PXL_FUSED_UPDATE", fused)
     from pixelssl_amd import ops
     from pixelssl_amd.nn.optimizer import PipelinedUpdate
     fx, algo = _mt(dtype, monkeypatch, {"PXL_PIPE_UPDATE": "0", "PXL_GRAPH": "0"})
@@ -83,8 +86,11 @@ def test_bucket_updates_equal_the_whole_buffer_step_bit_for_bit(dtype, monkeypat
     cuts = [conv_lo[k] for k in (len(conv_lo) - 1, len(conv_lo) - 7, len(conv_lo) // 2, len(conv_lo) // 5, 3, 1)]
     cuts = sorted(set(c for c in cuts if 0 < c < st.np), reverse=True)
     pipe = PipelinedUpdate(opt, s_core, t_core)
+    assert pipe.fused == (fused == "1")
     try:
         pipe.arm(s_plan, t_plan, alpha, None)
+        if pipe.fused:
+            assert pipe._segs[3] >= 90, pipe._segs[3]          # ~100 of the 105 convolutions of DeepLab-v2 are plain casts
         hi = st.np
         for lo in cuts + [0]:
             pipe._on_bucket(lo, hi, torch.cuda.current_stream().cuda_stream)
@@ -122,10 +128,10 @@ def test_the_executor_hands_out_buckets_that_tile_the_gradient_buffer(monkeypatc
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_mt_with_the_pipelined_update_is_the_reference_iteration(dtype, monkeypatch):
+@pytest.mark.parametrize("dtype,fused", [("fp32", "0"), ("bf16", "0"), ("bf16", "1")], ids=["fp32", "bf16", "bf16-fused"])
+def test_mt_with_the_pipelined_update_is_the_reference_iteration(dtype, fused, monkeypatch):
     from test_multistep import _check_losses, _check_weights
-    env = {"PXL_GRAPH": "0", "PXL_DETERMINISTIC": "1"}
+    env = {"PXL_GRAPH": "0", "PXL_DETERMINISTIC": "1", "PXL_FUSED_UPDATE": fused}
     fx, a0 = _mt(dtype, monkeypatch, dict(env, PXL_PIPE_UPDATE="0"))
     l0 = _steps(fx, a0)
     s0 = {k: v.detach().float().cpu() for k, v in a0.s_model.module.model.state_dict().items()}
@@ -134,6 +140,7 @@ def test_mt_with_the_pipelined_update_is_the_reference_iteration(dtype, monkeypa
     fx, a1 = _mt(dtype, monkeypatch, dict(env, PXL_PIPE_UPDATE="1"))
     l1 = _steps(fx, a1)
     assert a1._pipe is not None and a1._pipe.buckets >= 2 and a1.s_optimizer._steps_taken == len(l1)
+    assert a1._pipe.fused == (fused == "1")
     s1 = {k: v.detach().float().cpu() for k, v in a1.s_model.module.model.state_dict().items()}
     t1 = {k: v.detach().float().cpu() for k, v in a1.t_model.module.model.state_dict().items()}
     from test_multistep import subsample
