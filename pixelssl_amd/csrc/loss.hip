@@ -5,6 +5,11 @@
 //   * mean-squared error (nn.MSELoss(), ssl_mt.py:115,182-184)
 #include "common.h"
 
+// PXL_DETERMINISTIC=1 (read per call: these entry points have no executor to remember it): the loss VALUES -- per-sample sums that
+// the default launches combine with one fp32 atomic per block or wave -- come from ONE block (one wave for the wave-level kernels)
+// per sample, i.e. one add in a fixed order.  Gradients never depended on these sums; this makes the logged numbers bit-reproducible.
+static inline bool pxl_det_now() { const char* e = getenv("PXL_DETERMINISTIC"); return e != nullptr && e[0] == '1'; }
+
 namespace {
 
 constexpr int MAXC = 32;
@@ -182,6 +187,7 @@ extern "C" int pxl_ce_fwd(int N, int C, int HW, const float* logits, const float
   PXL_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float) * N, s));
   int gx = cdiv(HW, 256);
   if (gx > 512) gx = 512;
+  if (pxl_det_now()) gx = 1;
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(gx, N), dim3(256), 0, s, C, HW, logits, gt, ignore_index, loss);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
@@ -290,8 +296,9 @@ extern "C" int pxl_bce_logits_masked_fwd(int B, long HW, const float* x, const f
   PXL_REQUIRE(x && loss && B > 0 && HW > 0, "bce_logits_masked_fwd: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   PXL_CHECK_HIP(hipMemsetAsync(loss, 0, (size_t)B * sizeof(float), s));
-  const int gx = (int)((HW + 256 * 8 - 1) / (256 * 8));
-  hipLaunchKernelGGL(bce_masked_fwd_kernel, dim3(gx, B), dim3(256), 0, s, HW, x, task_gt, ignore_index, target, loss);
+  const bool det = pxl_det_now();
+  const int gx = det ? 1 : (int)((HW + 256 * 8 - 1) / (256 * 8));
+  hipLaunchKernelGGL(bce_masked_fwd_kernel, dim3(gx, B), dim3(det ? 64 : 256), 0, s, HW, x, task_gt, ignore_index, target, loss);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -354,8 +361,9 @@ extern "C" int pxl_bce_logits_fwd(int B, long HW, const float* x, const float* t
   PXL_REQUIRE(x && t && loss && B > 0 && HW > 0, "bce_logits_fwd: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   PXL_CHECK_HIP(hipMemsetAsync(loss, 0, (size_t)B * sizeof(float), s));
-  const int gx = (int)((HW + 256 * 8 - 1) / (256 * 8));
-  hipLaunchKernelGGL(bce_logits_fwd_kernel, dim3(gx, B), dim3(256), 0, s, HW, x, t, loss);
+  const bool det = pxl_det_now();
+  const int gx = det ? 1 : (int)((HW + 256 * 8 - 1) / (256 * 8));
+  hipLaunchKernelGGL(bce_logits_fwd_kernel, dim3(gx, B), dim3(det ? 64 : 256), 0, s, HW, x, t, loss);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -433,7 +441,7 @@ extern "C" int pxl_mse_fwd(long n, const float* a, const float* b, float* out, v
   const long n4 = vec ? n / 4 : 0;
   long g = ((vec ? n4 : n) + 255) / 256;
   if (g > 2048) g = 2048;
-  if (g < 1) g = 1;
+  if (g < 1 || pxl_det_now()) g = 1;
   hipLaunchKernelGGL(mse_fwd_kernel, dim3((int)g), dim3(256), 0, s, n4, n, a, b, 1.0f / (float)n, out);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
