@@ -26,7 +26,13 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 DEV = "cuda"
 
 LOSS_TOL = {"fp32": 1e-3, "bf16": 1e-2}
-WEIGHT_FRAC = {"fp32": 0.05, "bf16": 0.6}
+# PXL_DETERMINISTIC=1 (set for the whole pytest run: `PXL_DETERMINISTIC=1 python -m pytest tests/test_multistep.py -m gpu`) makes every
+# figure of the SupOnly / PSPNet / MT / AdvSSL / CutMix cases the same number in every run (profiles/r05_d_det_*: two consecutive runs,
+# identical prints), so the bf16 bars that the default mode keeps outside its run-to-run spread can sit at 1.25 x the value itself:
+# DeepLab-v2 weights 0.363 -> 0.45 (default 0.6), PSPNet 0.541 -> 0.65 (default 0.8), CutMix's consistency term 3.1 % -> 10 % (30 %)
+DET = os.environ.get("PXL_DETERMINISTIC") == "1"
+WEIGHT_FRAC = {"fp32": 0.05, "bf16": 0.45 if DET else 0.6}
+PSP_BF16_FRAC = 0.65 if DET else 0.8
 EPS32 = 1.1920929e-07
 # bf16 engine, CCT (seven decoders back-propagated through ~100 bf16 layers): bars on the direction of the six-step update
 # (measured on the MI355X: worst probed tensor 0.67-0.75 -- conv1 and layer4.2.conv2, whose gradient arrives through
@@ -199,7 +205,7 @@ def test_pspnet_suponly_six_iterations(dtype):
         _check_losses("pspnet suponly", i, {"task_loss": loss.item()}, fx["per_iter"][i], dtype)
     # bf16: PSPNet's six-step distance is larger than DeepLab's (measured 0.53 of the update on conv1 against 0.33; run-to-run
     # spread of a few hundredths): a 0.80 bar, plus the direction criterion that a no-op fails
-    _check_weights("pspnet suponly " + dtype, core.state_dict(), fx["updates"], dtype, frac=None if dtype == "fp32" else 0.8)
+    _check_weights("pspnet suponly " + dtype, core.state_dict(), fx["updates"], dtype, frac=None if dtype == "fp32" else PSP_BF16_FRAC)
     _check_update_direction("pspnet suponly " + dtype, core.state_dict(),
                             TO.condition_state(TO.init_pspnet_state(seed=fx["weight_seed"]), fx["gamma3"]), fx["updates"],
                             min_cos=0.99 if dtype == "fp32" else 0.7, ratio=(0.97, 1.03) if dtype == "fp32" else (0.8, 1.25))
@@ -331,7 +337,10 @@ def test_cutmix_six_iterations(dtype, fixture):
         # the engine's own run-to-run spread on it (fp32 atomics order the BN statistics differently every run) was measured
         # at 0.6 ... 11.2 % below the reference over seven runs on the MI355X (tools/rep_cutmix.sh): 30 x = a 30 % bar there
         if dtype == "bf16":
-            _check_losses("cutmix", i, got, fx["ref_per_iter"][i], dtype, very_loose=("cons",))
+            if DET:
+                _check_losses("cutmix", i, got, fx["ref_per_iter"][i], dtype, loose=("cons",))
+            else:
+                _check_losses("cutmix", i, got, fx["ref_per_iter"][i], dtype, very_loose=("cons",))
         else:
             _check_losses("cutmix", i, got, fx["ref_per_iter"][i], dtype, loose=("cons",))
     _check_weights("cutmix student " + dtype, algo.s_model.module.model.state_dict(), fx["student_updates"], dtype)
