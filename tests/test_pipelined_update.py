@@ -99,7 +99,10 @@ def test_bucket_updates_equal_the_whole_buffer_step_bit_for_bit(dtype, fused, mo
         torch.cuda.synchronize()
         assert pipe.buckets == len(cuts) + 1 and not pipe.pending and pipe.grads_clean
         assert torch.equal(st.params, want["p"]) and torch.equal(st.momentum, want["m"]) and torch.equal(tt.params, want["t"])
-        assert torch.equal(s_plan.packed, want["sp"]) and torch.equal(t_plan.packed, want["tp"])
+        for tag, got_pk, want_pk in (("student", s_plan.packed, want["sp"]), ("teacher", t_plan.packed, want["tp"])):
+            bad = (got_pk != want_pk).nonzero().flatten()
+            assert bad.numel() == 0, "%s packed weights differ in %d bytes, first at byte %d, last at %d of %d (got %s want %s)" % (
+                tag, bad.numel(), int(bad[0]), int(bad[-1]), got_pk.numel(), got_pk[bad[:8]].tolist(), want_pk[bad[:8]].tolist())
         assert float(st.grads.abs().max()) == 0.0
         assert opt._steps_taken == 4
     finally:
