@@ -296,12 +296,14 @@ class PipelinedUpdate:
         self.armed = False
         self.covered = 0
         self.buckets = 0
-        # PXL_FUSED_UPDATE=1 (bf16 engine): SGD + EMA + the bf16 forward copies of both networks + the gradient memset as ONE
+        # PXL_FUSED_UPDATE=1 (default; bf16 engine): SGD + EMA + the bf16 forward copies of both networks + the gradient memset as ONE
         # kernel per bucket (csrc/optim.hip: pxl_sgd_ema_pack), same arithmetic element for element
-        self.fused = os.environ.get('PXL_FUSED_UPDATE', '0') == '1' and s_core._code == _lib.PXL_BF16 and \
+        self.fused = os.environ.get('PXL_FUSED_UPDATE', '1') == '1' and s_core._code == _lib.PXL_BF16 and \
             (t_core is None or t_core._code == _lib.PXL_BF16)
         self._segs = None
-        mb = float(os.environ.get('PXL_UPDATE_BUCKET_MB', '16')) if bucket_mb is None else float(bucket_mb)
+        # bucket size: by default ONE bucket (the whole buffer at the end of the backward pass; smaller buckets pipeline the update
+        # behind the pass, measured no faster); multi-rank runs cut at the gradient exchange's buckets whatever this says
+        mb = float(os.environ.get('PXL_UPDATE_BUCKET_MB', '1000000')) if bucket_mb is None else float(bucket_mb)
         tail = int(os.environ.get('PXL_UPDATE_TAIL_FLOATS', '300000')) if tail_floats is None else int(tail_floats)
         s_core.set_update_hook(self._on_bucket, int(mb * (1 << 20) / 4), tail)
         optimizer._pipeline = self

@@ -42,9 +42,10 @@ class SSLMT(ssl_base._SSLBase):
         self.s_model = self.t_model = None
         self.s_optimizer = self.s_lrer = self.s_criterion = self.cons_criterion = None
         self.gaussian_noiser = None
-        # opt-in execution modes, fixed when the algorithm is built (pixelssl_amd/graph.py, nn/optimizer.py: PipelinedUpdate)
+        # execution modes, fixed when the algorithm is built (pixelssl_amd/graph.py, nn/optimizer.py: PipelinedUpdate)
         self._want_graph = pgraph.enabled()
-        self._want_pipe = os.environ.get('PXL_PIPE_UPDATE', '0') == '1'
+        # 'auto' (default): the fused parameter update where its kernel applies (bf16 engine); '1' / '0' force the hook on / off
+        self._want_pipe = os.environ.get('PXL_PIPE_UPDATE', 'auto')
         if self.args.cons_for_labeled or self.args.unlabeled_batch_size > 0:
             if self.args.cons_scale < 0:
                 logger.log_err('The argument - cons_scale - is not set (or invalid)\n'
@@ -184,15 +185,25 @@ class SSLMT(ssl_base._SSLBase):
                     cons_loss=cons_loss.detach()), s_resulter, t_resulter
 
     def _update_pipeline(self, s_head, t_head):
-        """PipelinedUpdate for this student / teacher pair, or None: not asked for (PXL_PIPE_UPDATE=1 opts in), an optimizer it does
-        not cover (anything but plain momentum SGD over the student's flat parameter store), task models that are not engine
-        networks.  OFF by default: measured neutral on one MI355X (MT 8 x 513 x 513, two pairs of runs in one call: 12.37 / 12.35 ms
-        with, 12.37 / 12.43 ms without; profiles/r05_b_pipe_*): the 0.7 ms of SGD + EMA + packing between two iterations do move
-        under the backward pass, and the backward pass gets 0.5 ms longer -- those kernels stream 2.2 GB at > 5 TB/s and the
-        data gradients beside them are bandwidth-bound themselves.  The step is the serial sum of its kernels' resource time."""
+        """PipelinedUpdate for this student / teacher pair, or None: switched off (PXL_PIPE_UPDATE=0), an optimizer it does not cover
+        (anything but plain momentum SGD over the student's flat parameter store), task models that are not engine networks, or
+        -- in the default 'auto' setting -- an engine dtype the fused update kernel does not serve (fp32).
+        Measured on one MI355X (MT 8 x 513 x 513, pairs of runs inside one call):
+          * separate SGD / EMA / pack kernels per bucket (PXL_FUSED_UPDATE=0): 12.37 / 12.35 ms against 12.37 / 12.43 ms without --
+            neutral: the 0.7 ms of update work move under the backward pass and the backward pass gets 0.5 ms longer (those kernels
+            stream 2.2 GB at > 5 TB/s next to bandwidth-bound data gradients);
+          * ONE fused kernel (SGD + EMA + both bf16 forward copies + gradient memset, 32 instead of 48 bytes per parameter):
+            11.94 / 11.99 ms in 16 MB buckets, 11.93 / 11.96 ms as one bucket at the end of the backward pass, against
+            12.12 / 12.13 ms -- fewer bytes and four launches less is what pays, not the overlap.  Hence the default: fused, one
+            bucket (PXL_UPDATE_BUCKET_MB), multi-rank runs bucket with the gradient exchange."""
         if not hasattr(self, '_pipe'):
             self._pipe = None
-            if self._want_pipe:
+            from .. import dist as pdist
+            # ('auto' stays off multi-rank: there the hook runs behind the bucketed all-reduce, a combination that has only
+            # ever executed on two processes sharing one GPU -- PXL_PIPE_UPDATE=1 opts in)
+            want = self._want_pipe == '1' or (self._want_pipe == 'auto' and os.environ.get('PXL_FUSED_UPDATE', '1') == '1' and
+                                              getattr(s_head.core, '_code', None) == 1 and not pdist.is_distributed())
+            if want:
                 from ..nn.optimizer import PipelinedUpdate
                 s_core, t_core = s_head.core, t_head.core
                 try:

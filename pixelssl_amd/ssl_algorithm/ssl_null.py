@@ -53,6 +53,9 @@ class SSLNULL(ssl_base._SSLBase):
             head = self.model.module.forward_deferred(inp)
             ce, _, _ = PF.head_losses(head, None, gt[0][:lbs], lbs, 0, 0, 1.0 / lbs, 0.0, self.args.ignore_index)
             task_loss = torch.mean(ce)
+            pipe = self._update_pipeline(head)
+            if pipe is not None:        # SGD + bf16 weight copies + gradient memset as one fused kernel from inside the backward pass
+                pipe.arm(head.plan)
             head.backward()
             self.optimizer.step()
             if not self.args.is_epoch_lrer:
@@ -69,6 +72,25 @@ class SSLNULL(ssl_base._SSLBase):
         if not self.args.is_epoch_lrer:
             self.lrer.step()
         return task_loss.detach(), resulter
+
+    def _update_pipeline(self, head):
+        """nn.optimizer.PipelinedUpdate for the model (fused parameter update, see SSLMT._update_pipeline), or None: PXL_PIPE_UPDATE=0,
+        an fp32 engine, several ranks ('auto'), an optimizer / model it does not cover"""
+        if not hasattr(self, '_pipe'):
+            import os
+            from .. import dist as pdist
+            self._pipe = None
+            mode = os.environ.get('PXL_PIPE_UPDATE', 'auto')
+            if mode == '1' or (mode == 'auto' and os.environ.get('PXL_FUSED_UPDATE', '1') == '1' and
+                               getattr(head.core, '_code', None) == 1 and not pdist.is_distributed()):
+                from ..nn.optimizer import PipelinedUpdate
+                try:
+                    if len(list(self.model.parameters())) != len(head.core._param_list):
+                        raise ValueError('the model holds parameters outside its engine network')
+                    self._pipe = PipelinedUpdate(self.optimizer, head.core, None)
+                except ValueError as e:
+                    logger.log_info('fused parameter update off: %s\n' % e)
+        return self._pipe
 
     def _train(self, data_loader, epoch):
         if not (self.args.ignore_unlabeled and self.args.unlabeled_batch_size == 0):
