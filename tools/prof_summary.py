@@ -31,6 +31,9 @@ def one_step(db_path, out_txt=None, marker="sgd_kernel", per_step=2, header=""):
     db = sqlite3.connect(db_path)
     rows = list(db.execute("select name, start, end, stream_id, queue_id from kernels order by start"))
     marks = [i for i, r in enumerate(rows) if marker in r[0]]
+    if not marks and marker == "sgd_kernel":      # round 5: the fused update kernel replaces the per-group SGD launches
+        marker = "sgd_ema_pack_kernel"
+        marks = [i for i, r in enumerate(rows) if marker in r[0]]
     # marker launches per step: MT / SupOnly have two (one per lr group); algorithms with several optimizers (AdvSSL, GCT, CCT)
     # have more -- derive it from the step count of the traced command line (--steps A --warmup B in the header)
     m = re.search(r"--steps (\d+) --warmup (\d+)", header or "")
