@@ -51,6 +51,12 @@ struct DmaArgs {
   int tiles_m, tiles_n;
   float* ws;         // split-K: pre-zeroed fp32 [M][Cout] accumulation buffer (blockIdx.y = K slice), else nullptr
   int nk_per;        // K steps per slice
+  // split-K by CHANNEL slice (multi-tap gather launches): slice blockIdx.y walks EVERY tap over input channels
+  // [kc_per * y, kc_per * (y + 1)) (bytes of the pixel's channel vector, a multiple of 128) instead of a contiguous run of
+  // (tap, channel) steps.  A slice of taps re-reads the whole input once per tap from HBM -- the 36-tap ASPP forward moved
+  // 673 MB per launch for 36 MB of input (profiles/r05_traffic.json) --; a channel slice reads its 1/S of every pixel's
+  // channels 36 times, from the L2 of the XCD that holds the image.  0: contiguous K slices.
+  unsigned kc_per;
   // forward with batch statistics: the LAST workgroup to finish turns the completed [sum, sumsq] into the BatchNorm
   // coefficients (what pxl_bn_finalize does), so no finalize launch and no replica reduction in the consumers
   pxl_bn_fin fin;    // fin.coef == nullptr: off
@@ -449,10 +455,14 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
 
   // ---- load cursor: tap t, byte offset kcb inside the pixel's channel vector, kwb inside the weight row
   const unsigned cin_bytes = (unsigned)p.Cin * 2;
-  const int ks_begin = blockIdx.y * p.nk_per;                   // split-K slice (whole range when gridDim.y == 1)
-  const int nk_here = min(p.nk, ks_begin + p.nk_per) - ks_begin;
-  int ld_t = (int)(((unsigned)ks_begin * 128u) / cin_bytes);
-  unsigned kcb = (unsigned)ks_begin * 128u - (unsigned)ld_t * cin_bytes, kwb = (unsigned)ks_begin * 128u;
+  const bool by_chan = GATHER && p.kc_per != 0;                 // (block-uniform)
+  const int ks_begin = by_chan ? 0 : blockIdx.y * p.nk_per;     // split-K slice (whole range when gridDim.y == 1)
+  const unsigned c_lo = by_chan ? blockIdx.y * p.kc_per : 0u;
+  const unsigned c_hi = by_chan ? min(cin_bytes, c_lo + p.kc_per) : cin_bytes;
+  const int nk_here = by_chan ? (int)((c_hi - c_lo) >> 7) * (int)(((unsigned)p.nk * 128u) / cin_bytes)
+                              : min(p.nk, ks_begin + p.nk_per) - ks_begin;
+  int ld_t = by_chan ? 0 : (int)(((unsigned)ks_begin * 128u) / cin_bytes);
+  unsigned kcb = by_chan ? c_lo : (unsigned)ks_begin * 128u - (unsigned)ld_t * cin_bytes, kwb = (unsigned)ks_begin * 128u;
   auto set_tap = [&](int t) {
     if constexpr (GATHER) {
       const int tp = p.taps[min(t, p.ntaps - 1)];
@@ -495,8 +505,8 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
     for (int q = 0; q < LB; ++q) dma16(r_w, sb + q * NW * 1024, voffB[q], kwb);
     kwb += 128;
     kcb += 128;
-    if (kcb == cin_bytes) {      // block-uniform: next tap
-      kcb = 0;
+    if (kcb == c_hi) {           // block-uniform: next tap (channel-sliced split-K: back to the slice's first channel)
+      kcb = c_lo;
       ++ld_t;
       set_tap(ld_t);
     }
@@ -828,6 +838,7 @@ int launch_abl(const DmaArgs& a, hipStream_t stream) {
   p.tiles_n = cdiv(p.Cout, BN);
   p.ws = nullptr;
   p.nk_per = p.nk;
+  p.kc_per = 0;
   p.fin.coef = nullptr;
   p.bin.coef = nullptr; p.bin_z = nullptr; p.trace = nullptr;
   constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
@@ -872,6 +883,25 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
   }
   p.nk_per = p.nk > 0 ? cdiv(p.nk, splitk) : 0;
   splitk = p.nk > 0 ? cdiv(p.nk, p.nk_per) : 1;          // (nk == 0: a read-back-only launch of a tap-less parity class)
+  p.kc_per = 0;
+  {
+    // multi-tap gather launches split K by channel slice (see DmaArgs::kc_per): the number of slices = the divisor of the
+    // K steps per tap nearest above what the heuristic asked for (ASPP: 32 steps per tap, 6 asked -> 8 slices of 4 steps).
+    // PXL_SPLITK_CHAN=0: contiguous (tap, channel) slices as in rounds 1-4, for A/B runs
+    static const bool chan_on = getenv("PXL_SPLITK_CHAN") == nullptr || getenv("PXL_SPLITK_CHAN")[0] != '0';
+    const int spt = p.Cin / 64;                           // K steps per tap
+    const int ntaps_walked = spt > 0 ? p.nk / spt : 0;
+    if (chan_on && gather && splitk > 1 && ntaps_walked > 1 && p.nk == ntaps_walked * spt) {
+      int s2 = 0;
+      for (int c = splitk; c <= spt && c <= 4 * splitk; ++c) if (spt % c == 0) { s2 = c; break; }
+      if (s2 == 0) for (int c = splitk; c >= 2; --c) if (spt % c == 0) { s2 = c; break; }
+      if (s2 >= 2) {
+        splitk = s2;
+        p.kc_per = (unsigned)(spt / s2) * 128u;
+        p.nk_per = (spt / s2) * ntaps_walked;             // (informational: K steps per slice)
+      }
+    }
+  }
   if (splitk > 1) PXL_CHECK_HIP(hipMemsetAsync(p.ws, 0, (size_t)p.M * p.Cout * sizeof(float), stream));
   else p.ws = nullptr;
   const bool bnin = p.bin.coef != nullptr;

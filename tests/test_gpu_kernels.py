@@ -539,12 +539,15 @@ def test_wgrad_with_prologue_and_tile_cfgs(dtype):
         assert rel_err(got, w.grad) < 2 * TOL[dtype], "cfg %d" % cfg
 
 
-def test_aspp_multirate_as_one_launch():
-    """36 taps (4 dilation groups) in one implicit GEMM == sum of four dilated convs (deeplab_v2.py:81-85)."""
+@pytest.mark.parametrize("Cin", [64, 256, 512])
+def test_aspp_multirate_as_one_launch(Cin):
+    """36 taps (4 dilation groups) in one implicit GEMM == sum of four dilated convs (deeplab_v2.py:81-85).  Cin = 256 / 512: several
+    K steps per tap, so the bf16 LDS-DMA kernel splits K by CHANNEL slice (round 5: every slice walks all 36 taps over its
+    share of the input channels; 2, 4 or 8 slices depending on the request)."""
     ops = _ops()
     dtype = torch.float32
     g = torch.Generator().manual_seed(11)
-    B, Cin, Cout, H, W = 2, 64, 21, 9, 9
+    B, Cout, H, W = 2, 21, 9, 9
     rates = (1, 2, 3, 4)
     x = torch.randn(B, Cin, H, W, generator=g)
     ws = [torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05 for _ in rates]
@@ -566,7 +569,7 @@ def test_aspp_multirate_as_one_launch():
         for gi, w in enumerate(ws):
             ops.pack_weights(dt, w.permute(0, 2, 3, 1).contiguous().to(DEV), Cout, 9, Cin, wf2, cip, T_total=36, t_off=9 * gi)
         ref2 = sum(F.conv2d(qround(x, dt), qround(w, dt), None, 1, r, r) for w, r in zip(ws, rates)) + bias.view(1, -1, 1, 1)
-        for sk in (0, 1, 5):
+        for sk in (0, 1, 2, 5, 8):
             o2 = torch.full((B, H, W, cop), 3.0, device=DEV, dtype=dt)
             wsb = torch.empty(B * H * W * cop, device=DEV, dtype=torch.float32)
             ops.conv_igemm(ops.conv_desc(dt, B, H, W, cip, H, W, cop, Cout, taps, split_k=sk), to_nhwc(x, cip, dt), wf2, o2,
