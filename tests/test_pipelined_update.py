@@ -82,6 +82,7 @@ def test_bucket_updates_equal_the_whole_buffer_step_bit_for_bit(dtype, fused, mo
     # ---- the same through buckets the executor would hand out (op boundaries of this network, descending)
     st.params.copy_(p0); st.momentum.copy_(m0); tt.params.copy_(t0); st.grads.copy_(grads)
     s_plan.packed.zero_(); t_plan.packed.zero_()
+    torch.cuda.synchronize()
     conv_lo = sorted({int(op.w_off[0]) for op in s_core._pb.ops if op.kind == 1})
     cuts = [conv_lo[k] for k in (len(conv_lo) - 1, len(conv_lo) - 7, len(conv_lo) // 2, len(conv_lo) // 5, 3, 1)]
     cuts = sorted(set(c for c in cuts if 0 < c < st.np), reverse=True)
@@ -91,10 +92,14 @@ def test_bucket_updates_equal_the_whole_buffer_step_bit_for_bit(dtype, fused, mo
         pipe.arm(s_plan, t_plan, alpha, None)
         if pipe.fused:
             assert pipe._segs[3] >= 90, pipe._segs[3]          # ~100 of the 105 convolutions of DeepLab-v2 are plain casts
+        # the buckets on a stream of their own, as the executor hands them out (its communication stream) -- never the null
+        # stream: inside the full suite a bucket enqueued through ExternalStream(0) was twice seen to run ahead of the zero fill above
+        bs = torch.cuda.Stream()
         hi = st.np
         for lo in cuts + [0]:
-            pipe._on_bucket(lo, hi, torch.cuda.current_stream().cuda_stream)
+            pipe._on_bucket(lo, hi, bs.cuda_stream)
             hi = lo
+        bs.synchronize()
         opt.step()                             # bookkeeping only
         torch.cuda.synchronize()
         assert pipe.buckets == len(cuts) + 1 and not pipe.pending and pipe.grads_clean
