@@ -730,8 +730,28 @@ def main():
             out["miou_vs_ref"] = miou_vs_oracle(cores[0], a)
     scale_legs = None
     if world > 1 and a.algo == "mt" and not a.no_scaling_legs:
+        # The legs below run AFTER the measured MT region and must never cost the MT line: a leg that wedges a rank (a collective
+        # whose peer died is a GPU-side wait no exception gets out of) would otherwise keep rank 0 from ever printing.  Watchdog on
+        # EVERY rank: past the deadline rank 0 prints the line it has (MT fields, the legs marked as timed out) and all ranks leave
+        # through os._exit(0), so the launcher returns.
+        import threading
+        deadline_s = float(os.environ.get("PXL_SCALING_LEGS_TIMEOUT_S", "300"))
+        legs_done = threading.Event()
+
+        def _watchdog():
+            if legs_done.wait(deadline_s):
+                return
+            if rank == 0:
+                line = dict(out)
+                line["scaling_legs"] = "timed out after %.0f s; the MT fields above were measured before the legs started" % deadline_s
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        threading.Thread(target=_watchdog, daemon=True).start()
         ms = 1e3 * elapsed / a.steps
-        scale_legs = scaling_legs(a, world, batches, fence, dev, ms)
+        try:
+            scale_legs = scaling_legs(a, world, batches, fence, dev, ms)
+        finally:
+            legs_done.set()
         if rank == 0:
             out.update(scale_legs)
     do_fp32 = a.dtype == "bf16" and not a.no_fp32_leg and world == 1      # (scaling runs stay the headline workload only)
