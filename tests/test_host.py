@@ -263,3 +263,55 @@ def test_pretrained_backbone_file_and_model_zoo_url(tmp_path, monkeypatch):
     tm = SM.DeepLabV2(args)
     assert torch.equal(tm.model.state_dict()["backbone.conv1.weight"], trunk["conv1.weight"] * 2)
     assert SM.PRETRAINED_BACKBONE_URLS["resnet101"].endswith("resnet101-5d3b4d8f.pth")
+
+
+def test_a_peer_time_out_stays_on_record_until_the_epoch_guard():
+    """after the opt-in fall-back retires the peer-mapped contexts, check_peers() -- the epoch-end guard of
+    ssl_base.train() -- iterated an EMPTY list and never raised.  The time-out is now sticky: whoever notices it (poll_peers, a
+    status read) records it, and check_peers() raises on the record whatever happened to the contexts since."""
+    from pixelssl_amd import dist as pdist, _lib
+    keep = dict(pdist._peer)
+    try:
+        pdist._peer.update(ctxs=[], timed_out=None)
+        pdist.check_peers()                                   # nothing on record, no contexts: fine
+        pdist._peer["timed_out"] = 3                          # rank 2 was given up on; the contexts are long retired
+        with pytest.raises(_lib.PixelHipError, match="rank 2"):
+            pdist.check_peers()
+        assert pdist.poll_peers() is False                    # (single process: nothing to poll, nothing raised)
+    finally:
+        pdist._peer.clear()
+        pdist._peer.update(keep)
+    assert pdist.PEER_TIMEOUT_MS >= 20000 or "PXL_PEER_TIMEOUT_MS" in os.environ
+
+
+def test_bytes_per_step_tool_reproduces_the_committed_figure():
+    """profiles/bytes_per_step.json (what bench.py reports as `bytes_per_step`) is tools/bytes_per_step.py applied to the committed
+    PMC traffic table and the committed one-step trace: re-derive it."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bytes_per_step as BPS
+    out = os.path.join(ROOT, "profiles", "_bps_check.json")
+    try:
+        BPS.main(os.path.join(ROOT, "profiles", "r05_traffic.json"), os.path.join(ROOT, "profiles", "r05_g_step_breakdown.txt"), None, out)
+        got = json.load(open(out))
+    finally:
+        if os.path.exists(out):
+            os.remove(out)
+    want = json.load(open(os.path.join(ROOT, "profiles", "bytes_per_step.json")))
+    assert got["bytes_per_step"] == want["bytes_per_step"] and 30e9 < got["bytes_per_step"] < 40e9
+    fam = got["families"]
+    assert fam["conv_dma_kernel"]["launches"] >= 300 and fam["sgd_ema_pack_kernel"]["launches"] == 2
+    # the dominant family carries about half of the step's bytes; nothing is counted twice
+    assert 0.40 < fam["conv_dma_kernel"]["bytes"] / got["bytes_per_step"] < 0.55
+    assert abs(sum(v["bytes"] for v in fam.values()) - got["bytes_per_step"]) <= len(fam)
+
+
+def test_per_variant_traffic_of_the_dominant_kernel_is_on_record():
+    """profiles/r05_traffic*.json: conv_dma grouped by epilogue variant -- the ASPP forward's re-reads before
+    and after the channel-sliced split-K"""
+    import json
+    before = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic_before_channel_split.json")))["conv_dma_variants"]
+    after = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic.json")))["conv_dma_variants"]
+    assert before["EM=-2"]["traffic_bytes_per_launch"] > 5 * after["EM=-2"]["traffic_bytes_per_launch"] > 0
+    assert sum(v["launches"] for v in after.values()) == 319
+    assert after["EM=29"]["traffic_bytes_per_launch"] > 2.5 * after["EM=4"]["traffic_bytes_per_launch"]
