@@ -92,6 +92,62 @@ def test_contour_boxes_host_routine_matches_restatement():
     assert len(C.external_contour_boxes(ring, 4)) == 1     # the island inside the hole is not an external contour
 
 
+def _scipy_external_boxes(m):
+    """The boxes derived WITHOUT any border following, from scipy.ndimage (an implementation neither the oracle nor csrc/contour.cpp
+    shares code with): 8-connected foreground components; a component is external iff one of its pixels has a 4-neighbour in the
+    background region that is 4-connected to the image frame (RETR_EXTERNAL: outer borders whose parent is the frame);
+    box = (min_x, max_x, min_y, max_y) of the component (= cv2.boundingRect of its outer border).  Raster order of the
+    components' first pixels."""
+    from scipy import ndimage as ndi
+    H, W = m.shape
+    pad = np.zeros((H + 2, W + 2), bool)
+    pad[1:-1, 1:-1] = m != 0
+    lab, n = ndi.label(pad, structure=np.ones((3, 3), int))
+    bg, _ = ndi.label(~pad, structure=np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]]))
+    outer = bg == bg[0, 0]
+    near_outer = ndi.binary_dilation(outer, structure=np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]]))
+    out = []
+    for k, sl in enumerate(ndi.find_objects(lab), start=1):
+        comp = lab[sl] == k
+        if not (comp & near_outer[sl]).any():
+            continue
+        ys, xs = np.nonzero(lab == k)
+        first = (ys.min(), xs[ys == ys.min()].min())
+        out.append((first, (int(xs.min()) - 1, int(xs.max()) - 1, int(ys.min()) - 1, int(ys.max()) - 1)))
+    return [b for _, b in sorted(out)]
+
+
+def test_contour_boxes_against_an_independent_component_analysis():
+    """Two of the three cv2.findContours rules G-Cutout depends on -- WHICH contours are external and their bounding boxes -- checked
+    against scipy.ndimage's connected-component labelling on random blob masks, nested rings and frame-touching shapes, for the
+    oracle AND the host routine (min_vertices = 0: every external contour).  The list order is the reverse of the raster order of
+    the components' first pixels (the third rule, like the > 50-vertex filter, rests on OpenCV's documented behaviour: still no
+    vector from a real OpenCV -- cv2 is not installed)."""
+    pytest.importorskip("scipy")
+    import cct_oracle as CO
+    from pixelssl_amd.ssl_algorithm import ssl_cct as C
+    cases = [_blob_mask(97, 113, 6, s) for s in range(8)] + [_blob_mask(65, 65, 9, 100 + s) for s in range(4)]
+    ring = np.zeros((80, 80), np.uint8)
+    yy, xx = np.mgrid[0:80, 0:80]
+    rr = (yy - 40) ** 2 + (xx - 40) ** 2
+    ring[(rr < 38 ** 2) & (rr > 25 ** 2)] = 1
+    ring[rr < 15 ** 2] = 1                                  # island in the hole: not external
+    ring[0:3, 0:5] = 1                                      # a shape touching the frame
+    ring[60:64, 70:80] = 1
+    cases += [ring, np.zeros((17, 19), np.uint8), np.ones((17, 19), np.uint8)]
+    diag = np.zeros((12, 12), np.uint8)
+    for i in range(10):
+        diag[i + 1, i + 1] = 1                              # one 8-connected component made of diagonal neighbours
+    cases.append(diag)
+    total = 0
+    for m in cases:
+        want = _scipy_external_boxes(m)
+        total += len(want)
+        assert CO.external_contour_boxes(m, -1) == want[::-1]
+        assert C.external_contour_boxes(m, -1) == want[::-1]
+    assert total > 100
+
+
 def _staircase(n, y0=0, x0=0, H=None, W=None):
     """n steps of 2 x 2 pixels: rows 2i, 2i+1 hold x in [0, 2(i+1))."""
     m = np.zeros((H or 2 * n + y0 + 1, W or 2 * n + x0 + 1), np.uint8)
