@@ -32,6 +32,10 @@ modules/imgproc/src/contours.cpp, recalled -- there is no network and no OpenCV 
     reverse-raster order and regenerated the G-Cutout fixtures.
 tests/test_cct.py holds hand-derived known answers for these three rules (nested blobs, a 3n+1-vertex staircase either
 side of the `> 50` filter, two blobs whose raster and list orders differ); a vector from a real OpenCV is still missing.
+Round 5: the first rule (which outer borders are external) and the bounding boxes are additionally checked against
+scipy.ndimage's connected-component labelling -- an implementation that shares nothing with this file or csrc/contour.cpp
+(tests/test_cct.py::test_contour_boxes_against_an_independent_component_analysis); the vertex rule and the list order
+remain restatements.
 
 Randomness: the reference draws from four host RNG streams (torch CPU generator: I-VAT's `torch.rand`, Dropout2d,
 F-Noise's Uniform.sample; numpy: F-Drop's threshold; python `random`: G-Cutout).  Every decoder function below takes
