@@ -728,7 +728,7 @@ def main():
             out["step_mfma_frac"] = round(out["value"] * flop_img / world / (peak * 1e12), 4) if a.size == 513 else None
         if world == 1 and not a.no_miou and a.algo in ("mt", "suponly") and a.size == 513:
             out["miou_vs_ref"] = miou_vs_oracle(cores[0], a)
-    scale_legs = None
+    scale_legs, legs_failed = None, None
     if world > 1 and a.algo == "mt" and not a.no_scaling_legs:
         # The legs below run AFTER the measured MT region and must never cost the MT line: a leg that wedges a rank (a collective
         # whose peer died is a GPU-side wait no exception gets out of) would otherwise keep rank 0 from ever printing.  Watchdog on
@@ -750,6 +750,9 @@ def main():
         ms = 1e3 * elapsed / a.steps
         try:
             scale_legs = scaling_legs(a, world, batches, fence, dev, ms)
+        except Exception as e:          # a leg that FAILS on this rank must not cost the MT line either
+            legs_failed = "%s: %s" % (type(e).__name__, e)
+            scale_legs = {"scaling_legs": "failed on rank %d (%s); the MT fields above were measured before the legs started" % (rank, legs_failed)}
         finally:
             legs_done.set()
         if rank == 0:
@@ -760,26 +763,46 @@ def main():
         del algo, one_step
         cores = None
         torch.cuda.empty_cache()
-    seq = sequential_leg(a, world, batches, fence) if do_seq else None
-    if do_fp32:
-        leg = fp32_parity_leg(a, world, batches, fence)
+    # Everything below is reported NEXT TO the measured line; a leg that raises is put on record (`leg_errors`) instead of costing the line
+    leg_errors = {}
+
+    def _leg(name, fn):
+        try:
+            return fn()
+        except Exception as e:
+            leg_errors[name] = "%s: %s" % (type(e).__name__, e)
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            return None
+    seq = _leg("sequential_leg", lambda: sequential_leg(a, world, batches, fence)) if do_seq else None
+    leg = _leg("fp32_parity_leg", lambda: fp32_parity_leg(a, world, batches, fence)) if do_fp32 else None
     if rank == 0:
         if seq is not None and "roofline" in out:
             dom = out["roofline"]["kernel"]
             out["roofline"]["one_kernel_at_a_time"] = dict(seq["kernels"].get(dom, {}), ms_per_step_with_kernel_events=seq["ms_per_step_with_kernel_events"],
                                                            note=seq["note"])
             out["kernels_one_at_a_time"] = seq["kernels"]
-        if do_fp32:
+        if do_fp32 and leg is not None:
             out["fp32_parity_mode"] = leg
         if world == 1 and not a.no_fixture_parity and a.algo == "mt" and a.size == 513:
             algo = None
             torch.cuda.empty_cache()
-            out["parity_vs_fixture"] = fixture_parity(a, fence)
+            out["parity_vs_fixture"] = _leg("fixture_parity", lambda: fixture_parity(a, fence))
         if world == 1 and not a.no_cpu_baseline:
             algo = None
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(a)
+            out["cpu_baseline"] = _leg("cpu_baseline", lambda: cpu_baseline(a))
+        if leg_errors:
+            out["leg_errors"] = leg_errors
         print(json.dumps(out), flush=True)
+    if legs_failed is not None:
+        # the other ranks may still sit in a collective of the leg this rank left: no closing barrier with them (their own watchdogs
+        # release them), the line -- if this is rank 0 -- is out
+        sys.stderr.write("bench.py: rank %d: a scaling leg failed (%s)\n" % (rank, legs_failed))
+        sys.stderr.flush()
+        os._exit(0)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
