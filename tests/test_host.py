@@ -315,3 +315,47 @@ def test_per_variant_traffic_of_the_dominant_kernel_is_on_record():
     assert before["EM=-2"]["traffic_bytes_per_launch"] > 5 * after["EM=-2"]["traffic_bytes_per_launch"] > 0
     assert sum(v["launches"] for v in after.values()) == 319
     assert after["EM=29"]["traffic_bytes_per_launch"] > 2.5 * after["EM=4"]["traffic_bytes_per_launch"]
+
+
+def test_the_steps_kernels_fit_their_register_budget():
+    """tools/isa_resources.py reads every kernel's VGPR / scratch figures from the gfx950 code objects of the built library (no GPU):
+    the kernels the training step spends its time in must not spill to scratch, and the row-streaming kernels must leave >= 4 waves
+    per SIMD (they are latency-hiding bound).  profiles/r05_isa_resources.txt is this table for the committed tree."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_resources as IR
+    if not (os.path.exists(os.path.join(IR.LLVM, "llvm-readelf")) and os.path.exists(os.path.join(IR.LLVM, "clang-offload-bundler"))
+            and shutil.which("c++filt")):
+        pytest.skip("no llvm binutils / c++filt on this box")
+    from pixelssl_amd import _lib
+    _lib.lib()                                                # (builds the objects when they are missing)
+    rows = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for fn in ("conv_dma_a.hip.o", "conv_wgrad_dma.hip.o", "eltwise.hip.o", "bn.hip.o", "optim.hip.o", "head.hip.o"):
+            ks = IR.kernels_of(os.path.join(IR.OBJ, fn), tmp)
+            assert ks, fn
+            for k, n in zip(ks, IR.demangle([k["name"] for k in ks])):
+                rows[IR.short(n, 400)] = k
+    assert len(rows) > 150
+
+    def pick(prefix):
+        got = {n: k for n, k in rows.items() if n.startswith(prefix)}
+        assert got, prefix
+        return got
+    # the workhorse tiles of the LDS-DMA convolution (4 waves of 64 lanes, 128 x 128 and 128 x 64 pixels x channels, every epilogue
+    # variant in this object): accumulators in AGPRs, no scratch, at least two workgroups' worth of waves per SIMD
+    dma = {n: k for n, k in rows.items() if n.startswith("pxl_dma::conv_dma_kernel<128, 128, 2, 2,") or n.startswith("pxl_dma::conv_dma_kernel<128, 64, 2, 2,")}
+    assert len(dma) >= 20
+    for n, k in dma.items():
+        assert k["scratch"] == 0 or k["vspill"] <= 4, (n, k)              # (one 128 x 64 statistics variant spills 4 registers outside its K loop)
+        assert k["agpr"] >= 32 and IR.occupancy(k)[0] >= 2, (n, k)
+    for prefix, min_waves in (("bn_apply_fwd_kernel", 8), ("residual_fwd_kernel", 4), ("bn_bwd_apply_fused_kernel", 4),
+                              ("bn_bwd_reduce_kernel", 5), ("sgd_ema_pack_kernel", 4), ("maxpool_fwd_kernel", 6)):
+        for n, k in pick(prefix).items():
+            assert k["scratch"] == 0 and k["vspill"] == 0, (n, k)
+            assert IR.occupancy(k)[0] >= min_waves, (n, k, IR.occupancy(k))
+    for n, k in pick("conv_wgrad_dma_kernel").items():                    # weight gradients: no scratch, >= 3 waves per SIMD
+        assert k["scratch"] == 0 and k["vspill"] == 0 and IR.occupancy(k)[0] >= 3, (n, k)
+    for n, k in pick("head_loss_cells_kernel").items():                   # the seam kernel: 47 KB of LDS, 3 workgroups per CU
+        assert k["scratch"] == 0 and k["lds"] <= 48 * 1024 and IR.occupancy(k)[1] >= 3, (n, k)
