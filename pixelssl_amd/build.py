@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libpixelhip.so")
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_dma_kernel.h"),
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_dma_kernel.h"), os.path.join(CSRC, "conv_halo_kernel.h"),
            os.path.join(os.path.dirname(HERE), "include", "pixelhip.h")]
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -117,7 +117,9 @@ extern "C" int pxl_conv_dma_bnin(const pxl_conv_desc* d, const void* y, const vo
   a.bin = *bin; a.bin_relu = bin_relu; a.bin_z = z; a.trace = nullptr;
   if (z != nullptr) {          // the activated tensor can only be written by a kernel that walks every input pixel exactly once per tile row
     bool plain = d->ntaps == 1 && d->dy[0] == 0 && d->dx[0] == 0 && d->out_stride == 1 && d->Ho == d->Hi && d->Wo == d->Wi;
-    if (!plain) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_bnin: z output needs a 1x1 / stride-1 convolution");
+    // (the halo-tile kernel, tile configurations 40..43, visits every pixel once as the CENTRE of a slab and writes z from there)
+    const bool halo = d->tile_cfg >= 40 && d->tile_cfg <= 43 && d->out_stride == 1 && d->Ho == d->Hi && d->Wo == d->Wi;
+    if (!plain && !halo) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_bnin: z output needs a 1x1 / stride-1 convolution");
   }
   return conv_dma_launch(d, a, 1, 0, stream);
 }
@@ -307,6 +309,7 @@ int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes,
     }
   }
   if (f32) return pxl_dma_f32_launch(cfg, a, gather, sk, ws_bytes, s);
+  if (cfg >= 40 && cfg <= 43) return pxl_halo_launch(cfg, a, s);       // halo-tile kernel (never split-K, never paired)
   DmaCapture* cap = tl_capture;
   if (cap != nullptr && cap->armed && !cap->held && cfg >= 8 && cfg <= 35 && a.addend == nullptr && a.bn_y == nullptr &&
       a.fin.coef == nullptr && a.trace == nullptr && (a.ws == nullptr || sk == 1 || a.stats != nullptr)) {

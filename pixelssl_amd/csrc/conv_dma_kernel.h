@@ -88,9 +88,9 @@ struct DmaArgs {
   int taps[64];      // (weight tap index << 24) | ((dy & 0xfff) << 12) | (dx & 0xfff): a launch may walk a SUBSET of the taps
 };
 __host__ __device__ inline int tap_encode(int wt, int dy, int dx) { return (int)(((unsigned)wt << 24) | (((unsigned)dy & 0xfffu) << 12) | ((unsigned)dx & 0xfffu)); }
-__device__ __forceinline__ int tap_dy(int tp) { return (tp << 8) >> 20; }
-__device__ __forceinline__ int tap_dx(int tp) { return (tp << 20) >> 20; }
-__device__ __forceinline__ unsigned tap_wt(int tp) { return (unsigned)tp >> 24; }
+__host__ __device__ __forceinline__ int tap_dy(int tp) { return (tp << 8) >> 20; }
+__host__ __device__ __forceinline__ int tap_dx(int tp) { return (tp << 20) >> 20; }
+__host__ __device__ __forceinline__ unsigned tap_wt(int tp) { return (unsigned)tp >> 24; }
 
 // timeline probe (tools/cbench.cpp; never on the product path): per workgroup, words 0..63 = s_memtime stamps of wave 0
 // (0 entry, 1 prologue issued, 2 + k = end of K step k (first 52), then loop drained / tile staged / pass 0 / pass 1 / stores
@@ -212,6 +212,9 @@ struct EpiCtx {
   __amdgpu_buffer_rsrc_t r_out, r_add, r_bny, r_msk;
   const float* bias; const float* bn_coef; int Kreal;
   int sub_mul, sub_py, sub_px, sub_hw, sub_w, out_H, out_W;      // output sub-grid (DmaArgs): generic (EM < 0) read-back only
+  // VIRT (conv_halo_kernel.h): row m is position (b, yy, xx) of a PADDED [B][vH + d][vW + d] grid; positions with yy >= vH or
+  // xx >= vW are padding -- computed, never stored, and kept out of every sum
+  int vH, vW, vHpWp, vWp; float vinv_hpwp, vinv_wp;
 };
 // Two rules, both from tools/cbench --trace (3.1-5.6 us of a 12 us workgroup sat in the round-3 loop):
 //  * straight-line code: out-of-tile rows / padded channel chunks are out-of-range BUFFER offsets (loads return 0, stores
@@ -220,7 +223,7 @@ struct EpiCtx {
 //  * every load of a group of <= 4 passes is issued before the group's first store.  gfx950 counts loads and stores on ONE
 //    counter (vmcnt) and hipcc treats a counter with both kinds pending as unordered: a load waited for after a store is
 //    waited for with `vmcnt(0)`, i.e. together with the store's acknowledgement (a full round trip per pass).
-template <int EM, int NPASS, int RPP, int TP, typename STAMP>
+template <int EM, int NPASS, int RPP, int TP, bool VIRT = false, typename STAMP>
 __device__ __forceinline__ void epi_passes(STAMP&& stamp, const EpiCtx& c, float (&s1)[8], float (&s2)[8], int rt_mode = 0) {
   const int em = EM >= 0 ? EM : rt_mode;
   const bool has_add = em & 1, has_bias = em & 2, has_stats = em & 4, has_bnr = em & 8, has_mask = em & 16, bn_relu = em & 32;
@@ -264,7 +267,15 @@ __device__ __forceinline__ void epi_passes(STAMP&& stamp, const EpiCtx& c, float
           pix = ((size_t)b * c.out_H + oy * c.sub_mul + c.sub_py) * c.out_W + ox * c.sub_mul + c.sub_px;
         }
       }
-      vo[q] = (g0 + q < NPASS && m < c.M && c.ncol) ? (unsigned)((pix * c.Cout + c.n) * 2) : EOOB;
+      bool real = true;
+      if constexpr (VIRT) {
+        int b, r, yy, xx;
+        fast_divmod(m, c.vHpWp, c.vinv_hpwp, b, r);
+        fast_divmod(r, c.vWp, c.vinv_wp, yy, xx);
+        real = yy < c.vH && xx < c.vW;
+        pix = ((size_t)b * c.vH + yy) * c.vW + xx;
+      }
+      vo[q] = (g0 + q < NPASS && m < c.M && c.ncol && real) ? (unsigned)((pix * c.Cout + c.n) * 2) : EOOB;
     }
     if (has_add) {
 #pragma unroll
@@ -287,6 +298,9 @@ __device__ __forceinline__ void epi_passes(STAMP&& stamp, const EpiCtx& c, float
       const int ps = g0 + q;
       if (ps >= NPASS) break;
       uint4 v = tv[q];
+      if constexpr (VIRT) {
+        if (vo[q] == EOOB) v = make_uint4(0u, 0u, 0u, 0u);       // a padding position holds a real (meaningless) accumulator
+      }
       if (has_bias || has_add || has_stats) {
         float f[8];
         Chunk<bf16_t>::unpack(v, f);
@@ -963,3 +977,6 @@ int pxl_dma_launch_c(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, si
 int pxl_dma_launch_d(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s, int groups);   // 24..27 (2-stage tall)
 int pxl_dma_launch_e(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s, int groups);   // 28..31 (8 waves)
 int pxl_dma_launch_f(int cfg, const pxl_dma::DmaArgs& a, bool gather, int sk, size_t ws_bytes, hipStream_t s, int groups);   // 32..35 (8 waves)
+// conv_halo.hip: tile configurations 40..43 = the halo-tile kernel (conv_halo_kernel.h) for "same" multi-tap convolutions
+int pxl_halo_reach(const pxl_dma::DmaArgs& a);                       // 0 = not eligible, else the padding reach d
+int pxl_halo_launch(int cfg, const pxl_dma::DmaArgs& a, hipStream_t s);

@@ -202,11 +202,18 @@ class FusedSGD(_FlatStateMixin, Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         pipe = getattr(self, '_pipeline', None)
+        self.last_step_pipelined = False
         if pipe is not None and pipe.pending:
             # the update of this step was applied bucket by bucket from inside the backward pass (PipelinedUpdate)
             _sync_foreign_grads(self._foreign)
             pipe.finish()
+            self.last_step_pipelined = True
             return loss
+        if pipe is not None and pipe.armed:
+            # armed, but the executor never called the hook (a program whose parameter offsets are not monotonic, weight gradients
+            # off, multi-rank with a partial gradient range): this IS the ordinary whole-buffer step -- the caller reads
+            # `last_step_pipelined` and performs what the buckets would have done besides SGD (Mean Teacher: the EMA update)
+            pipe.disarm()
         first = self._steps_taken == 0
         self._steps_taken += 1
         _sync_foreign_grads(self._foreign)
@@ -300,6 +307,18 @@ class PipelinedUpdate:
         # kernel per bucket (csrc/optim.hip: pxl_sgd_ema_pack), same arithmetic element for element
         self.fused = os.environ.get('PXL_FUSED_UPDATE', '1') == '1' and s_core._code == _lib.PXL_BF16 and \
             (t_core is None or t_core._code == _lib.PXL_BF16)
+        if self.fused:
+            # the fused kernel takes at most 8 learning-rate runs and ONE momentum / weight decay (checked HERE, not in the C
+            # callback during the backward: an optimizer with per-group weight decay must fall back to the ordinary step when the
+            # pipeline is built, not fail every iteration with 'parameter-update hook failed')
+            nr = sum(len(rr) for rr in optimizer._runs)
+            g0 = optimizer.param_groups[0]
+            mom, wd = float(g0['momentum']), float(g0['weight_decay'])
+            if nr > 8 or any(float(g['momentum']) != mom or float(g['weight_decay']) != wd for g in optimizer.param_groups):
+                if os.environ.get('PXL_FUSED_UPDATE_STRICT') == '1':
+                    raise ValueError('PipelinedUpdate (fused): needs <= 8 learning-rate runs and one momentum / weight decay '
+                                     'for every parameter group')
+                self.fused = False           # the per-group kernels of the unfused bucket update serve any plain-SGD groups
         self._segs = None
         # bucket size: by default ONE bucket (the whole buffer at the end of the backward pass; smaller buckets pipeline the update
         # behind the pass, measured no faster); multi-rank runs cut at the gradient exchange's buckets whatever this says
@@ -311,6 +330,12 @@ class PipelinedUpdate:
     def detach(self):
         self.s_core.set_update_hook(None)
         self.optimizer._pipeline = None
+
+    def disarm(self):
+        """an armed step whose backward never reached the hook: back to the state of an ordinary step (the gradients were not
+        zeroed bucket by bucket, nothing is pending)"""
+        self.armed, self.pending, self.grads_clean = False, False, False
+        self.covered, self.buckets = 0, 0
 
     def arm(self, s_plan, t_plan=None, ema_alpha=None, hyper=None):
         """before the backward of a step whose update is to be pipelined; ema_alpha: this step's EMA coefficient (ignored when

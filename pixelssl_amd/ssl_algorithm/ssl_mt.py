@@ -344,7 +344,10 @@ class SSLMT(ssl_base._SSLBase):
             pipe.arm(s_head.plan, t_head.plan, None if hyper is not None else min(1 - 1 / (cur_step + 1), self.args.ema_decay), hyper)
         s_head.backward()
         self.s_optimizer.step()
-        if pipe is None:
+        # the EMA update belongs to the buckets only when they RAN (FusedSGD.step reports it): an armed pipeline whose hook never
+        # fired -- weight gradients off, a program without monotonic parameter offsets, a partial multi-rank range -- took the
+        # ordinary step, and the teacher must not be skipped for it
+        if pipe is None or not getattr(self.s_optimizer, 'last_step_pipelined', False):
             self._update_ema_variables(self.s_model, self.t_model, self.args.ema_decay, cur_step)
         if not self.args.is_epoch_lrer:
             self.s_lrer.step()

@@ -171,3 +171,52 @@ def test_mt_with_the_pipelined_update_is_the_reference_iteration(dtype, fused, m
     assert wd <= (0.02 if dtype == "fp32" else 0.6), wd
     _check_weights("mt pipelined student " + dtype, s1, fx["student_updates"], dtype)
     _check_weights("mt pipelined teacher " + dtype, t1, fx["teacher_updates"], dtype)
+
+
+@pytest.mark.gpu
+def test_an_armed_pipeline_whose_hook_never_fires_still_updates_the_teacher(monkeypatch):
+    """`if pipe is None` skipped the EMA whenever a PipelinedUpdate object EXISTED.  With the executor's hook
+    removed (what a program without monotonic parameter offsets / a run without weight gradients amounts to) the iteration must
+    be the ordinary one: whole-buffer SGD step, EMA update of the teacher, pipeline disarmed, no error."""
+    fx, algo = _mt("bf16", monkeypatch, {"PXL_PIPE_UPDATE": "1", "PXL_GRAPH": "0"})
+    _steps(fx, algo, 1)
+    pipe = algo._pipe
+    assert pipe is not None and algo.s_optimizer.last_step_pipelined
+    s_core, t_core = algo.s_model.module.model, algo.t_model.module.model
+    s_core.set_update_hook(None)                       # the executor no longer calls back
+    t_before, p_before = t_core.flat.params.clone(), s_core.flat.params.clone()
+    _steps(fx, algo, 1)
+    assert not algo.s_optimizer.last_step_pipelined
+    assert not pipe.armed and not pipe.pending and not pipe.grads_clean
+    assert not torch.equal(s_core.flat.params, p_before), "the ordinary SGD step did not run"
+    assert not torch.equal(t_core.flat.params, t_before), "the teacher was not EMA-updated"
+    # EMA of THIS step: t = a * t + (1 - a) * p with a = min(1 - 1 / (step + 1), ema_decay), step = 0 for _steps(.., 1) -> a = 0
+    assert torch.allclose(t_core.flat.params, s_core.flat.params, rtol=0, atol=0)
+    assert algo.s_optimizer._steps_taken == 2
+
+
+@pytest.mark.gpu
+def test_per_group_weight_decay_falls_back_when_the_pipeline_is_built(monkeypatch):
+    """the fused kernel's preconditions (<= 8 learning-rate runs, one momentum / weight decay) were only
+    checked inside the C callback during the backward pass, so a plug-in optimizer without weight decay on some group failed
+    EVERY step.  Now PipelinedUpdate.__init__ drops to the per-group bucket kernels (fused = False) and the step works."""
+    from pixelssl_amd.nn.optimizer import PipelinedUpdate
+    fx, algo = _mt("bf16", monkeypatch, {"PXL_PIPE_UPDATE": "0", "PXL_GRAPH": "0"})
+    _steps(fx, algo, 1)
+    opt = algo.s_optimizer
+    s_core, t_core = algo.s_model.module.model, algo.t_model.module.model
+    if len(opt.param_groups) < 2:
+        pytest.skip("the factory built one parameter group")
+    opt.param_groups[-1]['weight_decay'] = 0.0
+    pipe = PipelinedUpdate(opt, s_core, t_core)
+    try:
+        assert pipe.fused is False
+        algo._pipe = pipe
+        _steps(fx, algo, 1)                            # must not raise 'parameter-update hook failed'
+        assert opt.last_step_pipelined and opt._steps_taken == 2
+        monkeypatch.setenv("PXL_FUSED_UPDATE_STRICT", "1")
+        with pytest.raises(ValueError):
+            PipelinedUpdate(opt, s_core, t_core)
+    finally:
+        pipe.detach()
+        algo._pipe = None
