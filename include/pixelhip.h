@@ -791,6 +791,10 @@ int pxl_conv_dma(const pxl_conv_desc* desc, const void* in, const void* w, void*
                  float* stats, void* workspace, size_t ws_bytes, void* stream);
 /* split-K epilogue shared by both convolution kernels: out[m][n] = T(ws[m][n] + bias[n]) for n < Kreal, 0 above */
 int pxl_splitk_finish(int dtype, long total, int Cout, int Kreal, const float* ws, const float* bias, void* out, void* stream);
+/* ... over nslab partial-sum slabs ws[nslab][total] written side by side (the LDS-DMA kernel's split-K when the workspace holds
+ * one slab per K slice: plain stores instead of fp32 atomics, no pre-zeroing, a fixed summation order) */
+int pxl_splitk_finish_slabs(int dtype, long total, int Cout, int Kreal, int nslab, const float* ws, const float* bias, void* out,
+                            void* stream);
 /* weight-gradient twins of the two above (pxl_conv_wgrad forwards here when eligible) */
 int pxl_conv_wgrad_dma_eligible(const pxl_conv_desc* desc, const float* in_scale);
 int pxl_conv_wgrad_dma(const pxl_conv_desc* desc, const void* in, const void* dy, float* dw, int creal, int dw_cpitch, void* stream);

@@ -57,6 +57,10 @@ struct DmaArgs {
   // 673 MB per launch for 36 MB of input (profiles/r05_traffic.json) --; a channel slice reads its 1/S of every pixel's
   // channels 36 times, from the L2 of the XCD that holds the image.  0: contiguous K slices.
   unsigned kc_per;
+  // split-K into SLABS: slice blockIdx.y stores its fp32 partial tile at ws + y * ws_slab (elements; 0: one shared buffer that the
+  // slices add into with atomics).  The uncoalesced atomics of the shared buffer ran at ~20 per ns (tools/cbench --splitk: 130 us
+  // for an 8712 x 256 tile grid); slabs are plain coalesced stores, need no memset and sum in a fixed order
+  size_t ws_slab;
   // forward with batch statistics: the LAST workgroup to finish turns the completed [sum, sumsq] into the BatchNorm
   // coefficients (what pxl_bn_finalize does), so no finalize launch and no replica reduction in the consumers
   pxl_bn_fin fin;    // fin.coef == nullptr: off
@@ -693,18 +697,60 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
 
   if constexpr (ABL & 16) return;
   if (EM == -2 || (EM == -1 && p.ws != nullptr)) {
-    // split-K: fp32 partial sums of this K slice -> workspace; bias / rounding happen in the finish kernel
+    // split-K: fp32 partial sums of this K slice -> workspace; bias / rounding happen in the finish kernel.
+    // The accumulator layout puts a wave's 64 lanes on 32 DIFFERENT rows: an atomic straight from the registers touches 64 cache
+    // lines per instruction (tools/cbench --splitk: 130 us for the 2.2 M atomics of an 8712 x 256 slab, 20 per ns).  Staged
+    // through LDS as an fp32 tile, a wave adds 4 whole row segments of 16 lanes x 16 bytes per instruction instead.
+    constexpr int TPF = BN * 4 + 16;                               // fp32 staging row pitch
+    if constexpr ((size_t)BM * TPF <= (size_t)NST * SB) {
+      float* T32 = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int j = 0; j < TNI; ++j)
+      for (int j = 0; j < TNI; ++j)
 #pragma unroll
-      for (int i = 0; i < TMI; ++i) {
-        const int m = m0 + (wm * TMI + i) * 32 + frow;
+        for (int i = 0; i < TMI; ++i) {
+          const int ml = (wm * TMI + i) * 32 + frow;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = n0 + (wn * TNI + j) * 32 + 8 * (r >> 2) + 4 * fhalf + (r & 3);
-          if (m < p.M && n < p.Kreal) atomicAdd(p.ws + (size_t)m * p.Cout + n, acc[j][i][r]);
+          for (int g = 0; g < 4; ++g) {
+            const int nl = (wn * TNI + j) * 32 + 8 * g + 4 * fhalf;
+            *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(T32) + ml * TPF + nl * 4) =
+                make_float4(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+          }
+        }
+      __syncthreads();
+      constexpr int TPR4 = BN / 4;                                 // threads per row (4 floats each)
+      constexpr int RPP4 = NT / TPR4;
+      const int c4 = tid % TPR4, r4 = tid / TPR4;
+      const int n = n0 + 4 * c4;
+#pragma unroll 4
+      for (int ps = 0; ps < BM / RPP4; ++ps) {
+        const int ml = ps * RPP4 + r4, m = m0 + ml;
+        if (p.ws_slab != 0) {
+          if (m < p.M && n < p.Cout) {
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(T32) + ml * TPF + c4 * 16);
+            *reinterpret_cast<float4*>(p.ws + (size_t)blockIdx.y * p.ws_slab + (size_t)m * p.Cout + n) = v;
+          }
+        } else if (m < p.M && n < p.Kreal) {
+          const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(T32) + ml * TPF + c4 * 16);
+          float* dst = p.ws + (size_t)m * p.Cout + n;
+          atomicAdd(dst, v.x);
+          if (n + 1 < p.Kreal) atomicAdd(dst + 1, v.y);
+          if (n + 2 < p.Kreal) atomicAdd(dst + 2, v.z);
+          if (n + 3 < p.Kreal) atomicAdd(dst + 3, v.w);
         }
       }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TNI; ++j)
+#pragma unroll
+        for (int i = 0; i < TMI; ++i) {
+          const int m = m0 + (wm * TMI + i) * 32 + frow;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = n0 + (wn * TNI + j) * 32 + 8 * (r >> 2) + 4 * fhalf + (r & 3);
+            if (m < p.M && n < p.Kreal) atomicAdd(p.ws + (size_t)m * p.Cout + n, acc[j][i][r]);
+          }
+        }
+    }
     return;
   }
   // ---- epilogue 1: accumulators -> bf16 tile T[m][n] in LDS.  C/D layout of the 32x32 MFMA with swapped
@@ -851,6 +897,7 @@ int launch_abl(const DmaArgs& a, hipStream_t stream) {
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.Cout, BN);
   p.ws = nullptr;
+  p.ws_slab = 0;
   p.nk_per = p.nk;
   p.kc_per = 0;
   p.fin.coef = nullptr;
@@ -865,6 +912,8 @@ int launch_abl(const DmaArgs& a, hipStream_t stream) {
 
 extern "C" int pxl_splitk_finish(int dtype, long total, int Cout, int Kreal, const float* ws, const float* bias, void* out,
                                  void* stream);
+extern "C" int pxl_splitk_finish_slabs(int dtype, long total, int Cout, int Kreal, int nslab, const float* ws, const float* bias,
+                                       void* out, void* stream);
 
 template <int BM, int BN, int WM, int WN, int NST, bool GATHER, bool BNIN, bool TRACE, int EM>
 int launch_one(dim3 grid, dim3 block, size_t smem, hipStream_t stream, const DmaArgs& p) {
@@ -916,8 +965,13 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
       }
     }
   }
-  if (splitk > 1) PXL_CHECK_HIP(hipMemsetAsync(p.ws, 0, (size_t)p.M * p.Cout * sizeof(float), stream));
-  else p.ws = nullptr;
+  // one slab per slice when the workspace holds them (and the tile's fp32 staging fits in the ring), else atomics into one buffer
+  constexpr bool can_stage = (size_t)BM * (BN * 4 + 16) <= (size_t)NST * (BM + BN) * 128;
+  p.ws_slab = 0;
+  if (splitk > 1 && can_stage && p.Cout % 4 == 0 && ws_bytes >= (size_t)splitk * p.M * p.Cout * sizeof(float))
+    p.ws_slab = (size_t)p.M * p.Cout;
+  if (splitk > 1 && p.ws_slab == 0) PXL_CHECK_HIP(hipMemsetAsync(p.ws, 0, (size_t)p.M * p.Cout * sizeof(float), stream));
+  if (splitk <= 1) p.ws = nullptr;
   const bool bnin = p.bin.coef != nullptr;
   const size_t smem = (size_t)NST * (BM + BN) * 128 + (bnin ? (size_t)p.Cin * 8 : 0);
   if (smem > 156 * 1024) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: tile + coefficient table exceed the LDS");
@@ -962,6 +1016,8 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
 #undef PXL_EM
 #undef PXL_EM_BNIN
   if (rc != PXL_OK) return rc;
+  if (splitk > 1 && p.ws_slab != 0)
+    return pxl_splitk_finish_slabs(PXL_BF16, (long)p.M * p.Cout, p.Cout, p.Kreal, splitk, p.ws, p.bias, p.out, stream);
   if (splitk > 1)
     return pxl_splitk_finish(PXL_BF16, (long)p.M * p.Cout, p.Cout, p.Kreal, p.ws, p.bias, p.out, stream);
   return PXL_OK;

@@ -438,6 +438,42 @@ extern "C" int pxl_conv_dma_eligible(const pxl_conv_desc* d, const float* in_sca
 extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* w, void* out, const float* bias,
                             const void* addend, float* stats, void* workspace, size_t ws_bytes, void* stream);
 
+// split-K epilogue over SLABS: the K slices wrote their partial tiles side by side (ws[slab][M][Cout], plain 16-byte stores, no
+// atomics, no pre-zeroed buffer); out = T(sum of the slabs in index order + bias) -- the same bits on every run
+template <typename T>
+__global__ void splitk_finish_slabs_kernel(long chunks, int Cout, int Kreal, int nslab, const float* __restrict__ ws,
+                                           const float* __restrict__ bias, T* __restrict__ out) {
+  const long total = chunks * 4;
+  for (long c = blockIdx.x * (long)blockDim.x + threadIdx.x; c < chunks; c += (long)gridDim.x * blockDim.x) {
+    float4 v = *reinterpret_cast<const float4*>(ws + 4 * c);
+    for (int s = 1; s < nslab; ++s) {
+      const float4 u = *reinterpret_cast<const float4*>(ws + (size_t)s * total + 4 * c);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int n = (int)((4 * c) % Cout);
+    float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[e] = n + e < Kreal ? f[e] + (bias ? bias[n + e] : 0.f) : 0.f;
+      out[4 * c + e] = from_f<T>(f[e]);
+    }
+  }
+}
+extern "C" int pxl_splitk_finish_slabs(int dtype, long total, int Cout, int Kreal, int nslab, const float* ws, const float* bias,
+                                       void* out, void* stream) {
+  PXL_REQUIRE(total % 4 == 0 && Cout % 4 == 0 && nslab >= 1, "splitk_finish_slabs: bad geometry");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long chunks = total / 4;
+  long g = (chunks + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(splitk_finish_slabs_kernel<float>, dim3((int)g), dim3(256), 0, s, chunks, Cout, Kreal, nslab, ws, bias, (float*)out);
+  else
+    hipLaunchKernelGGL(splitk_finish_slabs_kernel<bf16_t>, dim3((int)g), dim3(256), 0, s, chunks, Cout, Kreal, nslab, ws, bias, (bf16_t*)out);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
 // split-K epilogue shared with the LDS-DMA kernel: out = T(ws + bias)
 extern "C" int pxl_splitk_finish(int dtype, long total, int Cout, int Kreal, const float* ws, const float* bias, void* out,
                                  void* stream) {

@@ -528,7 +528,8 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
         if (d.need_dgrad) { op.wt_off = packed; packed += align_up((size_t)tin.Cp * op.ntaps * tout.Cp * n->esize); }
         if (d.b_off[0] >= 0) { op.bias_off = packed; packed += align_up((size_t)d.cout * 4); }
         if (d.bn_out < 0 && tout.Cp <= 32) {     // few output tiles + long reduction: allow split-K
-          op.ws_bytes = align_up((size_t)B * ho * wo * tout.Cp * 4);
+          // (room for one partial-sum slab per K slice -- up to 16 -- so that the slices store instead of adding with atomics)
+          op.ws_bytes = align_up((size_t)16 * B * ho * wo * tout.Cp * 4);
           op.ws_off = arena; arena += op.ws_bytes;
         }
         if (d.bn_out >= 0) {
