@@ -131,15 +131,18 @@ static double time_wgrad(const Problem& p, int cfg, int iters, hipStream_t s, hi
   }
   return best;
 }
-// --splitk N: the forward launch WITHOUT statistics as N K-slices through the existing split-K path (fp32 atomics into a
-// workspace + pxl_splitk_finish) -- what a split-K of the sub-one-wave grids costs before any last-arriver epilogue is built;
+// --splitk N: the forward launch WITHOUT statistics as N K-slices through the library's split-K path (one fp32 partial-sum slab
+// per slice + pxl_splitk_finish_slabs; PXL_CBENCH_SPLITK_ATOMICS=1: one shared buffer and fp32 atomics, the form of rounds 1-5)
+// -- what a split-K of the sub-one-wave grids costs before any last-arriver epilogue is built;
 // N = 1: the same launch unsplit (no statistics either), the like-for-like baseline
 static int g_splitk = 0;
 static void* g_ws = nullptr; static size_t g_ws_bytes = 0;
 static int launch(const Problem& p, bool dgrad, int cfg, hipStream_t s) {
   if (!dgrad && g_splitk > 0) {
     pxl_conv_desc q = p.fwd; q.tile_cfg = cfg; q.split_k = g_splitk;
-    const size_t need = (size_t)p.M * q.Cout * sizeof(float);
+    const size_t need = (size_t)g_splitk * p.M * q.Cout * sizeof(float);      // one partial-sum slab per slice: plain stores, no atomics
+    if (getenv("PXL_CBENCH_SPLITK_ATOMICS")) { const size_t one = (size_t)p.M * q.Cout * sizeof(float); if (g_ws_bytes < need) { if (g_ws) (void)hipFree(g_ws); CK(hipMalloc(&g_ws, need)); g_ws_bytes = need; }
+      return pxl_conv_igemm(&q, p.x, p.wf, p.y, nullptr, nullptr, nullptr, nullptr, nullptr, g_splitk > 1 ? g_ws : nullptr, g_splitk > 1 ? one : 0, s); }
     if (g_ws_bytes < need) { if (g_ws) (void)hipFree(g_ws); CK(hipMalloc(&g_ws, need)); g_ws_bytes = need; }
     return pxl_conv_igemm(&q, p.x, p.wf, p.y, nullptr, nullptr, nullptr, nullptr, nullptr, g_splitk > 1 ? g_ws : nullptr, g_splitk > 1 ? g_ws_bytes : 0, s);
   }
