@@ -618,6 +618,14 @@ int pxl_net_input_grad(pxl_net* net, const void* scratch, float* dx, void* strea
  * NULL); cleared by that pass.  pxl_net_input_grad_parts writes the input gradient as one NCHW tensor per part
  * (dsts[k] == NULL: not needed) -- what autograd's cat-backward + .contiguous() would produce. */
 int pxl_net_set_input_parts(pxl_net* net, int nparts, const float* const* srcs, const int* chans);
+/* Stem im2col patches of ONE input tensor shared by two networks with the same stem geometry (Mean Teacher without input noise
+ * feeds student and teacher the same tensor, ssl_mt.py:340-348: 203 MB of patches per network at 8 x 513 x 513).
+ * pxl_net_make_patches writes `net`'s patches for x into `arena` NOW (its next pxl_net_forward on that arena does not write them
+ * again) and returns their address / size; pxl_net_borrow_patches makes the NEXT pxl_net_forward of `net` (and the backward of
+ * that pass) read its stem operand from `patches` instead of producing its own -- the caller orders the lender's launch before
+ * the borrower's pass and keeps the lender's arena alive.  patches == NULL disarms.  PXL_ERR_UNSUPPORTED: no patch-mode stem. */
+int pxl_net_make_patches(pxl_net* net, const float* x, void* arena, size_t arena_bytes, void** patches, size_t* bytes, void* stream);
+int pxl_net_borrow_patches(pxl_net* net, const void* patches, size_t bytes);
 int pxl_net_input_grad_parts(pxl_net* net, const void* scratch, int nparts, float* const* dsts, const int* chans,
                              void* stream);
 /* Stem patches: im2col of a few-channel NCHW fp32 input, P[(b, oy, ox)][(ky*kw + kx)*C + c] (zero outside the image and

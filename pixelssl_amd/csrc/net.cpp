@@ -171,6 +171,12 @@ struct pxl_net {
   // dy): the contraction kernels of this network are ~1 workgroup per CU and latency-bound, two in flight fill
   // each other's bubbles.  Created lazily; PXL_SIDE_STREAM=0 disables it.
   bool stem_patches = getenv("PXL_STEM_PATCHES") == nullptr || getenv("PXL_STEM_PATCHES")[0] != '0';
+  // stem patches shared by two passes over ONE input tensor (Mean Teacher without input noise): `patches_made` -- this
+  // network's patches for the next forward are already in its arena (pxl_net_make_patches); `patch_src` -- this pass (and its
+  // backward) reads another network's patches instead of writing its own (pxl_net_borrow_patches arms `patch_src_next`)
+  bool patches_made = false;
+  const void* patch_src = nullptr;
+  const void* patch_src_next = nullptr;
   bool input_needed = true;              // some op reads the NHWC copy of the input (false: only patch-mode convolutions)
   int in_parts = 0;                      // > 0: the next forward gathers its input from these tensors
   const float* in_src[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -317,7 +323,7 @@ inline ConvIn conv_input(const pxl_net* n, const OpInfo& op, const void* arena) 
   const pxl_op& d = op.d;
   const TensorInfo& tin = n->tensors[d.in0];
   const unsigned char* base = reinterpret_cast<const unsigned char*>(arena);
-  if (op.patch) return {base + op.patch_off, nullptr, nullptr};
+  if (op.patch) return {n->patch_src != nullptr ? reinterpret_cast<const unsigned char*>(n->patch_src) : base + op.patch_off, nullptr, nullptr};
   if (d.bn_in0 < 0) return {base + tin.off, nullptr, nullptr};
   const BnInfo& b = n->bns[d.bn_in0];
   if (b.has_z) return {base + b.z_off, nullptr, nullptr};
@@ -1195,9 +1201,15 @@ int forward_op(pxl_net* n, size_t i, const FwdCtx& c, int phase, bool* fin_flag,
         bool fin_by_conv = false;
         if (op.patch) {
           if (x == nullptr) return pxl_set_error(PXL_ERR_ARG, "net_forward: the patch-mode stem reads ONE NCHW input tensor");
-          rc = pxl_stem_patches(dt, x, at(arena, op.patch_off), n->B, d.cin, tin.H, tin.W, d.kh, d.kw, d.stride, d.pads[0],
-                                tout.H, tout.W, op.patch_Kp, stream);
-          if (rc != PXL_OK) return rc;
+          if (n->patch_src != nullptr) {
+            // borrowed: the lender's launch (same input, same geometry) is ordered before this pass by the caller
+          } else if (n->patches_made) {
+            n->patches_made = false;        // written ahead of this pass by pxl_net_make_patches
+          } else {
+            rc = pxl_stem_patches(dt, x, at(arena, op.patch_off), n->B, d.cin, tin.H, tin.W, d.kh, d.kw, d.stride, d.pads[0],
+                                  tout.H, tout.W, op.patch_Kp, stream);
+            if (rc != PXL_OK) return rc;
+          }
         }
         // BN-apply on load: this convolution reads the raw output of its producer and finalizes + applies the BatchNorm
         // itself; the activated tensor is written only where a weight gradient will read it, on the side stream
@@ -1399,6 +1411,8 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
   PXL_REQUIRE(n && n->planned && params && packed && (x || n->in_parts > 0) && arena, "net_forward: bad argument (plan first)");
   if (arena_bytes < n->arena_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_forward: arena too small (%zu < %zu)", arena_bytes, n->arena_bytes);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  n->patch_src = n->patch_src_next;           // (a borrowed stem operand serves exactly this pass and its backward)
+  n->patch_src_next = nullptr;
   if (training && n->stats_region_bytes)
     PXL_CHECK_HIP(hipMemsetAsync(at(arena, n->stats_region_off), 0, n->stats_region_bytes, s));
   if (n->ibn_region_bytes)      // (instance statistics are computed in eval mode too)
@@ -1409,6 +1423,44 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
     const int rc = forward_op(n, i, ctx, 0, &fin);
     if (rc != PXL_OK) return rc;
   }
+  return PXL_OK;
+}
+
+// ---- stem patches of ONE input tensor shared by two networks (include/pixelhip.h) ----
+namespace {
+const OpInfo* patch_op(const pxl_net* n) {
+  for (const auto& op : n->ops) if (op.d.kind == PXL_OP_CONV && op.patch) return &op;
+  return nullptr;
+}
+size_t patch_bytes(const pxl_net* n, const OpInfo& op) {
+  const TensorInfo& tout = n->tensors[op.d.out];
+  return (size_t)n->B * tout.H * tout.W * op.patch_Kp * n->esize;
+}
+}  // namespace
+extern "C" int pxl_net_make_patches(pxl_net* n, const float* x, void* arena, size_t arena_bytes, void** patches, size_t* bytes,
+                                    void* stream) {
+  PXL_REQUIRE(n && n->planned && x && arena && patches && bytes, "net_make_patches: bad argument (plan first)");
+  if (arena_bytes < n->arena_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_make_patches: arena too small");
+  const OpInfo* op = patch_op(n);
+  if (op == nullptr || n->in_parts > 0) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net_make_patches: no patch-mode stem in this plan");
+  const pxl_op& d = op->d;
+  const TensorInfo& tin = n->tensors[d.in0];
+  const TensorInfo& tout = n->tensors[d.out];
+  const int rc = pxl_stem_patches(n->dtype, x, at(arena, op->patch_off), n->B, d.cin, tin.H, tin.W, d.kh, d.kw, d.stride, d.pads[0],
+                                  tout.H, tout.W, op->patch_Kp, stream);
+  if (rc != PXL_OK) return rc;
+  n->patches_made = true;
+  *patches = at(arena, op->patch_off);
+  *bytes = patch_bytes(n, *op);
+  return PXL_OK;
+}
+extern "C" int pxl_net_borrow_patches(pxl_net* n, const void* patches, size_t bytes) {
+  PXL_REQUIRE(n && n->planned, "net_borrow_patches: bad argument (plan first)");
+  if (patches == nullptr) { n->patch_src_next = nullptr; return PXL_OK; }
+  const OpInfo* op = patch_op(n);
+  if (op == nullptr || n->in_parts > 0) return pxl_set_error(PXL_ERR_UNSUPPORTED, "net_borrow_patches: no patch-mode stem in this plan");
+  if (bytes != patch_bytes(n, *op)) return pxl_set_error(PXL_ERR_ARG, "net_borrow_patches: %zu bytes lent, this stem reads %zu", bytes, patch_bytes(n, *op));
+  n->patch_src_next = patches;
   return PXL_OK;
 }
 
@@ -1449,6 +1501,7 @@ extern "C" int pxl_net_forward_pair(pxl_net* n0, pxl_net* n1, const float* param
                          {params1, packed1, running1, x1, logits1, prob1, arena1, training1, stream}};
   n0->pairs_last = 0;
   n0->pair_syncs_last = 0;
+  for (int k = 0; k < 2; ++k) { nets[k]->patch_src = nullptr; nets[k]->patch_src_next = nullptr; }
   for (size_t i = 0; i < n0->ops.size(); ++i) {
     if (n0->ops[i].d.kind != PXL_OP_CONV || n0->profile || n1->profile) {
       // (the finalize-folding element-wise kernels of the two networks -- residual joins, BN + ReLU -- pair up as well:

@@ -720,7 +720,42 @@ class SegNetCore(nn.Module):
         self._plan(B, H, W, None, inference=not need_graph and not self.training)
         return bool(lib().pxl_net_head_loss_supported(self._cur.net))
 
-    def forward_deferred(self, x):
+    def prepare_patches(self, x):
+        """Write the stem's im2col patches for `x` NOW, on the current stream, into the arena the next forward_deferred(x,
+        prepared=...) of this network will use (csrc/net.cpp: pxl_net_make_patches) -> a token (arena, patches address, bytes)
+        that another network with the same stem can borrow (borrow_patches), or None when this plan has no patch-mode stem.
+        Mean Teacher without input noise feeds both networks ONE tensor: one 203 MB patch tensor instead of two."""
+        if not x.is_cuda:
+            return None
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        need_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list[:1])
+        self._plan(B, H, W, None, inference=not need_graph and not self.training)
+        if not lib().pxl_net_head_loss_supported(self._cur.net):
+            return None
+        if need_graph:
+            arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
+        else:
+            if self._cur.eval_arena is None:
+                self._cur.eval_arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
+            arena = self._cur.eval_arena
+        pp, nb = ctypes.c_void_p(), ctypes.c_size_t()
+        rc = lib().pxl_net_make_patches(self._net, ptr(x), ptr(arena), arena.numel(), ctypes.byref(pp), ctypes.byref(nb), stream_ptr())
+        if rc != 0:
+            return None                     # (PXL_ERR_UNSUPPORTED: a plan without a patch-mode stem -- nothing was written)
+        return (arena, pp.value, nb.value, x, self._cur)
+
+    def borrow_patches(self, token, x):
+        """The NEXT forward of this network reads its stem operand from another network's patches (prepare_patches token) of the
+        same input tensor; False when the geometry does not match (the pass then writes its own)."""
+        if token is None or token[3].data_ptr() != x.data_ptr() or token[3].shape != x.shape:
+            return False
+        B, _, H, W = x.shape
+        need_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list[:1])
+        self._plan(B, H, W, None, inference=not need_graph and not self.training)
+        return lib().pxl_net_borrow_patches(self._net, ctypes.c_void_p(token[1]), token[2]) == 0
+
+    def forward_deferred(self, x, prepared=None):
         """Forward pass up to the LOW-RESOLUTION logits: the up-sampling / soft-max op is not run and no full-resolution
         plane is written.  -> DeferredHead, which pixelssl_amd.functional.head_losses consumes (criterion + consistency
         term + their backward on the low-resolution maps, csrc/head.hip) and whose .backward() runs the executor's
@@ -735,7 +770,9 @@ class SegNetCore(nn.Module):
         if not lib().pxl_net_head_loss_supported(self._cur.net):
             return None
         self._ensure_packed()
-        if need_graph:
+        if prepared is not None and prepared[4] is self._cur and prepared[3].data_ptr() == x.data_ptr():
+            arena = prepared[0]              # (prepare_patches allocated it and wrote the stem patches into it)
+        elif need_graph:
             arena = torch.empty(self._arena_bytes, device=x.device, dtype=torch.uint8)
         else:
             if self._cur.eval_arena is None:

@@ -98,6 +98,14 @@ class _DeferredForward:
                            'However, {0} inputs are given\n'.format(len(inp)))
         return self.model.forward_deferred(inp[0])
 
+    def forward_deferred_shared(self, inp, prepared=None, borrow=None):
+        """forward_deferred over an input tensor that a second network reads as well: `prepared` = this network's own
+        engine.prepare_patches token (its stem patches are already in the arena), `borrow` = the other network's token (this
+        pass reads those patches instead of writing its own)"""
+        if borrow is not None:
+            self.model.borrow_patches(borrow, inp[0])
+        return self.model.forward_deferred(inp[0], prepared=prepared)
+
 
 class DeepLabV2(model_template.TaskModel, _DeferredForward):
     def __init__(self, args):
