@@ -32,8 +32,9 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}    # /opt/skills/guides/MI355
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=3)
+    # (SURVEY.md 8d protocol: >= 10 warm-up and >= 50 timed iterations when the caller names nothing else: 0.75 s of GPU time)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--algo", default="mt", choices=["mt", "suponly", "adv", "gct", "cct"])
     p.add_argument("--size", type=int, default=513)
@@ -650,6 +651,15 @@ def main():
         # the iteration as ONE hipGraph launch (pixelssl_amd/graph.py; PXL_GRAPH=0 turns it off): replays inside this process so far
         out["graph"] = ({"captured": sg.graph is not None, "replays": int(sg.replays), "failed": sg.failed} if sg is not None
                         else {"captured": False, "replays": 0, "failed": None})
+        # which parameter update ran in the timed steps: the fused SGD + EMA + bf16-copy kernel from inside the backward pass
+        # (nn/optimizer.py: PipelinedUpdate; multi-rank: behind each gradient bucket's all-reduce) or the separate kernels after it
+        pipe = getattr(algo, "_pipe", None)
+        opt0 = getattr(algo, "s_optimizer", None) or getattr(algo, "optimizer", None)
+        out["update_path"] = {"pipelined": bool(pipe is not None and getattr(opt0, "last_step_pipelined", False)),
+                              "kernel": ("sgd_ema_pack (fused)" if getattr(pipe, "fused", False) else "sgd / ema / pack per bucket") if pipe is not None
+                              else "sgd, ema, pack after the backward pass",
+                              "buckets_last_step": int(cores[0].update_buckets()) if pipe is not None else 0,
+                              "behind_gradient_allreduce": bool(pipe is not None and world > 1)}
         if a.algo == "mt" and getattr(cores[0], "_cur", None) is not None:
             # paired student || teacher pass (the default with Sync-BN): convolutions issued as ONE launch for both networks and
             # Sync-BN statistics exchanges that carried both networks' sums (csrc/net.cpp: pxl_net_forward_pair)
@@ -701,6 +711,8 @@ def main():
             view = hbm_view if hbm_bound else mfma_view
             out["roofline"] = {"kernel": dom, "bound": "hbm" if hbm_bound else "mfma", "achieved": view["achieved"],
                                "peak": view["peak"], "unit": view["unit"], "frac": view["frac"],
+                               # both fractions side by side, whichever roof `bound` names: the north-star target is quoted on the MFMA one
+                               "frac_mfma": mfma_view["frac"], "frac_hbm": hbm_view["frac"],
                                "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": us,
                                "algorithmic_gflop_per_launch": gflop, "algorithmic_bytes_per_launch": int(abytes),
                                "intensity_flop_per_byte": {"algorithmic": round(inten_alg, 1) if inten_alg else None,
@@ -719,6 +731,13 @@ def main():
                     out["bytes_per_step"] = int(bj["bytes_per_step"])
                     out["hbm_frac"] = round(bj["bytes_per_step"] / (elapsed / a.steps) / (HBM_PEAK_GBPS * 1e9), 4)
                     out["bytes_per_step_source"] = "profiles/bytes_per_step.json (tools/bytes_per_step.py: " + " x ".join(bj.get("source", [])) + ")"
+                    out["hbm_frac_note"] = "bytes of a COMMITTED trace (static, see bytes_per_step_source) over THIS run's step time -- not counters of this run"
+                # one traced step of this workload (tools/prof_summary.py --one-step --json on a rocprofv3 kernel trace of this
+                # command; static like the two above): launches, sum of kernel durations, the non-contraction share
+                tj2 = json.load(open(os.path.join(ROOT, "profiles", "step_trace.json")))
+                if a.algo == "mt" and a.dtype == "bf16" and a.size == 513 and per_gpu == 8:
+                    out["step_trace"] = {k: tj2[k] for k in ("launches_per_step", "kernel_sum_ms", "contraction_ms", "noncontraction_ms",
+                                                             "conv_dma_ms", "conv_dma_launches", "wall_window_ms", "source") if k in tj2}
             except Exception:
                 pass
             out["kernels"] = kern
@@ -744,6 +763,7 @@ def main():
             if rank == 0:
                 line = dict(out)
                 line["scaling_legs"] = "timed out after %.0f s; the MT fields above were measured before the legs started" % deadline_s
+                line["ok"] = False
                 print(json.dumps(line), flush=True)
             os._exit(0)
         threading.Thread(target=_watchdog, daemon=True).start()
@@ -796,6 +816,8 @@ def main():
             out["cpu_baseline"] = _leg("cpu_baseline", lambda: cpu_baseline(a))
         if leg_errors:
             out["leg_errors"] = leg_errors
+        # one flag a reader (or a driver) can test: every leg that was asked for produced its figures
+        out["ok"] = not leg_errors and legs_failed is None and not (isinstance(scale_legs, dict) and "scaling_legs" in scale_legs)
         print(json.dumps(out), flush=True)
     if legs_failed is not None:
         # the other ranks may still sit in a collective of the leg this rank left: no closing barrier with them (their own watchdogs

@@ -198,11 +198,11 @@ class SSLMT(ssl_base._SSLBase):
             bucket (PXL_UPDATE_BUCKET_MB), multi-rank runs bucket with the gradient exchange."""
         if not hasattr(self, '_pipe'):
             self._pipe = None
-            from .. import dist as pdist
-            # ('auto' stays off multi-rank: there the hook runs behind the bucketed all-reduce, a combination that has only
-            # ever executed on two processes sharing one GPU -- PXL_PIPE_UPDATE=1 opts in)
+            # (multi-rank: the hook runs on the communication stream right behind each bucket's all-reduce + 1/world scaling, csrc/
+            # net.cpp `flush` -- the fused kernel consumes the AVERAGED bucket; pinned bit-identical to the separate kernels on two
+            # ranks in tests/test_gpu_dist.py.  A backward whose hook does not fire takes the ordinary step, see FusedSGD.step)
             want = self._want_pipe == '1' or (self._want_pipe == 'auto' and os.environ.get('PXL_FUSED_UPDATE', '1') == '1' and
-                                              getattr(s_head.core, '_code', None) == 1 and not pdist.is_distributed())
+                                              getattr(s_head.core, '_code', None) == 1)
             if want:
                 from ..nn.optimizer import PipelinedUpdate
                 s_core, t_core = s_head.core, t_head.core

@@ -75,14 +75,13 @@ class SSLNULL(ssl_base._SSLBase):
 
     def _update_pipeline(self, head):
         """nn.optimizer.PipelinedUpdate for the model (fused parameter update, see SSLMT._update_pipeline), or None: PXL_PIPE_UPDATE=0,
-        an fp32 engine, several ranks ('auto'), an optimizer / model it does not cover"""
+        an fp32 engine, an optimizer / model it does not cover (several ranks: behind the bucketed gradient all-reduce)"""
         if not hasattr(self, '_pipe'):
             import os
-            from .. import dist as pdist
             self._pipe = None
             mode = os.environ.get('PXL_PIPE_UPDATE', 'auto')
             if mode == '1' or (mode == 'auto' and os.environ.get('PXL_FUSED_UPDATE', '1') == '1' and
-                               getattr(head.core, '_code', None) == 1 and not pdist.is_distributed()):
+                               getattr(head.core, '_code', None) == 1):
                 from ..nn.optimizer import PipelinedUpdate
                 try:
                     if len(list(self.model.parameters())) != len(head.core._param_list):

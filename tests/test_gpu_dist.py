@@ -70,6 +70,80 @@ def _worker(rank, world, port, q, peer="1"):
     dist.destroy_process_group()
 
 
+def _mt_update_worker(rank, world, port, q):
+    """Mean Teacher on two ranks with the DEFAULT update (fused kernel per gradient bucket, behind the bucket's all-reduce): a spy
+    on the executor's hook keeps a copy of every averaged bucket before the update consumes it; the same step is then redone
+    with the SEPARATE whole-buffer kernels (SGD, EMA) from the saved parameters on those gradients -- bit for bit."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      PXL_FORCE_DEVICE="0", PXL_DIST_BACKEND="gloo", PXL_AUTOTUNE="0", PXL_GRAD_BUCKET_MB="8", PXL_GRAPH="0",
+                      PXL_PAIR_FORWARD="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+    import torch_oracle as TO
+    import pixelssl_amd as P
+    from pixelssl_amd import dist as pdist, ops
+    from pixelssl_amd.nn import optimizer as popt, lrer as plr
+    from test_multistep import _fx, _args, _deeplab_state
+    torch.cuda.set_device(0)
+    pdist.init_from_env()
+    fx = _fx("mt_cond_129.pt")
+    args = _args(fx, "bf16", cons_for_labeled=False, cons_scale=1.0, cons_rampup_epochs=3, ema_decay=0.99)
+    algo = P.ssl_algorithm.ssl_mt.ssl_mt(args, {"model": P.sseg.model.deeplabv2()}, {"model": popt.sgd(args)},
+                                        {"model": plr.polynomiallr(args)}, {"model": P.sseg.criterion.sseg_criterion()}, None)
+    algo.s_model.module.model.load_state_dict(_deeplab_state(fx["weight_seed"], fx["gamma3"]))
+    algo.t_model.module.model.load_state_dict(_deeplab_state(fx["weight_seed"] + 1, fx["gamma3"]))
+    algo.s_model.train(); algo.t_model.train()
+    s_core, t_core = algo.s_model.module.model, algo.t_model.module.model
+
+    def step(i):
+        x, gt = TO.synthetic_batch(fx["lbs"] + fx["ubs"], fx["size"], fx["lbs"], seed=fx["data_seeds"][i] + 17 * rank, block=fx["block"])
+        algo.train_step((x.cuda(),), (gt.cuda(),), i, fx["rampup_iters"])
+        torch.cuda.synchronize()
+    step(0)                                       # plans, the pipeline, momentum buffers that are not zero
+    pipe = algo._pipe
+    res = dict(pipe=pipe is not None, fused=bool(getattr(pipe, "fused", False)), pipelined=bool(algo.s_optimizer.last_step_pipelined),
+               buckets=int(s_core.update_buckets()), grad_buckets=int(s_core.grad_buckets()))
+    if pipe is not None:
+        st, tt = s_core.flat, t_core.flat
+        p0, m0, t0 = st.params.clone(), st.momentum.clone(), tt.params.clone()
+        saved = torch.zeros_like(st.grads)
+        orig = pipe._on_bucket
+
+        def spy(lo, hi, stream):
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                saved[lo:hi].copy_(st.grads[lo:hi])        # the bucket AFTER its all-reduce + 1 / world scaling
+            return orig(lo, hi, stream)
+        s_core.set_update_hook(spy, int(float(os.environ["PXL_GRAD_BUCKET_MB"]) * (1 << 20) / 4), 300000)
+        lr_used = [float(g["lr"]) for g in algo.s_optimizer.param_groups]      # (the scheduler steps at the end of the iteration)
+        step(1)
+        got = dict(p=st.params.clone(), m=st.momentum.clone(), t=tt.params.clone())
+        # the separate kernels on the same averaged gradients: the optimizer's own whole-buffer step + the EMA kernel from the
+        # restored state, with the learning rates iteration 1 used
+        res.update(pipelined2=bool(algo.s_optimizer.last_step_pipelined), buckets2=int(s_core.update_buckets()))
+        st.params.copy_(p0); st.momentum.copy_(m0); tt.params.copy_(t0); st.grads.copy_(saved)
+        pipe.detach()
+        for g, used in zip(algo.s_optimizer.param_groups, lr_used):
+            g["lr"] = used
+        algo.s_optimizer.step()
+        ops.ema_update(tt.params, st.params, min(1 - 1 / (1 + 1), args.ema_decay))
+        torch.cuda.synchronize()
+        res.update(same_p=bool(torch.equal(st.params, got["p"])), same_m=bool(torch.equal(st.momentum, got["m"])),
+                   same_t=bool(torch.equal(tt.params, got["t"])),
+                   dp=float((st.params - got["p"]).abs().max()), dt=float((tt.params - got["t"]).abs().max()))
+        # both ranks hold the same weights after the step
+        chk = torch.stack([got["p"].double().sum(), got["t"].double().sum()])
+        lo_, hi_ = chk.clone(), chk.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN); dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        res["ranks_agree"] = bool(torch.equal(lo_, hi_))
+    dist.barrier()
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _peer_worker(rank, world, port, q):
     """The exchange alone: random vectors of every length class against torch.distributed's sum (two ranks: a + b is exact in
     either order, so the comparison is bitwise), two contexts interleaved on two streams, and the time per exchange."""
@@ -172,6 +246,30 @@ def test_peer_mapped_exchange_two_processes_one_gpu():
     print("peer-mapped exchange, 2 processes on one MI355X, 2048 floats: %.1f us per exchange (rank 0), %.1f us (rank 1); "
           "torch.distributed/gloo: %.0f us" % (res[0]["us_peer"], res[1]["us_peer"], res[0]["us_gloo"]))
     assert res[0]["bad"] == 0 and res[1]["bad"] == 0
+
+
+def test_two_ranks_fused_update_behind_the_gradient_allreduce_is_the_separate_kernels():
+    """the fused SGD + EMA + bf16-copy update is the multi-rank default (nn/optimizer.py: PipelinedUpdate
+    behind csrc/net.cpp's bucketed all-reduce).  Two ranks on cuda:0: every bucket of the step went through the hook, and the
+    parameters / momentum / teacher it produced equal -- bit for bit -- the separate SGD and EMA kernels applied to the same
+    averaged gradients; both ranks end with the same weights."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mt_update_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        d = res[r]
+        print("rank", r, d)
+        assert d["pipe"] and d["fused"] and d["pipelined"] and d["pipelined2"], d
+        assert d["buckets"] == d["grad_buckets"] and d["buckets2"] >= 5, d        # 176 MB of gradients in 8 MB buckets
+        assert d["same_p"] and d["same_m"] and d["same_t"], d
+        assert d["ranks_agree"], d
 
 
 @pytest.mark.parametrize("peer,det", [("1", False), ("0", False), ("1", True)], ids=["peer", "hook", "peer-deterministic"])
@@ -347,6 +445,9 @@ def test_bench_two_ranks_on_one_gpu_through_torchrun():
     # the rest are the stem, the split-K ASPP and launches that differ between the networks)
     assert d["paired_convs"] >= 60 and d["paired_stat_exchanges"] >= 100, (d["paired_convs"], d["paired_stat_exchanges"])
     assert d["value"] > 0 and all(v == v and abs(v) < 1e6 for v in d["final_losses"].values())
+    # round 6: the fused SGD + EMA + bf16-copy update is the multi-rank default too, issued behind each gradient bucket's all-reduce
+    assert d["update_path"]["pipelined"] is True and d["update_path"]["kernel"].startswith("sgd_ema_pack") and \
+        d["update_path"]["behind_gradient_allreduce"] is True and d["update_path"]["buckets_last_step"] == d["grad_buckets"], d["update_path"]
     # the legs a multi-rank MT run appends (round 5): the GCT workload the scaling target is quoted on, one peer exchange timed
     # with HIP events, the MT step without its gradient exchange -- all three ran (a failed leg is reported as a string)
     assert isinstance(d["scaling_gct"], dict) and d["scaling_gct"]["value"] > 0 and d["scaling_gct"]["n_gpus"] == 2, d["scaling_gct"]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 rocpd sqlite database (kernel trace) into a per-kernel CSV + print the top rows;
 `--one-step <db> [out.txt] [header]`: breakdown of one steady-state training step (window between optimizer launches)."""
+import os
 import re
 import sqlite3
 import sys
@@ -98,6 +99,17 @@ def one_step(db_path, out_txt=None, marker="sgd_kernel", per_step=2, header=""):
         lines.append('"%s",%d,%d,%.1f,%.2f' % (n, c, t, t / c, 100 * t / tot))
     if out_txt:
         open(out_txt, "w").write("\n".join(lines) + "\n")
+        # the same step as figures a program can read (bench.py reports them as `step_trace`): launches, sum of kernel durations,
+        # the contraction families and everything else
+        import json
+        contr = lambda n: any(k in n for k in ("conv_dma_kernel", "conv_halo_kernel", "conv_igemm_kernel", "conv_wgrad"))
+        c_ns = sum(t for n, (c, t) in acc.items() if contr(n))
+        dma = [(c, t) for n, (c, t) in acc.items() if "conv_dma_kernel" in n or "conv_igemm_kernel" in n or "conv_halo_kernel" in n]
+        json.dump({"source": header, "wall_window_ms": round(wall, 3), "launches_per_step": len(win), "kernel_sum_ms": round(tot / 1e6, 3),
+                   "kernel_union_ms": round(busy / 1e6, 3), "contraction_ms": round(c_ns / 1e6, 3),
+                   "noncontraction_ms": round((tot - c_ns) / 1e6, 3), "conv_dma_ms": round(sum(t for _, t in dma) / 1e6, 3),
+                   "conv_dma_launches": sum(c for c, _ in dma)},
+                  open(os.path.splitext(out_txt)[0] + ".json", "w"), indent=1)
     print("\n".join(lines[:24]))
 
 
