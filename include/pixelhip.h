@@ -799,6 +799,21 @@ int pxl_conv_dma(const pxl_conv_desc* desc, const void* in, const void* w, void*
                  float* stats, void* workspace, size_t ws_bytes, void* stream);
 /* split-K epilogue shared by both convolution kernels: out[m][n] = T(ws[m][n] + bias[n]) for n < Kreal, 0 above */
 int pxl_splitk_finish(int dtype, long total, int Cout, int Kreal, const float* ws, const float* bias, void* out, void* stream);
+/* The LDS-DMA convolution as fp32 partial sums: K in `slices` equal slices (1 = unsplit), slice s stores its [M][Cout] tile at
+ * ws + s * M * Cout floats; no finish pass, nothing rounded -- the caller consumes the slabs (pxl_aspp_col2im).  bf16 only;
+ * PXL_ERR_UNSUPPORTED when the tile configuration cannot stage fp32 sums, K is not divisible or the workspace is too small. */
+int pxl_conv_dma_slabs(const pxl_conv_desc* desc, const void* in, const void* w, float* ws, size_t ws_bytes, int slices, void* stream);
+/* Multi-rate head (DeepLab-v2 ASPP classifier, deeplab_v2.py:76-85) as ONE GEMM (csrc/aspp.hip): P = X . Wp^T with a column
+ * j = g * GP + c * tpg + t_local per (dilation group g, class c, tap) -- per group the master weight layout [Cout][kh][kw][Cin];
+ * pxl_aspp_col2im: out[b,y,x,c] = bias[c] + sum_t sum_slabs P[(b, y + dy_t, x + dx_t)][j(t, c)] (fp32 sums, rounded once);
+ * pxl_aspp_dp_gather: dP[(b,y',x')][j(t, c)] = dOut[b, y' - dy_t, x' - dx_t, c], zero outside and in the padding columns;
+ * pxl_aspp_dw_scatter: grads[w_off[g] + r * Cin + k] += tmp[(g * GP + r) * Cpin + k] for r < rows: the GEMM's weight gradient
+ * into the master layout.  dy / dx: the ngroups * tpg tap offsets of the forward convolution (input minus output position). */
+int pxl_aspp_col2im(int dtype, int B, int H, int W, int J, int GP, int ngroups, int cout, int tpg, const int16_t* dy,
+                    const int16_t* dx, const float* P, int nslab, size_t slab_floats, const float* bias, void* out, int Cp, void* stream);
+int pxl_aspp_dp_gather(int dtype, int B, int H, int W, int J, int GP, int ngroups, int cout, int tpg, const int16_t* dy,
+                       const int16_t* dx, const void* dout, int Cp, void* dP, void* stream);
+int pxl_aspp_dw_scatter(const float* tmp, int ngroups, int GP, int rows, int Cin, int Cpin, float* grads, const long* w_off, void* stream);
 /* ... over nslab partial-sum slabs ws[nslab][total] written side by side (the LDS-DMA kernel's split-K when the workspace holds
  * one slab per K slice: plain stores instead of fp32 atomics, no pre-zeroing, a fixed summation order) */
 int pxl_splitk_finish_slabs(int dtype, long total, int Cout, int Kreal, int nslab, const float* ws, const float* bias, void* out,

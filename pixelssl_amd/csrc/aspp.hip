@@ -1,0 +1,159 @@
+// Multi-rate head (DeepLab-v2 ASPP classifier, deeplab_v2.py:76-85: out = sum_g conv3x3(x; dilation d_g) + bias_g, 2048 -> 21
+// channels, d = 6 / 12 / 18 / 24) as ONE dense GEMM plus two data-movement kernels.
+//
+// As a convolution the head is a terrible contraction: 21 output channels fill a third of a 64-wide tile, half of the 36 taps
+// of a 33 x 33 map fall into the zero padding, and a tap-per-K-step kernel re-reads the 35.7 MB input once per tap (round 5/6:
+// 117-141 us forward, 98-139 us data gradient, 75-113 us weight gradient at 8 x 33 x 33).  But
+//
+//     out[b, y, x, c] = sum_t  < X[b, y + dy_t, x + dx_t, :], W[t, c, :] >  =  sum_t  P[(b, y + dy_t, x + dx_t)][t, c]
+//     with  P = X . Wp^T,   Wp[(t, c)][:] = W[t, c, :]                       (M x 756 = a plain GEMM over K = 2048)
+//
+// so the forward pass is a 1x1 "convolution" with 756 output channels on the LDS-DMA kernel -- X read ONCE, no padding work, no
+// idle tile columns -- followed by a gather-sum of P (col2im).  The column order is j = g * GP + c * taps_per_group + t_local
+// with GP = 192 (189 rounded to the 64-channel granule of the DMA kernels): per group that is exactly the master weight layout
+// [Cout][kh][kw][Cin], so Wp is a cast of the master weights, its transpose is the data-gradient operand, and the weight
+// gradient of the GEMM lands in master order.  Backward: dP[(b, y', x')][t, c] = dOut[b, y' - dy_t, x' - dx_t, c] (zero outside)
+// is gathered once (13 MB), dX = dP . Wp and dWp = dP^T . X are plain GEMMs again.  P stays fp32 (the bf16 engine's GEMM leaves
+// fp32 partial-sum slabs, pxl_conv_dma_slabs), so the 36-term sum rounds once like the convolution did.
+#include "common.h"
+
+namespace {
+struct AsppGeo {
+  int B, H, W;
+  int J, GP, ngroups, cout, tpg;     // columns of P (pitch), columns per group, groups, classes, taps per group
+  int dy[64], dx[64];                // per global tap t = g * tpg + t_local
+};
+
+// out[m][c] (c < cout; padded channels zero) = bias[c] + sum over taps and slabs of P; one thread per (pixel, class)
+template <typename T>
+__global__ __launch_bounds__(256) void aspp_col2im_kernel(const AsppGeo g, const float* __restrict__ P, int nslab, size_t slab,
+                                                          const float* __restrict__ bias, T* __restrict__ out, int Cp) {
+  const long total = (long)g.B * g.H * g.W * Cp;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int c = (int)(i % Cp);
+    const long m = i / Cp;
+    float v = 0.f;
+    if (c < g.cout) {
+      const int x = (int)(m % g.W), y = (int)((m / g.W) % g.H);
+      const long b = m / ((long)g.W * g.H);
+      v = bias != nullptr ? bias[c] : 0.f;
+      const int ntaps = g.ngroups * g.tpg;
+      for (int t = 0; t < ntaps; ++t) {
+        const int yy = y + g.dy[t], xx = x + g.dx[t];
+        if ((unsigned)yy >= (unsigned)g.H || (unsigned)xx >= (unsigned)g.W) continue;
+        const int grp = t / g.tpg, tl = t - grp * g.tpg;
+        const size_t o = ((size_t)(b * g.H + yy) * g.W + xx) * g.J + grp * g.GP + c * g.tpg + tl;
+        float s = P[o];
+        for (int k = 1; k < nslab; ++k) s += P[o + k * slab];       // (slabs in index order: the same bits on every run)
+        v += s;
+      }
+    }
+    out[i] = from_f<T>(v);
+  }
+}
+
+// dP[m'][j] for the 8 columns of one 16-byte chunk; j = grp * GP + c * tpg + tl -> dOut[(y' - dy_t, x' - dx_t)][c], zero outside / padding
+template <typename T>
+__global__ __launch_bounds__(256) void aspp_dp_gather_kernel(const AsppGeo g, const T* __restrict__ dout, int Cp, T* __restrict__ dP) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int chunks = g.J / EPC;
+  const long total = (long)g.B * g.H * g.W * chunks;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int ch = (int)(i % chunks);
+    const long m = i / chunks;
+    const int x = (int)(m % g.W), y = (int)((m / g.W) % g.H);
+    const long b = m / ((long)g.W * g.H);
+    float v[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int j = ch * EPC + e;
+      const int grp = j / g.GP, r = j - grp * g.GP;
+      float f = 0.f;
+      if (r < g.cout * g.tpg) {
+        const int c = r / g.tpg, tl = r - c * g.tpg;
+        const int t = grp * g.tpg + tl;
+        const int yy = y - g.dy[t], xx = x - g.dx[t];
+        if ((unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W)
+          f = to_f(dout[((size_t)(b * g.H + yy) * g.W + xx) * Cp + c]);
+      }
+      v[e] = f;
+    }
+    if constexpr (sizeof(T) == 2) {
+      *reinterpret_cast<uint4*>(dP + (size_t)m * g.J + ch * EPC) = Chunk<bf16_t>::pack(v);
+    } else {
+      *reinterpret_cast<float4*>(dP + (size_t)m * g.J + ch * EPC) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+struct AsppOffs { long w_off[4]; };
+// master gradient rows of group grp += rows [grp * GP, grp * GP + R) of the GEMM's weight gradient [J][Cpin] (fp32)
+__global__ __launch_bounds__(256) void aspp_dw_scatter_kernel(const float* __restrict__ tmp, int ngroups, int GP, int R, int Cin, int Cpin,
+                                                              float* __restrict__ grads, const AsppOffs o) {
+  const long per = (long)R * Cin;
+  const long total = per * ngroups;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int grp = (int)(i / per);
+    const long q = i - grp * per;
+    const int r = (int)(q / Cin), k = (int)(q - (long)r * Cin);
+    grads[o.w_off[grp] + q] += tmp[((size_t)grp * GP + r) * Cpin + k];
+  }
+}
+
+int fill_geo(AsppGeo& g, int B, int H, int W, int J, int GP, int ngroups, int cout, int tpg, const int16_t* dy, const int16_t* dx) {
+  if (ngroups < 1 || ngroups > 4 || ngroups * tpg > 64 || cout * tpg > GP || ngroups * GP > J) return 1;
+  g.B = B; g.H = H; g.W = W; g.J = J; g.GP = GP; g.ngroups = ngroups; g.cout = cout; g.tpg = tpg;
+  for (int t = 0; t < 64; ++t) { g.dy[t] = t < ngroups * tpg ? dy[t] : 0; g.dx[t] = t < ngroups * tpg ? dx[t] : 0; }
+  return 0;
+}
+inline int grid_of(long total) { long b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+}  // namespace
+
+extern "C" int pxl_aspp_col2im(int dtype, int B, int H, int W, int J, int GP, int ngroups, int cout, int tpg, const int16_t* dy,
+                               const int16_t* dx, const float* P, int nslab, size_t slab_floats, const float* bias, void* out,
+                               int Cp, void* stream) {
+  AsppGeo g;
+  PXL_REQUIRE(P && out && dy && dx && nslab >= 1 && Cp >= cout && fill_geo(g, B, H, W, J, GP, ngroups, cout, tpg, dy, dx) == 0,
+              "aspp_col2im: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)B * H * W * Cp;
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(aspp_col2im_kernel<float>, dim3(grid_of(total)), dim3(256), 0, s, g, P, nslab, slab_floats, bias, (float*)out, Cp);
+  else if (dtype == PXL_BF16)
+    hipLaunchKernelGGL(aspp_col2im_kernel<bf16_t>, dim3(grid_of(total)), dim3(256), 0, s, g, P, nslab, slab_floats, bias, (bf16_t*)out, Cp);
+  else
+    return pxl_set_error(PXL_ERR_ARG, "aspp_col2im: bad dtype %d", dtype);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_aspp_dp_gather(int dtype, int B, int H, int W, int J, int GP, int ngroups, int cout, int tpg, const int16_t* dy,
+                                  const int16_t* dx, const void* dout, int Cp, void* dP, void* stream) {
+  AsppGeo g;
+  PXL_REQUIRE(dout && dP && dy && dx && Cp >= cout && J % 8 == 0 && fill_geo(g, B, H, W, J, GP, ngroups, cout, tpg, dy, dx) == 0,
+              "aspp_dp_gather: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PXL_F32) {
+    const long total = (long)B * H * W * (J / 4);
+    hipLaunchKernelGGL(aspp_dp_gather_kernel<float>, dim3(grid_of(total)), dim3(256), 0, s, g, (const float*)dout, Cp, (float*)dP);
+  } else if (dtype == PXL_BF16) {
+    const long total = (long)B * H * W * (J / 8);
+    hipLaunchKernelGGL(aspp_dp_gather_kernel<bf16_t>, dim3(grid_of(total)), dim3(256), 0, s, g, (const bf16_t*)dout, Cp, (bf16_t*)dP);
+  } else {
+    return pxl_set_error(PXL_ERR_ARG, "aspp_dp_gather: bad dtype %d", dtype);
+  }
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_aspp_dw_scatter(const float* tmp, int ngroups, int GP, int rows, int Cin, int Cpin, float* grads, const long* w_off,
+                                   void* stream) {
+  PXL_REQUIRE(tmp && grads && w_off && ngroups >= 1 && ngroups <= 4 && rows <= GP && Cin <= Cpin, "aspp_dw_scatter: bad argument");
+  AsppOffs o;
+  for (int g = 0; g < 4; ++g) o.w_off[g] = g < ngroups ? w_off[g] : 0;
+  const long total = (long)rows * Cin * ngroups;
+  hipLaunchKernelGGL(aspp_dw_scatter_kernel, dim3(grid_of(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tmp, ngroups, GP,
+                     rows, Cin, Cpin, grads, o);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}

@@ -52,12 +52,30 @@ extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* 
   DmaArgs a;
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = addend; a.stats = stats;
   a.ws = reinterpret_cast<float*>(workspace);
-  a.nk_per = 0;
+  a.nk_per = 0; a.raw_slabs = 0;
   a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
   const int sk = d->split_k;
   return conv_dma_launch(d, a, sk, ws_bytes, stream);
+}
+
+// The convolution as fp32 partial sums: K in `slices` equal slices (1 = unsplit), slice s stores its [M][Cout] tile at ws + s * M *
+// Cout floats with plain stores; NO finish pass, nothing rounded -- the caller consumes the slabs (aspp.hip: pxl_aspp_col2im sums
+// them together with the taps).  bf16 LDS-DMA kernel only; PXL_ERR_UNSUPPORTED otherwise (tile without fp32 staging, K not
+// divisible, workspace too small).
+extern "C" int pxl_conv_dma_slabs(const pxl_conv_desc* d, const void* in, const void* w, float* ws, size_t ws_bytes, int slices,
+                                  void* stream) {
+  PXL_REQUIRE(d && in && w && ws && slices >= 1, "conv_dma_slabs: bad argument");
+  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || d->dtype != PXL_BF16 || (d->tile_cfg >= 0 && d->tile_cfg < 8) || d->div != 1)
+    return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_slabs: descriptor is not eligible for the bf16 LDS-DMA kernel");
+  DmaArgs a;
+  a.in = in; a.w = w; a.out = nullptr; a.bias = nullptr; a.addend = nullptr; a.stats = nullptr;
+  a.ws = ws; a.nk_per = 0; a.raw_slabs = 1;
+  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
+  a.fin.coef = nullptr; a.fin_counter = nullptr;
+  a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
+  return conv_dma_launch(d, a, slices, ws_bytes, stream);
 }
 
 // Timeline probe of pxl_conv_dma (tools/cbench.cpp, not on the product path): the same launch built with cycle stamps;
@@ -69,7 +87,7 @@ extern "C" int pxl_conv_dma_trace(const pxl_conv_desc* d, const void* in, const 
     return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_trace: descriptor is not eligible for the LDS-DMA kernel");
   DmaArgs a;
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
-  a.ws = nullptr; a.nk_per = 0;
+  a.ws = nullptr; a.nk_per = 0; a.raw_slabs = 0;
   a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = trace;
@@ -88,7 +106,7 @@ extern "C" int pxl_conv_dma_finalize(const pxl_conv_desc* d, const void* in, con
     return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_finalize: descriptor is not eligible for the LDS-DMA kernel");
   DmaArgs a;
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
-  a.ws = nullptr; a.nk_per = 0;
+  a.ws = nullptr; a.nk_per = 0; a.raw_slabs = 0;
   a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin = *fin; a.fin_counter = counter;
   a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
@@ -111,7 +129,7 @@ extern "C" int pxl_conv_dma_bnin(const pxl_conv_desc* d, const void* y, const vo
     return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_bnin: descriptor is not eligible for the BN-on-load kernel");
   DmaArgs a;
   a.in = y; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
-  a.ws = nullptr; a.nk_per = 0;
+  a.ws = nullptr; a.nk_per = 0; a.raw_slabs = 0;
   a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bin = *bin; a.bin_relu = bin_relu; a.bin_z = z; a.trace = nullptr;
@@ -136,7 +154,7 @@ extern "C" int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, c
     return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dgrad_bnreduce: descriptor is not eligible for the LDS-DMA kernel");
   DmaArgs a;
   a.in = dy; a.w = wt; a.out = din; a.bias = nullptr; a.addend = addend; a.stats = bn_sums;
-  a.ws = nullptr; a.nk_per = 0;
+  a.ws = nullptr; a.nk_per = 0; a.raw_slabs = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = bn_relu; a.bn_mask = nullptr;
   a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
@@ -159,7 +177,7 @@ extern "C" int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy,
     return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dgrad_joinreduce: descriptor is not eligible for the LDS-DMA kernel");
   DmaArgs a;
   a.in = dy; a.w = wt; a.out = din; a.bias = nullptr; a.addend = addend; a.stats = bn_sums;
-  a.ws = nullptr; a.nk_per = 0;
+  a.ws = nullptr; a.nk_per = 0; a.raw_slabs = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = 0; a.bn_mask = join_out;
   a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
@@ -309,9 +327,12 @@ int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes,
     }
   }
   if (f32) return pxl_dma_f32_launch(cfg, a, gather, sk, ws_bytes, s);
-  if (cfg >= 40 && cfg <= 43) return pxl_halo_launch(cfg, a, s);       // halo-tile kernel (never split-K, never paired)
+  if (cfg >= 40 && cfg <= 43) {      // halo-tile kernel (never split-K, never paired)
+    if (a.raw_slabs) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_slabs: not a halo-tile launch");
+    return pxl_halo_launch(cfg, a, s);
+  }
   DmaCapture* cap = tl_capture;
-  if (cap != nullptr && cap->armed && !cap->held && cfg >= 8 && cfg <= 35 && a.addend == nullptr && a.bn_y == nullptr &&
+  if (cap != nullptr && cap->armed && !cap->held && !a.raw_slabs && cfg >= 8 && cfg <= 35 && a.addend == nullptr && a.bn_y == nullptr &&
       a.fin.coef == nullptr && a.trace == nullptr && (a.ws == nullptr || sk == 1 || a.stats != nullptr)) {
     // would this launch split K on its own?  (launch_dma's rule: few tiles and a long reduction, only with a workspace and no
     // statistics) -- those stay single launches

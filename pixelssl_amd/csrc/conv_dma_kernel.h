@@ -61,6 +61,9 @@ struct DmaArgs {
   // slices add into with atomics).  The uncoalesced atomics of the shared buffer ran at ~20 per ns (tools/cbench --splitk: 130 us
   // for an 8712 x 256 tile grid); slabs are plain coalesced stores, need no memset and sum in a fixed order
   size_t ws_slab;
+  // pxl_conv_dma_slabs: the caller wants the fp32 partial-sum slabs THEMSELVES (ws[slices][M][Cout]; one slab when K is not split)
+  // -- no finish kernel, nothing written to `out`; it sums them in a pass of its own (the multi-rate head's col2im, aspp.hip)
+  int raw_slabs;
   // forward with batch statistics: the LAST workgroup to finish turns the completed [sum, sumsq] into the BatchNorm
   // coefficients (what pxl_bn_finalize does), so no finalize launch and no replica reduction in the consumers
   pxl_bn_fin fin;    // fin.coef == nullptr: off
@@ -898,6 +901,7 @@ int launch_abl(const DmaArgs& a, hipStream_t stream) {
   p.tiles_n = cdiv(p.Cout, BN);
   p.ws = nullptr;
   p.ws_slab = 0;
+  p.raw_slabs = 0;
   p.nk_per = p.nk;
   p.kc_per = 0;
   p.fin.coef = nullptr;
@@ -944,6 +948,13 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
     if (splitk > p.nk) splitk = p.nk;
     if (splitk < 1) splitk = 1;
   }
+  if (p.raw_slabs) {
+    // exactly the slice count that was asked for, each slice a slab (the caller sized the workspace for it)
+    if (p.ws == nullptr || p.stats != nullptr || p.addend != nullptr || want_split < 1 || p.nk % want_split != 0 ||
+        ws_bytes < (size_t)want_split * p.M * p.Cout * sizeof(float) || p.Cout % 4 != 0 || groups != 1 || p.bin.coef != nullptr)
+      return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_slabs: %d slices of %d K steps into %zu workspace bytes", want_split, p.nk, ws_bytes);
+    splitk = want_split;
+  }
   p.nk_per = p.nk > 0 ? cdiv(p.nk, splitk) : 0;
   splitk = p.nk > 0 ? cdiv(p.nk, p.nk_per) : 1;          // (nk == 0: a read-back-only launch of a tap-less parity class)
   p.kc_per = 0;
@@ -968,10 +979,11 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
   // one slab per slice when the workspace holds them (and the tile's fp32 staging fits in the ring), else atomics into one buffer
   constexpr bool can_stage = (size_t)BM * (BN * 4 + 16) <= (size_t)NST * (BM + BN) * 128;
   p.ws_slab = 0;
-  if (splitk > 1 && can_stage && p.Cout % 4 == 0 && ws_bytes >= (size_t)splitk * p.M * p.Cout * sizeof(float))
+  if ((splitk > 1 || p.raw_slabs) && can_stage && p.Cout % 4 == 0 && ws_bytes >= (size_t)splitk * p.M * p.Cout * sizeof(float))
     p.ws_slab = (size_t)p.M * p.Cout;
+  if (p.raw_slabs && p.ws_slab == 0) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_slabs: this tile cannot stage its fp32 partial sums");
   if (splitk > 1 && p.ws_slab == 0) PXL_CHECK_HIP(hipMemsetAsync(p.ws, 0, (size_t)p.M * p.Cout * sizeof(float), stream));
-  if (splitk <= 1) p.ws = nullptr;
+  if (splitk <= 1 && !p.raw_slabs) p.ws = nullptr;
   const bool bnin = p.bin.coef != nullptr;
   const size_t smem = (size_t)NST * (BM + BN) * 128 + (bnin ? (size_t)p.Cin * 8 : 0);
   if (smem > 156 * 1024) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: tile + coefficient table exceed the LDS");
@@ -988,7 +1000,7 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
   const bool has_stats = p.stats != nullptr, has_bnr = has_stats && p.bn_y != nullptr, has_mask = has_bnr && p.bn_mask != nullptr;
   int em = (p.addend ? 1 : 0) | (p.bias ? 2 : 0) | (has_stats ? 4 : 0) | (has_bnr ? 8 : 0) | (has_mask ? 16 : 0) |
            ((has_bnr && !has_mask && p.bn_relu) ? 32 : 0);
-  if (splitk > 1) em = -2;
+  if (splitk > 1 || p.raw_slabs) em = -2;
   else if (p.sub_mul != 1) em = -1;          // sub-grid row addresses: the generic read-back
   int rc;
 #define PXL_EM(E) case E: rc = gather ? launch_one<BM, BN, WM, WN, NST, true, false, false, E>(g, b, smem, stream, p) \
@@ -1016,6 +1028,7 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
 #undef PXL_EM
 #undef PXL_EM_BNIN
   if (rc != PXL_OK) return rc;
+  if (p.raw_slabs) return PXL_OK;               // (the caller sums the slabs)
   if (splitk > 1 && p.ws_slab != 0)
     return pxl_splitk_finish_slabs(PXL_BF16, (long)p.M * p.Cout, p.Cout, p.Kreal, splitk, p.ws, p.bias, p.out, stream);
   if (splitk > 1)

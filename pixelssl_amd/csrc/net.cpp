@@ -42,6 +42,12 @@ int pxl_head_loss_ex(int dtype, int B, int h, int w, int Cp, int C, int H, int W
                      const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight,
                      float mse_weight, const float* mse_weight_dev, int kernel_choice, int ordered, void* dlow, void* workspace,
                      size_t ws_bytes, float* sums, void* stream);
+int pxl_conv_dma_slabs(const pxl_conv_desc* d, const void* in, const void* w, float* ws, size_t ws_bytes, int slices, void* stream);
+int pxl_aspp_col2im(int dtype, int B, int H, int W, int J, int GP, int ngroups, int cout, int tpg, const int16_t* dy,
+                    const int16_t* dx, const float* P, int nslab, size_t slab_floats, const float* bias, void* out, int Cp, void* stream);
+int pxl_aspp_dp_gather(int dtype, int B, int H, int W, int J, int GP, int ngroups, int cout, int tpg, const int16_t* dy,
+                       const int16_t* dx, const void* dout, int Cp, void* dP, void* stream);
+int pxl_aspp_dw_scatter(const float* tmp, int ngroups, int GP, int rows, int Cin, int Cpin, float* grads, const long* w_off, void* stream);
 int pxl_stem_patches(int dtype, const float* x, void* P, int B, int C, int H, int W, int kh, int kw, int stride, int pad,
                      int Ho, int Wo, int Kp, void* stream);
 int pxl_nchw_parts_to_nhwc(int dtype, int nparts, const float* const* srcs, const int* chans, void* y, int B, int H, int W,
@@ -127,6 +133,13 @@ struct OpInfo {
   // IBNorm op: arena [B][2][C] sums + [2*nb] folded BN part + [B][4][C] coefficients; scratch: the backward twins
   size_t ibn_sums = 0, ibn_bn = 0, ibn_coef = 0, ibn_bsums = 0, ibn_bbn = 0;
   size_t ws_off = 0, ws_bytes = 0;               // arena: split-K fp32 workspace (small-N, long-K convs)
+  // multi-rate head as ONE GEMM (csrc/aspp.hip): P = X . Wp^T with a column per (group, class, tap) -- J = ngroups * pg_GP
+  // columns -- in the op's workspace, then col2im; backward: dP gathered once (scratch), dX and dWp are plain GEMMs again
+  bool pg = false;
+  int pg_J = 0, pg_GP = 0;
+  pxl_conv_desc pg_fwd, pg_grp, pg_bwd;          // 1x1: Cin -> J (forward; weight gradient), J -> Cin (data gradient)
+  size_t pg_wf_off = 0, pg_wt_off = 0;           // packed: Wp [J][Cin] (= the master weights, cast) and its transpose [Cin][J]
+  size_t pg_dp_off = 0, pg_dw_off = 0;           // scratch: dP [M][J], the GEMM's weight gradient [J][cin] fp32
   // CONV: this op's data gradient is the last contribution to the gradient of residual join `join_op`'s output and
   // performs that join's backward in its epilogue; RESIDUAL: the convolution that does it (-1 = separate launch)
   int join_op = -1, join_conv = -1;
@@ -536,6 +549,33 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
         if (d.bn_out < 0 && tout.Cp <= 32) {     // few output tiles + long reduction: allow split-K
           // (room for one partial-sum slab per K slice -- up to 16 -- so that the slices store instead of adding with atomics)
           op.ws_bytes = align_up((size_t)16 * B * ho * wo * tout.Cp * 4);
+          // the head as one GEMM (aspp.hip; PXL_ASPP_GEMM=0: the 36-tap convolution of rounds 1-5): several tap groups of a "same"
+          // stride-1 convolution over a plain input with 64-channel granules
+          static const bool pg_on = getenv("PXL_ASPP_GEMM") == nullptr || getenv("PXL_ASPP_GEMM")[0] != '0';
+          op.pg = false;
+          if (pg_on && d.ngroups > 1 && d.stride == 1 && ho == tin.H && wo == tin.W && d.bn_in0 < 0 && tin.Cp % 64 == 0 &&
+              tin.Cp == d.cin && (long)d.cout * d.kh * d.kw <= 1024) {
+            const int tpg2 = d.kh * d.kw;
+            op.pg_GP = (d.cout * tpg2 + 63) / 64 * 64;
+            op.pg_J = d.ngroups * op.pg_GP;
+            pxl_conv_desc f;
+            std::memset(&f, 0, sizeof(f));
+            f.dtype = n->dtype; f.B = B; f.Hi = tin.H; f.Wi = tin.W; f.Cin = tin.Cp; f.Ho = ho; f.Wo = wo; f.Cout = op.pg_J; f.Kreal = op.pg_J;
+            f.ntaps = 1; f.out_stride = 1; f.div = 1; f.tile_cfg = -1; f.stats_rep = 1; f.split_k = 1;
+            op.pg_fwd = f;
+            op.pg_grp = f; op.pg_grp.split_k = 0;
+            pxl_conv_desc b = f;
+            b.Cin = op.pg_J; b.Cout = tin.Cp; b.Kreal = d.cin; b.split_k = 0;
+            op.pg_bwd = b;
+            if (pxl_conv_dma_eligible(&op.pg_fwd, nullptr, nullptr) && pxl_conv_dma_eligible(&op.pg_bwd, nullptr, nullptr)) {
+              op.pg = true;
+              op.ws_bytes = std::max(op.ws_bytes, align_up((size_t)B * ho * wo * op.pg_J * 4));          // P: ONE fp32 slab
+              op.pg_wf_off = packed; packed += align_up((size_t)op.pg_J * tin.Cp * n->esize);
+              if (d.need_dgrad) { op.pg_wt_off = packed; packed += align_up((size_t)tin.Cp * op.pg_J * n->esize); }
+              op.pg_dp_off = scratch; scratch += align_up((size_t)B * ho * wo * op.pg_J * n->esize);
+              op.pg_dw_off = scratch; scratch += align_up((size_t)op.pg_J * d.cin * 4);
+            }
+          }
           op.ws_off = arena; arena += op.ws_bytes;
         }
         if (d.bn_out >= 0) {
@@ -779,8 +819,9 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
       }
       if (!ok || first < 0) continue;
       OpInfo& oc = n->ops[first];
-      if (oc.d.kind != PXL_OP_CONV || oc.d.bn_in0 >= 0 || oc.d.ngroups != 1 || oc.join_op >= 0) continue;
-      if (!pxl_conv_dma_eligible(&oc.bwd, nullptr, nullptr) || oc.bwd.Kreal != oc.bwd.Cout || oc.bwd.Cout != o.C) continue;
+      if (oc.d.kind != PXL_OP_CONV || oc.d.bn_in0 >= 0 || (oc.d.ngroups != 1 && !oc.pg) || oc.join_op >= 0) continue;
+      const pxl_conv_desc& obw = oc.pg ? oc.pg_bwd : oc.bwd;       // (the multi-rate head: its data gradient is the GEMM J -> Cin)
+      if (!pxl_conv_dma_eligible(&obw, nullptr, nullptr) || obw.Kreal != obw.Cout || obw.Cout != o.C) continue;
       oc.join_op = (int)j;
       n->ops[j].join_conv = first;
     }
@@ -790,6 +831,7 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
     OpInfo& op = n->ops[i];
     if (op.d.kind != PXL_OP_CONV) continue;
     op.bwd.stats_rep = 1;
+    if (op.pg) op.pg_bwd.stats_rep = op.join_op >= 0 ? n->bns[n->ops[op.join_op].d.bn_in0].bnrep : 1;
     if (op.join_op >= 0) op.bwd.stats_rep = n->bns[n->ops[op.join_op].d.bn_in0].bnrep;
     else if (op.d.bn_in0 >= 0 && n->bns[op.d.bn_in0].fused_reduce_op == (int)i) op.bwd.stats_rep = n->bns[op.d.bn_in0].bnrep;
   }
@@ -897,8 +939,30 @@ int net_pack_impl(pxl_net* n, const float* params, void* packed, int which, long
     const bool want_t = (which & 2) && d.need_dgrad && n->pack_dgrad;
     // which & 4: forward layouts only of the convolutions the fused update kernel does not write (pxl_net_update_segments)
     const bool want_f = (which & 1) || ((which & 4) && !fwd_is_cast(n, op));
+    if (op.pg && (want_f || want_t)) {
+      // group g: rows [g * GP, g * GP + cout * taps) of Wp ARE the master weights [cout][kh][kw][Cin] (K = cout * taps rows of one
+      // "tap"); the transpose [Cin][ngroups][GP] is the data-gradient operand.  The padding rows / columns must be finite zeros
+      const size_t wf_bytes = (size_t)op.pg_J * tin.Cp * n->esize, wt_bytes = (size_t)tin.Cp * op.pg_J * n->esize;
+      if (want_f) PXL_CHECK_HIP(hipMemsetAsync(at(packed, op.pg_wf_off), 0, wf_bytes, reinterpret_cast<hipStream_t>(stream)));
+      if (want_t) PXL_CHECK_HIP(hipMemsetAsync(at(packed, op.pg_wt_off), 0, wt_bytes, reinterpret_cast<hipStream_t>(stream)));
+      for (int g = 0; g < d.ngroups; ++g) {
+        pxl_pack_item it;
+        it.src_off = d.w_off[g];
+        it.K = d.cout * tpg; it.T = 1; it.C = d.cin; it.Cp = tin.Cp;
+        if (want_f) {
+          it.wf_off = (int64_t)(op.pg_wf_off + (size_t)g * op.pg_GP * tin.Cp * n->esize); it.wt_off = -1;
+          it.T_total = 1; it.t_off = 0; it.Kp = op.pg_GP;
+          items.push_back(it);
+        }
+        if (want_t) {
+          it.wf_off = -1; it.wt_off = (int64_t)op.pg_wt_off;
+          it.T_total = d.ngroups; it.t_off = g; it.Kp = op.pg_GP;
+          items.push_back(it);
+        }
+      }
+    }
     for (int g = 0; g < d.ngroups; ++g) {
-      if (!want_f && !want_t) continue;
+      if ((!want_f && !want_t) || op.pg) continue;          // (a head that runs as a GEMM never reads the 36-tap layouts)
       pxl_pack_item it;
       it.src_off = d.w_off[g];
       it.wf_off = want_f ? (int64_t)op.wf_off : -1;
@@ -1049,6 +1113,51 @@ extern "C" int pxl_net_tune(pxl_net* n, const float* params, const void* packed,
     const float* sc = cin.sc; const float* sh = cin.sh;
     float* stats = d.bn_out >= 0 ? fat(arena, n->bns[d.bn_out].stats_off) : nullptr;
     const float* bias = d.b_off[0] >= 0 ? fat(packed, op.bias_off) : nullptr;
+    if (op.pg) {
+      // the multi-rate head as GEMMs (aspp.hip): its three launches, each over the tile configurations that can run it
+      const bool f32 = n->dtype == PXL_F32;
+      {
+        int best_cfg = -1; float best = 1e30f;
+        for (int cfg = 8; cfg < 36; ++cfg) {
+          if ((cfg >= 12 && cfg < 16) || (f32 && cfg >= 20) || !allowed(cfg)) continue;
+          pxl_conv_desc q = op.pg_fwd; q.tile_cfg = cfg;
+          int rc1 = PXL_OK;
+          const float t = time_launch([&]() {
+            rc1 = f32 ? pxl_conv_igemm(&q, cin.ptr, at(packed, op.pg_wf_off), fat(arena, op.ws_off), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream)
+                      : pxl_conv_dma_slabs(&q, cin.ptr, at(packed, op.pg_wf_off), fat(arena, op.ws_off), op.ws_bytes, 1, stream);
+            return rc1; }, s, a, b, reps);
+          if (t < 0) { if (rc1 != PXL_ERR_UNSUPPORTED) rc_all = PXL_ERR_HIP; continue; }      // (a tile without fp32 staging)
+          if (t < best) { best = t; best_cfg = cfg; }
+        }
+        op.pg_fwd.tile_cfg = best_cfg;
+      }
+      if (n->pack_dgrad) {
+        int best_cfg = -1; float best = 1e30f;
+        const bool wdma = pxl_conv_wgrad_dma_eligible(&op.pg_grp, nullptr) != 0;
+        for (int cfg = 0; cfg < (wdma ? 14 : 3); ++cfg) {
+          if (cfg >= 3 && cfg < 8) continue;
+          pxl_conv_desc q = op.pg_grp; q.tile_cfg = cfg;
+          const float t = time_launch([&]() { return pxl_conv_wgrad(&q, cin.ptr, nullptr, nullptr, at(scratch, op.pg_dp_off),
+                                                                    fat(scratch, op.pg_dw_off), d.cin, d.cin, stream); }, s, a, b, reps);
+          if (t < 0) { rc_all = PXL_ERR_HIP; continue; }
+          if (t < best) { best = t; best_cfg = cfg; }
+        }
+        op.pg_grp.tile_cfg = best_cfg;
+      }
+      if (d.need_dgrad && n->pack_dgrad) {
+        int best_cfg = -1; float best = 1e30f;
+        for (int cfg = 8; cfg < 36; ++cfg) {
+          if ((cfg >= 12 && cfg < 16) || (f32 && cfg >= 20) || !allowed(cfg)) continue;
+          pxl_conv_desc q = op.pg_bwd; q.tile_cfg = cfg;
+          const float t = time_launch([&]() { return pxl_conv_igemm(&q, at(scratch, op.pg_dp_off), at(packed, op.pg_wt_off), at(scratch, tin.goff),
+                                                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream); }, s, a, b, reps);
+          if (t < 0) { rc_all = PXL_ERR_HIP; continue; }
+          if (t < best) { best = t; best_cfg = cfg; }
+        }
+        op.pg_bwd.tile_cfg = best_cfg;
+      }
+      continue;
+    }
     // forward
     {
       int best_cfg = -1; float best = 1e30f;
@@ -1234,6 +1343,20 @@ int forward_op(pxl_net* n, size_t i, const FwdCtx& c, int phase, bool* fin_flag,
           } else {
             return rc;
           }
+        }
+        if (!onload_done && op.pg) {
+          // the multi-rate head as ONE GEMM + col2im (csrc/aspp.hip)
+          Timed t(n, s, 0, conv_flops(n, d, tout));
+          if (n->profile) n->prof_bytes[0] += conv_bytes(n, d, tin, tout, false);
+          float* P = fat(arena, op.ws_off);
+          if (n->dtype == PXL_BF16)
+            rc = pxl_conv_dma_slabs(&op.pg_fwd, cin.ptr, at(packed, op.pg_wf_off), P, op.ws_bytes, 1, stream);
+          else
+            rc = pxl_conv_igemm(&op.pg_fwd, cin.ptr, at(packed, op.pg_wf_off), P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
+          if (rc != PXL_OK) return rc;
+          rc = pxl_aspp_col2im(dt, n->B, tout.H, tout.W, op.pg_J, op.pg_GP, d.ngroups, d.cout, d.kh * d.kw, op.fwd.dy, op.fwd.dx, P, 1,
+                               (size_t)n->B * tout.H * tout.W * op.pg_J, bias, at(arena, tout.off), tout.Cp, stream);
+          onload_done = true;
         }
         if (!onload_done) {
           Timed t(n, s, 0, conv_flops(n, d, tout));
@@ -1980,6 +2103,32 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
       const int Mk = n->B * tok.H * tok.W;
       const void* dyk = at(scratch, dk.bn_out >= 0 ? tok.goff : wsrc[k]);
       const ConvIn cin = conv_input(n, opk, arena);
+      if (opk.pg) {
+        // ONE GEMM over the gathered dP (written on the main stream before the fork), then the groups' rows added into the master
+        // gradient layout
+        int rc;
+        float* tmp = fat(scratch, opk.pg_dw_off);
+        PXL_CHECK_HIP(hipMemsetAsync(tmp, 0, (size_t)opk.pg_J * dk.cin * 4, ws));
+        {
+          Timed t(n, ws, 1, conv_flops(n, dk, tok));
+          if (n->profile) n->prof_bytes[1] += conv_bytes(n, dk, tik, tok, true);
+          pxl_conv_desc q = opk.pg_grp;
+          if (n->deterministic) q.split_k = 1;
+          rc = pxl_conv_wgrad(&q, cin.ptr, nullptr, nullptr, at(scratch, opk.pg_dp_off), tmp, dk.cin, dk.cin, ws);
+        }
+        if (rc != PXL_OK) return rc;
+        long woffs[4] = {0, 0, 0, 0};
+        for (int g = 0; g < dk.ngroups; ++g) woffs[g] = dk.w_off[g];
+        rc = pxl_aspp_dw_scatter(tmp, dk.ngroups, opk.pg_GP, dk.cout * dk.kh * dk.kw, dk.cin, dk.cin, grads, woffs, ws);
+        if (rc != PXL_OK) return rc;
+        for (int g = 0; g < dk.ngroups; ++g) {
+          if (dk.b_off[g] < 0) continue;
+          rc = n->deterministic ? pxl_colsum_ordered(dt, Mk, tok.Cp, dk.cout, dyk, grads + dk.b_off[g], ws)
+                                : pxl_colsum(dt, Mk, tok.Cp, dk.cout, dyk, grads + dk.b_off[g], ws);
+          if (rc != PXL_OK) return rc;
+        }
+        continue;
+      }
       for (int g = 0; g < dk.ngroups; ++g) {
         int rc;
         {
@@ -2194,6 +2343,13 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
         // groups -- measured (MT 8x513x513, 20 steps): 1 -> 14.04 ms, 3 -> 14.2, 6 -> 14.2: the earlier start of the
         // weight gradients is worth more than the saved bubbles
         (void)sc; (void)sh;
+        if (op.pg && (n->wgrad_on || d.need_dgrad)) {
+          // dP[(b, y', x')][(g, c, t)] = dOut[b, y' - dy_t, x' - dx_t, c]: gathered ONCE on the main stream (before the weight
+          // gradient's fork event), both GEMMs of the head's backward read it
+          rc = pxl_aspp_dp_gather(dt, n->B, tout.H, tout.W, op.pg_J, op.pg_GP, d.ngroups, d.cout, d.kh * d.kw, op.fwd.dy, op.fwd.dx, dy,
+                                  tout.Cp, at(scratch, op.pg_dp_off), stream);
+          if (rc != PXL_OK) return rc;
+        }
         if (n->wgrad_on) {
           pending_w.push_back(i);
           const bool now = !n->use_side || !d.need_dgrad || (int)pending_w.size() >= (n->fork_every < 1 ? 1 : n->fork_every);
@@ -2204,19 +2360,23 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
           Timed t(n, s, 0, conv_flops(n, d, tout));
           if (n->profile) n->prof_bytes[0] += conv_bytes(n, d, tin, tout, false);
           const void* addend = written[d.in0] ? at(scratch, gsrc[d.in0]) : nullptr;
+          // (the multi-rate head: data gradient = the GEMM J -> Cin over dP)
+          const pxl_conv_desc* bwd = op.pg ? &op.pg_bwd : &op.bwd;
+          const void* bdy = op.pg ? at(scratch, op.pg_dp_off) : dy;
+          const void* bwt = op.pg ? at(packed, op.pg_wt_off) : at(packed, op.wt_off);
           if (op.join_op >= 0) {
             const pxl_op& dj = n->ops[op.join_op].d;
             const BnInfo& b3 = n->bns[dj.bn_in0];
-            rc = pxl_conv_dgrad_joinreduce(&op.bwd, dy, at(packed, op.wt_off), din, addend, at(arena, tin.off),
+            rc = pxl_conv_dgrad_joinreduce(bwd, bdy, bwt, din, addend, at(arena, tin.off),
                                            at(arena, n->tensors[dj.in0].off), fat(arena, b3.coef_off),
                                            fat(scratch, b3.bsum_off), stream);
             join_done[op.join_op] = 1;
           } else if (d.bn_in0 >= 0 && n->bns[d.bn_in0].fused_reduce_op == i) {
             const BnInfo& bi = n->bns[d.bn_in0];
-            rc = pxl_conv_dgrad_bnreduce(&op.bwd, dy, at(packed, op.wt_off), din, addend,
+            rc = pxl_conv_dgrad_bnreduce(bwd, bdy, bwt, din, addend,
                                          at(arena, tin.off), fat(arena, bi.coef_off), bi.relu, fat(scratch, bi.bsum_off), stream);
           } else {
-            rc = pxl_conv_igemm(&op.bwd, dy, at(packed, op.wt_off), din, nullptr, nullptr, nullptr,
+            rc = pxl_conv_igemm(bwd, bdy, bwt, din, nullptr, nullptr, nullptr,
                                 addend, nullptr, nullptr, 0, stream);
           }
           gsrc[d.in0] = tin.goff;
