@@ -804,16 +804,21 @@ int pxl_splitk_finish(int dtype, long total, int Cout, int Kreal, const float* w
  * PXL_ERR_UNSUPPORTED when the tile configuration cannot stage fp32 sums, K is not divisible or the workspace is too small. */
 int pxl_conv_dma_slabs(const pxl_conv_desc* desc, const void* in, const void* w, float* ws, size_t ws_bytes, int slices, void* stream);
 /* Multi-rate head (DeepLab-v2 ASPP classifier, deeplab_v2.py:76-85) as ONE GEMM (csrc/aspp.hip): P = X . Wp^T with a column
- * j = g * GP + c * tpg + t_local per (dilation group g, class c, tap) -- per group the master weight layout [Cout][kh][kw][Cin];
+ * j = g * GP + t_local * cout + c per (dilation group g, tap, class c), GP = cout * tpg rounded up to 64.
+ * pxl_aspp_pack: Wp [ngroups * GP][Cp] and / or its transpose Wd [Cp][ngroups * GP] from the master weights params + w_off[g]
+ * ([cout][kh][kw][Cin] each; padding rows / columns zero);
  * pxl_aspp_col2im: out[b,y,x,c] = bias[c] + sum_t sum_slabs P[(b, y + dy_t, x + dx_t)][j(t, c)] (fp32 sums, rounded once);
  * pxl_aspp_dp_gather: dP[(b,y',x')][j(t, c)] = dOut[b, y' - dy_t, x' - dx_t, c], zero outside and in the padding columns;
- * pxl_aspp_dw_scatter: grads[w_off[g] + r * Cin + k] += tmp[(g * GP + r) * Cpin + k] for r < rows: the GEMM's weight gradient
- * into the master layout.  dy / dx: the ngroups * tpg tap offsets of the forward convolution (input minus output position). */
+ * pxl_aspp_dw_scatter: master gradient row (c * tpg + t) of group g += row j(t, c) of the GEMM's weight gradient tmp [J][Cpin].
+ * dy / dx: the ngroups * tpg tap offsets of the forward convolution (input minus output position). */
+int pxl_aspp_pack(int dtype, const float* params, const long* w_off, int ngroups, int GP, int cout, int tpg, int Cin, int Cp,
+                  void* Wp, void* Wd, void* stream);
 int pxl_aspp_col2im(int dtype, int B, int H, int W, int J, int GP, int ngroups, int cout, int tpg, const int16_t* dy,
                     const int16_t* dx, const float* P, int nslab, size_t slab_floats, const float* bias, void* out, int Cp, void* stream);
 int pxl_aspp_dp_gather(int dtype, int B, int H, int W, int J, int GP, int ngroups, int cout, int tpg, const int16_t* dy,
                        const int16_t* dx, const void* dout, int Cp, void* dP, void* stream);
-int pxl_aspp_dw_scatter(const float* tmp, int ngroups, int GP, int rows, int Cin, int Cpin, float* grads, const long* w_off, void* stream);
+int pxl_aspp_dw_scatter(const float* tmp, int ngroups, int GP, int cout, int tpg, int Cin, int Cpin, float* grads, const long* w_off,
+                        void* stream);
 /* ... over nslab partial-sum slabs ws[nslab][total] written side by side (the LDS-DMA kernel's split-K when the workspace holds
  * one slab per K slice: plain stores instead of fp32 atomics, no pre-zeroing, a fixed summation order) */
 int pxl_splitk_finish_slabs(int dtype, long total, int Cout, int Kreal, int nslab, const float* ws, const float* bias, void* out,

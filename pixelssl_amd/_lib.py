@@ -199,7 +199,8 @@ SIGNATURES = {
     "pxl_conv_dma_slabs": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _Z, _I, _P]),
     "pxl_aspp_col2im": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _Z, _P, _P, _I, _P]),
     "pxl_aspp_dp_gather": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
-    "pxl_aspp_dw_scatter": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "pxl_aspp_dw_scatter": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "pxl_aspp_pack": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "pxl_splitk_finish_slabs": (_I, [_I, _L, _I, _I, _I, _P, _P, _P, _P]),
     "pxl_conv_wgrad_dma_eligible": (_I, [C.POINTER(ConvDesc), _P]),
     "pxl_conv_wgrad_dma": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _I, _I, _P]),

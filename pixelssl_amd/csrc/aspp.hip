@@ -9,10 +9,11 @@
 //     with  P = X . Wp^T,   Wp[(t, c)][:] = W[t, c, :]                       (M x 756 = a plain GEMM over K = 2048)
 //
 // so the forward pass is a 1x1 "convolution" with 756 output channels on the LDS-DMA kernel -- X read ONCE, no padding work, no
-// idle tile columns -- followed by a gather-sum of P (col2im).  The column order is j = g * GP + c * taps_per_group + t_local
-// with GP = 192 (189 rounded to the 64-channel granule of the DMA kernels): per group that is exactly the master weight layout
-// [Cout][kh][kw][Cin], so Wp is a cast of the master weights, its transpose is the data-gradient operand, and the weight
-// gradient of the GEMM lands in master order.  Backward: dP[(b, y', x')][t, c] = dOut[b, y' - dy_t, x' - dx_t, c] (zero outside)
+// idle tile columns -- followed by a gather-sum of P (col2im).  The column order is j = g * GP + t_local * Cout + c with GP = 192
+// (189 rounded to the 64-channel granule of the DMA kernels): TAP-major, so the Cout values one (pixel, tap) pair contributes
+// are contiguous (class-major -- the master weight layout [Cout][kh][kw][Cin] -- made col2im read one float per 64-byte line:
+// 24 us for 27 MB); pxl_aspp_pack writes Wp and its transpose (the data-gradient operand) in that order, pxl_aspp_dw_scatter
+// maps the GEMM's weight gradient back to the master rows.  Backward: dP[(b, y', x')][t, c] = dOut[b, y' - dy_t, x' - dx_t, c] (zero outside)
 // is gathered once (13 MB), dX = dP . Wp and dWp = dP^T . X are plain GEMMs again.  P stays fp32 (the bf16 engine's GEMM leaves
 // fp32 partial-sum slabs, pxl_conv_dma_slabs), so the 36-term sum rounds once like the convolution did.
 #include "common.h"
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void aspp_col2im_kernel(const AsppGeo g, const
         const int yy = y + g.dy[t], xx = x + g.dx[t];
         if ((unsigned)yy >= (unsigned)g.H || (unsigned)xx >= (unsigned)g.W) continue;
         const int grp = t / g.tpg, tl = t - grp * g.tpg;
-        const size_t o = ((size_t)(b * g.H + yy) * g.W + xx) * g.J + grp * g.GP + c * g.tpg + tl;
+        const size_t o = ((size_t)(b * g.H + yy) * g.W + xx) * g.J + grp * g.GP + tl * g.cout + c;
         float s = P[o];
         for (int k = 1; k < nslab; ++k) s += P[o + k * slab];       // (slabs in index order: the same bits on every run)
         v += s;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void aspp_col2im_kernel(const AsppGeo g, const
   }
 }
 
-// dP[m'][j] for the 8 columns of one 16-byte chunk; j = grp * GP + c * tpg + tl -> dOut[(y' - dy_t, x' - dx_t)][c], zero outside / padding
+// dP[m'][j] for the 8 columns of one 16-byte chunk; j = grp * GP + tl * cout + c -> dOut[(y' - dy_t, x' - dx_t)][c], zero outside / padding
 template <typename T>
 __global__ __launch_bounds__(256) void aspp_dp_gather_kernel(const AsppGeo g, const T* __restrict__ dout, int Cp, T* __restrict__ dP) {
   constexpr int EPC = Elem<T>::EPC;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void aspp_dp_gather_kernel(const AsppGeo g, co
       const int grp = j / g.GP, r = j - grp * g.GP;
       float f = 0.f;
       if (r < g.cout * g.tpg) {
-        const int c = r / g.tpg, tl = r - c * g.tpg;
+        const int tl = r / g.cout, c = r - tl * g.cout;
         const int t = grp * g.tpg + tl;
         const int yy = y - g.dy[t], xx = x - g.dx[t];
         if ((unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W)
@@ -87,16 +88,42 @@ __global__ __launch_bounds__(256) void aspp_dp_gather_kernel(const AsppGeo g, co
 }
 
 struct AsppOffs { long w_off[4]; };
-// master gradient rows of group grp += rows [grp * GP, grp * GP + R) of the GEMM's weight gradient [J][Cpin] (fp32)
-__global__ __launch_bounds__(256) void aspp_dw_scatter_kernel(const float* __restrict__ tmp, int ngroups, int GP, int R, int Cin, int Cpin,
-                                                              float* __restrict__ grads, const AsppOffs o) {
-  const long per = (long)R * Cin;
+// master gradient row (c * tpg + tl) of group grp += row grp * GP + tl * cout + c of the GEMM's weight gradient [J][Cpin] (fp32);
+// one thread per 4 consecutive input channels
+__global__ __launch_bounds__(256) void aspp_dw_scatter_kernel(const float* __restrict__ tmp, int ngroups, int GP, int cout, int tpg,
+                                                              int Cin, int Cpin, float* __restrict__ grads, const AsppOffs o) {
+  const int q4 = Cin / 4;
+  const long per = (long)cout * tpg * q4;
   const long total = per * ngroups;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
     const int grp = (int)(i / per);
     const long q = i - grp * per;
-    const int r = (int)(q / Cin), k = (int)(q - (long)r * Cin);
-    grads[o.w_off[grp] + q] += tmp[((size_t)grp * GP + r) * Cpin + k];
+    const int r = (int)(q / q4), k = (int)(q - (long)r * q4) * 4;          // r = master row c * tpg + tl
+    const int c = r / tpg, tl = r - c * tpg;
+    const float4 v = *reinterpret_cast<const float4*>(tmp + ((size_t)grp * GP + tl * cout + c) * Cpin + k);
+    float* dst = grads + o.w_off[grp] + (long)r * Cin + k;                // (parameter offsets are not 16-byte aligned in general)
+    dst[0] += v.x; dst[1] += v.y; dst[2] += v.z; dst[3] += v.w;
+  }
+}
+
+// Wp[(grp * GP + tl * cout + c)][k] = T(w_grp[c][tl][k]) and Wd[k][the same column] (either may be NULL); padding rows / columns
+// are written as zeros.  One thread per (column j, 8-channel chunk of k)
+template <typename T>
+__global__ __launch_bounds__(256) void aspp_pack_kernel(const float* __restrict__ params, const AsppOffs o, int ngroups, int GP, int cout,
+                                                        int tpg, int Cin, int Cp, T* __restrict__ Wp, T* __restrict__ Wd) {
+  const int J = ngroups * GP;
+  const long total = (long)J * Cp;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int k = (int)(i % Cp);
+    const int j = (int)(i / Cp);
+    const int grp = j / GP, r = j - grp * GP;
+    float v = 0.f;
+    if (r < cout * tpg && k < Cin) {
+      const int tl = r / cout, c = r - tl * cout;
+      v = params[o.w_off[grp] + ((long)c * tpg + tl) * Cin + k];
+    }
+    if (Wp != nullptr) Wp[(size_t)j * Cp + k] = from_f<T>(v);
+    if (Wd != nullptr) Wd[(size_t)k * J + j] = from_f<T>(v);
   }
 }
 
@@ -146,14 +173,32 @@ extern "C" int pxl_aspp_dp_gather(int dtype, int B, int H, int W, int J, int GP,
   return PXL_OK;
 }
 
-extern "C" int pxl_aspp_dw_scatter(const float* tmp, int ngroups, int GP, int rows, int Cin, int Cpin, float* grads, const long* w_off,
-                                   void* stream) {
-  PXL_REQUIRE(tmp && grads && w_off && ngroups >= 1 && ngroups <= 4 && rows <= GP && Cin <= Cpin, "aspp_dw_scatter: bad argument");
+extern "C" int pxl_aspp_dw_scatter(const float* tmp, int ngroups, int GP, int cout, int tpg, int Cin, int Cpin, float* grads,
+                                   const long* w_off, void* stream) {
+  PXL_REQUIRE(tmp && grads && w_off && ngroups >= 1 && ngroups <= 4 && cout * tpg <= GP && Cin <= Cpin && Cin % 4 == 0 && Cpin % 4 == 0,
+              "aspp_dw_scatter: bad argument");
   AsppOffs o;
   for (int g = 0; g < 4; ++g) o.w_off[g] = g < ngroups ? w_off[g] : 0;
-  const long total = (long)rows * Cin * ngroups;
+  const long total = (long)cout * tpg * (Cin / 4) * ngroups;
   hipLaunchKernelGGL(aspp_dw_scatter_kernel, dim3(grid_of(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tmp, ngroups, GP,
-                     rows, Cin, Cpin, grads, o);
+                     cout, tpg, Cin, Cpin, grads, o);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}
+
+extern "C" int pxl_aspp_pack(int dtype, const float* params, const long* w_off, int ngroups, int GP, int cout, int tpg, int Cin, int Cp,
+                             void* Wp, void* Wd, void* stream) {
+  PXL_REQUIRE(params && w_off && (Wp || Wd) && ngroups >= 1 && ngroups <= 4 && cout * tpg <= GP && Cin <= Cp, "aspp_pack: bad argument");
+  AsppOffs o;
+  for (int g = 0; g < 4; ++g) o.w_off[g] = g < ngroups ? w_off[g] : 0;
+  const long total = (long)ngroups * GP * Cp;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(aspp_pack_kernel<float>, dim3(grid_of(total)), dim3(256), 0, s, params, o, ngroups, GP, cout, tpg, Cin, Cp, (float*)Wp, (float*)Wd);
+  else if (dtype == PXL_BF16)
+    hipLaunchKernelGGL(aspp_pack_kernel<bf16_t>, dim3(grid_of(total)), dim3(256), 0, s, params, o, ngroups, GP, cout, tpg, Cin, Cp, (bf16_t*)Wp, (bf16_t*)Wd);
+  else
+    return pxl_set_error(PXL_ERR_ARG, "aspp_pack: bad dtype %d", dtype);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

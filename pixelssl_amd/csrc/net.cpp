@@ -47,7 +47,8 @@ int pxl_aspp_col2im(int dtype, int B, int H, int W, int J, int GP, int ngroups, 
                     const int16_t* dx, const float* P, int nslab, size_t slab_floats, const float* bias, void* out, int Cp, void* stream);
 int pxl_aspp_dp_gather(int dtype, int B, int H, int W, int J, int GP, int ngroups, int cout, int tpg, const int16_t* dy,
                        const int16_t* dx, const void* dout, int Cp, void* dP, void* stream);
-int pxl_aspp_dw_scatter(const float* tmp, int ngroups, int GP, int rows, int Cin, int Cpin, float* grads, const long* w_off, void* stream);
+int pxl_aspp_dw_scatter(const float* tmp, int ngroups, int GP, int cout, int tpg, int Cin, int Cpin, float* grads, const long* w_off, void* stream);
+int pxl_aspp_pack(int dtype, const float* params, const long* w_off, int ngroups, int GP, int cout, int tpg, int Cin, int Cp, void* Wp, void* Wd, void* stream);
 int pxl_stem_patches(int dtype, const float* x, void* P, int B, int C, int H, int W, int kh, int kw, int stride, int pad,
                      int Ho, int Wo, int Kp, void* stream);
 int pxl_nchw_parts_to_nhwc(int dtype, int nparts, const float* const* srcs, const int* chans, void* y, int B, int H, int W,
@@ -940,26 +941,12 @@ int net_pack_impl(pxl_net* n, const float* params, void* packed, int which, long
     // which & 4: forward layouts only of the convolutions the fused update kernel does not write (pxl_net_update_segments)
     const bool want_f = (which & 1) || ((which & 4) && !fwd_is_cast(n, op));
     if (op.pg && (want_f || want_t)) {
-      // group g: rows [g * GP, g * GP + cout * taps) of Wp ARE the master weights [cout][kh][kw][Cin] (K = cout * taps rows of one
-      // "tap"); the transpose [Cin][ngroups][GP] is the data-gradient operand.  The padding rows / columns must be finite zeros
-      const size_t wf_bytes = (size_t)op.pg_J * tin.Cp * n->esize, wt_bytes = (size_t)tin.Cp * op.pg_J * n->esize;
-      if (want_f) PXL_CHECK_HIP(hipMemsetAsync(at(packed, op.pg_wf_off), 0, wf_bytes, reinterpret_cast<hipStream_t>(stream)));
-      if (want_t) PXL_CHECK_HIP(hipMemsetAsync(at(packed, op.pg_wt_off), 0, wt_bytes, reinterpret_cast<hipStream_t>(stream)));
-      for (int g = 0; g < d.ngroups; ++g) {
-        pxl_pack_item it;
-        it.src_off = d.w_off[g];
-        it.K = d.cout * tpg; it.T = 1; it.C = d.cin; it.Cp = tin.Cp;
-        if (want_f) {
-          it.wf_off = (int64_t)(op.pg_wf_off + (size_t)g * op.pg_GP * tin.Cp * n->esize); it.wt_off = -1;
-          it.T_total = 1; it.t_off = 0; it.Kp = op.pg_GP;
-          items.push_back(it);
-        }
-        if (want_t) {
-          it.wf_off = -1; it.wt_off = (int64_t)op.pg_wt_off;
-          it.T_total = d.ngroups; it.t_off = g; it.Kp = op.pg_GP;
-          items.push_back(it);
-        }
-      }
+      // Wp [J][Cin] in the GEMM's column order (group, tap, class) and its transpose, the data-gradient operand (aspp.hip)
+      long woffs[4] = {0, 0, 0, 0};
+      for (int g = 0; g < d.ngroups; ++g) woffs[g] = d.w_off[g];
+      const int rc = pxl_aspp_pack(n->dtype, params, woffs, d.ngroups, op.pg_GP, d.cout, tpg, d.cin, tin.Cp,
+                                   want_f ? at(packed, op.pg_wf_off) : nullptr, want_t ? at(packed, op.pg_wt_off) : nullptr, stream);
+      if (rc != PXL_OK) return rc;
     }
     for (int g = 0; g < d.ngroups; ++g) {
       if ((!want_f && !want_t) || op.pg) continue;          // (a head that runs as a GEMM never reads the 36-tap layouts)
@@ -2119,7 +2106,7 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
         if (rc != PXL_OK) return rc;
         long woffs[4] = {0, 0, 0, 0};
         for (int g = 0; g < dk.ngroups; ++g) woffs[g] = dk.w_off[g];
-        rc = pxl_aspp_dw_scatter(tmp, dk.ngroups, opk.pg_GP, dk.cout * dk.kh * dk.kw, dk.cin, dk.cin, grads, woffs, ws);
+        rc = pxl_aspp_dw_scatter(tmp, dk.ngroups, opk.pg_GP, dk.cout, dk.kh * dk.kw, dk.cin, dk.cin, grads, woffs, ws);
         if (rc != PXL_OK) return rc;
         for (int g = 0; g < dk.ngroups; ++g) {
           if (dk.b_off[g] < 0) continue;

@@ -40,14 +40,16 @@ def test_multirate_head_as_one_gemm(geo, dtype):
         taps += ops.fwd_taps(3, 3, r, r)
     dy = (ctypes.c_int16 * 64)(*([t[0] for t in taps] + [0] * (64 - len(taps))))
     dx = (ctypes.c_int16 * 64)(*([t[1] for t in taps] + [0] * (64 - len(taps))))
-    # Wp [J][Cin]: per group the master layout [Cout][kh][kw][Cin] (a cast); its transpose [Cin][ng][GP]
-    Wp = torch.zeros(J, Cin, device=DEV, dtype=dtype)
-    Wd = torch.zeros(Cin, J, device=DEV, dtype=dtype)
-    scratch = torch.empty(Cout * tpg * ng, Cin, device=DEV, dtype=dtype)           # (pxl_pack_weights always writes a forward copy too)
+    # the groups' master weights [Cout][3][3][Cin] at scattered offsets of one flat buffer, as in the engine's parameter store
+    nparam = Cout * 9 * Cin
+    flat = torch.zeros(ng * (nparam + 5), device=DEV)
+    offs = (ctypes.c_long * 4)(*([gi * (nparam + 5) + 2 for gi in range(ng)] + [0] * (4 - ng)))
     for gi, w in enumerate(ws):
-        master = w.detach().permute(0, 2, 3, 1).contiguous().to(DEV)               # [Cout][3][3][Cin] fp32
-        ops.pack_weights(dtype, master, Cout * tpg, 1, Cin, Wp[gi * GP:], Cin)      # rows of group gi = the master rows, cast
-        ops.pack_weights(dtype, master, Cout * tpg, 1, Cin, scratch, Cin, T_total=ng, t_off=gi, wt=Wd, Kp=GP)
+        flat[offs[gi]:offs[gi] + nparam] = w.detach().permute(0, 2, 3, 1).reshape(-1).to(DEV)
+    Wp = torch.full((J, Cin), float("nan"), device=DEV, dtype=dtype)
+    Wd = torch.full((Cin, J), float("nan"), device=DEV, dtype=dtype)
+    check(lib().pxl_aspp_pack(code, ptr(flat), offs, ng, GP, Cout, tpg, Cin, Cin, ptr(Wp), ptr(Wd), stream_ptr()))
+    assert torch.equal(Wp.t().contiguous(), Wd) and torch.isfinite(Wp.float()).all()
     xd = to_nhwc(x.detach(), Cin, dtype)
     fdesc = ops.conv_desc(dtype, B, H, W, Cin, H, W, J, J, [(0, 0)], out_stride=1)
     P = torch.full((M, J), float("nan"), device=DEV, dtype=torch.float32)
@@ -74,10 +76,8 @@ def test_multirate_head_as_one_gemm(geo, dtype):
     assert rel_err(from_nhwc(dxd, Cin), x.grad) < TOL[dtype]
     tmp = torch.zeros(J, Cin, device=DEV)
     ops.conv_wgrad(fdesc, xd, dP.view(B, H, W, J), tmp, Cin, Cin)
-    nparam = Cout * 9 * Cin
     grads = torch.ones(ng * (nparam + 5), device=DEV)                  # (the groups' weights are NOT contiguous in the flat buffer)
-    offs = (ctypes.c_long * 4)(*([gi * (nparam + 5) + 2 for gi in range(ng)] + [0] * (4 - ng)))
-    check(lib().pxl_aspp_dw_scatter(ptr(tmp), ng, GP, Cout * tpg, Cin, Cin, ptr(grads), offs, stream_ptr()))
+    check(lib().pxl_aspp_dw_scatter(ptr(tmp), ng, GP, Cout, tpg, Cin, Cin, ptr(grads), offs, stream_ptr()))
     torch.cuda.synchronize()
     for gi, w in enumerate(ws):
         got = grads[offs[gi]:offs[gi] + nparam].cpu().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2) - 1.0       # (+= into ones)
