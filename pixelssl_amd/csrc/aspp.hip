@@ -29,6 +29,10 @@ struct AsppGeo {
 template <typename T>
 __global__ __launch_bounds__(256) void aspp_col2im_kernel(const AsppGeo g, const float* __restrict__ P, int nslab, size_t slab,
                                                           const float* __restrict__ bias, T* __restrict__ out, int Cp) {
+  // tap offsets in LDS: indexed from the argument block they cost a scalar load + wait per tap and thread
+  __shared__ int s_dy[64], s_dx[64];
+  if (threadIdx.x < 64) { s_dy[threadIdx.x] = g.dy[threadIdx.x]; s_dx[threadIdx.x] = g.dx[threadIdx.x]; }
+  __syncthreads();
   const long total = (long)g.B * g.H * g.W * Cp;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
     const int c = (int)(i % Cp);
@@ -37,16 +41,21 @@ __global__ __launch_bounds__(256) void aspp_col2im_kernel(const AsppGeo g, const
     if (c < g.cout) {
       const int x = (int)(m % g.W), y = (int)((m / g.W) % g.H);
       const long b = m / ((long)g.W * g.H);
+      const size_t img = (size_t)b * g.H * g.W;
       v = bias != nullptr ? bias[c] : 0.f;
-      const int ntaps = g.ngroups * g.tpg;
-      for (int t = 0; t < ntaps; ++t) {
-        const int yy = y + g.dy[t], xx = x + g.dx[t];
-        if ((unsigned)yy >= (unsigned)g.H || (unsigned)xx >= (unsigned)g.W) continue;
-        const int grp = t / g.tpg, tl = t - grp * g.tpg;
-        const size_t o = ((size_t)(b * g.H + yy) * g.W + xx) * g.J + grp * g.GP + tl * g.cout + c;
-        float s = P[o];
-        for (int k = 1; k < nslab; ++k) s += P[o + k * slab];       // (slabs in index order: the same bits on every run)
-        v += s;
+      for (int grp = 0; grp < g.ngroups; ++grp) {
+        const float* Pg = P + grp * g.GP + c;
+        // (independent, predicated loads: a `continue` per padding tap left one dependent load chain per thread)
+#pragma unroll 3
+        for (int tl = 0; tl < g.tpg; ++tl) {
+          const int t = grp * g.tpg + tl;
+          const int yy = y + s_dy[t], xx = x + s_dx[t];
+          const bool in = (unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
+          const size_t o = in ? (img + (size_t)yy * g.W + xx) * g.J + tl * g.cout : 0;
+          float sv = Pg[o];
+          for (int k = 1; k < nslab; ++k) sv += Pg[o + k * slab];      // (slabs in index order: the same bits on every run)
+          v += in ? sv : 0.f;
+        }
       }
     }
     out[i] = from_f<T>(v);
@@ -65,19 +74,21 @@ __global__ __launch_bounds__(256) void aspp_dp_gather_kernel(const AsppGeo g, co
     const int x = (int)(m % g.W), y = (int)((m / g.W) % g.H);
     const long b = m / ((long)g.W * g.H);
     float v[EPC];
+    int j0 = ch * EPC;
+    int grp = j0 / g.GP, r = j0 - grp * g.GP;
+    int tl = r / g.cout, c = r - tl * g.cout;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      const int j = ch * EPC + e;
-      const int grp = j / g.GP, r = j - grp * g.GP;
       float f = 0.f;
-      if (r < g.cout * g.tpg) {
-        const int tl = r / g.cout, c = r - tl * g.cout;
+      if (tl < g.tpg) {                                   // (tl >= tpg: the padding columns of the group)
         const int t = grp * g.tpg + tl;
         const int yy = y - g.dy[t], xx = x - g.dx[t];
         if ((unsigned)yy < (unsigned)g.H && (unsigned)xx < (unsigned)g.W)
           f = to_f(dout[((size_t)(b * g.H + yy) * g.W + xx) * Cp + c]);
       }
       v[e] = f;
+      if (++r == g.GP) { r = 0; ++grp; tl = 0; c = 0; }
+      else if (++c == g.cout) { c = 0; ++tl; }
     }
     if constexpr (sizeof(T) == 2) {
       *reinterpret_cast<uint4*>(dP + (size_t)m * g.J + ch * EPC) = Chunk<bf16_t>::pack(v);
@@ -107,24 +118,31 @@ __global__ __launch_bounds__(256) void aspp_dw_scatter_kernel(const float* __res
 }
 
 // Wp[(grp * GP + tl * cout + c)][k] = T(w_grp[c][tl][k]) and Wd[k][the same column] (either may be NULL); padding rows / columns
-// are written as zeros.  One thread per (column j, 8-channel chunk of k)
+// are written as zeros.  One block per 32 x 32 (column j, channel k) tile: read with k fastest, the transpose through LDS
 template <typename T>
 __global__ __launch_bounds__(256) void aspp_pack_kernel(const float* __restrict__ params, const AsppOffs o, int ngroups, int GP, int cout,
                                                         int tpg, int Cin, int Cp, T* __restrict__ Wp, T* __restrict__ Wd) {
+  __shared__ float tile[32][33];
   const int J = ngroups * GP;
-  const long total = (long)J * Cp;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
-    const int k = (int)(i % Cp);
-    const int j = (int)(i / Cp);
+  const int j0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int j = j0 + rr, k = k0 + tx;
     const int grp = j / GP, r = j - grp * GP;
     float v = 0.f;
-    if (r < cout * tpg && k < Cin) {
+    if (j < J && r < cout * tpg && k < Cin) {
       const int tl = r / cout, c = r - tl * cout;
       v = params[o.w_off[grp] + ((long)c * tpg + tl) * Cin + k];
     }
-    if (Wp != nullptr) Wp[(size_t)j * Cp + k] = from_f<T>(v);
-    if (Wd != nullptr) Wd[(size_t)k * J + j] = from_f<T>(v);
+    tile[rr][tx] = v;
+    if (Wp != nullptr && j < J && k < Cp) Wp[(size_t)j * Cp + k] = from_f<T>(v);
   }
+  __syncthreads();
+  if (Wd != nullptr)
+    for (int rr = ty; rr < 32; rr += 8) {
+      const int k = k0 + rr, j = j0 + tx;
+      if (k < Cp && j < J) Wd[(size_t)k * J + j] = from_f<T>(tile[tx][rr]);
+    }
 }
 
 int fill_geo(AsppGeo& g, int B, int H, int W, int J, int GP, int ngroups, int cout, int tpg, const int16_t* dy, const int16_t* dx) {
@@ -191,12 +209,12 @@ extern "C" int pxl_aspp_pack(int dtype, const float* params, const long* w_off, 
   PXL_REQUIRE(params && w_off && (Wp || Wd) && ngroups >= 1 && ngroups <= 4 && cout * tpg <= GP && Cin <= Cp, "aspp_pack: bad argument");
   AsppOffs o;
   for (int g = 0; g < 4; ++g) o.w_off[g] = g < ngroups ? w_off[g] : 0;
-  const long total = (long)ngroups * GP * Cp;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((Cp + 31) / 32, (ngroups * GP + 31) / 32);
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(aspp_pack_kernel<float>, dim3(grid_of(total)), dim3(256), 0, s, params, o, ngroups, GP, cout, tpg, Cin, Cp, (float*)Wp, (float*)Wd);
+    hipLaunchKernelGGL(aspp_pack_kernel<float>, grid, dim3(256), 0, s, params, o, ngroups, GP, cout, tpg, Cin, Cp, (float*)Wp, (float*)Wd);
   else if (dtype == PXL_BF16)
-    hipLaunchKernelGGL(aspp_pack_kernel<bf16_t>, dim3(grid_of(total)), dim3(256), 0, s, params, o, ngroups, GP, cout, tpg, Cin, Cp, (bf16_t*)Wp, (bf16_t*)Wd);
+    hipLaunchKernelGGL(aspp_pack_kernel<bf16_t>, grid, dim3(256), 0, s, params, o, ngroups, GP, cout, tpg, Cin, Cp, (bf16_t*)Wp, (bf16_t*)Wd);
   else
     return pxl_set_error(PXL_ERR_ARG, "aspp_pack: bad dtype %d", dtype);
   PXL_LAUNCH_CHECK();
