@@ -577,9 +577,15 @@ def main():
         prof.enable()
     t0 = time.perf_counter()
     last = None
-    for it in range(a.warmup, a.warmup + a.steps):
+    # host time to ENQUEUE a step, taken over the first <= 8 steps: the hardware queues hold that many, beyond them the
+    # runtime blocks the host on the GPU and the figure turns into the step time (one perf_counter read, no synchronisation)
+    n_host = min(8, a.steps)
+    host_mark = None
+    for k, it in enumerate(range(a.warmup, a.warmup + a.steps)):
         last = one_step(it)
-    host_enqueue = time.perf_counter() - t0          # host time to ENQUEUE the K steps (== elapsed: the step is host-bound)
+        if k + 1 == n_host:
+            host_mark = time.perf_counter()
+    host_enqueue = (host_mark - t0) * a.steps / n_host
     fence()
     elapsed = time.perf_counter() - t0
     if prof is not None:
