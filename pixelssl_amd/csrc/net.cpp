@@ -816,6 +816,9 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
         if (first < 0) first = (int)c;
         if (dc.kind == PXL_OP_CONV) ok = dc.in0 == dj.out && dc.need_dgrad;
         else if (dc.kind == PXL_OP_RESIDUAL) ok = dc.in1 == dj.out && dc.in0 != dj.out;
+        // (the HEAD op names the join output as its LATENT: it sends no gradient of its own there -- a seeded latent gradient,
+        // pxl_net_seed_latent_grad, arrives as the addend of the convolution that completes the join's gradient)
+        else if (dc.kind == PXL_OP_HEAD) ok = dc.in1 == dj.out && dc.in0 != dj.out && dc.bn_in1 < 0;
         else ok = false;
       }
       if (!ok || first < 0) continue;
