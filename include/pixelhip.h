@@ -120,6 +120,11 @@ int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, const void* 
  * PXL_ERR_UNSUPPORTED. */
 int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
                               const void* join_out, const void* bn_y, const float* bn_coef, float* bn_sums, void* stream);
+/* ... with the join's ReLU mask as ONE BIT per element -- join_bits [M][C / 8] bytes, bit e of a byte = channel 8 * chunk + e is
+ * positive, written by pxl_residual_fwd_bits / pxl_residual_finalize_fwd_bits -- instead of the join output: identical results,
+ * 1/16 of that operand's bytes (17.8 -> 1.1 MB per ResNet-101 stage-3 join).  bf16 only. */
+int pxl_conv_dgrad_joinreduce_bits(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
+                                   const void* join_bits, const void* bn_y, const float* bn_coef, float* bn_sums, void* stream);
 
 /* dw[k][t][c] += sum_m dy[m][k] * act(in)[m,t,c]   (fp32, atomically accumulated: zero dw first
  * unless accumulating).  `desc` describes the FORWARD conv (in = its input, Ho/Wo/Cout = dy).
@@ -203,6 +208,10 @@ int pxl_bn_finalize_apply_fwd(int dtype, long M, int C, const void* y, const pxl
  * pxl_residual_fwd); rfin == NULL: identity shortcut */
 int pxl_residual_finalize_fwd(int dtype, long M, int C, const void* y, const pxl_bn_fin* yfin, const void* res,
                               const pxl_bn_fin* rfin, void* out, void* stream);
+/* ... + `bits` (may be NULL): the ReLU mask of `out`, one byte per 16-byte chunk ([M][C / 8] for bf16), for
+ * pxl_conv_dgrad_joinreduce_bits */
+int pxl_residual_finalize_fwd_bits(int dtype, long M, int C, const void* y, const pxl_bn_fin* yfin, const void* res,
+                                   const pxl_bn_fin* rfin, void* out, void* bits, void* stream);
 
 /* Backward of the bottleneck join out = relu(bn3(y) + res) (resnet.py:44-48) fused with bn3's reduction: g = dout *
  * (out > 0) -> g (and g2 = the residual branch's copy, may be NULL); sums[0..C) += sum_m g, sums[C..2C) += sum_m g*xhat */
@@ -251,6 +260,8 @@ int pxl_ibn_bwd_apply(int dtype, int B, int HW, int C, int nb, const void* dout,
 /* out = relu( y*ycoef.scale+ycoef.shift + (rcoef ? res*rcoef.scale+rcoef.shift : res) )  resnet.py:44-48 */
 int pxl_residual_fwd(int dtype, long M, int C, const void* y, const float* ycoef, const void* res,
                      const float* rcoef, void* out, void* stream);
+int pxl_residual_fwd_bits(int dtype, long M, int C, const void* y, const float* ycoef, const void* res,
+                          const float* rcoef, void* out, void* bits, void* stream);       /* see pxl_residual_finalize_fwd_bits */
 /* nn.LeakyReLU(slope) forward / backward of the FCDiscriminator and FlawDetector stacks (ssl_adv.py:474,480-485;
  * ssl_gct.py:567-585): y = x > 0 ? x : slope*x ; dx = x > 0 ? dy : slope*dy */
 int pxl_leaky_fwd(int dtype, long n, const void* x, float slope, void* y, void* stream);

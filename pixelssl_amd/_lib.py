@@ -107,6 +107,9 @@ SIGNATURES = {
     "pxl_ibn_bwd_reduce_acc": (_I, [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P]),
     "pxl_ibn_bwd_apply": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _I, _F, _P, _P]),
     "pxl_residual_fwd": (_I, [_I, _L, _I, _P, _P, _P, _P, _P, _P]),
+    "pxl_residual_fwd_bits": (_I, [_I, _L, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "pxl_residual_finalize_fwd_bits": (_I, [_I, _L, _I, _P, C.POINTER(BnFin), _P, C.POINTER(BnFin), _P, _P, _P]),
+    "pxl_conv_dgrad_joinreduce_bits": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pxl_leaky_fwd": (_I, [_I, _L, _P, _F, _P, _P]),
     "pxl_leaky_bwd": (_I, [_I, _L, _P, _P, _F, _P, _P]),
     "pxl_relu_mask": (_I, [_I, _L, _P, _P, _P, _P, _P]),

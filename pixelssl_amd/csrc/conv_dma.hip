@@ -53,7 +53,7 @@ extern "C" int pxl_conv_dma(const pxl_conv_desc* d, const void* in, const void* 
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = addend; a.stats = stats;
   a.ws = reinterpret_cast<float*>(workspace);
   a.nk_per = 0; a.raw_slabs = 0;
-  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
+  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr; a.mask_bits = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
   const int sk = d->split_k;
@@ -72,7 +72,7 @@ extern "C" int pxl_conv_dma_slabs(const pxl_conv_desc* d, const void* in, const 
   DmaArgs a;
   a.in = in; a.w = w; a.out = nullptr; a.bias = nullptr; a.addend = nullptr; a.stats = nullptr;
   a.ws = ws; a.nk_per = 0; a.raw_slabs = 1;
-  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
+  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr; a.mask_bits = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
   return conv_dma_launch(d, a, slices, ws_bytes, stream);
@@ -88,7 +88,7 @@ extern "C" int pxl_conv_dma_trace(const pxl_conv_desc* d, const void* in, const 
   DmaArgs a;
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
   a.ws = nullptr; a.nk_per = 0; a.raw_slabs = 0;
-  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
+  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr; a.mask_bits = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = trace;
   return conv_dma_launch(d, a, 1, 0, stream);
@@ -107,7 +107,7 @@ extern "C" int pxl_conv_dma_finalize(const pxl_conv_desc* d, const void* in, con
   DmaArgs a;
   a.in = in; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
   a.ws = nullptr; a.nk_per = 0; a.raw_slabs = 0;
-  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
+  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr; a.mask_bits = 0;
   a.fin = *fin; a.fin_counter = counter;
   a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
   return conv_dma_launch(d, a, 1, 0, stream);
@@ -130,7 +130,7 @@ extern "C" int pxl_conv_dma_bnin(const pxl_conv_desc* d, const void* y, const vo
   DmaArgs a;
   a.in = y; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
   a.ws = nullptr; a.nk_per = 0; a.raw_slabs = 0;
-  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr;
+  a.bn_y = nullptr; a.bn_coef = nullptr; a.bn_relu = 0; a.bn_mask = nullptr; a.mask_bits = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
   a.bin = *bin; a.bin_relu = bin_relu; a.bin_z = z; a.trace = nullptr;
   if (z != nullptr) {          // the activated tensor can only be written by a kernel that walks every input pixel exactly once per tile row
@@ -156,7 +156,7 @@ extern "C" int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, c
   a.in = dy; a.w = wt; a.out = din; a.bias = nullptr; a.addend = addend; a.stats = bn_sums;
   a.ws = nullptr; a.nk_per = 0; a.raw_slabs = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
-  a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = bn_relu; a.bn_mask = nullptr;
+  a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = bn_relu; a.bn_mask = nullptr; a.mask_bits = 0;
   a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
   pxl_conv_desc q = *d;
   // bn_sums holds d->stats_rep replicas [stats_rep][2C] (<= 1: one vector); tile row t adds into replica t % stats_rep.  With at
@@ -169,9 +169,24 @@ extern "C" int pxl_conv_dgrad_bnreduce(const pxl_conv_desc* d, const void* dy, c
 // epilogue: g = dgrad(dy) (+ addend); din = g * (join_out > 0) -- the ReLU after the join -- and bn_sums[0..C) +=
 // sum_m din, bn_sums[C..2C) += sum_m din * xhat(bn_y) for the main branch's last BatchNorm (the one without a ReLU of its
 // own).  Replaces pxl_residual_bwd_reduce (3 tensor reads + 2 writes) by two extra reads in this epilogue.
+namespace { int joinreduce_impl(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend, const void* join_out,
+                                int mask_bits, const void* bn_y, const float* bn_coef, float* bn_sums, void* stream); }
 extern "C" int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
                                          const void* join_out, const void* bn_y, const float* bn_coef, float* bn_sums,
                                          void* stream) {
+  return joinreduce_impl(d, dy, wt, din, addend, join_out, 0, bn_y, bn_coef, bn_sums, stream);
+}
+// ... with the join's ReLU mask as the bit plane pxl_residual_fwd_bits wrote ([M][C / 8] bytes) instead of the join output itself:
+// the same results, 1/16 of that operand's bytes.  bf16 LDS-DMA kernel only.
+extern "C" int pxl_conv_dgrad_joinreduce_bits(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
+                                              const void* join_bits, const void* bn_y, const float* bn_coef, float* bn_sums,
+                                              void* stream) {
+  PXL_REQUIRE(d && d->dtype == PXL_BF16 && d->Cout % 8 == 0, "conv_dgrad_joinreduce_bits: bf16 launches with 8-channel chunks only");
+  return joinreduce_impl(d, dy, wt, din, addend, join_bits, 1, bn_y, bn_coef, bn_sums, stream);
+}
+namespace {
+int joinreduce_impl(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend, const void* join_out,
+                    int mask_bits, const void* bn_y, const float* bn_coef, float* bn_sums, void* stream) {
   PXL_REQUIRE(d && dy && wt && din && join_out && bn_y && bn_coef && bn_sums, "conv_dgrad_joinreduce: null argument");
   if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || d->Kreal != d->Cout || (d->tile_cfg >= 0 && d->tile_cfg < 8))
     return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dgrad_joinreduce: descriptor is not eligible for the LDS-DMA kernel");
@@ -179,7 +194,7 @@ extern "C" int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy,
   a.in = dy; a.w = wt; a.out = din; a.bias = nullptr; a.addend = addend; a.stats = bn_sums;
   a.ws = nullptr; a.nk_per = 0; a.raw_slabs = 0;
   a.fin.coef = nullptr; a.fin_counter = nullptr;
-  a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = 0; a.bn_mask = join_out;
+  a.bn_y = bn_y; a.bn_coef = bn_coef; a.bn_relu = 0; a.bn_mask = join_out; a.mask_bits = mask_bits;
   a.bin.coef = nullptr; a.bin_relu = 0; a.bin_z = nullptr; a.trace = nullptr;
   pxl_conv_desc q = *d;
   // bn_sums holds d->stats_rep replicas [stats_rep][2C] (<= 1: one vector); tile row t adds into replica t % stats_rep.  With at
@@ -187,6 +202,7 @@ extern "C" int pxl_conv_dgrad_joinreduce(const pxl_conv_desc* d, const void* dy,
   q.stats_rep = d->stats_rep >= 1 ? d->stats_rep : 1;
   return conv_dma_launch(&q, a, 1, 0, stream);
 }
+}  // namespace
 
 namespace {
 // PXL_S2_CLASSES=0: stride-2 data gradients as ONE launch that walks every tap (rounds 1-3), for A/B runs

@@ -43,6 +43,7 @@ struct DmaArgs {
   // ... of a residual join: the tensor being written is d(join output); gd = din * (bn_mask > 0) (bn_mask = the join's
   // post-ReLU output), the MASKED gradient is what gets stored, bn_y / bn_coef belong to the main branch's last BN
   const void* bn_mask;
+  int mask_bits;     // bn_mask is the join's ReLU mask as one BYTE per 8 channels ([M][Cout / 8], pxl_residual_fwd_bits), not the tensor
   int B, Hi, Wi, Cin;
   int Ho, Wo, Cout, Kreal;
   int ntaps, so;
@@ -234,6 +235,7 @@ template <int EM, int NPASS, int RPP, int TP, bool VIRT = false, typename STAMP>
 __device__ __forceinline__ void epi_passes(STAMP&& stamp, const EpiCtx& c, float (&s1)[8], float (&s2)[8], int rt_mode = 0) {
   const int em = EM >= 0 ? EM : rt_mode;
   const bool has_add = em & 1, has_bias = em & 2, has_stats = em & 4, has_bnr = em & 8, has_mask = em & 16, bn_relu = em & 32;
+  const bool mask_is_bits = em & 64;       // the join mask arrives as one byte per 8-channel chunk (1/16 of the tensor's bytes)
   // per-channel operands of THIS combination only (loaded here, not ahead of the dispatch: 40 registers held across the
   // switch were what pushed the 64 x 128 kernels over the 3-workgroups-per-CU register budget)
   float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -263,6 +265,7 @@ __device__ __forceinline__ void epi_passes(STAMP&& stamp, const EpiCtx& c, float
   for (int g0 = 0; g0 < NPASS; g0 += PG) {
     unsigned vo[PG];
     u32x4 xa[PG], xy[PG], xm[PG];
+    unsigned xb[PG];
 #pragma unroll
     for (int q = 0; q < PG; ++q) {
       const int m = c.m0 + (g0 + q) * RPP + c.er;
@@ -292,7 +295,11 @@ __device__ __forceinline__ void epi_passes(STAMP&& stamp, const EpiCtx& c, float
 #pragma unroll
       for (int q = 0; q < PG; ++q) xy[q] = __builtin_amdgcn_raw_buffer_load_b128(c.r_bny, (int)vo[q], 0, 0);
     }
-    if (has_mask) {
+    if (has_mask && mask_is_bits) {
+      // byte (pix * Cout + n) / 8 = vo / 16; an out-of-tile row stays out of range (EOOB >> 4 is far beyond the bit plane)
+#pragma unroll
+      for (int q = 0; q < PG; ++q) xb[q] = __builtin_amdgcn_raw_buffer_load_b8(c.r_msk, (int)(vo[q] >> 4), 0, 0);
+    } else if (has_mask) {
 #pragma unroll
       for (int q = 0; q < PG; ++q) xm[q] = __builtin_amdgcn_raw_buffer_load_b128(c.r_msk, (int)vo[q], 0, 0);
     }
@@ -329,7 +336,12 @@ __device__ __forceinline__ void epi_passes(STAMP&& stamp, const EpiCtx& c, float
         if (has_mask) {
           float fy[8], fm[8];
           Chunk<bf16_t>::unpack(make_uint4(xy[q][0], xy[q][1], xy[q][2], xy[q][3]), fy);
-          Chunk<bf16_t>::unpack(make_uint4(xm[q][0], xm[q][1], xm[q][2], xm[q][3]), fm);
+          if (mask_is_bits) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fm[e] = (xb[q] >> e) & 1u ? 1.f : 0.f;
+          } else {
+            Chunk<bf16_t>::unpack(make_uint4(xm[q][0], xm[q][1], xm[q][2], xm[q][3]), fm);
+          }
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float gd = fm[e] > 0.f ? f[e] : 0.f;
@@ -801,10 +813,10 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
     c.r_out = __builtin_amdgcn_make_buffer_rsrc(a_out, 0, out_bytes, 0x00020000);
     c.r_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.addend), 0, out_bytes, 0x00020000);
     c.r_bny = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bn_y), 0, out_bytes, 0x00020000);
-    c.r_msk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bn_mask), 0, out_bytes, 0x00020000);
+    c.r_msk = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bn_mask), 0, p.mask_bits ? out_bytes / 16 : out_bytes, 0x00020000);
     c.bias = a_bias; c.bn_coef = p.bn_coef; c.Kreal = p.Kreal;
     const int emode = (has_add ? 1 : 0) | (has_bias ? 2 : 0) | (has_stats ? 4 : 0) | (has_bnr ? 8 : 0) | (has_mask ? 16 : 0) |
-                      ((has_bnr && !has_mask && p.bn_relu) ? 32 : 0);
+                      ((has_bnr && !has_mask && p.bn_relu) ? 32 : 0) | ((has_mask && p.mask_bits) ? 64 : 0);
     if constexpr (EM >= 0) epi_passes<EM, NPASS, RPP, TP>(stamp, c, s1, s2);
     else epi_passes<-1, NPASS, RPP, TP>(stamp, c, s1, s2, emode);           // uncommon combinations: run-time flags
   }
@@ -999,7 +1011,7 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
   // operand combination of the read-back passes (epi_passes): a compile-time constant of the kernel that is launched
   const bool has_stats = p.stats != nullptr, has_bnr = has_stats && p.bn_y != nullptr, has_mask = has_bnr && p.bn_mask != nullptr;
   int em = (p.addend ? 1 : 0) | (p.bias ? 2 : 0) | (has_stats ? 4 : 0) | (has_bnr ? 8 : 0) | (has_mask ? 16 : 0) |
-           ((has_bnr && !has_mask && p.bn_relu) ? 32 : 0);
+           ((has_bnr && !has_mask && p.bn_relu) ? 32 : 0) | ((has_mask && p.mask_bits) ? 64 : 0);
   if (splitk > 1 || p.raw_slabs) em = -2;
   else if (p.sub_mul != 1) em = -1;          // sub-grid row addresses: the generic read-back
   int rc;
@@ -1015,6 +1027,7 @@ int launch_dma(const DmaArgs& a, bool gather, int want_split, size_t ws_bytes, h
       PXL_EM(12) PXL_EM(13)            // data gradient + BatchNorm-backward sums (+ addend)
       PXL_EM(44) PXL_EM(45)            // ... through the BN's ReLU
       PXL_EM(28) PXL_EM(29)            // ... of a residual join
+      PXL_EM(92) PXL_EM(93)            // ... with the join's ReLU mask as a bit plane
       default: rc = gather ? launch_one<BM, BN, WM, WN, NST, true, false, false, -1>(g, b, smem, stream, p)
                            : launch_one<BM, BN, WM, WN, NST, false, false, false, -1>(g, b, smem, stream, p);
     }

@@ -59,7 +59,25 @@ __device__ __forceinline__ void block_bn_finalize(const pxl_bn_fin& f, int C, in
 // per thread so the coefficients are loaded once into registers, two rows in flight per thread.  FIN: the BN finalize
 // of the operand(s) is folded into the prologue (yfin / rfin) instead of reading ready-made coefficients.
 // second operand set of a PAIRED launch (gridDim.z == 2: the same op of a second network, pxl_net_forward_pair)
-struct EltSecond { const void* y; const void* res; void* out; pxl_bn_fin yfin, rfin; };
+struct EltSecond { const void* y; const void* res; void* out; pxl_bn_fin yfin, rfin; unsigned char* bits; };
+
+// one bit per element of a packed 16-byte chunk: element e of Chunk<T>::unpack's order is non-zero (the join's post-ReLU output
+// is >= 0, so "non-zero" IS its ReLU mask: what the fused join backward of conv_dma_kernel.h needs from that tensor)
+template <typename T> __device__ __forceinline__ unsigned nz_bits(const uint4& v);
+template <> __device__ __forceinline__ unsigned nz_bits<bf16_t>(const uint4& v) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+  unsigned b = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    b |= ((w[k] & 0x7fffu) != 0u ? 1u : 0u) << (2 * k);
+    b |= ((w[k] & 0x7fff0000u) != 0u ? 1u : 0u) << (2 * k + 1);
+  }
+  return b;
+}
+template <> __device__ __forceinline__ unsigned nz_bits<float>(const uint4& v) {
+  return ((v.x & 0x7fffffffu) != 0u ? 1u : 0u) | ((v.y & 0x7fffffffu) != 0u ? 2u : 0u) | ((v.z & 0x7fffffffu) != 0u ? 4u : 0u) |
+         ((v.w & 0x7fffffffu) != 0u ? 8u : 0u);
+}
 
 // FIN kernels: request the first rows before the finalize prologue?  (PXL_ELT_PREFETCH; measured per workload)
 static bool elt_prefetch() {
@@ -73,15 +91,23 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T
                                                            const T* res,
                                                            const float* __restrict__ rcoef,
                                                            T* out, int rows_per_group, int cgmax,
-                                                           pxl_bn_fin yfin, pxl_bn_fin rfin, int has_rfin, EltSecond sec) {
+                                                           pxl_bn_fin yfin, pxl_bn_fin rfin, int has_rfin, EltSecond sec,
+                                                           unsigned char* bits) {
   constexpr int EPC = Elem<T>::EPC;
   if (blockIdx.z != 0) {        // paired launch (pxl_net_forward_pair): the same join of the second network
     y = static_cast<const T*>(sec.y); res = static_cast<const T*>(sec.res); out = static_cast<T*>(sec.out);
-    yfin = sec.yfin; rfin = sec.rfin;
+    yfin = sec.yfin; rfin = sec.rfin; bits = sec.bits;
   }
   const ColGeom g = col_geom(C, EPC, cgmax);
   const int ccol = threadIdx.x % g.cg, rlane = threadIdx.x / g.cg;
   const int cc = blockIdx.x * g.cg + ccol;
+  // bits (optional): the ReLU mask of the output, one BYTE per 16-byte chunk ([M][C / EPC]): the fused join backward reads 1/16
+  // of what the tensor itself costs (17.8 MB -> 1.1 MB per stage-3 join)
+  const int cpr = C / EPC;
+  auto put = [&](size_t o, int row, const uint4& r) {
+    *reinterpret_cast<uint4*>(out + o) = r;
+    if (bits != nullptr) bits[(size_t)row * cpr + cc] = (unsigned char)nz_bits<T>(r);
+  };
   // FIN: the first rows of both operands are requested BEFORE the finalize prologue (statistics loads + two barriers):
   // the launch is latency-bound (a few rows per thread), so the two round trips overlap instead of adding up
   const int m_begin = blockIdx.y * rows_per_group;
@@ -137,19 +163,19 @@ __global__ __launch_bounds__(256) void residual_fwd_kernel(int M, int C, const T
   if constexpr (FIN) {
 #pragma unroll
     for (int k = 0; k < PF; ++k)
-      if (m + k * g.rl < m_end) *reinterpret_cast<uint4*>(out + (size_t)(m + k * g.rl) * C + col) = one(pa[k], pb[k]);
+      if (m + k * g.rl < m_end) put((size_t)(m + k * g.rl) * C + col, m + k * g.rl, one(pa[k], pb[k]));
     m += PF * g.rl;
   }
   for (; m + g.rl < m_end; m += 2 * g.rl) {
     const size_t o0 = (size_t)m * C + col, o1 = o0 + step;
     const uint4 a0 = *reinterpret_cast<const uint4*>(y + o0), b0 = *reinterpret_cast<const uint4*>(res + o0);
     const uint4 a1 = *reinterpret_cast<const uint4*>(y + o1), b1 = *reinterpret_cast<const uint4*>(res + o1);
-    *reinterpret_cast<uint4*>(out + o0) = one(a0, b0);
-    *reinterpret_cast<uint4*>(out + o1) = one(a1, b1);
+    put(o0, m, one(a0, b0));
+    put(o1, m + g.rl, one(a1, b1));
   }
   if (m < m_end) {
     const size_t o0 = (size_t)m * C + col;
-    *reinterpret_cast<uint4*>(out + o0) = one(*reinterpret_cast<const uint4*>(y + o0), *reinterpret_cast<const uint4*>(res + o0));
+    put(o0, m, one(*reinterpret_cast<const uint4*>(y + o0), *reinterpret_cast<const uint4*>(res + o0)));
   }
 }
 
@@ -422,8 +448,16 @@ inline int row_grid(long M, int C, int epc) {
   return (int)g;
 }
 
+extern "C" int pxl_residual_fwd_bits(int dtype, long M, int C, const void* y, const float* ycoef, const void* res,
+                                     const float* rcoef, void* out, void* bits, void* stream);
 extern "C" int pxl_residual_fwd(int dtype, long M, int C, const void* y, const float* ycoef, const void* res,
                                 const float* rcoef, void* out, void* stream) {
+  return pxl_residual_fwd_bits(dtype, M, C, y, ycoef, res, rcoef, out, nullptr, stream);
+}
+// ... + the ReLU mask of `out` as one byte per 16-byte chunk (bits [M][C / (8 bf16 | 4 fp32)], may be NULL): conv_dma_kernel.h's
+// fused join backward reads it instead of the tensor
+extern "C" int pxl_residual_fwd_bits(int dtype, long M, int C, const void* y, const float* ycoef, const void* res,
+                                     const float* rcoef, void* out, void* bits, void* stream) {
   PXL_REQUIRE(y && ycoef && res && out, "residual_fwd: null argument");
   PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "residual_fwd: bad dtype");
   const int epc = dtype == PXL_F32 ? 4 : 8;
@@ -436,10 +470,12 @@ extern "C" int pxl_residual_fwd(int dtype, long M, int C, const void* y, const f
   const pxl_bn_fin none = {};
   if (dtype == PXL_F32)
     hipLaunchKernelGGL((residual_fwd_kernel<float, false>), grid, dim3(256), 0, s, (int)M, C,
-                       cp<float>(y), ycoef, cp<float>(res), rcoef, mp<float>(out), rpg, cgmax, none, none, 0, EltSecond{});
+                       cp<float>(y), ycoef, cp<float>(res), rcoef, mp<float>(out), rpg, cgmax, none, none, 0, EltSecond{},
+                       reinterpret_cast<unsigned char*>(bits));
   else
     hipLaunchKernelGGL((residual_fwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, (int)M, C,
-                       cp<bf16_t>(y), ycoef, cp<bf16_t>(res), rcoef, mp<bf16_t>(out), rpg, cgmax, none, none, 0, EltSecond{});
+                       cp<bf16_t>(y), ycoef, cp<bf16_t>(res), rcoef, mp<bf16_t>(out), rpg, cgmax, none, none, 0, EltSecond{},
+                       reinterpret_cast<unsigned char*>(bits));
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -458,11 +494,12 @@ struct EltHeld {
   bool armed = false, held = false;
   int kind = 0, dtype = 0, C = 0, relu = 0, has_rfin = 0; long M = 0; hipStream_t s = nullptr;
   const void* y = nullptr; const void* res = nullptr; void* out = nullptr; pxl_bn_fin yfin{}, rfin{};
+  unsigned char* bits = nullptr;
 };
 thread_local EltHeld tl_elt;
 
 int launch_residual_fin(int dtype, long M, int C, const void* y, const pxl_bn_fin& yfin, const void* res, const pxl_bn_fin& rf, int has_rfin,
-                        void* out, hipStream_t s, const EltSecond* sec) {
+                        void* out, hipStream_t s, const EltSecond* sec, unsigned char* bits = nullptr) {
   const int epc = dtype == PXL_F32 ? 4 : 8;
   const int cgmax = 16;                         // 16 chunks x EPC <= 128 channels per block (LDS coefficient arrays)
   const ColGeom g = col_geom(C, epc, cgmax);
@@ -471,10 +508,10 @@ int launch_residual_fin(int dtype, long M, int C, const void* y, const pxl_bn_fi
   const EltSecond e2 = sec ? *sec : EltSecond{};
   if (dtype == PXL_F32)
     hipLaunchKernelGGL((elt_prefetch() ? residual_fwd_kernel<float, true, 4> : residual_fwd_kernel<float, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<float>(y), nullptr,
-                       cp<float>(res), nullptr, mp<float>(out), rpg, cgmax, yfin, rf, has_rfin, e2);
+                       cp<float>(res), nullptr, mp<float>(out), rpg, cgmax, yfin, rf, has_rfin, e2, bits);
   else
     hipLaunchKernelGGL((elt_prefetch() ? residual_fwd_kernel<bf16_t, true, 4> : residual_fwd_kernel<bf16_t, true, 0>), grid, dim3(256), 0, s, (int)M, C, cp<bf16_t>(y), nullptr,
-                       cp<bf16_t>(res), nullptr, mp<bf16_t>(out), rpg, cgmax, yfin, rf, has_rfin, e2);
+                       cp<bf16_t>(res), nullptr, mp<bf16_t>(out), rpg, cgmax, yfin, rf, has_rfin, e2, bits);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -498,7 +535,7 @@ int issue_held() {
   EltHeld& h = tl_elt;
   if (!h.held) return PXL_OK;
   h.held = false;
-  return h.kind == 1 ? launch_residual_fin(h.dtype, h.M, h.C, h.y, h.yfin, h.res, h.rfin, h.has_rfin, h.out, h.s, nullptr)
+  return h.kind == 1 ? launch_residual_fin(h.dtype, h.M, h.C, h.y, h.yfin, h.res, h.rfin, h.has_rfin, h.out, h.s, nullptr, h.bits)
                      : launch_bn_fin_apply(h.dtype, h.M, h.C, h.y, h.yfin, h.relu, h.out, h.s, nullptr);
 }
 bool same_fin_shape(const pxl_bn_fin& a, const pxl_bn_fin& b) {
@@ -510,8 +547,15 @@ bool same_fin_shape(const pxl_bn_fin& a, const pxl_bn_fin& b) {
 extern "C" void pxl_elt_pair_begin(void) { tl_elt.armed = true; tl_elt.held = false; }
 extern "C" int pxl_elt_pair_end(void) { tl_elt.armed = false; return issue_held(); }
 
+extern "C" int pxl_residual_finalize_fwd_bits(int dtype, long M, int C, const void* y, const pxl_bn_fin* yfin, const void* res,
+                                              const pxl_bn_fin* rfin, void* out, void* bits, void* stream);
 extern "C" int pxl_residual_finalize_fwd(int dtype, long M, int C, const void* y, const pxl_bn_fin* yfin, const void* res,
                                          const pxl_bn_fin* rfin, void* out, void* stream) {
+  return pxl_residual_finalize_fwd_bits(dtype, M, C, y, yfin, res, rfin, out, nullptr, stream);
+}
+extern "C" int pxl_residual_finalize_fwd_bits(int dtype, long M, int C, const void* y, const pxl_bn_fin* yfin, const void* res,
+                                              const pxl_bn_fin* rfin, void* out, void* bits_, void* stream) {
+  unsigned char* bits = reinterpret_cast<unsigned char*>(bits_);
   PXL_REQUIRE(y && res && out && fin_ok(yfin) && (rfin == nullptr || fin_ok(rfin)), "residual_finalize_fwd: bad argument");
   PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "residual_finalize_fwd: bad dtype");
   const int epc = dtype == PXL_F32 ? 4 : 8;
@@ -523,16 +567,16 @@ extern "C" int pxl_residual_finalize_fwd(int dtype, long M, int C, const void* y
     if (h.held && h.kind == 1 && h.dtype == dtype && h.M == M && h.C == C && h.s == s && h.has_rfin == (rfin ? 1 : 0) &&
         same_fin_shape(h.yfin, *yfin) && (!rfin || same_fin_shape(h.rfin, rf))) {
       h.held = false;
-      const EltSecond sec{y, res, out, *yfin, rf};
-      return launch_residual_fin(dtype, M, C, h.y, h.yfin, h.res, h.rfin, h.has_rfin, h.out, s, &sec);
+      const EltSecond sec{y, res, out, *yfin, rf, bits};
+      return launch_residual_fin(dtype, M, C, h.y, h.yfin, h.res, h.rfin, h.has_rfin, h.out, s, &sec, h.bits);
     }
     const int rc = issue_held();
     if (rc != PXL_OK) return rc;
     h.held = true; h.kind = 1; h.dtype = dtype; h.M = M; h.C = C; h.s = s; h.has_rfin = rfin ? 1 : 0;
-    h.y = y; h.res = res; h.out = out; h.yfin = *yfin; h.rfin = rf;
+    h.y = y; h.res = res; h.out = out; h.yfin = *yfin; h.rfin = rf; h.bits = bits;
     return PXL_OK;
   }
-  return launch_residual_fin(dtype, M, C, y, *yfin, res, rf, rfin ? 1 : 0, out, s, nullptr);
+  return launch_residual_fin(dtype, M, C, y, *yfin, res, rf, rfin ? 1 : 0, out, s, nullptr, bits);
 }
 
 extern "C" int pxl_bn_apply_fwd(int dtype, long M, int C, const void* y, const float* coef, int relu, void* z,
@@ -568,7 +612,7 @@ extern "C" int pxl_bn_finalize_apply_fwd(int dtype, long M, int C, const void* y
   if (h.armed) {
     if (h.held && h.kind == 2 && h.dtype == dtype && h.M == M && h.C == C && h.s == s && h.relu == relu && same_fin_shape(h.yfin, *fin)) {
       h.held = false;
-      const EltSecond sec{y, nullptr, z, *fin, pxl_bn_fin{}};
+      const EltSecond sec{y, nullptr, z, *fin, pxl_bn_fin{}, nullptr};
       return launch_bn_fin_apply(dtype, M, C, h.y, h.yfin, relu, h.out, s, &sec);
     }
     const int rc = issue_held();

@@ -42,6 +42,12 @@ int pxl_head_loss_ex(int dtype, int B, int h, int w, int Cp, int C, int H, int W
                      const void* t_low, const float* gt, int ignore_index, int n_ce, int mse_lo, int mse_hi, float ce_weight,
                      float mse_weight, const float* mse_weight_dev, int kernel_choice, int ordered, void* dlow, void* workspace,
                      size_t ws_bytes, float* sums, void* stream);
+int pxl_conv_dgrad_joinreduce_bits(const pxl_conv_desc* d, const void* dy, const void* wt, void* din, const void* addend,
+                                   const void* join_bits, const void* bn_y, const float* bn_coef, float* bn_sums, void* stream);
+int pxl_residual_fwd_bits(int dtype, long M, int C, const void* y, const float* ycoef, const void* res, const float* rcoef, void* out,
+                          void* bits, void* stream);
+int pxl_residual_finalize_fwd_bits(int dtype, long M, int C, const void* y, const pxl_bn_fin* yfin, const void* res,
+                                   const pxl_bn_fin* rfin, void* out, void* bits, void* stream);
 int pxl_conv_dma_slabs(const pxl_conv_desc* d, const void* in, const void* w, float* ws, size_t ws_bytes, int slices, void* stream);
 int pxl_aspp_col2im(int dtype, int B, int H, int W, int J, int GP, int ngroups, int cout, int tpg, const int16_t* dy,
                     const int16_t* dx, const float* P, int nslab, size_t slab_floats, const float* bias, void* out, int Cp, void* stream);
@@ -144,6 +150,9 @@ struct OpInfo {
   // CONV: this op's data gradient is the last contribution to the gradient of residual join `join_op`'s output and
   // performs that join's backward in its epilogue; RESIDUAL: the convolution that does it (-1 = separate launch)
   int join_op = -1, join_conv = -1;
+  // RESIDUAL whose backward is fused into a bf16 LDS-DMA data gradient: the ReLU mask that launch needs, as one byte per 8 channels
+  // ([M][C / 8], arena) written by the join's forward kernel -- the backward reads 1/16 of the join output's bytes for it
+  size_t bits_off = 0; bool bits = false;
   // stem in patch mode (bf16 engine): the convolution reads the network input, has few input channels and needs no data
   // gradient -> its im2col patches [M][patch_Kp] are written once per forward (arena) and the convolution runs as a 1x1
   // convolution over patch_Kp channels on the LDS-DMA kernels, forward and weight gradient
@@ -828,6 +837,10 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
       if (!pxl_conv_dma_eligible(&obw, nullptr, nullptr) || obw.Kreal != obw.Cout || obw.Cout != o.C) continue;
       oc.join_op = (int)j;
       n->ops[j].join_conv = first;
+      // (bf16: that launch takes the join's ReLU mask as a bit plane, PXL_JOIN_BITS=0: the join output itself as in rounds 1-5)
+      static const bool bits_on = getenv("PXL_JOIN_BITS") == nullptr || getenv("PXL_JOIN_BITS")[0] != '0';
+      n->ops[j].bits = bits_on && n->dtype == PXL_BF16 && o.Cp % 8 == 0;
+      if (n->ops[j].bits) { n->ops[j].bits_off = arena; arena += align_up((size_t)n->B * o.H * o.W * (o.Cp / 8)); }
     }
   }
   // data gradients that produce BatchNorm-backward sums in their epilogue: as many replicas as the BatchNorm's sums have
@@ -1429,11 +1442,12 @@ int forward_op(pxl_net* n, size_t i, const FwdCtx& c, int phase, bool* fin_flag,
           const pxl_bn_fin yfin = make_fin(n, n->bns[d.bn_in0], params, running, arena, training);
           pxl_bn_fin rfin;
           if (d.bn_in1 >= 0) rfin = make_fin(n, n->bns[d.bn_in1], params, running, arena, training);
-          rc = pxl_residual_finalize_fwd(dt, (long)n->B * a.H * a.W, a.Cp, at(arena, a.off), &yfin, at(arena, r.off),
-                                         d.bn_in1 >= 0 ? &rfin : nullptr, at(arena, o.off), stream);
+          rc = pxl_residual_finalize_fwd_bits(dt, (long)n->B * a.H * a.W, a.Cp, at(arena, a.off), &yfin, at(arena, r.off),
+                                              d.bn_in1 >= 0 ? &rfin : nullptr, at(arena, o.off),
+                                              op.bits && n->pack_dgrad ? at(arena, op.bits_off) : nullptr, stream);
         } else {
-          rc = pxl_residual_fwd(dt, (long)n->B * a.H * a.W, a.Cp, at(arena, a.off), ac, at(arena, r.off), rcoef,
-                                at(arena, o.off), stream);
+          rc = pxl_residual_fwd_bits(dt, (long)n->B * a.H * a.W, a.Cp, at(arena, a.off), ac, at(arena, r.off), rcoef,
+                                     at(arena, o.off), op.bits && n->pack_dgrad ? at(arena, op.bits_off) : nullptr, stream);
         }
         break;
       }
@@ -2357,9 +2371,15 @@ int net_backward_impl(pxl_net* n, const float* params, const void* packed, const
           if (op.join_op >= 0) {
             const pxl_op& dj = n->ops[op.join_op].d;
             const BnInfo& b3 = n->bns[dj.bn_in0];
-            rc = pxl_conv_dgrad_joinreduce(bwd, bdy, bwt, din, addend, at(arena, tin.off),
-                                           at(arena, n->tensors[dj.in0].off), fat(arena, b3.coef_off),
-                                           fat(scratch, b3.bsum_off), stream);
+            const OpInfo& oj = n->ops[op.join_op];
+            if (oj.bits)
+              rc = pxl_conv_dgrad_joinreduce_bits(bwd, bdy, bwt, din, addend, at(arena, oj.bits_off),
+                                                  at(arena, n->tensors[dj.in0].off), fat(arena, b3.coef_off),
+                                                  fat(scratch, b3.bsum_off), stream);
+            else
+              rc = pxl_conv_dgrad_joinreduce(bwd, bdy, bwt, din, addend, at(arena, tin.off),
+                                             at(arena, n->tensors[dj.in0].off), fat(arena, b3.coef_off),
+                                             fat(scratch, b3.bsum_off), stream);
             join_done[op.join_op] = 1;
           } else if (d.bn_in0 >= 0 && n->bns[d.bn_in0].fused_reduce_op == i) {
             const BnInfo& bi = n->bns[d.bn_in0];

@@ -412,6 +412,25 @@ def test_conv_dgrad_with_fused_residual_join_backward(shape, cfg, dtype):
         torch.cuda.synchronize()
         assert torch.equal(got, ref) and (got == 0).float().mean().item() > 0.3
         assert rel_err(sums.cpu(), rs.cpu()) < 1e-4, (shape, cfg, addend is not None)
+        if dtype == torch.bfloat16:
+            # round 6: the join's ReLU mask as ONE BIT per element, written by the join's forward kernel (pxl_residual_fwd_bits):
+            # the same masked gradient bit for bit, the same sums
+            res0 = to_nhwc(torch.zeros(B, Cin, H, W), Cin, dtype)
+            ident = torch.cat([torch.zeros(2 * Cin), torch.ones(Cin), torch.zeros(Cin)]).to(DEV)      # bn(y) = y
+            bits = torch.full((B * H * W, Cin // 8), 0xAA, device=DEV, dtype=torch.uint8)
+            out2 = torch.empty_like(out)
+            check(lib().pxl_residual_fwd_bits(dtype_code(dtype), B * H * W, Cin, ptr(out), ptr(ident), ptr(res0), None, ptr(out2),
+                                              ptr(bits), stream_ptr()))          # relu(out + 0) = out, and its mask
+            want_bits = (out.reshape(B * H * W, Cin // 8, 8).float() > 0).to(torch.int32)
+            want_bits = (want_bits * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))).sum(-1).to(torch.uint8)
+            got_b = torch.empty_like(full)
+            sums_b = torch.zeros(2 * Cin, device=DEV)
+            check(lib().pxl_conv_dgrad_joinreduce_bits(bdesc, ptr(dy), ptr(wt), ptr(got_b), ptr(addend), ptr(bits), ptr(y), ptr(coef),
+                                                       ptr(sums_b), stream_ptr()))
+            torch.cuda.synchronize()
+            assert torch.equal(out2, out) and torch.equal(bits, want_bits)
+            assert torch.equal(got_b, ref)
+            assert rel_err(sums_b.cpu(), rs.cpu()) < 1e-4, (shape, cfg, "bits")
 
 
 WDMA_CASES = [
