@@ -85,7 +85,9 @@ def test_backward_is_bit_reproducible(dtype, seam, monkeypatch):
     rel = ((g - runs[0][1]).norm() / runs[0][1].norm()).item()
     # (fp32: a ReLU decision within an ulp of zero may flip; bf16: this randomly initialised trunk turns the different rounding
     # points of the two modes -- no BN-apply on load, no folded finalize -- into 0.28 of the gradient norm)
-    assert rel < (5e-3 if dtype == torch.float32 else 0.5), rel
+    # fp32 bar: five default-mode runs against one deterministic run measured 2.0e-3 .. 5.5e-3 (tools/det_probe.py, round 6, with
+    # either head implementation: each flipped ReLU of this random trunk is ~1e-3 of the gradient norm) -- 1e-2 is above the spread
+    assert rel < (1e-2 if dtype == torch.float32 else 0.5), rel
     assert abs(loss - runs[0][0]) < (1e-5 if dtype == torch.float32 else 2e-2) * abs(loss)
 
 
