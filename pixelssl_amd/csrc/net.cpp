@@ -539,7 +539,10 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
         if (rc != PXL_OK) return rc;
         const TensorInfo& tout = n->tensors[d.out];
         op.patch = false;
-        if (n->stem_patches && n->dtype == PXL_BF16 && d.in0 == n->input_tensor && !d.need_dgrad && d.ngroups == 1 &&
+        // (fp32 engine too, round 6: its stem ran on the generic kernels -- 2 x 624 us forward, 1441 us weight gradient at the tail of
+        // the backward pass; PXL_STEM_PATCHES_F32=0 restores that)
+        static const bool patches_f32 = getenv("PXL_STEM_PATCHES_F32") == nullptr || getenv("PXL_STEM_PATCHES_F32")[0] != '0';
+        if (n->stem_patches && (n->dtype == PXL_BF16 || (n->dtype == PXL_F32 && patches_f32)) && d.in0 == n->input_tensor && !d.need_dgrad && d.ngroups == 1 &&
             d.bn_in0 < 0 && d.kh * d.kw > 1 && d.cin * d.kh * d.kw <= 256 && tout.Cp % 8 == 0) {
           op.patch = true;
           op.patch_K = d.cin * d.kh * d.kw;
