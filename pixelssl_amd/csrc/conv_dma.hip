@@ -124,9 +124,12 @@ extern "C" int pxl_conv_dma_bnin(const pxl_conv_desc* d, const void* y, const vo
   PXL_REQUIRE(d && y && w && out && bin && bin->coef && bin->count > 0.f, "conv_dma_bnin: bad argument");
   PXL_REQUIRE(bin->training ? (bin->stats != nullptr && bin->nrep >= 1) : (bin->running_mean && bin->running_var),
               "conv_dma_bnin: missing statistics");
-  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || d->dtype != PXL_BF16 || d->div != 1 || d->Cin > 512 ||
-      (d->tile_cfg >= 0 && d->tile_cfg < 8))
+  if (!pxl_conv_dma_eligible(d, nullptr, nullptr) || d->div != 1 || d->Cin > 512 || (d->tile_cfg >= 0 && d->tile_cfg < 8))
     return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_bnin: descriptor is not eligible for the BN-on-load kernel");
+  if (d->dtype == PXL_F32) {       // fp32 (conv_dma_f32.hip): 1x1 / stride-1 launches only
+    const bool plain1 = d->ntaps == 1 && d->dy[0] == 0 && d->dx[0] == 0 && d->out_stride == 1 && d->Ho == d->Hi && d->Wo == d->Wi;
+    if (!plain1) return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma_bnin: the fp32 kernel applies the BatchNorm on load for 1x1 / stride-1 convolutions");
+  }
   DmaArgs a;
   a.in = y; a.w = w; a.out = out; a.bias = bias; a.addend = nullptr; a.stats = stats;
   a.ws = nullptr; a.nk_per = 0; a.raw_slabs = 0;
@@ -297,8 +300,8 @@ int conv_dma_launch(const pxl_conv_desc* d, DmaArgs& a, int sk, size_t ws_bytes,
   int cfg = d->tile_cfg;
   if (f32) {
     // conv_dma_f32.hip: plain launches only (the fp32 engine materialises its activations and finalizes on its own)
-    if (a.fin.coef != nullptr || a.bin.coef != nullptr || a.trace != nullptr)
-      return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: BN-on-load / in-kernel finalize / trace are bf16 launches");
+    if (a.fin.coef != nullptr || a.trace != nullptr)
+      return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma: in-kernel finalize / trace are bf16 launches");
     if (cfg < 8) cfg = a.Cout <= 64 ? 17 : 18;        // MFMA-bound: the small 2-stage tiles (3 workgroups per CU)
     if (cfg >= 12 && cfg < 16) cfg -= 4;
     if (cfg >= 20) cfg = 16 + (cfg & 3);

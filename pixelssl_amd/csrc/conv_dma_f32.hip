@@ -12,8 +12,10 @@
 //
 // What differs: the fp32 MFMA runs at 1/16 of the bf16 rate (256 flop/clk/CU), so a K step is 2048-4096 MFMA cycles per wave
 // against ~800 cycles of DMA -- the loop is MFMA-bound, small tiles suffice, and the epilogue's operand combination is a
-// run-time flag set (the ~3500-cycle dispatch that mattered for 12 us bf16 workgroups is 2 % of these).  No BN-on-load, no
-// paired launches, no in-kernel finalize: the fp32 engine materialises its activations (pxl_bn_apply_fwd).
+// run-time flag set (the ~3500-cycle dispatch that mattered for 12 us bf16 workgroups is 2 % of these).  No paired launches, no
+// in-kernel finalize.  BNIN (round 6, 1x1 / stride-1 launches): the A operand is the RAW output of the previous convolution and
+// relu?(bn(y)) is applied to the pieces in LDS by the lane that DMA'd them, exactly as in conv_dma_kernel.h -- in a loop that
+// waits for the MFMAs the transform is free, and the parity engine sheds its 66 pxl_bn_apply_fwd launches of 35 us.
 #include "conv_dma_kernel.h"
 
 namespace pxl_dma {
@@ -24,8 +26,9 @@ constexpr int f32_lds_bytes(int BM, int BN, int NST) {
   return ring > stage ? ring : stage;
 }
 
-template <int BM, int BN, int NST, bool GATHER>
+template <int BM, int BN, int NST, bool GATHER, bool BNIN = false>
 __global__ __launch_bounds__(256, ((BM / 64) * (BN / 64) <= 2 ? 3 : 2)) void conv_dma_f32_kernel(const DmaArgs p) {
+  static_assert(!(BNIN && GATHER), "BN-on-load: 1x1 / stride-1 launches");
   constexpr int WM = 2, WN = 2, NW = 4, NT = 256;
   constexpr int TMI = BM / WM / 32, TNI = BN / WN / 32;
   constexpr int LA = BM / (8 * NW), LB = BN / (8 * NW);
@@ -157,10 +160,76 @@ __global__ __launch_bounds__(256, ((BM / 64) * (BN / 64) <= 2 ? 3 : 2)) void con
   set_tap(ld_t);
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) issue(s);
+  // ---- BNIN: (scale, shift) of every input channel -> LDS table behind the ring / staging area (conv_dma_kernel.h)
+  unsigned ckc = 0;                                   // channel offset of the tile being consumed
+  const unsigned tab0 = lds0 + (unsigned)f32_lds_bytes(BM, BN, NST);
+  const int lchunk = (lane & 7) ^ ((wave * 4 + ((lane >> 3) >> 1)) & 7);     // the lane's (q-independent) source chunk
+  if constexpr (BNIN) {
+    float* tab = reinterpret_cast<float*>(smem + f32_lds_bytes(BM, BN, NST));
+    const pxl_bn_fin& f = p.bin;
+    const int C = p.Cin;
+    for (int c = tid; c < C; c += NT) {
+      float mean, var;
+      if (f.training) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = 0; r < f.nrep; ++r) { s1 += f.stats[(size_t)r * 2 * C + c]; s2 += f.stats[(size_t)r * 2 * C + C + c]; }
+        mean = s1 / f.count;
+        var = s2 / f.count - mean * mean;
+        if (var < 0.f) var = 0.f;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && f.running_mean != nullptr) {
+          const float unbiased = f.count > 1.f ? var * f.count / (f.count - 1.f) : var;
+          f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean;
+          f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
+        }
+      } else {
+        mean = f.running_mean[c];
+        var = f.running_var[c];
+      }
+      const float rstd = f.clamp_var ? rsqrtf(fmaxf(var, f.eps)) : rsqrtf(var + f.eps);
+      const float ga = f.gamma ? f.gamma[c] : 1.f, be = f.beta ? f.beta[c] : 0.f;
+      const float scale = ga * rstd, shift = be - mean * scale;
+      tab[c] = scale;
+      tab[C + c] = shift;
+      if (blockIdx.x == 0 && blockIdx.y == 0) { f.coef[c] = mean; f.coef[C + c] = rstd; f.coef[2 * C + c] = scale; f.coef[3 * C + c] = shift; }
+    }
+    __syncthreads();
+    ckc = ((unsigned)ks_begin * 32u) % (unsigned)C;
+  }
   __builtin_amdgcn_s_waitcnt(0xc07f);          // retire the scalar argument loads before the loop (conv_dma_kernel.h)
   int st_c = 0, st_l = NST - 1;
   for (int ks = 0; ks < nk_here; ++ks) {
     wait_vmcnt<(NST - 2) * (LA + LB)>();
+    if constexpr (BNIN) {
+      // relu?(scale * y + shift) on the pieces THIS lane has DMA'd, in place (fp32: no rounding); rows past M stay zero
+      const unsigned pa = lds0 + st_c * SB + wave * 1024 + lane * 16;
+      const unsigned tb = tab0 + (ckc + (unsigned)lchunk * 4u) * 4u;
+      u32x4 cf[4], dd[LA];
+      cf[0] = lds_read128<0>(tb);
+      cf[1] = lds_read128<0>(tb + (unsigned)p.Cin * 4u);
+      cf[2] = cf[0]; cf[3] = cf[1];
+      XformLoad<0, LA, NW * 1024>::run(dd, pa);
+      wait_xform<LA>(dd, cf);
+#pragma unroll
+      for (int q = 0; q < LA; ++q) {
+        u32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = __uint_as_float(dd[q][e]) * __uint_as_float(cf[0][e]) + __uint_as_float(cf[1][e]);
+          r[e] = __float_as_uint(p.bin_relu ? fmaxf(v, 0.f) : v);
+        }
+        dd[q] = voffA[q] != OOB ? r : dd[q];
+      }
+      XformStore<0, LA, NW * 1024>::run(dd, pa);
+      if (p.bin_z != nullptr && tn == 0) {
+        const __amdgpu_buffer_rsrc_t r_z = __builtin_amdgcn_make_buffer_rsrc(p.bin_z, 0, p.in_bytes, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < LA; ++q)
+          __builtin_amdgcn_raw_buffer_store_b128(dd[q], r_z, (int)voffA[q], (int)(ckc * 4u), 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ckc += 32;
+      if (ckc == (unsigned)p.Cin) ckc = 0;
+    }
     __builtin_amdgcn_s_barrier();
     issue(st_l);
     const unsigned sbase = lds0 + st_c * SB;
@@ -365,6 +434,21 @@ int launch_dma_f32(const DmaArgs& a, bool gather, int want_split, size_t ws_byte
   else p.ws = nullptr;
   constexpr size_t smem = (size_t)f32_lds_bytes(BM, BN, NST);
   static_assert(smem <= 156 * 1024, "LDS");
+  if (p.bin.coef != nullptr) {
+    // BN-apply on load: the 1x1 / stride-1 kernel with the coefficient table behind its ring
+    const size_t smem_b = smem + (size_t)p.Cin * 8;
+    if (gather || splitk > 1 || smem_b > 156 * 1024)
+      return pxl_set_error(PXL_ERR_UNSUPPORTED, "conv_dma (fp32): BN-on-load needs a 1x1 / stride-1 launch whose table fits the LDS");
+    static bool raised_b = false;
+    if (!raised_b) {
+      PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_f32_kernel<BM, BN, NST, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+      raised_b = true;
+    }
+    hipLaunchKernelGGL((conv_dma_f32_kernel<BM, BN, NST, false, true>), dim3(grid, 1), dim3(256), smem_b, stream, p);
+    PXL_LAUNCH_CHECK();
+    return PXL_OK;
+  }
   static bool raised[2] = {false, false};
   if (!raised[gather ? 1 : 0]) {
     if (gather) PXL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_f32_kernel<BM, BN, NST, true>),

@@ -727,7 +727,9 @@ extern "C" int pxl_net_plan_out(pxl_net* n, int B, int H, int W, int Hout, int W
   // BN-apply on load (see BnInfo::onload): materialised BNs with exactly one consumer, a convolution the LDS-DMA kernel
   // can run with its coefficient table in LDS
   for (auto& b : n->bns) b.onload = false;
-  if (n->dtype == PXL_BF16 && n->bn_onload) {
+  // (fp32, round 6: conv_dma_f32.hip applies the BatchNorm on load too -- PXL_BN_ONLOAD_F32=0: materialised as in rounds 1-5)
+  static const bool onload_f32 = getenv("PXL_BN_ONLOAD_F32") == nullptr || getenv("PXL_BN_ONLOAD_F32")[0] != '0';
+  if ((n->dtype == PXL_BF16 || (n->dtype == PXL_F32 && onload_f32)) && n->bn_onload) {
     std::vector<int> ncons(n->bns.size(), 0), conv_of(n->bns.size(), -1);
     for (size_t i = 0; i < n->ops.size(); ++i) {
       const pxl_op& d = n->ops[i].d;

@@ -290,6 +290,51 @@ def test_conv_with_bn_apply_on_load(case, cfg, training):
         assert torch.equal(out_a[..., :Cout], out_b[..., :Cout])
 
 
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("cfg", [-1, 8, 9, 10, 11, 16, 17, 18, 19])
+@pytest.mark.parametrize("case", BNIN_CASES[:3], ids=[c[0] for c in BNIN_CASES[:3]])
+def test_conv_f32_with_bn_apply_on_load(case, cfg, training):
+    """fp32 engine, round 6 (csrc/conv_dma_f32.hip BNIN): pxl_conv_dma_bnin(y, BN) against pxl_bn_finalize + pxl_bn_apply_fwd +
+    pxl_conv_igemm.  fp32 keeps every bit of the transformed tile, so the two paths may differ by the contraction of
+    scale * y + shift (fma or not) in the last place: 1e-6 instead of bit equality; coefficients and running statistics equal."""
+    ops = _ops()
+    dtype = torch.float32
+    name, B, Cin, Cout, H, W, k, s, d, p = case
+    g = torch.Generator().manual_seed(_seed(name) + 13)
+    y = torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.4
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    gamma, beta = (torch.rand(Cin, generator=g) + 0.5).to(DEV), (torch.randn(Cin, generator=g) * 0.5 + 0.3).to(DEV)
+    cip, cop = _pitch(Cin), _pitch(Cout)
+    taps = ops.fwd_taps(k, k, d, p)
+    yd = to_nhwc(y, cip, dtype)
+    wf, _ = pack_w(w, dtype, cip)
+    nrep, count = 4, float(B * H * W)
+    yf = yd.reshape(-1, cip)
+    st = torch.zeros(nrep, 2 * Cin, device=DEV)
+    for r in range(nrep):
+        part = yf[r::nrep]
+        st[r, :Cin], st[r, Cin:] = part.sum(0), (part * part).sum(0)
+    desc = ops.conv_desc(dtype, B, H, W, cip, H, W, cop, Cout, taps, out_stride=1, tile_cfg=cfg, stats_rep=4)
+    rm_a, rv_a = torch.full((Cin,), 0.25, device=DEV), torch.full((Cin,), 1.5, device=DEV)
+    coef_a = ops.bn_finalize(st, count, gamma, beta, rm_a, rv_a, nrep=nrep, training=training)
+    z = ops.bn_apply_fwd(yd, coef_a, relu=True)
+    out_a = torch.full((B, H, W, cop), 3.0, device=DEV, dtype=dtype)
+    st_a = torch.zeros(4, 2 * Cout, device=DEV)
+    ops.conv_igemm(desc, z, wf, out_a, stats=st_a)
+    rm_b, rv_b = torch.full((Cin,), 0.25, device=DEV), torch.full((Cin,), 1.5, device=DEV)
+    coef_b = torch.full((4 * Cin,), float("nan"), device=DEV)
+    fin = ops.bn_fin(st, nrep, count, gamma, beta, rm_b, rv_b, coef_b, training=training)
+    out_b = torch.full((B, H, W, cop), 5.0, device=DEV, dtype=dtype)
+    st_b = torch.zeros(4, 2 * Cout, device=DEV)
+    z_b = torch.full_like(yd, 9.0)
+    ops.conv_dma_bnin(desc, yd, wf, out_b, fin, relu=True, stats=st_b, z=z_b)
+    torch.cuda.synchronize()
+    assert torch.equal(coef_a, coef_b) and torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+    assert rel_err(z_b.cpu(), z.cpu()) < 1e-6 and (z_b == 0).float().mean().item() > 0.1
+    assert rel_err(out_b[..., :Cout].cpu(), out_a[..., :Cout].cpu()) < 2e-6, (name, cfg)
+    assert rel_err(st_b.sum(0).cpu(), st_a.sum(0).cpu()) < 1e-5
+
+
 _FUSED_CFGS = [(c, torch.bfloat16) for c in (-1, 8, 10, 11, 18, 20, 21, 26, 28, 30, 34)] + \
               [(c, torch.float32) for c in (-1, 8, 11, 17, 18)]
 
