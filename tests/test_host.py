@@ -292,7 +292,7 @@ def test_bytes_per_step_tool_reproduces_the_committed_figure():
     import bytes_per_step as BPS
     out = os.path.join(ROOT, "profiles", "_bps_check.json")
     try:
-        BPS.main(os.path.join(ROOT, "profiles", "r05_traffic.json"), os.path.join(ROOT, "profiles", "r05_g_step_breakdown.txt"), None, out)
+        BPS.main(os.path.join(ROOT, "profiles", "r06_traffic.json"), os.path.join(ROOT, "profiles", "r06_c_step_breakdown.txt"), None, out)
         got = json.load(open(out))
     finally:
         if os.path.exists(out):
@@ -304,6 +304,12 @@ def test_bytes_per_step_tool_reproduces_the_committed_figure():
     # the dominant family carries about half of the step's bytes; nothing is counted twice
     assert 0.40 < fam["conv_dma_kernel"]["bytes"] / got["bytes_per_step"] < 0.55
     assert abs(sum(v["bytes"] for v in fam.values()) - got["bytes_per_step"]) <= len(fam)
+    # round 6: ONE stem-patch launch serves both networks (Mean Teacher without input noise), the head runs as a GEMM
+    assert fam["stem_patches_kernel"]["launches"] == 1 and fam["aspp_col2im_kernel"]["launches"] == 2
+    # profiles/step_trace.json (bench.py: `step_trace`) is the same committed trace
+    st = json.load(open(os.path.join(ROOT, "profiles", "step_trace.json")))
+    assert st["launches_per_step"] == sum(v["launches"] for v in fam.values()) and st["conv_dma_launches"] == 320
+    assert abs(st["kernel_sum_ms"] - st["contraction_ms"] - st["noncontraction_ms"]) < 0.01 and st["conv_dma_ms"] < st["contraction_ms"]
 
 
 def test_per_variant_traffic_of_the_dominant_kernel_is_on_record():
@@ -315,6 +321,9 @@ def test_per_variant_traffic_of_the_dominant_kernel_is_on_record():
     assert before["EM=-2"]["traffic_bytes_per_launch"] > 5 * after["EM=-2"]["traffic_bytes_per_launch"] > 0
     assert sum(v["launches"] for v in after.values()) == 319
     assert after["EM=29"]["traffic_bytes_per_launch"] > 2.5 * after["EM=4"]["traffic_bytes_per_launch"]
+    # round 6: the join backward reads its ReLU mask as a bit plane (EM = 93 = 29 | 64): 17.8 MB less per stage-3 launch
+    r6 = json.load(open(os.path.join(ROOT, "profiles", "r06_traffic.json")))["conv_dma_variants"]
+    assert "EM=93" in r6 and r6["EM=93"]["traffic_bytes_per_launch"] < after["EM=29"]["traffic_bytes_per_launch"] - 10e6
 
 
 def test_the_steps_kernels_fit_their_register_budget():
