@@ -1,6 +1,7 @@
 // SSLCCT auxiliary-decoder perturbations on the encoder latent (NCHW fp32 [B][C][h*w], ~1M elements: HBM/launch
 // bound, one fused kernel per perturbation) and the guidance masks they use.
 //   reference: pixelssl/ssl_algorithm/ssl_cct.py:535-745 (VAT / DropOut / CutOut / Con-Msk / Obj-Msk / F-Drop / F-Noise)
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -153,8 +154,12 @@ extern "C" int pxl_l2_normalize_persample(int B, long n, const float* x, float s
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int gx = (int)((n + 256 * 8 - 1) / (256 * 8));
   if (gx > 512) gx = 512;
+  // PXL_DETERMINISTIC=1: ONE block per sample for the squared norm (its four wave sums are added in wave order, one add onto the
+  // zeroed slot): I-VAT's direction, and with it every figure of a CCT step, is then the same on every run
+  const char* de = getenv("PXL_DETERMINISTIC");
+  const int gxn = (de != nullptr && de[0] == '1') ? 1 : gx;
   l2_zero_kernel<<<1, 256, 0, s>>>(B, norm2);
-  l2_norm2_kernel<<<dim3(gx, B), 256, 0, s>>>(n, x, norm2);
+  l2_norm2_kernel<<<dim3(gxn, B), 256, 0, s>>>(n, x, norm2);
   l2_scale_kernel<<<dim3(gx, B), 256, 0, s>>>(n, x, norm2, scale, out);
   PXL_LAUNCH_CHECK();
   return PXL_OK;

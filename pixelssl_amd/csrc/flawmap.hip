@@ -201,17 +201,31 @@ __global__ void dcgt_kernel(int B, int C, long HW, const float* __restrict__ lp,
   }
 }
 
+// PXL_DETERMINISTIC=1 (read per call): the two loss sums below run as ONE block per output whose wave sums are folded in wave
+// order and stored once -- the same bits on every run (the default: many blocks, one atomic per wave, any order)
+static inline bool flaw_det_now() { const char* e = getenv("PXL_DETERMINISTIC"); return e != nullptr && e[0] == '1'; }
+__device__ __forceinline__ void block_add_ordered(float s, float scale, float* dst, bool ordered) {
+  s = wave_sum(s);
+  if (!ordered) {
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst, s * scale);
+    return;
+  }
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *dst += (((ws[0] + ws[1]) + ws[2]) + ws[3]) * scale;          // (one block per output: no one else writes it)
+}
+
 // loss[b] = mean_i (a - g)^2 ; da = 2 (a - g) / n * gout[b]
-__global__ void mse_ps_fwd_kernel(long n, const float* __restrict__ a, const float* __restrict__ g,
-                                  float* __restrict__ loss) {
+__global__ __launch_bounds__(256) void mse_ps_fwd_kernel(long n, const float* __restrict__ a, const float* __restrict__ g,
+                                                         float* __restrict__ loss, int ordered) {
   const int b = blockIdx.y;
   float s = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float d = a[b * n + i] - g[b * n + i];
     s += d * d;
   }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(loss + b, s / (float)n);
+  block_add_ordered(s, 1.f / (float)n, loss + b, ordered != 0);
 }
 __global__ void mse_ps_bwd_kernel(long n, const float* __restrict__ a, const float* __restrict__ g,
                                   const float* __restrict__ gout, float* __restrict__ da) {
@@ -221,13 +235,12 @@ __global__ void mse_ps_bwd_kernel(long n, const float* __restrict__ a, const flo
     da[b * n + i] = k * (a[b * n + i] - g[b * n + i]);
 }
 
-__global__ void masked_sq_fwd_kernel(long n, const float* __restrict__ x, const float* __restrict__ mask,
-                                     float* __restrict__ out) {
+__global__ __launch_bounds__(256) void masked_sq_fwd_kernel(long n, const float* __restrict__ x, const float* __restrict__ mask,
+                                                            float* __restrict__ out, int ordered) {
   float s = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     s += mask[i] * x[i] * x[i];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s / (float)n);
+  block_add_ordered(s, 1.f / (float)n, out, ordered != 0);
 }
 __global__ void masked_sq_bwd_kernel(long n, const float* __restrict__ x, const float* __restrict__ mask,
                                      const float* __restrict__ gout, float* __restrict__ dx) {
@@ -334,8 +347,9 @@ extern "C" int pxl_mse_persample_fwd(int B, long n, const float* a, const float*
   PXL_REQUIRE(a && g && loss && B > 0 && n > 0, "mse_persample_fwd: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   PXL_CHECK_HIP(hipMemsetAsync(loss, 0, (size_t)B * sizeof(float), s));
-  const int gx = (int)((n + 256 * 8 - 1) / (256 * 8));
-  hipLaunchKernelGGL(mse_ps_fwd_kernel, dim3(gx, B), dim3(256), 0, s, n, a, g, loss);
+  const bool det = flaw_det_now();
+  const int gx = det ? 1 : (int)((n + 256 * 8 - 1) / (256 * 8));
+  hipLaunchKernelGGL(mse_ps_fwd_kernel, dim3(gx, B), dim3(256), 0, s, n, a, g, loss, det ? 1 : 0);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -353,8 +367,9 @@ extern "C" int pxl_masked_sq_mean_fwd(long n, const float* x, const float* mask,
   PXL_REQUIRE(x && mask && out && n > 0, "masked_sq_mean_fwd: bad argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   PXL_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), s));
-  long g = (n + 256 * 8 - 1) / (256 * 8);
-  hipLaunchKernelGGL(masked_sq_fwd_kernel, dim3((int)(g > 2048 ? 2048 : g)), dim3(256), 0, s, n, x, mask, out);
+  const bool det = flaw_det_now();
+  long g = det ? 1 : (n + 256 * 8 - 1) / (256 * 8);
+  hipLaunchKernelGGL(masked_sq_fwd_kernel, dim3((int)(g > 2048 ? 2048 : g)), dim3(256), 0, s, n, x, mask, out, det ? 1 : 0);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }

@@ -202,11 +202,15 @@ inline bool ok_dtype(int dtype) { return dtype == PXL_F32 || dtype == PXL_BF16; 
 
 }  // namespace
 
-#define IBN_GEOM(target)                                        \
+// PXL_DETERMINISTIC=1 (read per call: these entry points are also used without an executor): the REDUCING launches take one row
+// group per (sample, channel group), so every sum receives exactly one add onto its zeroed slot -- the same bits on every run
+// (the default spreads a sample's rows over several blocks whose atomics land in any order)
+static inline bool ibn_det_now() { const char* e = getenv("PXL_DETERMINISTIC"); return e != nullptr && e[0] == '1'; }
+#define IBN_GEOM(target, reducing)                              \
   const int epc = dtype == PXL_F32 ? 4 : 8;                     \
   PXL_REQUIRE(C % epc == 0, "ibnorm: C=%d must be a multiple of %d", C, epc); \
   const ColGeom g = col_geom(C, epc);                           \
-  const int rpg = rows_per_group(HW, g, (target) / B > 0 ? (target) / B : 1); \
+  const int rpg = ((reducing) && ibn_det_now()) ? (HW + g.rl - 1) / g.rl * g.rl : rows_per_group(HW, g, (target) / B > 0 ? (target) / B : 1); \
   const dim3 grid(g.ncg, cdiv(HW, rpg), B);                     \
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
@@ -220,7 +224,7 @@ extern "C" int pxl_ibn_stats_acc(int dtype, int B, int HW, int C, const void* y,
 }
 static int ibn_stats_impl(int dtype, int B, int HW, int C, const void* y, float* sums, int zero, void* stream) {
   PXL_REQUIRE(y && sums && B > 0 && HW > 0 && ok_dtype(dtype), "ibn_stats: bad argument");
-  IBN_GEOM(1024)
+  IBN_GEOM(1024, true)
   if (zero) PXL_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)B * 2 * C * sizeof(float), s));
   if (dtype == PXL_F32)
     hipLaunchKernelGGL((ibn_reduce_kernel<float, 0>), grid, dim3(256), 0, s, HW, C, (const float*)y, nullptr, nullptr, 0.f, sums, rpg);
@@ -252,7 +256,7 @@ extern "C" int pxl_ibn_coef(int B, int C, int nb, int HW, float count_bn, const 
 extern "C" int pxl_ibn_apply_fwd(int dtype, int B, int HW, int C, const void* y, const float* coef, float slope, void* out,
                                  void* stream) {
   PXL_REQUIRE(y && coef && out && B > 0 && ok_dtype(dtype), "ibn_apply_fwd: bad argument");
-  IBN_GEOM(2048)
+  IBN_GEOM(2048, false)
   if (dtype == PXL_F32)
     hipLaunchKernelGGL(ibn_apply_fwd_kernel<float>, grid, dim3(256), 0, s, HW, C, (const float*)y, coef, slope, (float*)out, rpg);
   else
@@ -274,7 +278,7 @@ extern "C" int pxl_ibn_bwd_reduce_acc(int dtype, int B, int HW, int C, const voi
 static int ibn_bwd_reduce_impl(int dtype, int B, int HW, int C, const void* dout, const void* y, const float* coef, float slope,
                                float* bsums, int zero, void* stream) {
   PXL_REQUIRE(dout && y && coef && bsums && B > 0 && ok_dtype(dtype), "ibn_bwd_reduce: bad argument");
-  IBN_GEOM(1024)
+  IBN_GEOM(1024, true)
   if (zero) PXL_CHECK_HIP(hipMemsetAsync(bsums, 0, (size_t)B * 2 * C * sizeof(float), s));
   if (dtype == PXL_F32)
     hipLaunchKernelGGL((ibn_reduce_kernel<float, 1>), grid, dim3(256), 0, s, HW, C, (const float*)y, (const float*)dout, coef, slope, bsums, rpg);
@@ -288,7 +292,7 @@ extern "C" int pxl_ibn_bwd_apply(int dtype, int B, int HW, int C, int nb, const 
                                  const float* coef, const float* bsums, const float* bn, float count_bn, int training,
                                  float slope, void* dy, void* stream) {
   PXL_REQUIRE(dout && y && coef && bsums && bn && dy && B > 0 && ok_dtype(dtype), "ibn_bwd_apply: bad argument");
-  IBN_GEOM(2048)
+  IBN_GEOM(2048, false)
   if (dtype == PXL_F32)
     hipLaunchKernelGGL(ibn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, HW, C, nb, (const float*)dout, (const float*)y, coef,
                        bsums, bn, 1.f / count_bn, 1.f / (float)HW, training, slope, (float*)dy, rpg);

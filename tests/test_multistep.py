@@ -42,9 +42,12 @@ EPS32 = 1.1920929e-07
 # 0.65 ... 0.74 and the largest norm ratio over 1.03 ... 1.35, and one run in ten left the first version of these bars
 # (0.55 / 1.45).  They now sit where that spread cannot reach; a no-op (ratio 0) or a wrong-signed update (cosine < 0)
 # still fails.
-CCT_BF16_MIN_COS = 0.45
-CCT_BF16_MEDIAN_COS = 0.95
-CCT_BF16_RATIO = (0.8, 1.8)
+# Round 6: PXL_DETERMINISTIC=1 now covers GCT and CCT as well (ordered IBNorm sums, flaw-map loss sums, I-VAT's norm: two consecutive
+# runs print identical figures, profiles/r06_det_run{1,2}_figures.txt) -- under the mode the bars sit at 1.25 x the deterministic
+# values (worst cosine 0.694 / 0.698 on conv1, largest norm ratio 1.30, median cosine 0.997) instead of below the default spread
+CCT_BF16_MIN_COS = 0.55 if DET else 0.45
+CCT_BF16_MEDIAN_COS = 0.98 if DET else 0.95
+CCT_BF16_RATIO = (0.8, 1.65) if DET else (0.8, 1.8)
 
 
 def _fx(name):
