@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpixelhip.so")
+# (PXL_LIB_PATH: a variant build of the same library for A/B runs -- tools/build_alt.sh; the default is the in-tree build)
+LIB_PATH = os.environ.get("PXL_LIB_PATH") or os.path.join(_HERE, "libpixelhip.so")
 
 PXL_F32, PXL_BF16 = 0, 1
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_RESIDUAL, OP_HEAD, OP_ACT, OP_IBN = 0, 1, 2, 3, 4, 5, 6

@@ -110,8 +110,13 @@ constexpr unsigned OOB = 0x80000000u;
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// cache policy of the tile DMAs (the builtin's aux immediate: 1 = sc0, 2 = nt, 16 = sc1): compile-time constants, 0 in the product
+// build; tools/build_alt.sh builds variants of the library with other values (DMA_AUX_A=2 ...) for A/B runs
+constexpr int DMA_AUX_A = 0;
+constexpr int DMA_AUX_W = 0;
+template <int AUX = 0>
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds, 16, (int)voff, (int)soff, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds, 16, (int)voff, (int)soff, 0, AUX);
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
   auto issue = [&](int stage) {
     unsigned char* sa = smem + stage * SB + wave * 1024;
 #pragma unroll
-    for (int q = 0; q < LA; ++q) dma16(r_in, sa + q * NW * 1024, voffA[q], kcb);
+    for (int q = 0; q < LA; ++q) dma16<DMA_AUX_A>(r_in, sa + q * NW * 1024, voffA[q], kcb);
     if constexpr (BNIN) {
       unsigned bits = 0;
 #pragma unroll
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(WM * WN * 64, dma_waves_per_simd(WM * WN, (BM / WM 
     }
     unsigned char* sb = smem + stage * SB + BM * 128 + wave * 1024;
 #pragma unroll
-    for (int q = 0; q < LB; ++q) dma16(r_w, sb + q * NW * 1024, voffB[q], kwb);
+    for (int q = 0; q < LB; ++q) dma16<DMA_AUX_W>(r_w, sb + q * NW * 1024, voffB[q], kwb);
     kwb += 128;
     kcb += 128;
     if (kcb == c_hi) {           // block-uniform: next tap (channel-sliced split-K: back to the slice's first channel)
