@@ -573,6 +573,12 @@ def main():
     prof = None
     if a.host_profile:
         import cProfile
+        from pixelssl_amd import _lib as plib
+        call_stats = plib.enable_call_profile()
+        one_step(a.warmup)                     # (binds the timing wrappers outside the timed region)
+        fence()
+        for v in call_stats.values():
+            v[0], v[1] = 0, 0.0
         prof = cProfile.Profile()
         prof.enable()
     t0 = time.perf_counter()
@@ -597,6 +603,11 @@ def main():
         st.sort_stats("tottime").print_stats(45)
         st.sort_stats("cumulative").print_stats(60)
         sys.stderr.write(buf.getvalue())
+        tot = sum(v[1] for v in call_stats.values())
+        sys.stderr.write("host time inside the C-ABI per step (of %.3f ms/step wall; under cProfile): %.3f ms over %d calls\n"
+                         % (1e3 * elapsed / a.steps, 1e3 * tot / a.steps, sum(v[0] for v in call_stats.values()) // a.steps))
+        for name, (c, sec) in sorted(call_stats.items(), key=lambda kv: -kv[1][1])[:30]:
+            sys.stderr.write("  %-40s %6.1f calls/step %8.3f ms/step %7.2f us/call\n" % (name, c / a.steps, 1e3 * sec / a.steps, 1e6 * sec / max(c, 1)))
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

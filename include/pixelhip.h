@@ -616,6 +616,27 @@ int pxl_net_head_loss(pxl_net* net, const void* arena, const pxl_net* teacher, c
 int pxl_net_backward_low(pxl_net* net, const float* params, const void* packed, float* grads, void* arena,
                          size_t arena_bytes, void* scratch, size_t scratch_bytes, int training, void* stream);
 
+/* Consistency seam of one SSLCCT auxiliary decoder: everything the reference runs between the decoder's own-resolution logits
+ * and their gradient -- F.interpolate(bilinear, align_corners=False) to the main prediction's size, the channel soft-max
+ * (sslcct_activate_ad_preds), nn.MSELoss against the detached soft-max of the main decoder (ssl_cct.py:482-484) and autograd's
+ * backward through the three -- without the full-resolution planes.  low: NHWC [B][h][w][Cp] in the engine dtype; target: NCHW
+ * fp32 [B][C][H][W].  pxl_cons_head_fwd writes loss[0] (the MSE mean; ordered != 0: folded in row order, bit-reproducible) and
+ * parks the row-reduced gradient for a UNIT incoming gradient in `workspace` (pxl_cons_head_workspace bytes);
+ * pxl_cons_head_bwd writes d(low) = gout[0] * that gradient (gout: device scalar, the incoming gradient of the scalar loss).
+ * PXL_ERR_UNSUPPORTED when an output row does not fit the LDS staging (pxl_cons_head_lds_bytes > 64 KiB).
+ * pxl_net_cons_head_*: the same on the low-resolution logits of a pxl_net_forward that ran with logits == NULL; the backward
+ * half leaves d(low) where pxl_net_backward_low starts from. */
+size_t pxl_cons_head_lds_bytes(int C, int W);
+size_t pxl_cons_head_workspace(int B, int w, int C, int H);
+int pxl_cons_head_fwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* low,
+                      const float* target, void* workspace, size_t ws_bytes, float* loss, int ordered, void* stream);
+int pxl_cons_head_bwd(int dtype, int B, int h, int w, int Cp, int C, int H, int align_corners, const void* workspace,
+                      size_t ws_bytes, const float* gout, void* dlow, void* stream);
+int pxl_net_cons_head_supported(const pxl_net* net);
+int pxl_net_cons_head_fwd(pxl_net* net, const void* arena, const float* target, void* scratch, size_t scratch_bytes, float* loss,
+                          void* stream);
+int pxl_net_cons_head_bwd(pxl_net* net, void* scratch, size_t scratch_bytes, const float* gout, void* stream);
+
 /* Seed the gradient of the latent tensor before pxl_net_backward (auxiliary decoders that consume the latent outside
  * this program, SSLCCT): dlatent NCHW fp32 [B,C,h,w]; consumed (and cleared) by the next backward */
 int pxl_net_seed_latent_grad(pxl_net* net, void* scratch, size_t scratch_bytes, const float* dlatent, void* stream);

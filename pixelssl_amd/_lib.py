@@ -267,6 +267,13 @@ SIGNATURES = {
     "pxl_head_loss_hp": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _Z, _P, _P]),
     "pxl_net_head_loss_hp": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _Z, _P, _P]),
     "pxl_net_backward_low": (_I, [_P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
+    "pxl_cons_head_lds_bytes": (_Z, [_I, _I]),
+    "pxl_cons_head_workspace": (_Z, [_I, _I, _I, _I]),
+    "pxl_cons_head_fwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P, _I, _P]),
+    "pxl_cons_head_bwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _P]),
+    "pxl_net_cons_head_supported": (_I, [_P]),
+    "pxl_net_cons_head_fwd": (_I, [_P, _P, _P, _P, _Z, _P, _P]),
+    "pxl_net_cons_head_bwd": (_I, [_P, _P, _Z, _P, _P]),
     "pxl_net_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
 }
 
@@ -288,6 +295,36 @@ def lib():
             fn.argtypes = args
         _lib = h
     return _lib
+
+
+class _CallProfile:
+    """Proxy of the ctypes handle that accumulates host wall time and call counts per C-ABI symbol (bench.py --host-profile:
+    where a host-paced step spends its time).  Off unless enable_call_profile() was called."""
+
+    def __init__(self, h):
+        self._h, self.stats = h, {}
+
+    def __getattr__(self, name):
+        import time
+        fn, st = getattr(self._h, name), self.stats.setdefault(name, [0, 0.0])
+
+        def timed(*a):
+            t0 = time.perf_counter()
+            r = fn(*a)
+            st[1] += time.perf_counter() - t0
+            st[0] += 1
+            return r
+        setattr(self, name, timed)
+        return timed
+
+
+def enable_call_profile():
+    """Route every later lib() call through a timing proxy; returns its {symbol: [calls, seconds]} table."""
+    global _lib
+    h = lib()
+    if not isinstance(h, _CallProfile):
+        _lib = _CallProfile(h)
+    return _lib.stats
 
 
 def check(rc):

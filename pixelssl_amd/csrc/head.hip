@@ -156,7 +156,8 @@ __global__ __launch_bounds__(320) void upsample_bwd_rows_kernel(int C, int H, in
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(int B, int h, int w, int Cp, int C, int H,
                                                                 float sy, int align, const float* __restrict__ tmp,
-                                                                T* __restrict__ dlow) {
+                                                                T* __restrict__ dlow, const float* __restrict__ scale_dev) {
+  const float scale = scale_dev != nullptr ? scale_dev[0] : 1.f;     // (pxl_cons_head_bwd: the incoming gradient of a scalar loss)
   const long total = (long)B * h * w * Cp;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cp);
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(int B, int h, in
         if (wgt != 0.f) acc += wgt * tmp[(((size_t)b * H + y) * w + x0) * C + c];
       }
     }
-    dlow[i] = from_f<T>(acc);
+    dlow[i] = from_f<T>(scale_dev != nullptr ? acc * scale : acc);
   }
 }
 
@@ -657,10 +658,10 @@ extern "C" int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, 
   if (grid > 4096) grid = 4096;
   if (dtype == PXL_F32)
     hipLaunchKernelGGL(upsample_bwd_cols_kernel<float>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
-                       (const float*)workspace, (float*)dlow);
+                       (const float*)workspace, (float*)dlow, nullptr);
   else
     hipLaunchKernelGGL(upsample_bwd_cols_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
-                       (const float*)workspace, (bf16_t*)dlow);
+                       (const float*)workspace, (bf16_t*)dlow, nullptr);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -761,10 +762,10 @@ int head_loss_impl(int dtype, int B, int h, int w, int Cp, int C, int H, int W, 
   if (grid > 4096) grid = 4096;
   if (dtype == PXL_F32)
     hipLaunchKernelGGL(upsample_bwd_cols_kernel<float>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
-                       (const float*)workspace, (float*)dlow);
+                       (const float*)workspace, (float*)dlow, nullptr);
   else
     hipLaunchKernelGGL(upsample_bwd_cols_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
-                       (const float*)workspace, (bf16_t*)dlow);
+                       (const float*)workspace, (bf16_t*)dlow, nullptr);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
 }
@@ -800,3 +801,187 @@ extern "C" int pxl_head_loss_hp(int dtype, int B, int h, int w, int Cp, int C, i
                         1.0f, mse_weight_dev, dlow, workspace, ws_bytes, sums, stream);
 }
 
+
+namespace {
+// ---- consistency seam of one SSLCCT auxiliary decoder ---------------------------------------------------------------------
+// The reference resizes every auxiliary prediction to the size of the main prediction (F.interpolate, bilinear,
+// align_corners=False), applies the channel soft-max (task/sseg/func.py sslcct_activate_ad_preds) and takes nn.MSELoss against
+// the detached soft-max of the main decoder (ssl_cct.py:482-484); autograd then walks back through the MSE, the soft-max and
+// the resize.  Per decoder at 4 x 21 x 513 x 513 that is five launches over 88 MB planes (up-sampling + soft-max 44 us, MSE
+// forward 51, MSE backward 47, the two adjoint passes 129 + 67).  Everything between the decoder's own-resolution logits and
+// their gradient is a function of (low, target): this kernel evaluates it per output row in registers / LDS --
+//   per pixel:  z = bilinear(low), p = softmax(z), d = p - target, loss += d^2,
+//               dp = (2 / n) d,   G = p (dp - sum_c dp p)                               (the same expressions as the separate kernels)
+//   then the x-reduction of upsample_bwd_rows_kernel on G -> tmp[b][y][x0][c]
+// -- for a UNIT incoming gradient; the loss is a scalar, so pxl_cons_head_bwd only scales: upsample_bwd_cols_kernel finishes
+// d(low) and multiplies by the incoming gradient read from device memory.  One block per (row y, sample b); LDS: G [C][W+1]
+// and the column tables (the low-resolution corners come from global memory as 16-byte chunks, like the forward kernel).
+template <typename T>
+__global__ __launch_bounds__(320) void cons_rows_kernel(int C, int Cp, int h, int w, int H, int W, float sy, float sx, int align,
+                                                        const T* __restrict__ low, const float* __restrict__ target,
+                                                        float two_inv_n, float inv_n, float* __restrict__ tmp,
+                                                        float* __restrict__ loss, float* __restrict__ rowpart) {
+  extern __shared__ float g[];   // [C][W+1] | ci0[W] ci1[W] cl1[W]
+  __shared__ float red[8];
+  const int y = blockIdx.x, b = blockIdx.y;
+  const int ld = W + 1;
+  int* ci0 = reinterpret_cast<int*>(g + (size_t)C * ld);
+  int* ci1 = ci0 + W;
+  float* cl1 = reinterpret_cast<float*>(ci1 + W);
+  int y0, y1;
+  float ly;
+  src_coord(y, sy, align, h, y0, y1, ly);
+  const size_t plane = (size_t)H * W;
+  const size_t base = (size_t)b * C * plane + (size_t)y * W;
+  constexpr int EPC = Elem<T>::EPC;
+  float acc = 0.f;
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    int x0, x1;
+    float lx;
+    src_coord(x, sx, align, w, x0, x1, lx);
+    ci0[x] = x0; ci1[x] = x1; cl1[x] = lx;
+    float t[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) t[c] = c < C ? target[base + c * plane + x] : 0.f;      // (every plane load in flight before the first use)
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    const T* p00 = low + ((size_t)(b * h + y0) * w + x0) * Cp;
+    const T* p01 = low + ((size_t)(b * h + y0) * w + x1) * Cp;
+    const T* p10 = low + ((size_t)(b * h + y1) * w + x0) * Cp;
+    const T* p11 = low + ((size_t)(b * h + y1) * w + x1) * Cp;
+    float v[MAXC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < MAXC / EPC; ++q) {
+      if (q * EPC < C) {
+        float a[EPC], bq[EPC], cq[EPC], d[EPC];
+        Chunk<T>::unpack(*reinterpret_cast<const uint4*>(p00 + q * EPC), a);
+        Chunk<T>::unpack(*reinterpret_cast<const uint4*>(p01 + q * EPC), bq);
+        Chunk<T>::unpack(*reinterpret_cast<const uint4*>(p10 + q * EPC), cq);
+        Chunk<T>::unpack(*reinterpret_cast<const uint4*>(p11 + q * EPC), d);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const int c = q * EPC + e;
+          v[c] = w00 * a[e] + w01 * bq[e] + w10 * cq[e] + w11 * d[e];          // (upsample_softmax_fwd_kernel's expression)
+          if (c < C) mx = fmaxf(mx, v[c]);
+        }
+      }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) { v[c] = __expf(v[c] - mx); sum += v[c]; }
+    const float inv = 1.f / sum;
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) {
+        v[c] = v[c] * inv;                       // p
+        const float d = v[c] - t[c];
+        acc += d * d;
+        t[c] = two_inv_n * d;                    // dp (mse_bwd_kernel with a unit incoming gradient)
+        dot += t[c] * v[c];
+      }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) g[c * ld + x] = v[c] * (t[c] - dot);       // soft-max Jacobian (upsample_bwd_rows_kernel's expression)
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < w * C; o += blockDim.x) {
+    const int c = o % C, x0 = o / C;
+    const float xoff = align ? 0.f : 0.5f;
+    int xlo = (int)floorf(((float)(x0 - 1) + xoff) / sx - xoff) - 1;
+    int xhi = (int)ceilf(((float)(x0 + 1) + xoff) / sx - xoff) + 1;
+    if (xlo < 0) xlo = 0;
+    if (xhi > W - 1) xhi = W - 1;
+    float a = 0.f;
+    for (int x = xlo; x <= xhi; ++x) {
+      const float l1 = cl1[x];
+      float wgt = 0.f;
+      if (ci0[x] == x0) wgt += 1.f - l1;
+      if (ci1[x] == x0) wgt += l1;
+      a += wgt * g[c * ld + x];
+    }
+    tmp[(((size_t)b * H + y) * w + x0) * C + c] = a;
+  }
+  // the loss: one atomic per block -- or, rowpart != NULL, one plain store per block, folded in row order afterwards
+  const float v = wave_sum(acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) tot += red[k];
+    tot *= inv_n;
+    if (rowpart != nullptr) rowpart[(size_t)b * H + y] = tot; else atomicAdd(loss, tot);
+  }
+}
+
+__global__ void cons_rows_finish_kernel(int n, const float* __restrict__ rowpart, float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float a = 0.f;
+    for (int i = 0; i < n; ++i) a += rowpart[i];
+    loss[0] = a;
+  }
+}
+}  // namespace
+
+extern "C" size_t pxl_cons_head_lds_bytes(int C, int W) { return (size_t)C * (W + 1) * sizeof(float) + (size_t)W * 3 * sizeof(float); }
+extern "C" size_t pxl_cons_head_workspace(int B, int w, int C, int H) { return pxl_upsample_bwd_workspace(B, w, C, H) + (size_t)B * H * sizeof(float); }
+
+// low: NHWC [B][h][w][Cp] in the engine dtype (the decoder's own-resolution logits); target: NCHW fp32 [B][C][H][W] (the main
+// decoder's soft-max, detached).  Writes loss[0] = mean((softmax(resize(low)) - target)^2) and, into `workspace`
+// (pxl_cons_head_workspace bytes), the row-reduced gradient for a unit incoming gradient -- consumed by pxl_cons_head_bwd.
+// ordered != 0: the loss is folded in row order (bit-reproducible).
+extern "C" int pxl_cons_head_fwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* low,
+                                 const float* target, void* workspace, size_t ws_bytes, float* loss, int ordered, void* stream) {
+  PXL_REQUIRE(low && target && workspace && loss, "cons_head_fwd: null argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "cons_head_fwd: bad dtype");
+  PXL_REQUIRE(C >= 1 && C <= MAXC && C <= Cp && Cp % 8 == 0, "cons_head_fwd: C=%d / pitch %d unsupported (max %d, pitch a multiple of 8)", C, Cp, MAXC);
+  PXL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && h >= 1 && w >= 1 && (!align_corners || (H > 1 && W > 1)), "cons_head_fwd: degenerate sizes");
+  if (ws_bytes < pxl_cons_head_workspace(B, w, C, H)) return pxl_set_error(PXL_ERR_WORKSPACE, "cons_head_fwd: workspace too small");
+  const size_t smem = pxl_cons_head_lds_bytes(C, W);
+  if (smem > 64 * 1024) return pxl_set_error(PXL_ERR_UNSUPPORTED, "cons_head_fwd: row too wide for LDS staging (W=%d)", W);
+  const int align = align_corners ? 1 : 0;
+  const float sy = align ? (float)(h - 1) / (float)(H - 1) : (float)h / (float)H;
+  const float sx = align ? (float)(w - 1) / (float)(W - 1) : (float)w / (float)W;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const double n = (double)B * C * (double)H * W;
+  float* rowpart = ordered ? reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + pxl_upsample_bwd_workspace(B, w, C, H)) : nullptr;
+  if (!ordered) PXL_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
+  const int threads = (W > 256 && W <= 640) ? 320 : 256;
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(cons_rows_kernel<float>, dim3(H, B), dim3(threads), smem, s, C, Cp, h, w, H, W, sy, sx, align, (const float*)low,
+                       target, (float)(2.0 / n), (float)(1.0 / n), (float*)workspace, loss, rowpart);
+  else
+    hipLaunchKernelGGL(cons_rows_kernel<bf16_t>, dim3(H, B), dim3(threads), smem, s, C, Cp, h, w, H, W, sy, sx, align, (const bf16_t*)low,
+                       target, (float)(2.0 / n), (float)(1.0 / n), (float*)workspace, loss, rowpart);
+  PXL_LAUNCH_CHECK();
+  if (ordered) {
+    hipLaunchKernelGGL(cons_rows_finish_kernel, dim3(1), dim3(64), 0, s, B * H, rowpart, loss);
+    PXL_LAUNCH_CHECK();
+  }
+  return PXL_OK;
+}
+
+// d(low) [B][h][w][Cp] (engine dtype) = gout[0] * (the gradient pxl_cons_head_fwd left in `workspace`); gout: device scalar
+extern "C" int pxl_cons_head_bwd(int dtype, int B, int h, int w, int Cp, int C, int H, int align_corners, const void* workspace,
+                                 size_t ws_bytes, const float* gout, void* dlow, void* stream) {
+  PXL_REQUIRE(workspace && gout && dlow, "cons_head_bwd: null argument");
+  PXL_REQUIRE(dtype == PXL_F32 || dtype == PXL_BF16, "cons_head_bwd: bad dtype");
+  PXL_REQUIRE(C >= 1 && C <= MAXC && C <= Cp, "cons_head_bwd: C=%d unsupported (max %d)", C, MAXC);
+  if (ws_bytes < pxl_upsample_bwd_workspace(B, w, C, H)) return pxl_set_error(PXL_ERR_WORKSPACE, "cons_head_bwd: workspace too small");
+  const int align = align_corners ? 1 : 0;
+  const float sy = align ? (float)(h - 1) / (float)(H - 1) : (float)h / (float)H;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)B * h * w * Cp;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (dtype == PXL_F32)
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<float>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
+                       (const float*)workspace, (float*)dlow, gout);
+  else
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
+                       (const float*)workspace, (bf16_t*)dlow, gout);
+  PXL_LAUNCH_CHECK();
+  return PXL_OK;
+}

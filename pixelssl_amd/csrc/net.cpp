@@ -1958,6 +1958,34 @@ extern "C" int pxl_net_head_forward(pxl_net* n, const void* arena, float* logits
                                   logits, prob, stream);
 }
 
+// Consistency seam of an SSLCCT auxiliary decoder (csrc/head.hip: pxl_cons_head_fwd / _bwd) on the low-resolution logits of a pass
+// that ran with logits == NULL: the forward half writes the loss and parks the row-reduced gradient (for a unit incoming gradient)
+// in the plan's up-sampling workspace; the backward half turns it into d(loss)/d(low) in the gradient slot pxl_net_backward_low
+// starts from, scaled by the incoming gradient gout[0] (device memory).  Nothing else of this plan may run in between.
+extern "C" int pxl_net_cons_head_supported(const pxl_net* n) {
+  if (!n || !n->planned || n->head_op < 0) return 0;
+  const TensorInfo& low = n->tensors[n->ops[n->head_op].d.in0];
+  return n->classes <= 32 && low.Cp % 8 == 0 && pxl_cons_head_lds_bytes(n->classes, n->Wo) <= 64 * 1024 &&
+         n->up_ws_bytes >= pxl_cons_head_workspace(n->B, low.W, n->classes, n->Ho) ? 1 : 0;
+}
+extern "C" int pxl_net_cons_head_fwd(pxl_net* n, const void* arena, const float* target, void* scratch, size_t scratch_bytes, float* loss,
+                                     void* stream) {
+  PXL_REQUIRE(n && n->planned && arena && target && scratch && loss && n->head_op >= 0, "net_cons_head_fwd: bad argument (plan first)");
+  if (scratch_bytes < n->scratch_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_cons_head_fwd: scratch too small");
+  const pxl_op& d = n->ops[n->head_op].d;
+  const TensorInfo& low = n->tensors[d.in0];
+  return pxl_cons_head_fwd(n->dtype, n->B, low.H, low.W, low.Cp, n->classes, n->Ho, n->Wo, d.stride, at(arena, low.off), target,
+                           at(scratch, n->up_ws_off), n->up_ws_bytes, loss, n->deterministic ? 1 : 0, stream);
+}
+extern "C" int pxl_net_cons_head_bwd(pxl_net* n, void* scratch, size_t scratch_bytes, const float* gout, void* stream) {
+  PXL_REQUIRE(n && n->planned && scratch && gout && n->head_op >= 0, "net_cons_head_bwd: bad argument (plan first)");
+  if (scratch_bytes < n->scratch_bytes) return pxl_set_error(PXL_ERR_WORKSPACE, "net_cons_head_bwd: scratch too small");
+  const pxl_op& d = n->ops[n->head_op].d;
+  const TensorInfo& low = n->tensors[d.in0];
+  return pxl_cons_head_bwd(n->dtype, n->B, low.H, low.W, low.Cp, n->classes, n->Ho, d.stride, at(scratch, n->up_ws_off), n->up_ws_bytes,
+                           gout, at(scratch, low.goff), stream);
+}
+
 // 1 when pxl_net_head_loss can run on this plan (the full-resolution row fits the kernel's LDS staging)
 extern "C" int pxl_net_head_loss_supported(const pxl_net* n) {
   if (!n || !n->planned || n->head_op < 0) return 0;

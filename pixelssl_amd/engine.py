@@ -755,19 +755,23 @@ class SegNetCore(nn.Module):
         self._plan(B, H, W, None, inference=not need_graph and not self.training)
         return lib().pxl_net_borrow_patches(self._net, ctypes.c_void_p(token[1]), token[2]) == 0
 
-    def forward_deferred(self, x, prepared=None):
+    def forward_deferred(self, x, prepared=None, out_size=None, force_graph=False, seam="head"):
         """Forward pass up to the LOW-RESOLUTION logits: the up-sampling / soft-max op is not run and no full-resolution
         plane is written.  -> DeferredHead, which pixelssl_amd.functional.head_losses consumes (criterion + consistency
         term + their backward on the low-resolution maps, csrc/head.hip) and whose .backward() runs the executor's
         backward from the gradient that call left behind.  A consumer that wants the planes after all calls
-        .materialize().  None when this plan cannot run the fused seam (the caller then uses forward())."""
+        .materialize().  None when this plan cannot run the fused seam (the caller then uses forward()).
+        out_size: the HEAD's output size when it is not the input size (SSLCCT's auxiliary decoders); force_graph: a pass that
+        will be differentiated although grad mode is off here (the caller is an autograd Function's forward); seam: which fused
+        seam must be able to run on the plan -- "head" (functional.head_losses) or "cons" (functional.decoder_consistency)."""
         if not x.is_cuda:
             raise _lib.PixelHipError("SegNetCore runs on the GPU only (input is on %s); there is no CPU path" % x.device)
         x = x.contiguous().float()
         B, _, H, W = x.shape
-        need_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list[:1])
-        self._plan(B, H, W, None, inference=not need_graph and not self.training)
-        if not lib().pxl_net_head_loss_supported(self._cur.net):
+        need_graph = bool(force_graph) or (torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list[:1]))
+        self._plan(B, H, W, out_size, inference=not need_graph and not self.training)
+        ok = lib().pxl_net_cons_head_supported(self._cur.net) if seam == "cons" else lib().pxl_net_head_loss_supported(self._cur.net)
+        if not ok:
             return None
         self._ensure_packed()
         if prepared is not None and prepared[4] is self._cur and prepared[3].data_ptr() == x.data_ptr():

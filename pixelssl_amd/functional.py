@@ -154,6 +154,65 @@ def head_losses(s_head, t_head, gt, n_ce, mse_lo, mse_hi, ce_weight, mse_weight,
     return sums[:n_ce], (sums[B:B + n_ce] if t_head is not None else None), sums[2 * B]
 
 
+class _DecoderConsistency(torch.autograd.Function):
+    """One SSLCCT auxiliary decoder from its (perturbed) latent to its consistency term, without the full-resolution planes:
+    the decoder's executor stops at its own-resolution logits, csrc/head.hip: pxl_cons_head_fwd evaluates resize + soft-max + MSE
+    and parks the gradient for a unit incoming gradient; the backward scales it by the incoming gradient (a device scalar), runs
+    the executor's backward from there and returns the latent's gradient (ssl_cct.py:476-484 + autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, core, target, out_size, holder):
+        head = core.forward_deferred(x, out_size=out_size, force_graph=True, seam="cons")
+        if head is None:
+            raise _lib.PixelHipError("decoder_consistency: the fused seam cannot run on this plan (check decoder_consistency_supported first)")
+        pl = head.plan
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        check(lib().pxl_net_cons_head_fwd(pl.net, ptr(head.arena), ptr(target), ptr(pl.scratch), pl.scratch.numel(), ptr(loss), stream_ptr()))
+        pl.grad_gen = getattr(pl, "grad_gen", 0) + 1         # the parked gradient is this plan's seam state from here on
+        head._parked_gen = pl.grad_gen
+        ctx.head, ctx.x_shape = head, tuple(x.shape)
+        holder.append(head)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        head = ctx.head
+        pl, core = head.plan, head.core
+        if getattr(head, "_parked_gen", None) != getattr(pl, "grad_gen", 0):
+            raise _lib.PixelHipError("decoder_consistency: the gradient parked by the forward has been overwritten (another pass / seam ran "
+                                     "on the same plan before this backward)")
+        g = gout.detach().reshape(1).contiguous().float()
+        check(lib().pxl_net_cons_head_bwd(pl.net, ptr(pl.scratch), pl.scratch.numel(), ptr(g), stream_ptr()))
+        head.mark_grad()
+        head.backward()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(ctx.x_shape, device=g.device, dtype=torch.float32)
+            check(lib().pxl_net_input_grad(pl.net, ptr(pl.scratch), ptr(dx), stream_ptr()))
+        ctx.head = None
+        return dx, None, None, None, None, None
+
+
+def decoder_consistency_supported(core, x, target, out_size):
+    """can decoder_consistency run for this decoder / latent / target?  (plans the shape, runs nothing)"""
+    if not (x.is_cuda and target.is_cuda and x.dim() == 4 and target.dim() == 4):
+        return False
+    B, _, H, W = x.shape
+    if tuple(target.shape) != (B, core.num_classes) + tuple(out_size) or target.dtype != torch.float32:
+        return False
+    core._plan(B, H, W, out_size, inference=False)
+    return bool(lib().pxl_net_cons_head_supported(core._cur.net))
+
+
+def decoder_consistency(core, x, target, out_size):
+    """MSE(softmax(resize(decoder(x), out_size)), target) of an engine.AuxDecoderCore as ONE differentiable scalar (gradients: the
+    decoder's parameters and x).  -> (term, DeferredHead); head.materialize() yields the resized prediction when somebody wants it."""
+    _gpu(x, target)
+    holder = []
+    term = _DecoderConsistency.apply(x.contiguous().float(), core._anchor, core, target.detach().contiguous(), tuple(out_size), holder)
+    return term, holder[0]
+
+
 class MSELoss(torch.nn.Module):
     """Drop-in for the `nn.MSELoss()` the SSL algorithms instantiate."""
 

@@ -13,6 +13,7 @@ Device mapping:
     the reference's cv2 call (csrc/contour.cpp);
   * the gradient the decoders send into the latent is seeded into the main model's backward (engine._SegNetFn).
 """
+import collections.abc
 import math
 import os
 import random
@@ -26,6 +27,7 @@ from ..utils import CLASSIFICATION, logger, cmd, tool
 from ..nn import func
 from ..nn.module import patch_replication_callback
 from ..functional import MSELoss
+from .. import functional as PF
 from ..engine import AuxDecoderCore
 from .. import _lib, streams
 from .. import dist as pdist
@@ -197,6 +199,14 @@ class _AuxDecoder(nn.Module):
             out_size = (x.shape[2] * self.upscale, x.shape[3] * self.upscale)
         return self._decode(self.perturb(x, pred_of_main_decoder), out_size)
 
+    def consistency(self, x, pred_of_main_decoder, target, out_size):
+        """The decoder's whole branch of ssl_cct.py:476-484 as one differentiable scalar: perturbation, decoder body, resize to
+        `out_size`, soft-max and MSE against `target` (functional.decoder_consistency: no full-resolution plane is written).
+        -> (term, DeferredHead) or None when the fused seam cannot run for these shapes (the caller then uses forward())."""
+        if not PF.decoder_consistency_supported(self.upsample, x, target, out_size):
+            return None
+        return PF.decoder_consistency(self.upsample, self.perturb(x, pred_of_main_decoder), target, out_size)
+
 
 class VATDecoder(_AuxDecoder):
     def __init__(self, upscale, in_channels, num_classes, xi=1e-1, eps=10.0, iterations=1, **kw):
@@ -362,6 +372,26 @@ class FeatureNoiseDecoder(_AuxDecoder):
 # wrapped model
 # ----------------------------------------------------------------------------------------------------------------------
 
+class _LazyPreds(collections.abc.Sequence):
+    """resulter['ul_ad_preds'] (ssl_cct.py:478): the auxiliary predictions, resized to the main prediction's size.  The reference's
+    training loop fetches the list and never reads it (ssl_cct.py:267); entries of decoders that ran the fused seam are
+    materialised from the decoder's low-resolution logits on first access."""
+
+    def __init__(self, items):
+        self._items = list(items)
+
+    def __len__(self):
+        return len(self._items)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self._items)))]
+        it = self._items[i]
+        if not torch.is_tensor(it):
+            it = self._items[i] = it.materialize(want_prob=False)[0]
+        return it
+
+
 class WrappedCCTModel(nn.Module):
     """ssl_cct.py:425-491: main model + auxiliary decoders + both criterions in one module; param_groups = the main
     model's groups + one group for all decoders at lr * ad_lr_scale."""
@@ -417,6 +447,10 @@ class WrappedCCTModel(nn.Module):
                 for i in cuts:
                     self.auxiliary_decoders[i].prefetch(ul_main_pred)
                 order = [i for i in order if i not in cuts] + cuts
+            # (SSLCCT.train_step: the labeled backward is enqueued HERE -- behind the unlabeled forward, ahead of the decoders)
+            hook, self.after_main_forward = getattr(self, 'after_main_forward', None), None
+            if hook is not None:
+                hook()
             # The decoders are independent between the latent and their loss term and each is a chain of ~30 small
             # kernels: they are dealt round-robin onto the main stream and PXL_CCT_STREAMS side streams (autograd runs
             # each decoder's backward on the stream of its forward)
@@ -425,18 +459,28 @@ class WrappedCCTModel(nn.Module):
             for st in lanes:
                 st.wait_stream(main)
             ul_ad_preds, terms = [None] * len(order), []
+            # PXL_CCT_FUSED_SEAM (default on): a decoder's resize + soft-max + MSE and their backward run as the fused seam on its
+            # own-resolution logits (_AuxDecoder.consistency); its resized prediction is produced only if somebody reads it
+            fused = os.environ.get('PXL_CCT_FUSED_SEAM', '1') != '0' and isinstance(self.cons_criterion, MSELoss)
+
+            def branch(ad):
+                got = ad.consistency(ul_ad_inp, ul_main_pred, ul_ad_gt, size) if fused else None
+                if got is not None:
+                    return got[1], got[0]
+                pred, act = ad.forward(ul_ad_inp, pred_of_main_decoder=ul_main_pred, out_size=size)
+                return pred, self.cons_criterion.forward(act, ul_ad_gt)
+
             for k, i in enumerate(order):
                 ad = self.auxiliary_decoders[i]
                 lane = lanes[k % (len(lanes) + 1) - 1] if lanes and k % (len(lanes) + 1) else None
                 if lane is None:
-                    pred, act = ad.forward(ul_ad_inp, pred_of_main_decoder=ul_main_pred, out_size=size)
-                    term = self.cons_criterion.forward(act, ul_ad_gt)
+                    pred, term = branch(ad)
                 else:
                     with torch.cuda.stream(lane):
-                        pred, act = ad.forward(ul_ad_inp, pred_of_main_decoder=ul_main_pred, out_size=size)
-                        term = self.cons_criterion.forward(act, ul_ad_gt)
-                    for t in (pred, act, term):
-                        t.record_stream(main)
+                        pred, term = branch(ad)
+                    for t in (pred, term):
+                        if torch.is_tensor(t):
+                            t.record_stream(main)
                 ul_ad_preds[i] = pred
                 terms.append(term)
             for st in lanes:
@@ -444,7 +488,7 @@ class WrappedCCTModel(nn.Module):
             cons = terms[0]
             for term in terms[1:]:
                 cons = cons + term
-            resulter['ul_ad_preds'] = ul_ad_preds
+            resulter['ul_ad_preds'] = _LazyPreds(ul_ad_preds)
             resulter['cons_loss'] = torch.mean(cons) / len(ul_ad_preds)
         else:
             resulter['ul_ad_preds'] = None
@@ -525,6 +569,11 @@ class SSLCCT(ssl_base._SSLBase):
         # buffers and stay ordered.  PXL_CCT_SPLIT_BACKWARD=0: one backward over the sum, as the reference.
         side = self._labeled_stream() if has_ul else None
         main = torch.cuda.current_stream() if side is not None else None
+        # PXL_CCT_LATE_LBWD (default on): the labeled BACKWARD is enqueued after the unlabeled forward of the main model (and the
+        # start of G-Cutout's mask copy) instead of before it.  The host then reaches the copy's event with the labeled backward
+        # and six decoders queued behind it: the contour search on the host (~2.3 ms) no longer leaves the GPU idle, and the
+        # labeled backward runs beside the unlabeled forward and the decoders instead of in front of them.
+        late = side is not None and os.environ.get('PXL_CCT_LATE_LBWD', '1') != '0'
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -532,8 +581,14 @@ class SSLCCT(ssl_base._SSLBase):
                 task_loss = tool.dict_value(l_res, 'task_loss', err=True).mean()
                 fwd_done = torch.cuda.Event()
                 fwd_done.record()
-                task_loss.backward()
+                if not late:
+                    task_loss.backward()
             main.wait_event(fwd_done)
+            if late:
+                def labeled_backward():
+                    with torch.cuda.stream(side):
+                        task_loss.backward()
+                self.model.module.after_main_forward = labeled_backward
             for v in l_res.values():
                 for t in (v if isinstance(v, (tuple, list)) else (v,)):
                     if torch.is_tensor(t):
@@ -547,6 +602,9 @@ class SSLCCT(ssl_base._SSLBase):
             ul_gt = func.split_tensor_tuple(gt, lbs, self.args.batch_size)
             ul_inp = func.split_tensor_tuple(inp, lbs, self.args.batch_size)
             ul_res, _ = self.model.forward(ul_inp, ul_gt, True)
+            pending, self.model.module.after_main_forward = getattr(self.model.module, 'after_main_forward', None), None
+            if pending is not None:         # (the wrapped model did not reach its decoders: nothing ran the labeled backward yet)
+                pending()
             cons_loss = ramp * self.args.cons_scale * tool.dict_value(ul_res, 'cons_loss', err=True).mean()
         else:
             cons_loss = torch.zeros((), device=task_loss.device)
