@@ -67,6 +67,18 @@ def ssl_cct(args, model_dict, optimizer_dict, lrer_dict, criterion_dict, task_fu
 # device ops
 # ----------------------------------------------------------------------------------------------------------------------
 
+# step timeline (tools/cct_timeline.py): TIMELINE = [] switches marks on; each mark = (name, host perf_counter, an event recorded on
+# the current stream).  None (the default): mark() returns at once.
+TIMELINE = None
+
+
+def mark(name):
+    if TIMELINE is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        TIMELINE.append((name, time.perf_counter(), ev))
+
+
 def _f32(t):
     return None if t is None else t.contiguous().float()
 
@@ -294,7 +306,9 @@ class CutOutDecoder(_AuxDecoder):
         pre = getattr(self, '_prefetched', None)
         if pre is not None:
             self._prefetched = None
+            mark('cutout: before the copy event')
             pre[1].synchronize()
+            mark('cutout: copy event reached')
             fg = pre[0].numpy()
         else:
             fg = fg_mask_nearest(output, (H, W)).to(torch.uint8).cpu().numpy()    # D2H + sync, like the reference
@@ -325,6 +339,7 @@ class CutOutDecoder(_AuxDecoder):
                 used += [uw, uh]
                 sw, sh = int(uw * (nw + 1)), int(uh * (nh + 1))
                 out[b, min_h + sh:min_h + sh + int(bb_h * erase), min_w + sw:min_w + sw + int(bb_w * erase)] = 0
+        mark('cutout: contours done')
         self.last_boxes = used_boxes
         self.last_draw = used
         ys = np.minimum(np.floor(np.arange(resize[0], dtype=np.float32) * np.float32(H / resize[0])).astype(np.int64), H - 1)
@@ -448,6 +463,7 @@ class WrappedCCTModel(nn.Module):
                     self.auxiliary_decoders[i].prefetch(ul_main_pred)
                 order = [i for i in order if i not in cuts] + cuts
             # (SSLCCT.train_step: the labeled backward is enqueued HERE -- behind the unlabeled forward, ahead of the decoders)
+            mark('unlabeled: main forward enqueued')
             hook, self.after_main_forward = getattr(self, 'after_main_forward', None), None
             if hook is not None:
                 hook()
@@ -485,6 +501,7 @@ class WrappedCCTModel(nn.Module):
                 terms.append(term)
             for st in lanes:
                 main.wait_stream(st)
+            mark('unlabeled: decoders enqueued')
             cons = terms[0]
             for term in terms[1:]:
                 cons = cons + term
@@ -567,6 +584,7 @@ class SSLCCT(ssl_base._SSLBase):
         # stream; the unlabeled forward starts once the labeled FORWARD is done (same running-statistics order as the
         # reference) and overlaps with the labeled backward; the two backward passes accumulate into the same gradient
         # buffers and stay ordered.  PXL_CCT_SPLIT_BACKWARD=0: one backward over the sum, as the reference.
+        mark('step start')
         side = self._labeled_stream() if has_ul else None
         main = torch.cuda.current_stream() if side is not None else None
         # PXL_CCT_LATE_LBWD (default on): the labeled BACKWARD is enqueued after the unlabeled forward of the main model (and the
@@ -581,13 +599,16 @@ class SSLCCT(ssl_base._SSLBase):
                 task_loss = tool.dict_value(l_res, 'task_loss', err=True).mean()
                 fwd_done = torch.cuda.Event()
                 fwd_done.record()
+                mark('labeled: forward enqueued (side)')
                 if not late:
                     task_loss.backward()
+                    mark('labeled: backward enqueued (side)')
             main.wait_event(fwd_done)
             if late:
                 def labeled_backward():
                     with torch.cuda.stream(side):
                         task_loss.backward()
+                        mark('labeled: backward enqueued (side)')
                 self.model.module.after_main_forward = labeled_backward
             for v in l_res.values():
                 for t in (v if isinstance(v, (tuple, list)) else (v,)):
@@ -611,12 +632,14 @@ class SSLCCT(ssl_base._SSLBase):
         if side is not None:
             main.wait_stream(side)              # the labeled backward has finished accumulating
             cons_loss.backward()
+            mark('unlabeled: backward enqueued')
         else:
             (task_loss + cons_loss).backward()
         lanes = getattr(self.model.module, '_lane_streams', [])
         for st in lanes:                    # the decoders' backward ran on their lanes and wrote the flat gradient buffers
             torch.cuda.current_stream().wait_stream(st)
         self.optimizer.step()
+        mark('optimizer enqueued')
         if not self.args.is_epoch_lrer:
             self.lrer.step()
         return dict(task_loss=task_loss.detach(), cons_loss=cons_loss.detach()), l_res, ul_res
