@@ -368,3 +368,50 @@ def test_the_steps_kernels_fit_their_register_budget():
         assert k["scratch"] == 0 and k["vspill"] == 0 and IR.occupancy(k)[0] >= 3, (n, k)
     for n, k in pick("head_loss_cells_kernel").items():                   # the seam kernel: 47 KB of LDS, 3 workgroups per CU
         assert k["scratch"] == 0 and k["lds"] <= 48 * 1024 and IR.occupancy(k)[1] >= 3, (n, k)
+
+
+def test_call_profile_proxy_counts_calls_and_keeps_results():
+    """_lib._CallProfile (bench.py --host-profile: host time per C-ABI symbol): a transparent proxy -- same return values, one
+    [calls, seconds] row per symbol, wrappers bound once."""
+    from pixelssl_amd import _lib
+
+    class Fake:
+        def __init__(self):
+            self.n = 0
+
+        def pxl_a(self, x, y):
+            self.n += 1
+            return x + y
+
+        def pxl_b(self):
+            return 7
+
+    h = Fake()
+    p = _lib._CallProfile(h)
+    assert p.pxl_a(2, 3) == 5 and p.pxl_a(1, 1) == 2 and p.pxl_b() == 7 and h.n == 2
+    assert p.stats["pxl_a"][0] == 2 and p.stats["pxl_b"][0] == 1 and p.stats["pxl_a"][1] >= 0.0
+    assert p.pxl_a is p.pxl_a                      # (bound on first use: no __getattr__ on the hot path)
+    with pytest.raises(AttributeError):
+        p.pxl_missing
+
+
+def test_lazy_auxiliary_predictions_materialise_on_first_access():
+    """ssl_cct._LazyPreds (resulter['ul_ad_preds'] when the decoders ran the fused seam): a sequence whose entries are produced from
+    the decoder's low-resolution logits when somebody reads them, once."""
+    from pixelssl_amd.ssl_algorithm.ssl_cct import _LazyPreds
+
+    class Head:
+        calls = 0
+
+        def materialize(self, want_prob=True):
+            assert want_prob is False
+            Head.calls += 1
+            return torch.full((1, 2), 3.0), None
+
+    t = torch.zeros(1, 2)
+    lp = _LazyPreds([t, Head(), Head()])
+    assert len(lp) == 3 and Head.calls == 0
+    assert lp[0] is t and float(lp[1].sum()) == 6.0 and Head.calls == 1
+    assert lp[1] is lp[1] and Head.calls == 1
+    assert [tuple(v.shape) for v in lp] == [(1, 2)] * 3 and Head.calls == 2
+    assert len(lp[1:]) == 2
