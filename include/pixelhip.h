@@ -626,7 +626,7 @@ int pxl_net_backward_low(pxl_net* net, const float* params, const void* packed, 
  * PXL_ERR_UNSUPPORTED when an output row does not fit the LDS staging (pxl_cons_head_lds_bytes > 64 KiB).
  * pxl_net_cons_head_*: the same on the low-resolution logits of a pxl_net_forward that ran with logits == NULL; the backward
  * half leaves d(low) where pxl_net_backward_low starts from. */
-size_t pxl_cons_head_lds_bytes(int C, int W);
+size_t pxl_cons_head_lds_bytes(int w, int C, int W);
 size_t pxl_cons_head_workspace(int B, int w, int C, int H);
 int pxl_cons_head_fwd(int dtype, int B, int h, int w, int Cp, int C, int H, int W, int align_corners, const void* low,
                       const float* target, void* workspace, size_t ws_bytes, float* loss, int ordered, void* stream);

@@ -267,7 +267,7 @@ SIGNATURES = {
     "pxl_head_loss_hp": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _Z, _P, _P]),
     "pxl_net_head_loss_hp": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _Z, _P, _P]),
     "pxl_net_backward_low": (_I, [_P, _P, _P, _P, _P, _Z, _P, _Z, _I, _P]),
-    "pxl_cons_head_lds_bytes": (_Z, [_I, _I]),
+    "pxl_cons_head_lds_bytes": (_Z, [_I, _I, _I]),
     "pxl_cons_head_workspace": (_Z, [_I, _I, _I, _I]),
     "pxl_cons_head_fwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P, _I, _P]),
     "pxl_cons_head_bwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P, _P]),

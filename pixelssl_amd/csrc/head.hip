@@ -24,6 +24,51 @@ __device__ __forceinline__ void src_coord(int o, float scale, int align, int in_
   l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
 }
 
+// The source index i0 of src_coord is monotone in the destination index: start(v) = the first destination index whose i0 is >= v
+// (start(in_size) = out_size), found by bisection.  The destinations that touch source index v are then two contiguous runs --
+// [start(v-1), start(v)) through their i1 (weight l1) and [start(v), start(v+1)) through their i0 (weight 1 - l1; at the clamped last
+// index i1 == i0, so the weight is (1 - l1) + l1) -- which is what the adjoint passes below walk instead of testing every candidate
+// of a padded interval.
+__device__ __forceinline__ int first_dst_ge(int v, float scale, int align, int in_size, int out_size) {
+  if (v <= 0) return 0;
+  if (v >= in_size) return out_size;
+  int lo = 0, hi = out_size;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    int a0, a1; float l;
+    src_coord(mid, scale, align, in_size, a0, a1, l);
+    if (a0 >= v) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+// sum over the destinations x that touch source index x0 of weight(x) * g[x * gs], in ascending x; cs = the start() table in LDS,
+// l1 = the interpolation weights of the destinations (LDS).  Loads of four terms are issued together.
+__device__ __forceinline__ float adjoint_run_lds(const float* __restrict__ g, int gs, const float* __restrict__ l1, const int* __restrict__ cs,
+                                                 int x0, int in_size) {
+  const int a = cs[x0 > 0 ? x0 - 1 : 0], m = cs[x0], e = cs[x0 + 1];
+  const bool last = x0 == in_size - 1;
+  float acc = 0.f;
+  for (int x = (x0 > 0 ? a : m); x < e; x += 4) {
+    float lv[4], gv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int xx = x + k < e ? x + k : e - 1;
+      lv[k] = l1[xx];
+      gv[k] = g[(size_t)xx * gs];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (x + k < e) {
+        float wgt = 0.f;
+        if (x + k >= m) { wgt += 1.f - lv[k]; if (last) wgt += lv[k]; } else wgt += lv[k];
+        acc += wgt * gv[k];
+      }
+    }
+  }
+  return acc;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_softmax_fwd_kernel(int B, int h, int w, int Cp, int C, int H,
                                                                    int W, float sy, float sx, int align,
@@ -91,19 +136,19 @@ __global__ __launch_bounds__(320) void upsample_bwd_rows_kernel(int C, int H, in
                                                                 const float* __restrict__ dprob,
                                                                 const float* __restrict__ prob,
                                                                 float* __restrict__ tmp) {
-  extern __shared__ float g[];   // [C][W+1], then per full-res column: i0, i1 (int) and l1 (float)
+  extern __shared__ float g[];   // [C][W+1], then l1 per full-res column [W] and the start() table [w + 1]
   const int y = blockIdx.x, b = blockIdx.y;
   const size_t plane = (size_t)H * W;
   const size_t base = (size_t)b * C * plane + (size_t)y * W;
   const int ld = W + 1;
-  int* ci0 = reinterpret_cast<int*>(g + (size_t)C * ld);
-  int* ci1 = ci0 + W;
-  float* cl1 = reinterpret_cast<float*>(ci1 + W);
+  float* cl1 = g + (size_t)C * ld;
+  int* cs = reinterpret_cast<int*>(cl1 + W);
+  for (int v = threadIdx.x; v <= w; v += blockDim.x) cs[v] = first_dst_ge(v, sx, align, w, W);
   for (int x = threadIdx.x; x < W; x += blockDim.x) {
     int i0, i1;
     float l1;
     src_coord(x, sx, align, w, i0, i1, l1);      // once per column (the reduction below used to redo it 2 * C times)
-    ci0[x] = i0; ci1[x] = i1; cl1[x] = l1;
+    cl1[x] = l1;
     // every channel plane load of this column is issued before the first use (a loop over the run-time C kept one HBM
     // round trip per channel in flight: 179 us for 177 MB)
     float dl[MAXC], dp[MAXC], pr[MAXC];
@@ -130,24 +175,10 @@ __global__ __launch_bounds__(320) void upsample_bwd_rows_kernel(int C, int H, in
       }
   }
   __syncthreads();
-  // each output (x0, c): full-res x with floor(sx*x) == x0 contribute (1-l), with floor == x0-1 contribute l
+  // each output (x0, c): the full-res x whose i0 is x0 contribute (1 - l), those whose i0 is x0 - 1 contribute l
   for (int o = threadIdx.x; o < w * C; o += blockDim.x) {
     const int c = o % C, x0 = o / C;
-    // candidate range: x in ((x0-1)/sx, (x0+1)/sx)
-    const float xoff = align ? 0.f : 0.5f;     // dst = (src + off) / scale - off
-    int xlo = (int)floorf(((float)(x0 - 1) + xoff) / sx - xoff) - 1;
-    int xhi = (int)ceilf(((float)(x0 + 1) + xoff) / sx - xoff) + 1;
-    if (xlo < 0) xlo = 0;
-    if (xhi > W - 1) xhi = W - 1;
-    float acc = 0.f;
-    for (int x = xlo; x <= xhi; ++x) {
-      const float l1 = cl1[x];
-      float wgt = 0.f;
-      if (ci0[x] == x0) wgt += 1.f - l1;
-      if (ci1[x] == x0) wgt += l1;
-      acc += wgt * g[c * ld + x];
-    }
-    tmp[(((size_t)b * H + y) * w + x0) * C + c] = acc;
+    tmp[(((size_t)b * H + y) * w + x0) * C + c] = adjoint_run_lds(g + c * ld, 1, cl1, cs, x0, w);
   }
 }
 
@@ -157,8 +188,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(int B, int h, int w, int Cp, int C, int H,
                                                                 float sy, int align, const float* __restrict__ tmp,
                                                                 T* __restrict__ dlow, const float* __restrict__ scale_dev) {
+  extern __shared__ float cols_lds[];      // l1 per full-res row [H], then the start() table [h + 1]
+  float* rl1 = cols_lds;
+  int* rs = reinterpret_cast<int*>(rl1 + H);
+  for (int v = threadIdx.x; v <= h; v += blockDim.x) rs[v] = first_dst_ge(v, sy, align, h, H);
+  for (int y = threadIdx.x; y < H; y += blockDim.x) {
+    int i0, i1;
+    float l1;
+    src_coord(y, sy, align, h, i0, i1, l1);
+    rl1[y] = l1;
+  }
+  __syncthreads();
   const float scale = scale_dev != nullptr ? scale_dev[0] : 1.f;     // (pxl_cons_head_bwd: the incoming gradient of a scalar loss)
   const long total = (long)B * h * w * Cp;
+  const size_t ystride = (size_t)w * C;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cp);
     long r = i / Cp;
@@ -167,19 +210,24 @@ __global__ __launch_bounds__(256) void upsample_bwd_cols_kernel(int B, int h, in
     const int b = (int)(r / h);
     float acc = 0.f;
     if (c < C) {
-      const float yoff = align ? 0.f : 0.5f;
-      int ylo = (int)floorf(((float)(y0 - 1) + yoff) / sy - yoff) - 1;
-      int yhi = (int)ceilf(((float)(y0 + 1) + yoff) / sy - yoff) + 1;
-      if (ylo < 0) ylo = 0;
-      if (yhi > H - 1) yhi = H - 1;
-      for (int y = ylo; y <= yhi; ++y) {
-        int i0, i1;
-        float l1;
-        src_coord(y, sy, align, h, i0, i1, l1);
-        float wgt = 0.f;
-        if (i0 == y0) wgt += 1.f - l1;
-        if (i1 == y0) wgt += l1;
-        if (wgt != 0.f) acc += wgt * tmp[(((size_t)b * H + y) * w + x0) * C + c];
+      // the rows that touch y0: [start(y0 - 1), start(y0)) through i1, [start(y0), start(y0 + 1)) through i0; eight loads in flight
+      // (four outputs per thread and trip on top of that were measured: no faster)
+      const int m = rs[y0], e = rs[y0 + 1];
+      const bool last = y0 == h - 1;
+      const float* col = tmp + ((size_t)b * H * w + x0) * C + c;
+      for (int y = (y0 > 0 ? rs[y0 - 1] : m); y < e; y += 8) {
+        float tv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tv[k] = col[(size_t)(y + k < e ? y + k : e - 1) * ystride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (y + k < e) {
+            const float l1 = rl1[y + k];
+            float wgt = 0.f;
+            if (y + k >= m) { wgt += 1.f - l1; if (last) wgt += l1; } else wgt += l1;
+            if (wgt != 0.f) acc += wgt * tv[k];
+          }
+        }
       }
     }
     dlow[i] = from_f<T>(scale_dev != nullptr ? acc * scale : acc);
@@ -646,7 +694,7 @@ extern "C" int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, 
   const float sy = align ? (float)(h - 1) / (float)(H - 1) : (float)h / (float)H;
   const float sx = align ? (float)(w - 1) / (float)(W - 1) : (float)w / (float)W;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const size_t smem = (size_t)C * (W + 1) * sizeof(float) + (size_t)W * 3 * sizeof(float);
+  const size_t smem = (size_t)C * (W + 1) * sizeof(float) + (size_t)(W + w + 1) * sizeof(float);      // G, l1 per column, the start() table
   PXL_REQUIRE(smem <= 64 * 1024, "upsample_softmax_bwd: row too wide for LDS staging (W=%d)", W);
   // threads per row: W = 513 in two even passes (320 + 193) instead of 256 + 256 + 1
   const int rows_threads = (W > 256 && W <= 640) ? 320 : 256;
@@ -657,10 +705,10 @@ extern "C" int pxl_upsample_softmax_bwd(int dtype, int B, int h, int w, int Cp, 
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(upsample_bwd_cols_kernel<float>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<float>, dim3(grid), dim3(256), (size_t)(H + h + 1) * sizeof(float), s, B, h, w, Cp, C, H, sy, align,
                        (const float*)workspace, (float*)dlow, nullptr);
   else
-    hipLaunchKernelGGL(upsample_bwd_cols_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<bf16_t>, dim3(grid), dim3(256), (size_t)(H + h + 1) * sizeof(float), s, B, h, w, Cp, C, H, sy, align,
                        (const float*)workspace, (bf16_t*)dlow, nullptr);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
@@ -761,10 +809,10 @@ int head_loss_impl(int dtype, int B, int h, int w, int Cp, int C, int H, int W, 
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(upsample_bwd_cols_kernel<float>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<float>, dim3(grid), dim3(256), (size_t)(H + h + 1) * sizeof(float), s, B, h, w, Cp, C, H, sy, align,
                        (const float*)workspace, (float*)dlow, nullptr);
   else
-    hipLaunchKernelGGL(upsample_bwd_cols_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<bf16_t>, dim3(grid), dim3(256), (size_t)(H + h + 1) * sizeof(float), s, B, h, w, Cp, C, H, sy, align,
                        (const float*)workspace, (bf16_t*)dlow, nullptr);
   PXL_LAUNCH_CHECK();
   return PXL_OK;
@@ -816,43 +864,48 @@ namespace {
 // -- for a UNIT incoming gradient; the loss is a scalar, so pxl_cons_head_bwd only scales: upsample_bwd_cols_kernel finishes
 // d(low) and multiplies by the incoming gradient read from device memory.  One block per (row y, sample b); LDS: G [C][W+1]
 // and the column tables (the low-resolution corners come from global memory as 16-byte chunks, like the forward kernel).
-template <typename T>
-__global__ __launch_bounds__(320) void cons_rows_kernel(int C, int Cp, int h, int w, int H, int W, float sy, float sx, int align,
+// CT: the class count as a compile-time constant (21: the sseg workloads; registers for 21 instead of MAXC channels and no guards)
+// or 0 = run-time C <= MAXC.
+template <typename T, int CT>
+__global__ __launch_bounds__(320) void cons_rows_kernel(int Crt, int Cp, int h, int w, int H, int W, float sy, float sx, int align,
                                                         const T* __restrict__ low, const float* __restrict__ target,
                                                         float two_inv_n, float inv_n, float* __restrict__ tmp,
                                                         float* __restrict__ loss, float* __restrict__ rowpart) {
-  extern __shared__ float g[];   // [C][W+1] | ci0[W] ci1[W] cl1[W]
+  constexpr int CC = CT ? CT : MAXC;
+  const int C = CT ? CT : Crt;
+  extern __shared__ float g[];   // [C][W+1] | l1 per column [W] | the start() table [w + 1]
   __shared__ float red[8];
   const int y = blockIdx.x, b = blockIdx.y;
   const int ld = W + 1;
-  int* ci0 = reinterpret_cast<int*>(g + (size_t)C * ld);
-  int* ci1 = ci0 + W;
-  float* cl1 = reinterpret_cast<float*>(ci1 + W);
+  float* cl1 = g + (size_t)C * ld;
+  int* cs = reinterpret_cast<int*>(cl1 + W);
+  for (int v = threadIdx.x; v <= w; v += blockDim.x) cs[v] = first_dst_ge(v, sx, align, w, W);
   int y0, y1;
   float ly;
   src_coord(y, sy, align, h, y0, y1, ly);
   const size_t plane = (size_t)H * W;
   const size_t base = (size_t)b * C * plane + (size_t)y * W;
   constexpr int EPC = Elem<T>::EPC;
+  constexpr int NQ = (CC + EPC - 1) / EPC;
   float acc = 0.f;
   for (int x = threadIdx.x; x < W; x += blockDim.x) {
     int x0, x1;
     float lx;
     src_coord(x, sx, align, w, x0, x1, lx);
-    ci0[x] = x0; ci1[x] = x1; cl1[x] = lx;
-    float t[MAXC];
+    cl1[x] = lx;
+    float t[CC];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) t[c] = c < C ? target[base + c * plane + x] : 0.f;      // (every plane load in flight before the first use)
+    for (int c = 0; c < CC; ++c) t[c] = (CT || c < C) ? target[base + c * plane + x] : 0.f;      // (every plane load in flight before the first use)
     const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
     const T* p00 = low + ((size_t)(b * h + y0) * w + x0) * Cp;
     const T* p01 = low + ((size_t)(b * h + y0) * w + x1) * Cp;
     const T* p10 = low + ((size_t)(b * h + y1) * w + x0) * Cp;
     const T* p11 = low + ((size_t)(b * h + y1) * w + x1) * Cp;
-    float v[MAXC];
+    float v[NQ * EPC];
     float mx = -INFINITY;
 #pragma unroll
-    for (int q = 0; q < MAXC / EPC; ++q) {
-      if (q * EPC < C) {
+    for (int q = 0; q < NQ; ++q) {
+      if (CT || q * EPC < C) {
         float a[EPC], bq[EPC], cq[EPC], d[EPC];
         Chunk<T>::unpack(*reinterpret_cast<const uint4*>(p00 + q * EPC), a);
         Chunk<T>::unpack(*reinterpret_cast<const uint4*>(p01 + q * EPC), bq);
@@ -868,13 +921,13 @@ __global__ __launch_bounds__(320) void cons_rows_kernel(int C, int Cp, int h, in
     }
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < C) { v[c] = __expf(v[c] - mx); sum += v[c]; }
+    for (int c = 0; c < CC; ++c)
+      if (CT || c < C) { v[c] = __expf(v[c] - mx); sum += v[c]; }
     const float inv = 1.f / sum;
     float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < C) {
+    for (int c = 0; c < CC; ++c)
+      if (CT || c < C) {
         v[c] = v[c] * inv;                       // p
         const float d = v[c] - t[c];
         acc += d * d;
@@ -882,31 +935,18 @@ __global__ __launch_bounds__(320) void cons_rows_kernel(int C, int Cp, int h, in
         dot += t[c] * v[c];
       }
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < C) g[c * ld + x] = v[c] * (t[c] - dot);       // soft-max Jacobian (upsample_bwd_rows_kernel's expression)
+    for (int c = 0; c < CC; ++c)
+      if (CT || c < C) g[c * ld + x] = v[c] * (t[c] - dot);       // soft-max Jacobian (upsample_bwd_rows_kernel's expression)
   }
   __syncthreads();
   for (int o = threadIdx.x; o < w * C; o += blockDim.x) {
     const int c = o % C, x0 = o / C;
-    const float xoff = align ? 0.f : 0.5f;
-    int xlo = (int)floorf(((float)(x0 - 1) + xoff) / sx - xoff) - 1;
-    int xhi = (int)ceilf(((float)(x0 + 1) + xoff) / sx - xoff) + 1;
-    if (xlo < 0) xlo = 0;
-    if (xhi > W - 1) xhi = W - 1;
-    float a = 0.f;
-    for (int x = xlo; x <= xhi; ++x) {
-      const float l1 = cl1[x];
-      float wgt = 0.f;
-      if (ci0[x] == x0) wgt += 1.f - l1;
-      if (ci1[x] == x0) wgt += l1;
-      a += wgt * g[c * ld + x];
-    }
-    tmp[(((size_t)b * H + y) * w + x0) * C + c] = a;
+    tmp[(((size_t)b * H + y) * w + x0) * C + c] = adjoint_run_lds(g + c * ld, 1, cl1, cs, x0, w);
   }
   // the loss: one atomic per block -- or, rowpart != NULL, one plain store per block, folded in row order afterwards
-  const float v = wave_sum(acc);
+  const float vs = wave_sum(acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) red[wave] = v;
+  if (lane == 0) red[wave] = vs;
   __syncthreads();
   if (threadIdx.x == 0) {
     float tot = 0.f;
@@ -925,7 +965,7 @@ __global__ void cons_rows_finish_kernel(int n, const float* __restrict__ rowpart
 }
 }  // namespace
 
-extern "C" size_t pxl_cons_head_lds_bytes(int C, int W) { return (size_t)C * (W + 1) * sizeof(float) + (size_t)W * 3 * sizeof(float); }
+extern "C" size_t pxl_cons_head_lds_bytes(int w, int C, int W) { return (size_t)C * (W + 1) * sizeof(float) + (size_t)(W + w + 1) * sizeof(float); }
 extern "C" size_t pxl_cons_head_workspace(int B, int w, int C, int H) { return pxl_upsample_bwd_workspace(B, w, C, H) + (size_t)B * H * sizeof(float); }
 
 // low: NHWC [B][h][w][Cp] in the engine dtype (the decoder's own-resolution logits); target: NCHW fp32 [B][C][H][W] (the main
@@ -939,7 +979,7 @@ extern "C" int pxl_cons_head_fwd(int dtype, int B, int h, int w, int Cp, int C, 
   PXL_REQUIRE(C >= 1 && C <= MAXC && C <= Cp && Cp % 8 == 0, "cons_head_fwd: C=%d / pitch %d unsupported (max %d, pitch a multiple of 8)", C, Cp, MAXC);
   PXL_REQUIRE(B >= 1 && H >= 1 && W >= 1 && h >= 1 && w >= 1 && (!align_corners || (H > 1 && W > 1)), "cons_head_fwd: degenerate sizes");
   if (ws_bytes < pxl_cons_head_workspace(B, w, C, H)) return pxl_set_error(PXL_ERR_WORKSPACE, "cons_head_fwd: workspace too small");
-  const size_t smem = pxl_cons_head_lds_bytes(C, W);
+  const size_t smem = pxl_cons_head_lds_bytes(w, C, W);
   if (smem > 64 * 1024) return pxl_set_error(PXL_ERR_UNSUPPORTED, "cons_head_fwd: row too wide for LDS staging (W=%d)", W);
   const int align = align_corners ? 1 : 0;
   const float sy = align ? (float)(h - 1) / (float)(H - 1) : (float)h / (float)H;
@@ -949,12 +989,19 @@ extern "C" int pxl_cons_head_fwd(int dtype, int B, int h, int w, int Cp, int C, 
   float* rowpart = ordered ? reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + pxl_upsample_bwd_workspace(B, w, C, H)) : nullptr;
   if (!ordered) PXL_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
   const int threads = (W > 256 && W <= 640) ? 320 : 256;
-  if (dtype == PXL_F32)
-    hipLaunchKernelGGL(cons_rows_kernel<float>, dim3(H, B), dim3(threads), smem, s, C, Cp, h, w, H, W, sy, sx, align, (const float*)low,
-                       target, (float)(2.0 / n), (float)(1.0 / n), (float*)workspace, loss, rowpart);
+  const float s2 = (float)(2.0 / n), s1 = (float)(1.0 / n);
+  if (dtype == PXL_F32 && C == 21)
+    hipLaunchKernelGGL((cons_rows_kernel<float, 21>), dim3(H, B), dim3(threads), smem, s, C, Cp, h, w, H, W, sy, sx, align, (const float*)low,
+                       target, s2, s1, (float*)workspace, loss, rowpart);
+  else if (dtype == PXL_F32)
+    hipLaunchKernelGGL((cons_rows_kernel<float, 0>), dim3(H, B), dim3(threads), smem, s, C, Cp, h, w, H, W, sy, sx, align, (const float*)low,
+                       target, s2, s1, (float*)workspace, loss, rowpart);
+  else if (C == 21)
+    hipLaunchKernelGGL((cons_rows_kernel<bf16_t, 21>), dim3(H, B), dim3(threads), smem, s, C, Cp, h, w, H, W, sy, sx, align, (const bf16_t*)low,
+                       target, s2, s1, (float*)workspace, loss, rowpart);
   else
-    hipLaunchKernelGGL(cons_rows_kernel<bf16_t>, dim3(H, B), dim3(threads), smem, s, C, Cp, h, w, H, W, sy, sx, align, (const bf16_t*)low,
-                       target, (float)(2.0 / n), (float)(1.0 / n), (float*)workspace, loss, rowpart);
+    hipLaunchKernelGGL((cons_rows_kernel<bf16_t, 0>), dim3(H, B), dim3(threads), smem, s, C, Cp, h, w, H, W, sy, sx, align, (const bf16_t*)low,
+                       target, s2, s1, (float*)workspace, loss, rowpart);
   PXL_LAUNCH_CHECK();
   if (ordered) {
     hipLaunchKernelGGL(cons_rows_finish_kernel, dim3(1), dim3(64), 0, s, B * H, rowpart, loss);
@@ -977,10 +1024,10 @@ extern "C" int pxl_cons_head_bwd(int dtype, int B, int h, int w, int Cp, int C, 
   int grid = (int)((total + 255) / 256);
   if (grid > 4096) grid = 4096;
   if (dtype == PXL_F32)
-    hipLaunchKernelGGL(upsample_bwd_cols_kernel<float>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<float>, dim3(grid), dim3(256), (size_t)(H + h + 1) * sizeof(float), s, B, h, w, Cp, C, H, sy, align,
                        (const float*)workspace, (float*)dlow, gout);
   else
-    hipLaunchKernelGGL(upsample_bwd_cols_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, B, h, w, Cp, C, H, sy, align,
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel<bf16_t>, dim3(grid), dim3(256), (size_t)(H + h + 1) * sizeof(float), s, B, h, w, Cp, C, H, sy, align,
                        (const float*)workspace, (bf16_t*)dlow, gout);
   PXL_LAUNCH_CHECK();
   return PXL_OK;

@@ -1965,7 +1965,7 @@ extern "C" int pxl_net_head_forward(pxl_net* n, const void* arena, float* logits
 extern "C" int pxl_net_cons_head_supported(const pxl_net* n) {
   if (!n || !n->planned || n->head_op < 0) return 0;
   const TensorInfo& low = n->tensors[n->ops[n->head_op].d.in0];
-  return n->classes <= 32 && low.Cp % 8 == 0 && pxl_cons_head_lds_bytes(n->classes, n->Wo) <= 64 * 1024 &&
+  return n->classes <= 32 && low.Cp % 8 == 0 && pxl_cons_head_lds_bytes(low.W, n->classes, n->Wo) <= 64 * 1024 &&
          n->up_ws_bytes >= pxl_cons_head_workspace(n->B, low.W, n->classes, n->Ho) ? 1 : 0;
 }
 extern "C" int pxl_net_cons_head_fwd(pxl_net* n, const void* arena, const float* target, void* scratch, size_t scratch_bytes, float* loss,

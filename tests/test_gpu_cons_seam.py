@@ -66,7 +66,7 @@ def test_cons_seam_argument_checks():
     from pixelssl_amd._lib import lib, ptr, stream_ptr
     t = torch.zeros(64, device=DEV)
     # an output row that does not fit the LDS staging is refused (never a silent fallback), as is a short workspace
-    assert lib().pxl_cons_head_lds_bytes(21, 1025) > 64 * 1024
+    assert lib().pxl_cons_head_lds_bytes(8, 21, 1025) > 64 * 1024
     assert lib().pxl_cons_head_fwd(0, 1, 8, 8, 32, 21, 1025, 1025, 0, ptr(t), ptr(t), ptr(t), 1 << 40, ptr(t), 0, stream_ptr()) != 0
     assert lib().pxl_cons_head_fwd(0, 1, 8, 8, 32, 21, 9, 9, 0, ptr(t), ptr(t), ptr(t), 16, ptr(t), 0, stream_ptr()) != 0
     assert lib().pxl_cons_head_fwd(0, 1, 8, 8, 32, 40, 9, 9, 0, ptr(t), ptr(t), ptr(t), 1 << 20, ptr(t), 0, stream_ptr()) != 0
