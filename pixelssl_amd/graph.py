@@ -76,12 +76,40 @@ class HyperBlock:
         return self.dev[self.names[name]]
 
 
+class HostState:
+    """The scalar host-side state (counters, flags, learning rates) of the objects a captured body touches WHILE BEING RECORDED: the
+    scheduler's step count, the optimizer's counters and per-group learning rates, the update pipeline's flags.  A capture that fails
+    has already advanced them once; StepGraph restores the snapshot before it runs the same iteration eagerly."""
+
+    _SCALAR = (int, float, bool, str, type(None))
+
+    def __init__(self, objs=(), param_groups=()):
+        self.objs = [o for o in objs if o is not None]
+        self.groups = list(param_groups)
+        self._snap = None
+
+    def save(self):
+        self._snap = ([{k: v for k, v in vars(o).items() if isinstance(v, self._SCALAR)} for o in self.objs],
+                      [{k: v for k, v in g.items() if isinstance(v, self._SCALAR)} for g in self.groups])
+
+    def restore(self):
+        if self._snap is None:
+            return
+        for o, d in zip(self.objs, self._snap[0]):
+            for k, v in d.items():
+                setattr(o, k, v)
+        for g, d in zip(self.groups, self._snap[1]):
+            g.update(d)
+        self._snap = None
+
+
 class StepGraph:
     """fn(*tensors) -> flat tuple of 0-dim / small tensors (the step's logged values); scalars_fn(*step_args) -> {name: float};
     after_fn(): the host bookkeeping of one step (called after every replay; the eager calls do theirs inside fn)."""
 
-    def __init__(self, fn, scalars_fn, after_fn, device, warmup=2):
+    def __init__(self, fn, scalars_fn, after_fn, device, warmup=2, host_state=None):
         self.fn, self.scalars_fn, self.after_fn = fn, scalars_fn, after_fn
+        self.host_state = host_state          # HostState: rolled back when a capture attempt fails (its body ran the host half once)
         self.hyper = HyperBlock(device)
         self.warmup = int(os.environ.get("PXL_GRAPH_WARMUP", warmup))
         self.calls = 0
@@ -135,6 +163,8 @@ class StepGraph:
         self.hyper.upload(self.scalars_fn(*step_args))
         g = torch.cuda.CUDAGraph()
         _current[0] = self.hyper
+        if self.host_state is not None:
+            self.host_state.save()
         try:
             # relaxed: libpixelhip's side streams join the capture through events, and other threads of the process (data
             # loader workers pinning memory) must stay free to call the runtime
@@ -148,6 +178,8 @@ class StepGraph:
             logger.log_warn("step capture failed (%s); the training step stays on eager launches\n" % self.failed)
             if os.environ.get("PXL_GRAPH_STRICT") == "1":
                 raise
+            if self.host_state is not None:     # the recorded body stepped the scheduler / counters; the eager run below does it again
+                self.host_state.restore()
             return self._eager(tensors, step_args)
         finally:
             _current[0] = None

@@ -253,7 +253,8 @@ class SSLMT(ssl_base._SSLBase):
             if not self.args.is_epoch_lrer:
                 self.s_lrer.step()
 
-        self._sgraph = pgraph.StepGraph(body, scalars, after_replay, torch.device('cuda', torch.cuda.current_device()))
+        host = pgraph.HostState([self.s_lrer, self.s_optimizer, getattr(self, '_pipe', None)], self.s_optimizer.param_groups)
+        self._sgraph = pgraph.StepGraph(body, scalars, after_replay, torch.device('cuda', torch.cuda.current_device()), host_state=host)
         return self._sgraph
 
     def _train_step_fused_seam(self, s_inp, t_inp, l_gt, lbs, ramp, cur_step):

@@ -415,3 +415,26 @@ def test_lazy_auxiliary_predictions_materialise_on_first_access():
     assert lp[1] is lp[1] and Head.calls == 1
     assert [tuple(v.shape) for v in lp] == [(1, 2)] * 3 and Head.calls == 2
     assert len(lp[1:]) == 2
+
+
+def test_graph_host_state_rolls_back_scalars_only():
+    """graph.HostState (a failed capture attempt has already stepped the scheduler and the optimizer's counters; the
+    eager run of the same iteration must not step them a second time)."""
+    from pixelssl_amd.graph import HostState
+
+    class Sched:
+        def __init__(self):
+            self.last_epoch, self.name, self.table = 3, "poly", [1, 2]
+
+    sc = Sched()
+    groups = [{"lr": 0.1, "params": [torch.zeros(1)]}, {"lr": 1.0, "params": []}]
+    hs = HostState([sc, None], groups)
+    hs.save()
+    sc.last_epoch, sc.table = 4, [9]
+    groups[0]["lr"], groups[1]["lr"] = 0.05, 0.5
+    hs.restore()
+    assert sc.last_epoch == 3 and sc.table == [9]            # scalars rolled back, containers left alone
+    assert groups[0]["lr"] == 0.1 and groups[1]["lr"] == 1.0 and len(groups[0]["params"]) == 1
+    sc.last_epoch = 7
+    hs.restore()                                             # nothing saved: a no-op
+    assert sc.last_epoch == 7
