@@ -63,21 +63,22 @@ def _sync_foreign_grads(groups):
     ps = [p for foreign in groups for p in foreign]
     if not ps:
         return
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])
+    # which tensors received a gradient on ANY rank rides in the SAME all-reduce (one flag per tensor appended to the gradients;
+    # its mean is > 0 iff some rank had one): those step with the mean on EVERY rank -- a rank that had none contributed zeros to
+    # the mean and must apply it too, or the replicas drift apart; tensors without a gradient anywhere keep grad = None (the
+    # optimizers skip them, like torch's).  The flags are read back (a device sync) only on a rank that misses a gradient.
+    dev = ps[0].device
+    flags = torch.tensor([0.0 if p.grad is None else 1.0 for p in ps], device=dev, dtype=ps[0].dtype)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(ps[0].dtype) for p in ps] + [flags])
     pdist.allreduce_mean_(flat)
-    # which tensors received a gradient on ANY rank (one more small all-reduce): those step with the mean on EVERY rank -- a
-    # rank that had none contributed zeros to the mean and must apply it too, or the replicas drift apart; tensors without a
-    # gradient anywhere keep grad = None (the optimizers skip them, like torch's)
-    had = torch.tensor([0.0 if p.grad is None else 1.0 for p in ps], device=flat.device)
-    pdist.allreduce_sum_(had)
-    had = had.tolist()
+    had = flat[-len(ps):].tolist() if any(p.grad is None for p in ps) else None
     off = 0
     for k, p in enumerate(ps):
         n = p.numel()
         if p.grad is not None:
             p.grad.copy_(flat[off:off + n].view_as(p.grad))
         elif had[k] > 0:
-            p.grad = flat[off:off + n].view_as(p).clone()
+            p.grad = flat[off:off + n].view_as(p).clone().to(p.dtype)
         off += n
 
 
