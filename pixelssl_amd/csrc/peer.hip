@@ -95,6 +95,7 @@ struct pxl_peer {
   unsigned* host_status = nullptr;       // hipHostMalloc'ed mirror of the status word (NULL: not available)
   unsigned epoch = 0;
   long long timeout_ticks = 0;
+  unsigned long exchanges = 0;           // exchanges issued on this context (the first ones wait longer: start-up skew)
 };
 
 extern "C" int pxl_peer_create(int rank, int world, int slot_floats, int timeout_ms, pxl_peer** out) {
@@ -181,11 +182,18 @@ int peer_exchange(pxl_peer* p, float* buf0, float* buf1, long n_each, int nrep, 
   a.status = reinterpret_cast<unsigned*>(p->local + p->status_off);
   a.host_status = p->host_status;
   a.rank = p->rank; a.world = p->world; a.slot = p->slot; a.timeout_ticks = p->timeout_ticks;
+  // Start-up skew: the ranks reach their first exchanges seconds apart (per-rank autotune of several networks, first-touch page-ins, a
+  // rank-0 validation pass outside the epoch barrier) -- not a dead peer.  The first PXL_PEER_WARM_EXCHANGES (1024: about three
+  // Mean-Teacher steps) exchanges of a context wait PXL_PEER_WARM_SCALE (15) times as long before they give up; no hidden barrier.
+  static const long warm_n = getenv("PXL_PEER_WARM_EXCHANGES") ? atol(getenv("PXL_PEER_WARM_EXCHANGES")) : 1024;
+  static const long warm_scale = getenv("PXL_PEER_WARM_SCALE") ? atol(getenv("PXL_PEER_WARM_SCALE")) : 15;
+  if ((long)p->exchanges < warm_n && warm_scale > 1) a.timeout_ticks = p->timeout_ticks * warm_scale;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const long total = buf1 != nullptr ? 2 * n_each : n_each;
   for (long off = 0; off < total; off += p->slot) {
     const int m = (int)((total - off) < p->slot ? (total - off) : p->slot);
     p->epoch += 1;
+    p->exchanges += 1;
     if (p->epoch == 0) p->epoch = 2;            // 0 is what the zero-filled buffer carries; keep the parity sequence
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3(m > 1024 ? 4 : 1), dim3(256), 0, s, a, buf0, buf1, (int)n_each, nrep, (int)off, m,
                        p->epoch, add_lo, add_hi);

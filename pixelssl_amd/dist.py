@@ -180,7 +180,9 @@ _peer = {"ok": None, "ctxs": [], "hook": None}
 PEER_SLOT_FLOATS = 8192            # 2 networks x 2 * 2048 channels: the widest BatchNorm of a student || teacher pair in one exchange
 PEER_TIMEOUT_MS = int(os.environ.get("PXL_PEER_TIMEOUT_MS", "20000"))      # one exchange is ~6 us; 20 s is a dead (or wedged) peer,
 # well above ordinary rank skew (a per-rank autotune, a rank-0 checkpoint save or validation pass).  A time-out is sticky and costs its
-# 20 s once; the exchange that times out returns NaN sums (csrc/peer.hip), never stale ones.
+# 20 s once; the exchange that times out returns NaN sums (csrc/peer.hip), never stale ones.  The FIRST exchanges of a context
+# (PXL_PEER_WARM_EXCHANGES = 1024, about three Mean-Teacher steps) wait PXL_PEER_WARM_SCALE = 15 times as long: start-up skew between
+# ranks (uneven autotune of several networks, first-touch page-ins) is not a dead peer and there is no hidden barrier to absorb it.
 # What a time-out does: by default the run ABORTS at the next optimizer step (poll_peers reads the status word from mapped host
 # memory every step, no device sync) -- at most one update on NaN statistics, and that one is detectably invalid.
 # PXL_PEER_FALLBACK=1 (opt-in): every PEER_POLL_STEPS-th step the ranks agree on the status and move the statistics to RCCL /
