@@ -257,14 +257,14 @@ __global__ __launch_bounds__(256) void head_loss_rows_kernel(int C, int Cp, int 
                                                              float* __restrict__ tmp, float* __restrict__ sums, int B,
                                                              const float* __restrict__ mse_w_dev, float* __restrict__ rowpart) {
   if (mse_w_dev != nullptr) mse_scale *= mse_w_dev[0];      // (consistency weight in device memory: pxl_head_loss_hp)
-  extern __shared__ float g[];   // [C][W+1] | ci0[W] ci1[W] cl1[W] | srow[2][w][C] | trow[2][w][C]
+  extern __shared__ float g[];   // [C][W+1] | the start() table [w + 1 <= 2 W] | cl1[W] | srow[2][w][C] | trow[2][w][C]
   __shared__ float red[4];
   const int y = blockIdx.x, b = blockIdx.y;
   const int ld = W + 1;
-  int* ci0 = reinterpret_cast<int*>(g + (size_t)C * ld);
-  int* ci1 = ci0 + W;
-  float* cl1 = reinterpret_cast<float*>(ci1 + W);
+  int* cs = reinterpret_cast<int*>(g + (size_t)C * ld);
+  float* cl1 = reinterpret_cast<float*>(cs + 2 * W);
   float* srow = cl1 + W;
+  for (int v = threadIdx.x; v <= w; v += blockDim.x) cs[v] = first_dst_ge(v, sx, align, w, W);
   float* trow = srow + 2 * w * C;
   int y0, y1;
   float ly;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void head_loss_rows_kernel(int C, int Cp, int 
     int x0, x1;
     float lx;
     src_coord(x, sx, align, w, x0, x1, lx);
-    ci0[x] = x0; ci1[x] = x1; cl1[x] = lx;
+    cl1[x] = lx;
     const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
     const float* s00 = srow + x0 * C; const float* s01 = srow + x1 * C;
     const float* s10 = srow + (w + x0) * C; const float* s11 = srow + (w + x1) * C;
@@ -342,20 +342,7 @@ __global__ __launch_bounds__(256) void head_loss_rows_kernel(int C, int Cp, int 
   __syncthreads();
   for (int o = threadIdx.x; o < w * C; o += blockDim.x) {
     const int c = o % C, x0 = o / C;
-    const float xoff = align ? 0.f : 0.5f;
-    int xlo = (int)floorf(((float)(x0 - 1) + xoff) / sx - xoff) - 1;
-    int xhi = (int)ceilf(((float)(x0 + 1) + xoff) / sx - xoff) + 1;
-    if (xlo < 0) xlo = 0;
-    if (xhi > W - 1) xhi = W - 1;
-    float acc = 0.f;
-    for (int x = xlo; x <= xhi; ++x) {
-      const float l1 = cl1[x];
-      float wgt = 0.f;
-      if (ci0[x] == x0) wgt += 1.f - l1;
-      if (ci1[x] == x0) wgt += l1;
-      acc += wgt * g[c * ld + x];
-    }
-    tmp[(((size_t)b * H + y) * w + x0) * C + c] = acc;
+    tmp[(((size_t)b * H + y) * w + x0) * C + c] = adjoint_run_lds(g + c * ld, 1, cl1, cs, x0, w);
   }
   // loss sums: one atomic per block and quantity (as ce_fwd_kernel / mse_fwd_kernel do) -- or, rowpart != NULL, one plain
   // store per block into rowpart[b][y][3], summed in row order by head_loss_rows_finish_kernel (bit-reproducible values)
@@ -743,6 +730,7 @@ int head_loss_impl(int dtype, int B, int h, int w, int Cp, int C, int H, int W, 
   if (ws_bytes < pxl_upsample_bwd_workspace(B, w, C, H)) return pxl_set_error(PXL_ERR_WORKSPACE, "head_loss: workspace too small");
   const size_t smem = pxl_head_loss_lds_bytes(w, C, W);
   if (smem > 64 * 1024) return pxl_set_error(PXL_ERR_UNSUPPORTED, "head_loss: row too wide for LDS staging (W=%d)", W);
+  if (w + 1 > 2 * W) return pxl_set_error(PXL_ERR_UNSUPPORTED, "head_loss: a head that shrinks its input by more than 2 (w=%d -> W=%d)", w, W);
   const int align = align_corners ? 1 : 0;
   const float sy = align ? (float)(h - 1) / (float)(H - 1) : (float)h / (float)H;
   const float sx = align ? (float)(w - 1) / (float)(W - 1) : (float)w / (float)W;
