@@ -667,14 +667,61 @@ class SegNetCore(nn.Module):
         logits = None if deferred else torch.empty(B, self.num_classes, H, W, device=x.device, dtype=torch.float32)
         prob = torch.empty_like(logits) if want_prob and not deferred else None
         training = self.training and not self.freeze_bn
-        check(lib().pxl_net_forward(self._net, ptr(self._store.params), ptr(self._packed), ptr(self._store.running),
+        detour = getattr(self, "_running_detour", None) if training else None
+        running = detour["tmp"] if detour is not None else self._store.running
+        check(lib().pxl_net_forward(self._net, ptr(self._store.params), ptr(self._packed), ptr(running),
                                     ptr(x), ptr(logits), ptr(prob), ptr(arena), arena.numel(), int(training),
                                     stream_ptr()))
         if training:
             # every BN's num_batches_tracked is a view of this buffer; a pass that stands for `_bn_repeat` identical passes
             # (set_bn_repeat: SSLGCT's PXL_GCT_REUSE_FORWARD) counts as that many, like its running statistics
-            self._nbt += getattr(self, "_bn_repeat", 1)
+            if detour is not None:
+                detour["passes"] += getattr(self, "_bn_repeat", 1)
+            else:
+                self._nbt += getattr(self, "_bn_repeat", 1)
         return logits, prob
+
+    def detour_running(self):
+        """The training passes from here to fold_running() write their BatchNorm running-statistics update into a zeroed side
+        buffer instead of the running statistics: a pass may then run CONCURRENTLY with another training pass of this network on
+        another stream (two read-modify-write updates of one buffer would race).  Every kernel computes r' = (1 - m) r + m s
+        (bn.hip / the fused finalize of the convolution kernels); on r = 0 that leaves m s, and fold_running() applies
+        r <- (1 - m) r + (m s) -- the update the pass would have made had it run after everything that touched r in between
+        (1 ulp: the sum is rounded twice).  One pass per detour (a second one would need (1 - m) applied to the first's term)."""
+        if getattr(self, "_running_detour", None) is not None:
+            raise _lib.PixelHipError("detour_running: already active (fold_running() first)")
+        tmp = getattr(self, "_running_tmp", None)
+        if tmp is None or tmp.numel() != self._store.running.numel():
+            tmp = torch.empty_like(self._store.running)
+            object.__setattr__(self, "_running_tmp", tmp)
+        tmp.zero_()
+        object.__setattr__(self, "_running_detour", {"tmp": tmp, "passes": 0})
+
+    def fold_running(self):
+        """End of detour_running(): fold the parked update into the running statistics ON THE CURRENT STREAM (the caller has
+        ordered it after the detoured pass and after every other pass that updates the running statistics)."""
+        d = getattr(self, "_running_detour", None)
+        object.__setattr__(self, "_running_detour", None)
+        if d is None or d["passes"] == 0:
+            return
+        if d["passes"] != 1:
+            raise _lib.PixelHipError("fold_running: %d passes ran inside one detour (one is supported)" % d["passes"])
+        self._store.running.mul_(1.0 - SynchronizedBatchNorm2d.momentum).add_(d["tmp"])
+        self._nbt += d["passes"]
+
+    def side_backward_buffers(self, plan=None):
+        """-> (gradient buffer, scratch) of their own for a backward pass of this network that runs CONCURRENTLY with another backward
+        pass of it (SSLCCT: the labeled pass beside the unlabeled one; both would otherwise accumulate into one flat gradient buffer
+        and share the plan's scratch).  The caller zeroes the gradient buffer, brackets the pass's backward with `_alt_backward =
+        (grads, scratch)` / None and adds the buffer onto the parameters' gradients once both passes are done."""
+        pl = plan if plan is not None else self._cur
+        g = getattr(self, "_alt_grads", None)
+        if g is None or g.numel() != self._store.grads.numel():
+            g = torch.zeros_like(self._store.grads)
+            object.__setattr__(self, "_alt_grads", g)
+        if getattr(pl, "scratch_alt", None) is None or pl.scratch_alt.numel() != pl.scratch.numel():
+            pl.scratch_alt = torch.empty_like(pl.scratch)
+        return g, pl.scratch_alt
 
     def _bn_leaves(self):
         if not hasattr(self, "_bn_cache"):
@@ -1022,13 +1069,17 @@ class _SegNetFn(torch.autograd.Function):
         pl = ctx.plan
         if pl.wt_ready is not None:
             torch.cuda.current_stream().wait_event(pl.wt_ready)
+        # (side_backward_buffers: a pass that runs beside another backward pass of this network has its own gradient buffer and scratch)
+        alt = getattr(core, "_alt_backward", None)
+        grads, scratch = (alt if alt is not None else (s.grads, pl.scratch))
         if dlatent is not None:
             dlatent = dlatent.contiguous().float()
-            check(lib().pxl_net_seed_latent_grad(pl.net, ptr(pl.scratch), pl.scratch.numel(), ptr(dlatent), stream_ptr()))
-        pl.grad_gen = getattr(pl, "grad_gen", 0) + 1          # (a seam gradient parked in this plan's scratch is gone after this pass)
+            check(lib().pxl_net_seed_latent_grad(pl.net, ptr(scratch), scratch.numel(), ptr(dlatent), stream_ptr()))
+        if alt is None:
+            pl.grad_gen = getattr(pl, "grad_gen", 0) + 1      # (a seam gradient parked in this plan's scratch is gone after this pass)
         check(lib().pxl_net_backward(pl.net, ptr(s.params), ptr(pl.packed), ptr(dlogits), ptr(dprob), ptr(prob),
-                                     ptr(s.grads), ptr(ctx.arena), ctx.arena.numel(), ptr(pl.scratch),
-                                     pl.scratch.numel(), int(ctx.bn_training), stream_ptr()))
+                                     ptr(grads), ptr(ctx.arena), ctx.arena.numel(), ptr(scratch),
+                                     scratch.numel(), int(ctx.bn_training), stream_ptr()))
         dx, dextra = None, [None] * nextra
         want = [ctx.needs_input_grad[0]] + [ctx.needs_input_grad[5 + k] for k in range(nextra)]
         if nextra and any(want):           # concatenated input: one NCHW gradient per part that asks for it
@@ -1036,11 +1087,11 @@ class _SegNetFn(torch.autograd.Function):
                     for shp, w in zip(ctx.part_shapes, want)]
             dsts = (ctypes.c_void_p * len(outs))(*[t.data_ptr() if t is not None else None for t in outs])
             chans = (ctypes.c_int * len(outs))(*[shp[1] for shp in ctx.part_shapes])
-            check(lib().pxl_net_input_grad_parts(pl.net, ptr(pl.scratch), len(outs), dsts, chans, stream_ptr()))
+            check(lib().pxl_net_input_grad_parts(pl.net, ptr(scratch), len(outs), dsts, chans, stream_ptr()))
             dx, dextra = outs[0], outs[1:]
         elif ctx.needs_input_grad[0]:      # discriminator / flaw detector: gradient w.r.t. the task model's softmax
             dx = torch.empty(ctx.x_shape, device=core._device, dtype=torch.float32)
-            check(lib().pxl_net_input_grad(pl.net, ptr(pl.scratch), ptr(dx), stream_ptr()))
+            check(lib().pxl_net_input_grad(pl.net, ptr(scratch), ptr(dx), stream_ptr()))
         hook = getattr(core, "_post_backward_hook", None)
         if hook is not None and core._wgrad_on:
             hook(core)

@@ -592,6 +592,22 @@ class SSLCCT(ssl_base._SSLBase):
         # and six decoders queued behind it: the contour search on the host (~2.3 ms) no longer leaves the GPU idle, and the
         # labeled backward runs beside the unlabeled forward and the decoders instead of in front of them.
         late = side is not None and os.environ.get('PXL_CCT_LATE_LBWD', '1') != '0'
+        # PXL_CCT_CONCURRENT (one rank): the labeled pass -- forward AND backward -- and the unlabeled pass run as two independent
+        # chains on two streams from the first launch to the optimizer.  A 4-image pass at 33 x 33 launches grids of 35-70 workgroups
+        # on 256 CUs; beside each other two such kernels run at 1.3-1.5 x the serial rate (profiles/r06_h_cct.txt).  What the chains
+        # share is separated by hand: the weights are packed before the streams fork; the unlabeled pass parks its BatchNorm
+        # running-statistics update (engine.detour_running) and folds it in behind the labeled pass's own (the reference's order:
+        # labeled, then unlabeled); the labeled backward accumulates into a gradient buffer and a scratch of its own
+        # (engine.side_backward_buffers), added onto the parameters' gradients before the optimizer.  Not with Sync-BN / a gradient
+        # exchange: two passes issuing collectives from two streams have no common order across ranks.
+        core = getattr(self.model.module.main_model, 'model', None)
+        conc = late and os.environ.get('PXL_CCT_CONCURRENT', '0') == '1' and pdist.world_size() == 1 and \
+            hasattr(core, 'side_backward_buffers') and core.training and not core.freeze_bn and l_inp[0].is_cuda and \
+            getattr(core, '_post_backward_hook', None) is None
+        if conc:
+            for t in (l_inp[0], func.split_tensor_tuple(inp, lbs, self.args.batch_size)[0]):
+                core._plan(t.shape[0], t.shape[2], t.shape[3], None, inference=False)
+                core._ensure_packed()
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -603,13 +619,29 @@ class SSLCCT(ssl_base._SSLBase):
                 if not late:
                     task_loss.backward()
                     mark('labeled: backward enqueued (side)')
-            main.wait_event(fwd_done)
+                if conc:
+                    l_plan = core._cur
+                    alt = core.side_backward_buffers(l_plan)
+                    alt[0].zero_()
+            if not conc:
+                main.wait_event(fwd_done)
             if late:
                 def labeled_backward():
+                    if conc:
+                        main.wait_event(fwd_done)       # (the labeled pass has made its running-statistics update)
+                        core.fold_running()
                     with torch.cuda.stream(side):
-                        task_loss.backward()
+                        if conc:
+                            core._alt_backward = alt
+                        try:
+                            task_loss.backward()
+                        finally:
+                            if conc:
+                                core._alt_backward = None
                         mark('labeled: backward enqueued (side)')
                 self.model.module.after_main_forward = labeled_backward
+            if conc:
+                core.detour_running()
             for v in l_res.values():
                 for t in (v if isinstance(v, (tuple, list)) else (v,)):
                     if torch.is_tensor(t):
@@ -630,8 +662,13 @@ class SSLCCT(ssl_base._SSLBase):
         else:
             cons_loss = torch.zeros((), device=task_loss.device)
         if side is not None:
-            main.wait_stream(side)              # the labeled backward has finished accumulating
+            if not conc:
+                main.wait_stream(side)          # the labeled backward has finished accumulating
             cons_loss.backward()
+            if conc:                            # the labeled pass's gradients join the unlabeled pass's
+                main.wait_stream(side)
+                core.ensure_grad_views()
+                core._store.grads.add_(alt[0])
             mark('unlabeled: backward enqueued')
         else:
             (task_loss + cons_loss).backward()
