@@ -592,7 +592,7 @@ class SSLCCT(ssl_base._SSLBase):
         # and six decoders queued behind it: the contour search on the host (~2.3 ms) no longer leaves the GPU idle, and the
         # labeled backward runs beside the unlabeled forward and the decoders instead of in front of them.
         late = side is not None and os.environ.get('PXL_CCT_LATE_LBWD', '1') != '0'
-        # PXL_CCT_CONCURRENT (one rank): the labeled pass -- forward AND backward -- and the unlabeled pass run as two independent
+        # PXL_CCT_CONCURRENT (default on, one rank): the labeled pass -- forward AND backward -- and the unlabeled pass run as two independent
         # chains on two streams from the first launch to the optimizer.  A 4-image pass at 33 x 33 launches grids of 35-70 workgroups
         # on 256 CUs; beside each other two such kernels run at 1.3-1.5 x the serial rate (profiles/r06_h_cct.txt).  What the chains
         # share is separated by hand: the weights are packed before the streams fork; the unlabeled pass parks its BatchNorm
@@ -601,7 +601,7 @@ class SSLCCT(ssl_base._SSLBase):
         # (engine.side_backward_buffers), added onto the parameters' gradients before the optimizer.  Not with Sync-BN / a gradient
         # exchange: two passes issuing collectives from two streams have no common order across ranks.
         core = getattr(self.model.module.main_model, 'model', None)
-        conc = late and os.environ.get('PXL_CCT_CONCURRENT', '0') == '1' and pdist.world_size() == 1 and \
+        conc = late and os.environ.get('PXL_CCT_CONCURRENT', '1') != '0' and pdist.world_size() == 1 and \
             hasattr(core, 'side_backward_buffers') and core.training and not core.freeze_bn and l_inp[0].is_cuda and \
             getattr(core, '_post_backward_hook', None) is None
         if conc:
