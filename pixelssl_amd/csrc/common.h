@@ -27,6 +27,12 @@ int pxl_tune_get(int key);
                            hipGetErrorString(_e), __FILE__, __LINE__);             \
   } while (0)
 #define PXL_LAUNCH_CHECK() PXL_CHECK_HIP(hipGetLastError())
+// PXL_HOST_TRACE=1: host nanoseconds per slot, printed when the process ends (csrc/net.cpp): where the executor's per-launch host time goes
+namespace pxlht {
+extern bool on;
+long now();
+void add(int slot, long ns);
+}
 #define PXL_REQUIRE(cond, ...)                                                     \
   do {                                                                             \
     if (!(cond)) return pxl_set_error(PXL_ERR_ARG, __VA_ARGS__);                   \

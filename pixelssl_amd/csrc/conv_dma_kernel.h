@@ -944,8 +944,10 @@ int launch_one(dim3 grid, dim3 block, size_t smem, hipStream_t stream, const Dma
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     raised = true;
   }
+  const long t0 = pxlht::on ? pxlht::now() : 0;
   hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, NST, GATHER, 0, BNIN, TRACE, EM>), grid, block, smem, stream, p);
   PXL_LAUNCH_CHECK();
+  if (pxlht::on) pxlht::add(16, pxlht::now() - t0);
   return PXL_OK;
 }
 

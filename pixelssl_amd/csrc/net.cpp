@@ -78,6 +78,25 @@ int pxl_peer_allreduce_fold(pxl_peer* p, float* buf0, float* buf1, long n, int n
 int pxl_peer_allreduce_bnbwd(pxl_peer* p, float* sums, int C, float* dgamma, float* dbeta, void* stream);
 }
 
+#include <chrono>
+namespace pxlht {
+bool on = getenv("PXL_HOST_TRACE") != nullptr && getenv("PXL_HOST_TRACE")[0] == '1';
+static long g_ns[64], g_cnt[64];
+long now() { return (long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void add(int slot, long ns) { g_ns[slot] += ns; g_cnt[slot] += 1; }
+static struct Dump {
+  ~Dump() {
+    if (!on) return;
+    static const char* names[64] = {"fwd INPUT", "fwd CONV", "fwd MAXPOOL", "fwd RESIDUAL", "fwd HEAD", "fwd ACT", "fwd IBN", "fwd AVGPOOL", "fwd CONCAT",
+                                    "fwd UPCAT", "fwd PIXSHUF", nullptr, nullptr, nullptr, nullptr, nullptr,
+                                    "launch_one: hipLaunchKernelGGL + check", "launch_dma (whole)", "pxl_net_forward (whole)", "pxl_net_backward (whole)",
+                                    "bwd: issue_wgrads", "bwd: flush / joins"};
+    for (int k = 0; k < 64; ++k)
+      if (g_cnt[k]) fprintf(stderr, "PXL_HOST_TRACE %-44s %8ld calls %10.3f ms %8.2f us/call\n", names[k] ? names[k] : "?", g_cnt[k], g_ns[k] / 1e6, g_ns[k] / 1e3 / g_cnt[k]);
+  }
+} g_dump;
+}  // namespace pxlht
+
 namespace {
 
 constexpr size_t ALIGN = 256;
@@ -1550,11 +1569,15 @@ extern "C" int pxl_net_forward(pxl_net* n, const float* params, const void* pack
   if (n->ibn_region_bytes)      // (instance statistics are computed in eval mode too)
     PXL_CHECK_HIP(hipMemsetAsync(at(arena, n->ibn_region_off), 0, n->ibn_region_bytes, s));
   const FwdCtx ctx{params, packed, running, x, logits, prob, arena, training, stream};
+  const long t_all = pxlht::on ? pxlht::now() : 0;
   for (size_t i = 0; i < n->ops.size(); ++i) {
     bool fin = false;
+    const long t0 = pxlht::on ? pxlht::now() : 0;
     const int rc = forward_op(n, i, ctx, 0, &fin);
+    if (pxlht::on) pxlht::add(n->ops[i].d.kind & 15, pxlht::now() - t0);
     if (rc != PXL_OK) return rc;
   }
+  if (pxlht::on) pxlht::add(18, pxlht::now() - t_all);
   return PXL_OK;
 }
 
