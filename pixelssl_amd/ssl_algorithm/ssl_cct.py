@@ -604,6 +604,8 @@ class SSLCCT(ssl_base._SSLBase):
         conc = late and os.environ.get('PXL_CCT_CONCURRENT', '1') != '0' and pdist.world_size() == 1 and \
             hasattr(core, 'side_backward_buffers') and core.training and not core.freeze_bn and l_inp[0].is_cuda and \
             getattr(core, '_post_backward_hook', None) is None
+        if core is not None and (getattr(core, '_running_detour', None) is not None or getattr(core, '_alt_backward', None) is not None):
+            core._running_detour = core._alt_backward = None       # (an iteration that raised half-way: do not inherit its state)
         if conc:
             for t in (l_inp[0], func.split_tensor_tuple(inp, lbs, self.args.batch_size)[0]):
                 core._plan(t.shape[0], t.shape[2], t.shape[3], None, inference=False)
