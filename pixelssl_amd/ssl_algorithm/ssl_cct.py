@@ -427,7 +427,10 @@ class WrappedCCTModel(nn.Module):
 
     def _lanes(self, device):
         if not hasattr(self, '_lane_streams'):
-            n = int(os.environ.get('PXL_CCT_STREAMS', '2')) if device.type == 'cuda' else 0
+            # (several ranks: every decoder's gradient all-reduce would be issued on its lane's stream -- collectives of one
+            # communicator from streams that are not ordered against each other; one stream then, unless PXL_CCT_STREAMS says otherwise)
+            default = '0' if pdist.is_distributed() else '2'
+            n = int(os.environ.get('PXL_CCT_STREAMS', default)) if device.type == 'cuda' else 0
             # decoder lanes: dealt over the queues that are not the main stream's (AUX first: the labeled pass holds SIDE)
             self._lane_streams = [streams.role_stream(streams.AUX, device=device, index=i) for i in range(max(n, 0))]
         return self._lane_streams
@@ -567,7 +570,12 @@ class SSLCCT(ssl_base._SSLBase):
 
     def _labeled_stream(self):
         if not hasattr(self, '_l_stream'):
-            on = os.environ.get('PXL_CCT_SPLIT_BACKWARD', '1') != '0' and torch.cuda.is_available()
+            # One rank only: with Sync-BN the labeled and the unlabeled pass of the SAME network would issue their statistics
+            # exchanges on ONE exchange context from two streams -- its two slots (epoch parity, csrc/peer.hip) order two exchanges in
+            # flight, not the three that two unordered streams can produce.  Several ranks run the reference's order on one stream
+            # (PXL_CCT_SPLIT_BACKWARD=force overrides, for runs without Sync-BN).
+            mode = os.environ.get('PXL_CCT_SPLIT_BACKWARD', '1')
+            on = mode != '0' and torch.cuda.is_available() and (mode == 'force' or not pdist.is_distributed())
             self._l_stream = streams.role_stream(streams.SIDE) if on else None
         return self._l_stream
 
